@@ -1,0 +1,196 @@
+"""oracle/oracle.py — ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (gst-plugins-rs_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    u8p, f32p, f64p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.hsv_from_rgb.argtypes = [u8p, f32p]
+    L.hsv_from_bgr.argtypes = [u8p, f32p]
+    L.hsv_to_rgb.argtypes = [f32p, u8p]
+    L.hsv_to_bgr.argtypes = [f32p, u8p]
+    L.oracle_hsvfilter_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.oracle_hsvfilter_frame_mt.argtypes = L.oracle_hsvfilter_frame.argtypes + [C.c_int]
+    L.oracle_hsvdetect_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.oracle_cube_parse.restype = C.c_void_p
+    L.oracle_cube_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.oracle_cube_from_table.restype = C.c_void_p
+    L.oracle_cube_from_table.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
+    L.oracle_cube_free.argtypes = [C.c_void_p]
+    L.oracle_cube_is3d.argtypes = [C.c_void_p]
+    L.oracle_cube_size.argtypes = [C.c_void_p]
+    L.oracle_cube_size.restype = C.c_size_t
+    L.oracle_cube_table.argtypes = [C.c_void_p]
+    L.oracle_cube_table.restype = f32p
+    L.oracle_cube_domain.argtypes = [C.c_void_p, f32p, f32p]
+    L.oracle_colorlut_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.oracle_colorlut_rgba8_mt.argtypes = L.oracle_colorlut_rgba8.argtypes + [C.c_int]
+    L.oracle_colorlut_rgba64.argtypes = L.oracle_colorlut_rgba8.argtypes + [C.c_int]
+    L.oracle_echo_ring_len.restype = C.c_size_t
+    L.oracle_echo_ring_len.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    L.oracle_echo_delay_samples.restype = C.c_size_t
+    L.oracle_echo_delay_samples.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.oracle_echo_new.restype = C.c_void_p
+    L.oracle_echo_new.argtypes = [C.c_size_t]
+    L.oracle_echo_free.argtypes = [C.c_void_p]
+    L.oracle_echo_ring.restype = f64p
+    L.oracle_echo_ring.argtypes = [C.c_void_p]
+    L.oracle_echo_pos.restype = C.c_size_t
+    L.oracle_echo_pos.argtypes = [C.c_void_p]
+    L.oracle_echo_process_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+    L.oracle_echo_process_f64.argtypes = L.oracle_echo_process_f32.argtypes
+    _LIB = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ---- hsv ----
+def from_rgb(p, bgr=False):
+    a = np.ascontiguousarray(p, dtype=np.uint8)
+    out = np.zeros(3, np.float32)
+    (lib().hsv_from_bgr if bgr else lib().hsv_from_rgb)(a.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(out))
+    return out
+
+
+def to_rgb(hsv, bgr=False):
+    a = _f32(hsv)
+    out = np.zeros(3, np.uint8)
+    (lib().hsv_to_bgr if bgr else lib().hsv_to_rgb)(_fp(a), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def hsvfilter(frame, width, stride, pixel_stride, first, bgr, settings, nthreads=1):
+    """In-place on a contiguous uint8 numpy buffer (plane 0)."""
+    assert frame.dtype == np.uint8 and frame.flags.c_contiguous and frame.flags.writeable
+    s = _f32(settings)
+    if nthreads > 1:
+        lib().oracle_hsvfilter_frame_mt(frame.ctypes.data, frame.size, width, stride, pixel_stride, first, int(bgr), _fp(s), nthreads)
+    else:
+        lib().oracle_hsvfilter_frame(frame.ctypes.data, frame.size, width, stride, pixel_stride, first, int(bgr), _fp(s))
+    return frame
+
+
+def hsvdetect(src, in_stride, in_pixel_stride, in_first, in_bgr, dst, out_stride, out_alpha_first, out_bgr, width, settings):
+    s = _f32(settings)
+    lib().oracle_hsvdetect_frame(src.ctypes.data, src.size, in_stride, in_pixel_stride, in_first, int(in_bgr),
+                                 dst.ctypes.data, dst.size, out_stride, int(out_alpha_first), int(out_bgr), width, _fp(s))
+    return dst
+
+
+# ---- colorlut ----
+class Cube:
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("null cube")
+        self.h = handle
+
+    @classmethod
+    def parse(cls, text):
+        if isinstance(text, str):
+            text = text.encode("utf-8")
+        err = C.create_string_buffer(256)
+        h = lib().oracle_cube_parse(text, len(text), err, 256)
+        if not h:
+            raise ValueError(err.value.decode("utf-8", "replace"))
+        return cls(h)
+
+    @classmethod
+    def from_table(cls, is3d, size, table, scale=(1, 1, 1), offset=(0, 0, 0)):
+        t, s, o = _f32(table).ravel(), _f32(scale), _f32(offset)
+        assert t.size == (4 * size ** 3 if is3d else 3 * size)
+        return cls(lib().oracle_cube_from_table(int(is3d), size, _fp(t), _fp(s), _fp(o)))
+
+    @property
+    def is3d(self):
+        return bool(lib().oracle_cube_is3d(self.h))
+
+    @property
+    def size(self):
+        return lib().oracle_cube_size(self.h)
+
+    @property
+    def table(self):
+        n = 4 * self.size ** 3 if self.is3d else 3 * self.size
+        return np.ctypeslib.as_array(lib().oracle_cube_table(self.h), shape=(n,)).copy()
+
+    @property
+    def domain(self):
+        s, o = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        lib().oracle_cube_domain(self.h, _fp(s), _fp(o))
+        return s, o
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_cube_free(self.h)
+            self.h = None
+
+
+def colorlut_rgba8(cube, src, src_stride, dst, dst_stride, width, height, nthreads=1):
+    if nthreads > 1:
+        lib().oracle_colorlut_rgba8_mt(cube.h, src.ctypes.data, src_stride, dst.ctypes.data, dst_stride, width, height, nthreads)
+    else:
+        lib().oracle_colorlut_rgba8(cube.h, src.ctypes.data, src_stride, dst.ctypes.data, dst_stride, width, height)
+    return dst
+
+
+def colorlut_rgba64(cube, src, src_stride, dst, dst_stride, width, height, le=True):
+    lib().oracle_colorlut_rgba64(cube.h, src.ctypes.data, src_stride, dst.ctypes.data, dst_stride, width, height, int(le))
+    return dst
+
+
+# ---- echo ----
+class Echo:
+    def __init__(self, max_delay_ns, rate, channels):
+        self.rate, self.channels, self.max_delay_ns = rate, channels, max_delay_ns
+        self.ring_len = lib().oracle_echo_ring_len(max_delay_ns, rate, channels)
+        self.h = lib().oracle_echo_new(self.ring_len)
+
+    def process(self, data, delay_ns, intensity, feedback):
+        d = lib().oracle_echo_delay_samples(delay_ns, self.max_delay_ns, self.rate, self.channels)
+        fn = lib().oracle_echo_process_f32 if data.dtype == np.float32 else lib().oracle_echo_process_f64
+        rc = fn(self.h, data.ctypes.data, data.size, d, intensity, feedback)
+        if rc != 0:
+            raise RuntimeError("ring buffer assertion (size >= delay, size != 0) failed")
+        return data
+
+    @property
+    def ring(self):
+        return np.ctypeslib.as_array(lib().oracle_echo_ring(self.h), shape=(max(self.ring_len, 1),)).copy()
+
+    @property
+    def pos(self):
+        return lib().oracle_echo_pos(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_echo_free(self.h)
+            self.h = None
