@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: 3840x2160 RGBA frames/s through hsvfilter -> colorlut (33^3, trilinear)
+on MI355X, with the HBM roofline fraction of the dominant kernel and the CPU oracle timed beside it.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+torch.distributed.run with one rank per GPU. One JSON line on rank 0.
+
+A "step" = one pass of the hot path over one batch of `--batch` device-resident 4K RGBA frames:
+one hsvfilter launch (in place, hue-shift=90) + one colorlut launch (33^3 LUT) — the two-kernel mode
+of SURVEY.md §8d (algorithmic 16 B/pixel/frame = 132,710,400 B per frame). Successive steps walk a
+ring of batches larger than the 256 MiB Infinity Cache so every step streams from HBM.
+Streams are independent: ranks share nothing (no collective on the data path), scaling = "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gst-plugins-rs_amd"))
+
+W, H = 3840, 2160
+FRAME_BYTES = W * H * 4
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_FRAME_PER_KERNEL = 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="4K frames per launch (one step = one batch)")
+    ap.add_argument("--ring", type=int, default=2, help="distinct batches cycled through (working set > Infinity Cache)")
+    ap.add_argument("--content", default="smooth", choices=["smooth", "noise"], help="headline frame content")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
+    return ap.parse_args()
+
+
+def make_batches(torch, synth, dev, batch, ring, content):
+    """`ring` batches of `batch` frames each, generated from two seeded base frames per batch and
+    cheap byte rotations (keeps host generation time small while making every frame distinct)."""
+    gen = synth.smooth_frame if content == "smooth" else synth.noise_frame
+    bufs = []
+    for r in range(ring):
+        base = torch.from_numpy(gen(W, H, seed=synth.SEED + 17 * r)).to(dev)  # (H, W*4) uint8
+        frames = [torch.roll(base, shifts=4 * 97 * i, dims=1) for i in range(batch)]  # whole-pixel shifts
+        bufs.append(torch.stack(frames).contiguous())
+    return bufs
+
+
+def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record):
+    """K steps on ctx's stream (== torch current stream). Optionally records in-stream events around
+    every launch; returns the event triples."""
+    evs = []
+    pitch = FRAME_BYTES
+    for k in range(steps):
+        s = srcs[k % len(srcs)]
+        d = dsts[k % len(dsts)]
+        if record:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+        ctx.hsvfilter_frames_device(s.data_ptr(), batch, pitch, W, H, W * 4, "RGBA", settings)
+        if record:
+            e1.record()
+        ctx.colorlut_frames_device(s.data_ptr(), pitch, W * 4, d.data_ptr(), pitch, W * 4, batch, W, H, "RGBA")
+        if record:
+            e2.record()
+            evs.append((e0, e1, e2))
+    return evs
+
+
+def cpu_baseline(synth, settings, cube_text, seconds_target=12.0):
+    """The CPU oracle ("port" of the reference's scalar loops) on the host cores of this box:
+    hsvfilter then colorlut on 4K smooth frames, 1 thread (what one reference pipeline does: both
+    elements run on the single upstream streaming thread)."""
+    from oracle import oracle as O
+    cube = O.Cube.parse(cube_text)
+    frame = synth.smooth_frame(W, H)
+    out = np.zeros_like(frame)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        buf = frame.copy().reshape(-1)
+        O.hsvfilter(buf, W, W * 4, 4, 0, False, settings)
+        O.colorlut_rgba8(cube, buf, W * 4, out, W * 4, W, H)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or n >= 64:
+            break
+    one = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d 4K smooth frames, hsvfilter(hue-shift=90)+colorlut(33^3), oracle C -O3 -ffp-contract=off, 1 thread" % n}
+    # all host cores, row-sliced (the reference's only scaling axis is more independent streams)
+    nc = os.cpu_count() or 1
+    n2, t0 = 0, time.perf_counter()
+    while True:
+        buf = frame.copy().reshape(-1)
+        O.hsvfilter(buf, W, W * 4, 4, 0, False, settings, nthreads=nc)
+        O.colorlut_rgba8(cube, buf, W * 4, out, W * 4, W, H, nthreads=nc)
+        n2 += 1
+        dt2 = time.perf_counter() - t0
+        if dt2 >= seconds_target / 2 or n2 >= 256:
+            break
+    return one, {"value": n2 / dt2, "unit": "frames/s", "cores": nc, "kind": "port"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import mi355fx
+    from mi355fx import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (torch.cuda unavailable); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    settings = synth.HSV_SETTINGS["hue90"]
+    cube_text = synth.cube_text_3d(33)
+    # product-side LUT parse: the host mirror of CubeLut::parse lives in the C++ host layer; here the
+    # table is produced numerically the same way (decimal text -> f32) via numpy to avoid any oracle use
+    from mi355fx.cube import parse_cube
+    lut = parse_cube(cube_text)
+
+    ctx = mi355fx.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx.set_stream(stream.cuda_stream)
+        ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+
+        def measure(content, steps, warmup, record):
+            srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
+            dsts = [torch.empty_like(s) for s in srcs]
+            run_region(torch, ctx, srcs, dsts, settings, warmup, args.batch, False)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            evs = run_region(torch, ctx, srcs, dsts, settings, steps, args.batch, record)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            hsv_ms = lut_ms = None
+            if record and evs:
+                hsv_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)
+                lut_ms = sum(b.elapsed_time(c) for _, b, c in evs) / len(evs)
+            del srcs, dsts
+            return dt, hsv_ms, lut_ms
+
+        dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
+        extra = None
+        if not args.no_extra and rank == 0 and world == 1:
+            other = "noise" if args.content == "smooth" else "smooth"
+            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 2, True)
+            extra = {"content": other, "frames_per_s": max(10, args.steps // 2) * args.batch / dt2,
+                     "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2}
+
+    fps = world * args.steps * args.batch / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        # dominant kernel = the longer of the two launches
+        per_launch_bytes = BYTES_PER_FRAME_PER_KERNEL * args.batch
+        if lut_ms >= hsv_ms:
+            dom, dom_ms = "colorlut3d_lds_kernel", lut_ms
+        else:
+            dom, dom_ms = "hsvfilter_flat_kernel", hsv_ms
+        achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+        chain_gbs = 2 * per_launch_bytes / ((hsv_ms + lut_ms) * 1e-3) / 1e9
+        out = {
+            "metric": "4K RGBA frames/sec through hsvfilter+colorlut at 1 GPU; % HBM roofline",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
+                       "frames_per_step": args.batch, "ring_batches": args.ring, "content": args.content,
+                       "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms},
+            "kernels": {"hsvfilter_ms_per_launch": hsv_ms, "colorlut_ms_per_launch": lut_ms,
+                        "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,
+                        "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
+                        "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS},
+        }
+        if extra:
+            out["other_content"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            one, mt = cpu_baseline(synth, settings, cube_text)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = mt
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,500 @@
+// ctx.hip — the extern "C" layer of libmi355fx.so (declared in include/mi355fx.h): context
+// lifetime, staging of host buffers, argument validation, dispatch to the kernel launchers.
+#include "internal.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+namespace mi355 {
+
+bool pixfmt_of(int format, PixFmt *out) {
+  switch (format) {
+    case MI355_FMT_RGBX: *out = {4, 0, 0, 0}; return true;
+    case MI355_FMT_RGBA: *out = {4, 0, 0, 1}; return true;
+    case MI355_FMT_XRGB: *out = {4, 1, 0, 0}; return true;
+    case MI355_FMT_ARGB: *out = {4, 1, 0, 1}; return true;
+    case MI355_FMT_BGRX: *out = {4, 0, 1, 0}; return true;
+    case MI355_FMT_BGRA: *out = {4, 0, 1, 1}; return true;
+    case MI355_FMT_XBGR: *out = {4, 1, 1, 0}; return true;
+    case MI355_FMT_ABGR: *out = {4, 1, 1, 1}; return true;
+    case MI355_FMT_RGB: *out = {3, 0, 0, 0}; return true;
+    case MI355_FMT_BGR: *out = {3, 0, 1, 0}; return true;
+    default: return false;
+  }
+}
+
+int set_error(mi355_ctx *ctx, int status, const std::string &msg) {
+  if (ctx) ctx->last_error = msg;
+  return status;
+}
+
+int check_hip(mi355_ctx *ctx, hipError_t e, const char *what) {
+  if (e == hipSuccess) return MI355_OK;
+  std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+  const int st = (e == hipErrorOutOfMemory) ? MI355_ERR_OUT_OF_MEMORY : MI355_ERR_HIP;
+  return set_error(ctx, st, msg);
+}
+
+static int ensure_stage(mi355_ctx *ctx, int slot, size_t bytes) {
+  if (ctx->d_stage_bytes[slot] >= bytes && ctx->d_stage[slot]) return MI355_OK;
+  if (ctx->d_stage[slot]) (void)hipFree(ctx->d_stage[slot]);
+  ctx->d_stage[slot] = nullptr;
+  ctx->d_stage_bytes[slot] = 0;
+  int rc = check_hip(ctx, hipMalloc(&ctx->d_stage[slot], bytes ? bytes : 16), "hipMalloc(staging)");
+  if (rc) return rc;
+  ctx->d_stage_bytes[slot] = bytes ? bytes : 16;
+  return MI355_OK;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+template <typename F>
+static int time_launches(mi355_ctx *ctx, int iters, float *ms_per_launch, F &&launch) {
+  if (iters <= 0 || !ms_per_launch) return set_error(ctx, MI355_ERR_INVALID_ARG, "timing: bad iters/output");
+  hipEvent_t e0, e1;
+  int rc = check_hip(ctx, hipEventCreate(&e0), "hipEventCreate");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipEventCreate(&e1), "hipEventCreate");
+  if (rc) { (void)hipEventDestroy(e0); return rc; }
+  rc = check_hip(ctx, hipEventRecord(e0, ctx->stream), "hipEventRecord");
+  for (int i = 0; i < iters && rc == MI355_OK; i++) rc = launch();
+  if (rc == MI355_OK) rc = check_hip(ctx, hipEventRecord(e1, ctx->stream), "hipEventRecord");
+  if (rc == MI355_OK) rc = check_hip(ctx, hipEventSynchronize(e1), "hipEventSynchronize");
+  float ms = 0.0f;
+  if (rc == MI355_OK) rc = check_hip(ctx, hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc == MI355_OK) *ms_per_launch = ms / (float)iters;
+  return rc;
+}
+
+
+#define REQUIRE_CTX(ctx) \
+  do { if (!(ctx)) return MI355_ERR_INVALID_ARG; } while (0)
+#define BIND_DEVICE(ctx)                                                                  \
+  do { int rc__ = check_hip((ctx), hipSetDevice((ctx)->device), "hipSetDevice");          \
+       if (rc__) return rc__; } while (0)
+
+extern "C" {
+
+int mi355_abi_version(void) { return MI355FX_ABI_VERSION; }
+
+int mi355_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *mi355_status_string(int status) {
+  switch (status) {
+    case MI355_OK: return "ok";
+    case MI355_ERR_INVALID_ARG: return "invalid argument";
+    case MI355_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case MI355_ERR_HIP: return "HIP runtime error";
+    case MI355_ERR_NOT_CONFIGURED: return "element not configured";
+    case MI355_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case MI355_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+mi355_ctx *mi355_ctx_create(int device, int *status) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+    if (status) *status = MI355_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    if (status) *status = MI355_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    if (status) *status = MI355_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  // The code objects in this library are gfx950-only: refuse anything else loudly.
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "mi355fx: device %d is %s, this library only carries gfx950 code\n", device, prop.gcnArchName);
+    if (status) *status = MI355_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  mi355_ctx *ctx = new mi355_ctx();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    if (status) *status = MI355_ERR_HIP;
+    return nullptr;
+  }
+  ctx->own_stream = true;
+  if (status) *status = MI355_OK;
+  return ctx;
+}
+
+void mi355_ctx_destroy(mi355_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  lut_release(ctx);
+  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
+  for (int i = 0; i < 2; i++)
+    if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *mi355_ctx_last_error(const mi355_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+void *mi355_ctx_stream(mi355_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  if (ctx->own_stream && ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return MI355_OK;
+}
+
+int mi355_ctx_synchronize(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
+  REQUIRE_CTX(ctx);
+  if (flag == MI355_FLAG_FORCE_GENERIC) { ctx->force_generic = value != 0; return MI355_OK; }
+  return set_error(ctx, MI355_ERR_INVALID_ARG, "unknown flag");
+}
+
+void *mi355_device_alloc(mi355_ctx *ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  void *p = nullptr;
+  if (check_hip(ctx, hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
+  return p;
+}
+
+int mi355_device_free(mi355_ctx *ctx, void *dptr) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return check_hip(ctx, hipFree(dptr), "hipFree");
+}
+
+int mi355_memcpy_h2d(mi355_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  int rc = check_hip(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int mi355_memcpy_d2h(mi355_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  int rc = check_hip(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+/* ------------------------------------------------------------------ hsvfilter */
+
+int mi355_hsvfilter_frames_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
+                                  int height, int stride, int format, const mi355_hsv_settings *settings) {
+  REQUIRE_CTX(ctx);
+  PixFmt fmt;
+  if (!settings || !pixfmt_of(format, &fmt)) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: bad settings/format");
+  if (n_frames < 0 || width < 0 || height < 0 || stride < 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: negative size");
+  if (n_frames == 0 || width == 0 || height == 0) return MI355_OK;
+  if (!d_data) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: null data");
+  if ((size_t)stride < (size_t)width * fmt.pixel_stride)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: stride smaller than width*pixel_stride");
+  BIND_DEVICE(ctx);
+  return launch_hsvfilter(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, *settings);
+}
+
+int mi355_hsvfilter_frame_ip(mi355_ctx *ctx, uint8_t *data, size_t data_len, int width, int stride, int format,
+                             const mi355_hsv_settings *settings) {
+  REQUIRE_CTX(ctx);
+  PixFmt fmt;
+  if (!settings || !pixfmt_of(format, &fmt)) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: bad settings/format");
+  if (width < 0 || stride <= 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: bad width/stride");
+  // assert_eq!(data.len() % nb_channels, 0) (hsvfilter/imp.rs:92)
+  if (data_len % (size_t)fmt.pixel_stride != 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: plane length not a multiple of pixel stride");
+  const size_t rows = data_len / (size_t)stride;  // chunks_exact_mut(stride)
+  if (rows == 0 || width == 0) return MI355_OK;
+  if (!data) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: null data");
+  // line[..line_bytes] panics in the reference when line_bytes > stride
+  if ((size_t)width * fmt.pixel_stride > (size_t)stride) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: width*pixel_stride exceeds stride");
+  if (rows > 0x7fffffffu) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: too many rows");
+  BIND_DEVICE(ctx);
+  const size_t bytes = rows * (size_t)stride;
+  int rc = ensure_stage(ctx, 0, bytes);
+  if (rc) return rc;
+  uint8_t *d = (uint8_t *)ctx->d_stage[0];
+  rc = check_hip(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D frame)");
+  if (rc) return rc;
+  rc = launch_hsvfilter(ctx, d, 1, bytes, width, (int)rows, stride, fmt, *settings);
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H frame)");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvfilter: stream synchronize");
+}
+
+/* ------------------------------------------------------------------ hsvdetector */
+
+static bool detect_out_fmt(int fmt, int *alpha_first, int *bgr) {
+  switch (fmt) {
+    case MI355_FMT_RGBA: *alpha_first = 0; *bgr = 0; return true;
+    case MI355_FMT_ARGB: *alpha_first = 1; *bgr = 0; return true;
+    case MI355_FMT_BGRA: *alpha_first = 0; *bgr = 1; return true;
+    case MI355_FMT_ABGR: *alpha_first = 1; *bgr = 1; return true;
+    default: return false;
+  }
+}
+static bool detect_in_fmt(int fmt, PixFmt *p) {
+  // hsvdetector/imp.rs:78-87: Rgbx, Xrgb, Bgrx, Xbgr, Rgb, Bgr
+  switch (fmt) {
+    case MI355_FMT_RGBX: case MI355_FMT_XRGB: case MI355_FMT_BGRX: case MI355_FMT_XBGR:
+    case MI355_FMT_RGB: case MI355_FMT_BGR: return pixfmt_of(fmt, p);
+    default: return false;
+  }
+}
+
+int mi355_hsvdetect_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, int src_format,
+                                  uint8_t *d_dst, size_t dst_pitch, int dst_stride, int dst_format, int n_frames,
+                                  int width, int height, const mi355_hsvdetect_settings *settings) {
+  REQUIRE_CTX(ctx);
+  PixFmt sfmt;
+  int af = 0, bgr = 0;
+  if (!settings || !detect_in_fmt(src_format, &sfmt) || !detect_out_fmt(dst_format, &af, &bgr))
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: bad settings/format");
+  if (n_frames < 0 || width < 0 || height < 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: negative size");
+  if (n_frames == 0 || width == 0 || height == 0) return MI355_OK;
+  if (!d_src || !d_dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: null data");
+  if ((size_t)src_stride < (size_t)width * sfmt.pixel_stride || (size_t)dst_stride < (size_t)width * 4)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: line bytes exceed stride");
+  BIND_DEVICE(ctx);
+  return launch_hsvdetect(ctx, d_src, src_pitch, src_stride, sfmt, d_dst, dst_pitch, dst_stride, af, bgr, n_frames, width, height, *settings);
+}
+
+int mi355_hsvdetect_frame(mi355_ctx *ctx, const uint8_t *src, size_t src_len, int src_stride, int src_format, uint8_t *dst,
+                          size_t dst_len, int dst_stride, int dst_format, int width, const mi355_hsvdetect_settings *settings) {
+  REQUIRE_CTX(ctx);
+  PixFmt sfmt;
+  int af = 0, bgr = 0;
+  if (!settings || !detect_in_fmt(src_format, &sfmt) || !detect_out_fmt(dst_format, &af, &bgr))
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: bad settings/format");
+  if (width < 0 || src_stride <= 0 || dst_stride <= 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: bad width/stride");
+  const size_t rows_in = src_len / (size_t)src_stride, rows_out = dst_len / (size_t)dst_stride;
+  // assert_eq!(out_data.len() / out_stride, in_data.len() / in_stride) (hsvdetector/imp.rs:123)
+  if (rows_in != rows_out) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: input/output row count mismatch");
+  if (src_len % (size_t)sfmt.pixel_stride != 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: plane length not a multiple of pixel stride");
+  if ((size_t)width * sfmt.pixel_stride > (size_t)src_stride || (size_t)width * 4 > (size_t)dst_stride)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: line bytes exceed stride");
+  if (rows_in == 0 || width == 0) return MI355_OK;
+  if (!src || !dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: null data");
+  BIND_DEVICE(ctx);
+  const size_t sb = rows_in * (size_t)src_stride, db = rows_out * (size_t)dst_stride;
+  int rc = ensure_stage(ctx, 0, sb);
+  if (rc) return rc;
+  rc = ensure_stage(ctx, 1, db);
+  if (rc) return rc;
+  uint8_t *ds = (uint8_t *)ctx->d_stage[0], *dd = (uint8_t *)ctx->d_stage[1];
+  rc = check_hip(ctx, hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D src)");
+  if (rc) return rc;
+  // only out_line[..width*4] is written by the reference: bring the rest of dst over unchanged
+  rc = check_hip(ctx, hipMemcpyAsync(dd, dst, db, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D dst)");
+  if (rc) return rc;
+  rc = launch_hsvdetect(ctx, ds, sb, src_stride, sfmt, dd, db, dst_stride, af, bgr, 1, width, (int)rows_in, *settings);
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H dst)");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvdetector: stream synchronize");
+}
+
+/* ------------------------------------------------------------------ colorlut */
+
+int mi355_colorlut_load(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float domain_scale[3],
+                        const float domain_offset[3]) {
+  REQUIRE_CTX(ctx);
+  if (!table || !domain_scale || !domain_offset) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: null LUT data");
+  // validate_lut_size (parser.rs:305-318, limits :12-16)
+  if (is3d ? (size < 2 || size > 256) : (size < 2 || size > 65536))
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: LUT size out of range");
+  BIND_DEVICE(ctx);
+  int rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "colorlut: stream synchronize");
+  if (rc) return rc;
+  return lut_upload(ctx, is3d ? 1 : 0, size, table, domain_scale, domain_offset);
+}
+
+int mi355_colorlut_unload(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  lut_release(ctx);
+  return MI355_OK;
+}
+
+static int colorlut_bpp(int format) {
+  if (format == MI355_FMT_RGBA) return 4;
+  if (format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) return 8;
+  return 0;
+}
+
+int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                                 size_t dst_pitch, int dst_stride, int n_frames, int width, int height, int format) {
+  REQUIRE_CTX(ctx);
+  const int bpp = colorlut_bpp(format);
+  if (!bpp) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: format must be RGBA, RGBA64_LE or RGBA64_BE");
+  if (!ctx->lut.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (n_frames < 0 || width < 0 || height < 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: negative size");
+  if (n_frames == 0 || width == 0 || height == 0) return MI355_OK;
+  if (!d_src || !d_dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: null data");
+  if ((size_t)src_stride < (size_t)width * bpp || (size_t)dst_stride < (size_t)width * bpp)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: stride smaller than row bytes");
+  BIND_DEVICE(ctx);
+  return launch_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
+}
+
+int mi355_colorlut_frame(mi355_ctx *ctx, const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width,
+                         int height, int format) {
+  REQUIRE_CTX(ctx);
+  const int bpp = colorlut_bpp(format);
+  if (!bpp) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: format must be RGBA, RGBA64_LE or RGBA64_BE");
+  if (!ctx->lut.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (width < 0 || height < 0 || src_stride <= 0 || dst_stride <= 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: bad size/stride");
+  if (width == 0 || height == 0) return MI355_OK;
+  if (!src || !dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: null data");
+  // RGBA64 rows are addressed in u16 units: plane_stride / 2 (imp.rs:358-359)
+  const size_t s_stride = bpp == 8 ? (size_t)(src_stride / 2) * 2 : (size_t)src_stride;
+  const size_t d_stride = bpp == 8 ? (size_t)(dst_stride / 2) * 2 : (size_t)dst_stride;
+  const size_t row_bytes = (size_t)width * bpp;
+  if (row_bytes > s_stride || row_bytes > d_stride) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: row bytes exceed stride");
+  BIND_DEVICE(ctx);
+  // Stage both planes tightly packed on the device (pitch = row_bytes): only the `width` pixels of
+  // each row are read and written, exactly what the reference touches.
+  const size_t packed = row_bytes * (size_t)height;
+  int rc = ensure_stage(ctx, 0, packed);
+  if (rc) return rc;
+  rc = ensure_stage(ctx, 1, packed);
+  if (rc) return rc;
+  uint8_t *ds = (uint8_t *)ctx->d_stage[0], *dd = (uint8_t *)ctx->d_stage[1];
+  rc = check_hip(ctx, hipMemcpy2DAsync(ds, row_bytes, src, s_stride, row_bytes, (size_t)height, hipMemcpyHostToDevice, ctx->stream),
+                 "hipMemcpy2DAsync(H2D src)");
+  if (rc) return rc;
+  rc = launch_colorlut(ctx, ds, packed, (int)row_bytes, dd, packed, (int)row_bytes, 1, width, height, format);
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpy2DAsync(dst, d_stride, dd, row_bytes, row_bytes, (size_t)height, hipMemcpyDeviceToHost, ctx->stream),
+                 "hipMemcpy2DAsync(D2H dst)");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "colorlut: stream synchronize");
+}
+
+/* ------------------------------------------------------------------ rsaudioecho */
+
+int mi355_echo_setup(mi355_ctx *ctx, size_t ring_len) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
+  ctx->echo = EchoDevice{};
+  int rc = check_hip(ctx, hipMalloc((void **)&ctx->echo.d_ring, (ring_len ? ring_len : 1) * sizeof(double)), "hipMalloc(echo ring)");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemset(ctx->echo.d_ring, 0, (ring_len ? ring_len : 1) * sizeof(double)), "hipMemset(echo ring)");
+  if (rc) return rc;
+  ctx->echo.ring_len = ring_len;
+  ctx->echo.pos = 0;
+  ctx->echo.configured = true;
+  return MI355_OK;
+}
+
+int mi355_echo_reset(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
+  ctx->echo = EchoDevice{};
+  return MI355_OK;
+}
+
+int mi355_echo_process_device(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay_samples, double intensity,
+                              double feedback) {
+  REQUIRE_CTX(ctx);
+  if (n && !d_data) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: null data");
+  BIND_DEVICE(ctx);
+  return launch_echo(ctx, d_data, n, is_f64, delay_samples, intensity, feedback);
+}
+
+static int echo_host(mi355_ctx *ctx, void *data, size_t n, int is_f64, size_t delay, double intensity, double feedback) {
+  REQUIRE_CTX(ctx);
+  if (n && !data) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: null data");
+  if (!ctx->echo.configured) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "rsaudioecho: not negotiated (setup not called)");
+  BIND_DEVICE(ctx);
+  const size_t bytes = n * (is_f64 ? sizeof(double) : sizeof(float));
+  int rc = ensure_stage(ctx, 0, bytes);
+  if (rc) return rc;
+  if (n) {
+    rc = check_hip(ctx, hipMemcpyAsync(ctx->d_stage[0], data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D audio)");
+    if (rc) return rc;
+  }
+  rc = launch_echo(ctx, ctx->d_stage[0], n, is_f64, delay, intensity, feedback);
+  if (rc) return rc;
+  if (n) {
+    rc = check_hip(ctx, hipMemcpyAsync(data, ctx->d_stage[0], bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H audio)");
+    if (rc) return rc;
+  }
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "rsaudioecho: stream synchronize");
+}
+
+int mi355_echo_process_f32(mi355_ctx *ctx, float *data, size_t n, size_t delay_samples, double intensity, double feedback) {
+  return echo_host(ctx, data, n, 0, delay_samples, intensity, feedback);
+}
+int mi355_echo_process_f64(mi355_ctx *ctx, double *data, size_t n, size_t delay_samples, double intensity, double feedback) {
+  return echo_host(ctx, data, n, 1, delay_samples, intensity, feedback);
+}
+
+int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size_t *pos_out) {
+  REQUIRE_CTX(ctx);
+  if (!ctx->echo.configured) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "rsaudioecho: not negotiated (setup not called)");
+  BIND_DEVICE(ctx);
+  if (pos_out) *pos_out = ctx->echo.pos;
+  if (ring_out) {
+    const size_t n = ring_len < ctx->echo.ring_len ? ring_len : ctx->echo.ring_len;
+    int rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (rc) return rc;
+    if (n) return check_hip(ctx, hipMemcpy(ring_out, ctx->echo.d_ring, n * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(echo ring)");
+  }
+  return MI355_OK;
+}
+
+/* ------------------------------------------------------------------ measurement helpers */
+
+int mi355_time_hsvfilter_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width, int height,
+                                int stride, int format, const mi355_hsv_settings *settings, int iters, float *ms_per_launch) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return time_launches(ctx, iters, ms_per_launch, [&]() {
+    return mi355_hsvfilter_frames_device(ctx, d_data, n_frames, frame_pitch, width, height, stride, format, settings);
+  });
+}
+
+int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                               size_t dst_pitch, int dst_stride, int n_frames, int width, int height, int format, int iters,
+                               float *ms_per_launch) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return time_launches(ctx, iters, ms_per_launch, [&]() {
+    return mi355_colorlut_frames_device(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
+  });
+}
+
+}  // extern "C"

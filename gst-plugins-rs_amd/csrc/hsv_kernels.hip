@@ -1,0 +1,318 @@
+// hsv_kernels.hip — gfx950 kernels for hsvfilter / hsvdetector.
+//
+// Reference loops replaced (gst-plugins-rs tree):
+//   video/hsv/src/hsvutils.rs:44-128    from_rgb / from_bgr
+//   video/hsv/src/hsvutils.rs:132-198   to_rgb / to_bgr
+//   video/hsv/src/hsvfilter/imp.rs:96-118     per-pixel filter body
+//   video/hsv/src/hsvdetector/imp.rs:126-156  per-pixel detector body
+//
+// Two arithmetic variants per kernel:
+//   GENERIC — literal transliteration (IEEE `/`, fmodf, every branch incl. NaN/inf settings).
+//   FAST    — strength-reduced but bit-identical for `hue_shift == 0 || 1e-30 <= |hue_shift| <= 360`
+//             (finite): exact constant divisions (exact_math.hpp), rcp+residual quotients,
+//             bounded-range fmod, sextant select as one LDS lookup + v_perm_b32.
+//             Facts it relies on, all checked exhaustively over the 2^24 colours by the tests:
+//             hue in [0,360) before the shift (so `hue % 360` is the identity), saturation and
+//             value already inside [0,1], results of to_rgb inside [0,255.0001].
+// The pixel filters are pure streaming kernels: 4 B read + 4 B written per pixel, HBM-bound
+// once the VALU work per pixel is below ~80 instructions.
+#include "internal.hpp"
+#include "exact_math.hpp"
+
+namespace mi355 {
+
+struct HsvK {
+  float hue_shift, sat_mul, sat_off, val_mul, val_off;
+};
+
+// ---------------------------------------------------------------- RGB -> HSV
+
+// r8,g8,b8: integer-valued floats 0..255.
+template <bool FAST>
+__device__ __forceinline__ void hsv_from_rgb(float r8, float g8, float b8, float &hue, float &sat,
+                                             float &val) {
+  if constexpr (FAST) {
+    const float r = div255_u8(r8), g = div255_u8(g8), b = div255_u8(b8);
+    // x/255 is monotone, so max of the quotients == quotient of the max (hsvutils.rs:49-59).
+    const float value = fmaxf(fmaxf(r, g), b);
+    const float minv = fminf(fminf(r, g), b);
+    const float chroma = value - minv;
+    // |value - c| < 1e-5  <=>  c == value: distinct u8/255 quotients differ by > 3.9e-3.
+    const bool is_r = (r == value);
+    const bool is_g = (g == value);
+    const float na = is_r ? g : (is_g ? b : r);
+    const float nb = is_r ? b : (is_g ? r : g);
+    const float add = is_r ? 0.0f : (is_g ? 2.0f : 4.0f);
+    // chroma == 0 => all channels equal => numerator 0 => quotient 0 => hue 0 (hsvutils.rs:61-62).
+    const float q = div_rcp_refine(na - nb, fmaxf(chroma, 1e-30f));
+    float h = 60.0f * (add + q);
+    h = (h < 0.0f) ? h + 360.0f : h;
+    hue = h;  // h in [0,360): `% 360.0` is the identity
+    // value == 0 => chroma == 0 => 0 (hsvutils.rs:77); quotient already within [0,1].
+    sat = div_rcp_refine(chroma, fmaxf(value, 1e-30f));
+    val = value;
+  } else {
+    const float r = r8 / 255.0f, g = g8 / 255.0f, b = b8 / 255.0f;
+    const float value = fmaxf(fmaxf(r8, g8), b8) / 255.0f;
+    const float chroma = value - (fminf(fminf(r8, g8), b8) / 255.0f);
+    const float EPS = 0.00001f;
+    float h;
+    if (chroma == 0.0f) {
+      h = 0.0f;
+    } else if (fabsf(value - r) < EPS) {
+      h = 60.0f * ((g - b) / chroma);
+    } else if (fabsf(value - g) < EPS) {
+      h = 60.0f * (2.0f + ((b - r) / chroma));
+    } else if (fabsf(value - b) < EPS) {
+      h = 60.0f * (4.0f + ((r - g) / chroma));
+    } else {
+      h = 0.0f;
+    }
+    if (h < 0.0f) h += 360.0f;
+    const float s = (value == 0.0f) ? 0.0f : chroma / value;
+    hue = fmodf(h, 360.0f);
+    sat = rs_clamp(s, 0.0f, 1.0f);
+    val = rs_clamp(value, 0.0f, 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------- HSV -> RGB (generic)
+
+__device__ __forceinline__ void hsv_to_rgb_generic(float h, float s, float v, uint32_t &r, uint32_t &g,
+                                                   uint32_t &b) {
+  const float c = v * s;
+  const float hp = h / 60.0f;
+  const float x = c * (1.0f - fabsf(fmodf(hp, 2.0f) - 1.0f));
+  float rp, gp, bp;
+  if (hp < 0.0f) { rp = 0.0f; gp = 0.0f; bp = 0.0f; }
+  else if (hp <= 1.0f) { rp = c; gp = x; bp = 0.0f; }
+  else if (hp <= 2.0f) { rp = x; gp = c; bp = 0.0f; }
+  else if (hp <= 3.0f) { rp = 0.0f; gp = c; bp = x; }
+  else if (hp <= 4.0f) { rp = 0.0f; gp = x; bp = c; }
+  else if (hp <= 5.0f) { rp = x; gp = 0.0f; bp = c; }
+  else if (hp <= 6.0f) { rp = c; gp = 0.0f; bp = x; }
+  else { rp = 0.0f; gp = 0.0f; bp = 0.0f; }
+  const float m = v - c;
+  r = rs_as_u8(rs_clamp((rp + m) * 255.0f, 0.0f, 255.0f));
+  g = rs_as_u8(rs_clamp((gp + m) * 255.0f, 0.0f, 255.0f));
+  b = rs_as_u8(rs_clamp((bp + m) * 255.0f, 0.0f, 255.0f));
+}
+
+// ---------------------------------------------------------------- sextant selector table
+// FAST to_rgb produces three byte candidates A=(c+m), B=(x+m), C=(m) packed as bytes 0,1,2 of one
+// dword; the sextant decides which candidate lands in which channel (hsvutils.rs:138-154):
+//   k=ceil(h/60): 0,1 -> (R,G,B)=(A,B,C)  2 -> (B,A,C)  3 -> (C,A,B)  4 -> (C,B,A)  5 -> (B,C,A)  6 -> (A,C,B)
+// v_perm_b32(orig_pixel, packedABC, sel): selector byte 0..3 picks a byte of packedABC, 4..7 a byte
+// of the original pixel (the untouched x/alpha byte).
+__host__ __device__ constexpr uint32_t hsv_sel_entry(int k, int rpos, int gpos, int bpos, int npos) {
+  const int codes[7][3] = {{0, 1, 2}, {0, 1, 2}, {1, 0, 2}, {2, 0, 1}, {2, 1, 0}, {1, 2, 0}, {0, 2, 1}};
+  uint32_t sel = 0;
+  sel |= (uint32_t)codes[k][0] << (8 * rpos);
+  sel |= (uint32_t)codes[k][1] << (8 * gpos);
+  sel |= (uint32_t)codes[k][2] << (8 * bpos);
+  sel |= (uint32_t)(4 + npos) << (8 * npos);
+  return sel;
+}
+
+// One pixel, 4-byte formats. RPOS/GPOS/BPOS = byte index of each channel inside the little-endian
+// dword, NPOS = the untouched byte.
+template <bool FAST, int RPOS, int GPOS, int BPOS, int NPOS>
+__device__ __forceinline__ uint32_t hsvfilter_px(uint32_t p, const HsvK &k, const uint32_t *sel_tab) {
+  const float r8 = (float)((p >> (8 * RPOS)) & 0xffu);
+  const float g8 = (float)((p >> (8 * GPOS)) & 0xffu);
+  const float b8 = (float)((p >> (8 * BPOS)) & 0xffu);
+  float h, s, v;
+  hsv_from_rgb<FAST>(r8, g8, b8, h, s, v);
+  if constexpr (FAST) {
+    // (h + shift) % 360 with h in [0,360), |shift| <= 360: one conditional exact subtraction
+    // (Sterbenz for t in [360,720]); t == -360 maps to +0 instead of fmod's -0 (indistinguishable
+    // downstream). Then the reference's `if h < 0 { h += 360 }` (hsvfilter/imp.rs:102-105).
+    float t = h + k.hue_shift;
+    t = (t >= 360.0f) ? t - 360.0f : t;
+    t = (t < 0.0f) ? t + 360.0f : t;
+    // crate Clamp trait = max-then-min, NaN -> 0 (hsvfilter/imp.rs:106-115, hsvutils.rs:23-38)
+    s = fminf(fmaxf(k.sat_mul * s + k.sat_off, 0.0f), 1.0f);
+    v = fminf(fmaxf(k.val_mul * v + k.val_off, 0.0f), 1.0f);
+    // to_rgb / to_bgr (hsvutils.rs:132-198), t in [0,360], s,v in [0,1]
+    const float c = v * s;
+    const float hp = div60_hue(t);
+    // hp % 2 == 2*fract(hp/2) exactly for hp >= 0; (hp % 2) - 1 rounds once in the fma.
+    const float w = __builtin_fmaf(2.0f, __builtin_amdgcn_fractf(hp * 0.5f), -1.0f);
+    const float x = c * (1.0f - fabsf(w));
+    const float m = v - c;
+    const uint32_t a8 = (uint32_t)((c + m) * 255.0f);  // values in [0,255.0001]: trunc == `as u8`
+    const uint32_t b8o = (uint32_t)((x + m) * 255.0f);
+    const uint32_t c8 = (uint32_t)(m * 255.0f);
+    const uint32_t packed = a8 | (b8o << 8) | (c8 << 16);
+    const uint32_t sel = sel_tab[(uint32_t)ceilf(hp)];
+    return __builtin_amdgcn_perm(p, packed, sel);
+  } else {
+    h = fmodf(h + k.hue_shift, 360.0f);
+    if (h < 0.0f) h += 360.0f;
+    s = fminf(fmaxf(k.sat_mul * s + k.sat_off, 0.0f), 1.0f);
+    v = fminf(fmaxf(k.val_mul * v + k.val_off, 0.0f), 1.0f);
+    uint32_t r, g, b;
+    hsv_to_rgb_generic(h, s, v, r, g, b);
+    const uint32_t keep = p & (0xffu << (8 * NPOS));
+    return keep | (r << (8 * RPOS)) | (g << (8 * GPOS)) | (b << (8 * BPOS));
+  }
+}
+
+// ---------------------------------------------------------------- hsvfilter kernels
+
+// Flat streaming kernel for 4-byte formats on contiguous storage (stride == width*4 and frames
+// back to back): each lane owns 16 B (4 pixels) per iteration -> global_load/store_dwordx4.
+template <bool FAST, int FIRST, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__ data, size_t n_vec,
+                                                             HsvK k) {
+  constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
+  constexpr int NPOS = FIRST == 0 ? 3 : 0;
+  __shared__ uint32_t sel_tab[8];
+  if (threadIdx.x < 7) sel_tab[threadIdx.x] = hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    uint4 p = data[i];
+    p.x = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.x, k, sel_tab);
+    p.y = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.y, k, sel_tab);
+    p.z = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.z, k, sel_tab);
+    p.w = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.w, k, sel_tab);
+    data[i] = p;
+  }
+}
+
+// General kernel: any stride / pixel stride (3 or 4) / triple offset, one pixel per lane, byte
+// accesses. Only `line[..width*pixel_stride]` of each row is touched (hsvfilter/imp.rs:94-97).
+template <bool FAST>
+__global__ __launch_bounds__(256) void hsvfilter_rows_kernel(uint8_t *__restrict__ data, int n_frames,
+                                                             size_t frame_pitch, int width, int height,
+                                                             int stride, int pixel_stride, int first,
+                                                             int bgr, HsvK k) {
+  __shared__ uint32_t sel_tab[8];
+  if (threadIdx.x < 7) sel_tab[threadIdx.x] = hsv_sel_entry(threadIdx.x, 0, 1, 2, 3);
+  __syncthreads();
+  const size_t per_frame = (size_t)width * (size_t)height;
+  const size_t total = per_frame * (size_t)n_frames;
+  const size_t gstride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const size_t f = i / per_frame;
+    const size_t r = i - f * per_frame;
+    const size_t row = r / (size_t)width;
+    const size_t col = r - row * (size_t)width;
+    uint8_t *px = data + f * frame_pitch + row * (size_t)stride + col * (size_t)pixel_stride + first;
+    const uint32_t c0 = px[0], c1 = px[1], c2 = px[2];
+    const uint32_t p = bgr ? (c2 | (c1 << 8) | (c0 << 16)) : (c0 | (c1 << 8) | (c2 << 16));
+    const uint32_t o = hsvfilter_px<FAST, 0, 1, 2, 3>(p, k, sel_tab);
+    const uint8_t orr = (uint8_t)(o & 0xff), og = (uint8_t)((o >> 8) & 0xff), ob = (uint8_t)((o >> 16) & 0xff);
+    px[0] = bgr ? ob : orr;
+    px[1] = og;
+    px[2] = bgr ? orr : ob;
+  }
+}
+
+static bool hsv_fast_ok(const mi355_hsv_settings &s) {
+  const float a = fabsf(s.hue_shift);
+  // NaN fails every comparison -> generic path.
+  return (s.hue_shift == 0.0f) || (a >= 1e-30f && a <= 360.0f);
+}
+
+static int grid_for(mi355_ctx *ctx, size_t work_items, int block, int blocks_per_cu) {
+  size_t blocks = (work_items + (size_t)block - 1) / (size_t)block;
+  size_t cap = (size_t)ctx->n_cu * (size_t)blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <bool FAST>
+static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, int first, int bgr, int grid) {
+  dim3 g(grid), b(256);
+  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 0, false>), g, b, 0, ctx->stream, d, n_vec, k);
+  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 0, true>), g, b, 0, ctx->stream, d, n_vec, k);
+  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 1, false>), g, b, 0, ctx->stream, d, n_vec, k);
+  else hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
+}
+
+int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
+                     int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s) {
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;  // nothing to do
+  const HsvK k{s.hue_shift, s.saturation_mul, s.saturation_off, s.value_mul, s.value_off};
+  const bool fast = hsv_fast_ok(s) && !ctx->force_generic;
+  const size_t row_bytes = (size_t)width * (size_t)fmt.pixel_stride;
+  const bool contiguous = fmt.pixel_stride == 4 && (size_t)stride == row_bytes &&
+                          (n_frames == 1 || frame_pitch == row_bytes * (size_t)height);
+  const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+  if (contiguous && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
+    const size_t n_vec = total_bytes / 16;
+    const int grid = grid_for(ctx, n_vec, 256, 8);
+    if (fast) launch_flat<true>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
+    else launch_flat<false>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
+  } else {
+    const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
+    const int grid = grid_for(ctx, total, 256, 8);
+    if (fast)
+      hipLaunchKernelGGL((hsvfilter_rows_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_data, n_frames,
+                         frame_pitch, width, height, stride, fmt.pixel_stride, fmt.first, fmt.bgr, k);
+    else
+      hipLaunchKernelGGL((hsvfilter_rows_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, d_data, n_frames,
+                         frame_pitch, width, height, stride, fmt.pixel_stride, fmt.first, fmt.bgr, k);
+  }
+  return check_hip(ctx, hipGetLastError(), "hsvfilter kernel launch");
+}
+
+// ---------------------------------------------------------------- hsvdetector
+
+struct HsvDetK {
+  float hue_ref, hue_var, sat_ref, sat_var, val_ref, val_var;
+};
+
+// One pixel per lane; input 3 or 4 bytes/pixel, output always 4 (hsvdetector/imp.rs:118-156).
+// Arithmetic is the GENERIC conversion (IEEE ops) — the detector is a "next" row.
+__global__ __launch_bounds__(256) void hsvdetect_rows_kernel(const uint8_t *__restrict__ src, size_t src_pitch,
+                                                             int src_stride, int in_pixel_stride, int in_first,
+                                                             int in_bgr, uint8_t *__restrict__ dst, size_t dst_pitch,
+                                                             int dst_stride, int out_alpha_first, int out_bgr,
+                                                             int n_frames, int width, int height, HsvDetK k) {
+  const size_t per_frame = (size_t)width * (size_t)height;
+  const size_t total = per_frame * (size_t)n_frames;
+  const size_t gstride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const size_t f = i / per_frame;
+    const size_t r = i - f * per_frame;
+    const size_t row = r / (size_t)width;
+    const size_t col = r - row * (size_t)width;
+    const uint8_t *ip = src + f * src_pitch + row * (size_t)src_stride + col * (size_t)in_pixel_stride + in_first;
+    uint8_t *op = dst + f * dst_pitch + row * (size_t)dst_stride + col * 4;
+    const uint32_t c0 = ip[0], c1 = ip[1], c2 = ip[2];
+    const uint32_t r8 = in_bgr ? c2 : c0, g8 = c1, b8 = in_bgr ? c0 : c2;
+    float h, s, v;
+    hsv_from_rgb<false>((float)r8, (float)g8, (float)b8, h, s, v);
+    const float ref_hue_offset = 180.0f - k.hue_ref;
+    float sh = h + ref_hue_offset;
+    if (sh < 0.0f) sh += 360.0f;
+    sh = fmodf(sh, 360.0f);
+    const bool hit = fabsf(sh - 180.0f) <= k.hue_var && fabsf(s - k.sat_ref) <= k.sat_var &&
+                     fabsf(v - k.val_ref) <= k.val_var;
+    const uint8_t alpha = hit ? 255 : 0;
+    uint8_t *c = op + (out_alpha_first ? 1 : 0);
+    if (out_bgr) { c[0] = (uint8_t)b8; c[1] = (uint8_t)g8; c[2] = (uint8_t)r8; }
+    else { c[0] = (uint8_t)r8; c[1] = (uint8_t)g8; c[2] = (uint8_t)b8; }
+    op[out_alpha_first ? 0 : 3] = alpha;
+  }
+}
+
+int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                     const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
+                     int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,
+                     const mi355_hsvdetect_settings &s) {
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
+  const HsvDetK k{s.hue_ref, s.hue_var, s.saturation_ref, s.saturation_var, s.value_ref, s.value_var};
+  const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
+  const int grid = grid_for(ctx, total, 256, 8);
+  hipLaunchKernelGGL(hsvdetect_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_src, src_pitch, src_stride,
+                     sfmt.pixel_stride, sfmt.first, sfmt.bgr, d_dst, dst_pitch, dst_stride, dst_alpha_first, dst_bgr,
+                     n_frames, width, height, k);
+  return check_hip(ctx, hipGetLastError(), "hsvdetect kernel launch");
+}
+
+}  // namespace mi355

@@ -1,0 +1,78 @@
+// internal.hpp — shared declarations between the C-ABI layer (ctx.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include "../../include/mi355fx.h"
+
+namespace mi355 {
+
+// Device-side copy of a loaded CubeLut (video/colorlut/src/parser.rs:69-75).
+struct LutDevice {
+  int is3d = 0;
+  int size = 0;
+  float scale[3] = {1, 1, 1};
+  float offset[3] = {0, 0, 0};
+  float *d_cells = nullptr;   // 3D: [size^3][4] as the reference stores it; 1D: r|g|b planes
+  float *d_planar = nullptr;  // 3D only: three channel planes padded for the LDS kernel (see colorlut_kernels.hip)
+  size_t planar_plane_floats = 0;  // floats per padded plane
+  bool lds_ok = false;        // LDS fast path legal for this LUT (fits, finite, bounded)
+  bool unit_domain = false;   // scale == 1 && offset == 0 on all channels
+  bool loaded = false;
+};
+
+struct EchoDevice {
+  double *d_ring = nullptr;
+  size_t ring_len = 0;
+  size_t pos = 0;
+  bool configured = false;
+};
+
+}  // namespace mi355
+
+struct mi355_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  // staging for the host entry points
+  void *d_stage[2] = {nullptr, nullptr};
+  size_t d_stage_bytes[2] = {0, 0};
+  mi355::LutDevice lut;
+  mi355::EchoDevice echo;
+  bool force_generic = false;
+  std::string last_error;
+};
+
+namespace mi355 {
+
+// pixel layout of a packed-RGB format
+struct PixFmt {
+  int pixel_stride;  // bytes per pixel: 3, 4 (8 for RGBA64)
+  int first;         // byte offset of the colour triple
+  int bgr;           // triple stored B,G,R
+  int has_alpha;     // 4th byte is alpha (vs padding) — informational
+};
+bool pixfmt_of(int format, PixFmt *out);
+
+int set_error(mi355_ctx *ctx, int status, const std::string &msg);
+int check_hip(mi355_ctx *ctx, hipError_t e, const char *what);
+
+// kernel launchers (asynchronous on ctx->stream)
+int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
+                     int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s);
+int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                     const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
+                     int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,
+                     const mi355_hsvdetect_settings &s);
+int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                    uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames, int width,
+                    int height, int format);
+int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float scale[3],
+               const float offset[3]);
+void lut_release(mi355_ctx *ctx);
+int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay, double intensity,
+                double feedback);
+
+}  // namespace mi355

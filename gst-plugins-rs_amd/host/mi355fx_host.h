@@ -1,0 +1,30 @@
+/* mi355fx_host.h — host-side mirror (C++ implementation, C linkage) of the parts of the reference
+ * elements that stay on the CPU: the .cube reader today; the element objects (properties, caps,
+ * start/stop, transform vfuncs) in host/elements.*.
+ * Reference: video/colorlut/src/parser.rs (CubeLut::parse / parse_file). */
+#ifndef MI355FX_HOST_H
+#define MI355FX_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi355h_cube mi355h_cube;
+
+/* CubeLut::parse (parser.rs:110-281). NULL on error; `err` receives the CubeParseError text. */
+mi355h_cube *mi355h_cube_parse(const char *text, size_t len, char *err, size_t errlen);
+/* CubeLut::parse_file (parser.rs:105-108). */
+mi355h_cube *mi355h_cube_parse_file(const char *path, char *err, size_t errlen);
+void mi355h_cube_free(mi355h_cube *c);
+int mi355h_cube_is3d(const mi355h_cube *c);
+size_t mi355h_cube_size(const mi355h_cube *c);
+/* 3D: Lut3D::as_flat() (size^3 x [r,g,b,1]); 1D: r|g|b planes. Layout == mi355_colorlut_load input. */
+const float *mi355h_cube_table(const mi355h_cube *c);
+size_t mi355h_cube_table_len(const mi355h_cube *c);
+void mi355h_cube_domain(const mi355h_cube *c, float scale[3], float offset[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

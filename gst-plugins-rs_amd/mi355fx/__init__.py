@@ -1,0 +1,236 @@
+"""mi355fx — ctypes binding of libmi355fx.so (the C ABI of include/mi355fx.h).
+
+This is plumbing for tests/, bench.py and __graft_entry__.py: it loads the in-tree shared library
+built by gst-plugins-rs_amd/Makefile and exposes its entry points 1:1. There is NO fallback: if the
+library is missing the import raises, and on a box without a gfx950 device Context() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "libmi355fx.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "mi355fx.h")
+
+# mi355_video_format
+FMT = {"RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
+       "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11}
+# (pixel_stride, first, bgr) per format — mirrors the match arms of video/hsv/src/hsvfilter/imp.rs:327-373
+FMT_LAYOUT = {"RGBx": (4, 0, 0), "RGBA": (4, 0, 0), "RGB": (3, 0, 0), "xRGB": (4, 1, 0), "ARGB": (4, 1, 0),
+              "BGRx": (4, 0, 1), "BGRA": (4, 0, 1), "BGR": (3, 0, 1), "xBGR": (4, 1, 1), "ABGR": (4, 1, 1)}
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_OOM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+FLAG_FORCE_GENERIC = 1
+
+
+class HsvSettings(C.Structure):
+    _fields_ = [("hue_shift", C.c_float), ("saturation_mul", C.c_float), ("saturation_off", C.c_float),
+                ("value_mul", C.c_float), ("value_off", C.c_float)]
+
+
+class HsvDetectSettings(C.Structure):
+    _fields_ = [("hue_ref", C.c_float), ("hue_var", C.c_float), ("saturation_ref", C.c_float),
+                ("saturation_var", C.c_float), ("value_ref", C.c_float), ("value_var", C.c_float)]
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("mi355fx status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmi355fx.so (built in-tree). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmi355fx.so not built: run `make -C %s` (or __graft_entry__.build())" % PKG_ROOT)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+    f32p = C.POINTER(C.c_float)
+    sig = {
+        "mi355_abi_version": (i, []),
+        "mi355_device_count": (i, []),
+        "mi355_ctx_create": (vp, [i, C.POINTER(i)]),
+        "mi355_ctx_destroy": (None, [vp]),
+        "mi355_ctx_last_error": (C.c_char_p, [vp]),
+        "mi355_status_string": (C.c_char_p, [i]),
+        "mi355_ctx_stream": (vp, [vp]),
+        "mi355_ctx_set_stream": (i, [vp, vp]),
+        "mi355_ctx_synchronize": (i, [vp]),
+        "mi355_ctx_set_flag": (i, [vp, i, i]),
+        "mi355_device_alloc": (vp, [vp, sz]),
+        "mi355_device_free": (i, [vp, vp]),
+        "mi355_memcpy_h2d": (i, [vp, vp, vp, sz]),
+        "mi355_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "mi355_hsvfilter_frame_ip": (i, [vp, u8p, sz, i, i, i, C.POINTER(HsvSettings)]),
+        "mi355_hsvfilter_frames_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings)]),
+        "mi355_hsvdetect_frame": (i, [vp, u8p, sz, i, i, u8p, sz, i, i, i, C.POINTER(HsvDetectSettings)]),
+        "mi355_hsvdetect_frames_device": (i, [vp, u8p, sz, i, i, u8p, sz, i, i, i, i, i, C.POINTER(HsvDetectSettings)]),
+        "mi355_colorlut_load": (i, [vp, i, sz, f32p, f32p, f32p]),
+        "mi355_colorlut_unload": (i, [vp]),
+        "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
+        "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
+        "mi355_echo_setup": (i, [vp, sz]),
+        "mi355_echo_reset": (i, [vp]),
+        "mi355_echo_process_f32": (i, [vp, vp, sz, sz, C.c_double, C.c_double]),
+        "mi355_echo_process_f64": (i, [vp, vp, sz, sz, C.c_double, C.c_double]),
+        "mi355_echo_process_device": (i, [vp, vp, sz, i, sz, C.c_double, C.c_double]),
+        "mi355_echo_get_state": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "mi355_time_hsvfilter_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
+        "mi355_time_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i, i, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled lazily by tests from the header
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a  # raw device pointer (int)
+
+
+class Context:
+    """One element instance's device context (mi355_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        st = C.c_int(0)
+        self.h = self.L.mi355_ctx_create(device, C.byref(st))
+        if not self.h:
+            raise Mi355Error(st.value, self.L.mi355_status_string(st.value).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi355_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise Mi355Error(rc, self.L.mi355_ctx_last_error(self.h).decode("utf-8", "replace"))
+
+    # ---- plumbing
+    @property
+    def stream(self):
+        return self.L.mi355_ctx_stream(self.h)
+
+    def set_stream(self, hip_stream):
+        self._ck(self.L.mi355_ctx_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        self._ck(self.L.mi355_ctx_synchronize(self.h))
+
+    def set_flag(self, flag, value):
+        self._ck(self.L.mi355_ctx_set_flag(self.h, flag, int(value)))
+
+    def alloc(self, nbytes):
+        p = self.L.mi355_device_alloc(self.h, nbytes)
+        if not p:
+            raise Mi355Error(ERR_OOM, self.L.mi355_ctx_last_error(self.h).decode())
+        return p
+
+    def free(self, dptr):
+        self._ck(self.L.mi355_device_free(self.h, dptr))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.L.mi355_memcpy_h2d(self.h, dptr, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags.c_contiguous
+        self._ck(self.L.mi355_memcpy_d2h(self.h, arr.ctypes.data, dptr, arr.nbytes))
+
+    # ---- hsvfilter
+    def hsvfilter_frame_ip(self, data, width, stride, fmt, settings, data_len=None):
+        s = HsvSettings(*[float(v) for v in settings])
+        n = data.nbytes if data_len is None else data_len
+        self._ck(self.L.mi355_hsvfilter_frame_ip(self.h, _ptr(data), n, width, stride, FMT[fmt], C.byref(s)))
+        return data
+
+    def hsvfilter_frames_device(self, dptr, n_frames, frame_pitch, width, height, stride, fmt, settings):
+        s = HsvSettings(*[float(v) for v in settings])
+        self._ck(self.L.mi355_hsvfilter_frames_device(self.h, dptr, n_frames, frame_pitch, width, height, stride, FMT[fmt], C.byref(s)))
+
+    def time_hsvfilter_device(self, dptr, n_frames, frame_pitch, width, height, stride, fmt, settings, iters):
+        s = HsvSettings(*[float(v) for v in settings])
+        ms = C.c_float(0)
+        self._ck(self.L.mi355_time_hsvfilter_device(self.h, dptr, n_frames, frame_pitch, width, height, stride, FMT[fmt], C.byref(s), iters, C.byref(ms)))
+        return ms.value
+
+    # ---- hsvdetector
+    def hsvdetect_frame(self, src, src_stride, src_fmt, dst, dst_stride, dst_fmt, width, settings):
+        s = HsvDetectSettings(*[float(v) for v in settings])
+        self._ck(self.L.mi355_hsvdetect_frame(self.h, _ptr(src), src.nbytes, src_stride, FMT[src_fmt], _ptr(dst), dst.nbytes,
+                                              dst_stride, FMT[dst_fmt], width, C.byref(s)))
+        return dst
+
+    # ---- colorlut
+    def colorlut_load(self, is3d, size, table, scale=(1.0, 1.0, 1.0), offset=(0.0, 0.0, 0.0)):
+        t = np.ascontiguousarray(table, dtype=np.float32).ravel()
+        assert t.size == (4 * size ** 3 if is3d else 3 * size), "table size mismatch"
+        sc = np.ascontiguousarray(scale, dtype=np.float32)
+        of = np.ascontiguousarray(offset, dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self._ck(self.L.mi355_colorlut_load(self.h, int(is3d), size, t.ctypes.data_as(fp), sc.ctypes.data_as(fp), of.ctypes.data_as(fp)))
+
+    def colorlut_unload(self):
+        self._ck(self.L.mi355_colorlut_unload(self.h))
+
+    def colorlut_frame(self, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
+        self._ck(self.L.mi355_colorlut_frame(self.h, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt]))
+        return dst
+
+    def colorlut_frames_device(self, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, fmt="RGBA"):
+        self._ck(self.L.mi355_colorlut_frames_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, FMT[fmt]))
+
+    def time_colorlut_device(self, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, fmt, iters):
+        ms = C.c_float(0)
+        self._ck(self.L.mi355_time_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, FMT[fmt], iters, C.byref(ms)))
+        return ms.value
+
+    # ---- rsaudioecho
+    def echo_setup(self, ring_len):
+        self._ck(self.L.mi355_echo_setup(self.h, ring_len))
+
+    def echo_reset(self):
+        self._ck(self.L.mi355_echo_reset(self.h))
+
+    def echo_process(self, data, delay_samples, intensity, feedback):
+        fn = self.L.mi355_echo_process_f64 if data.dtype == np.float64 else self.L.mi355_echo_process_f32
+        assert data.dtype in (np.float32, np.float64) and data.flags.c_contiguous
+        self._ck(fn(self.h, data.ctypes.data, data.size, delay_samples, float(intensity), float(feedback)))
+        return data
+
+    def echo_state(self, ring_len):
+        ring = np.zeros(max(ring_len, 1), np.float64)
+        pos = C.c_size_t(0)
+        self._ck(self.L.mi355_echo_get_state(self.h, ring.ctypes.data, ring_len, C.byref(pos)))
+        return ring, pos.value

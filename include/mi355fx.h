@@ -1,0 +1,180 @@
+/* mi355fx.h — C ABI of the MI355X (gfx950) kernel library behind gst-plugins-rs' per-buffer
+ * DSP elements (hsvfilter, hsvdetector, colorlut, rsaudioecho).
+ *
+ * This header is the drop-in boundary: each entry point replaces exactly one inner loop of the
+ * reference (file:line cited per function, relative to the gst-plugins-rs tree) and takes what
+ * that loop takes — plane pointer, stride, width/height, format, the settings snapshot.
+ * The reference element keeps its GObject/BaseTransform surface and calls these through
+ * `extern "C"` FFI (binding shown in INTEGRATION.md). Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - Every function returns MI355_OK (0) or a negative mi355_status; mi355_ctx_last_error()
+ *     gives a human-readable message for the last failure on that context. The element maps any
+ *     non-zero status to GST_FLOW_ERROR (transform vfuncs) or an ErrorMessage (start/setup).
+ *   - One context = one element instance. A context is used by one thread at a time (the
+ *     streaming thread, serialised by the pad stream lock); different contexts are independent.
+ *   - "host" entry points borrow the caller's buffer for the duration of the call only
+ *     (GstVideoFrame / GstBuffer map semantics): H2D copy, kernel, D2H copy, then return.
+ *   - "_device" entry points take device pointers, enqueue on the context's stream and return
+ *     without synchronising (adjacent mi355 elements, benchmarks).
+ *   - There is no CPU fallback: without a usable gfx950 device every call fails loudly.
+ */
+#ifndef MI355FX_H
+#define MI355FX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355FX_ABI_VERSION 1
+
+typedef enum mi355_status {
+  MI355_OK = 0,
+  MI355_ERR_INVALID_ARG = -1,   /* bad pointer / size / format            */
+  MI355_ERR_NO_DEVICE = -2,     /* no gfx950 device, or HIP init failed   */
+  MI355_ERR_HIP = -3,           /* a HIP runtime call or kernel failed    */
+  MI355_ERR_NOT_CONFIGURED = -4,/* e.g. colorlut without a loaded LUT (colorlut/imp.rs:209-212),
+                                   echo before setup (audioecho/imp.rs:210 NotNegotiated) */
+  MI355_ERR_OUT_OF_MEMORY = -5,
+  MI355_ERR_UNSUPPORTED = -6
+} mi355_status;
+
+/* Packed-RGB formats of the hot path. Values are stable ABI.
+ * hsvfilter caps: video/hsv/src/hsvfilter/imp.rs:274-312; colorlut caps: video/colorlut/src/colorlut/imp.rs:118-157. */
+typedef enum mi355_video_format {
+  MI355_FMT_RGBX = 0,
+  MI355_FMT_XRGB = 1,
+  MI355_FMT_BGRX = 2,
+  MI355_FMT_XBGR = 3,
+  MI355_FMT_RGBA = 4,
+  MI355_FMT_ARGB = 5,
+  MI355_FMT_BGRA = 6,
+  MI355_FMT_ABGR = 7,
+  MI355_FMT_RGB = 8,
+  MI355_FMT_BGR = 9,
+  MI355_FMT_RGBA64_LE = 10,
+  MI355_FMT_RGBA64_BE = 11
+} mi355_video_format;
+
+typedef struct mi355_ctx mi355_ctx;
+
+/* ---------------------------------------------------------------- context / plumbing */
+
+int mi355_abi_version(void);
+/* Number of visible HIP devices (0 if none or the runtime cannot initialise). */
+int mi355_device_count(void);
+/* Create a context on `device` (its own non-blocking stream). NULL on failure; *status set if non-NULL. */
+mi355_ctx *mi355_ctx_create(int device, int *status);
+void mi355_ctx_destroy(mi355_ctx *ctx);
+const char *mi355_ctx_last_error(const mi355_ctx *ctx);
+const char *mi355_status_string(int status);
+/* hipStream_t of the context (as void*). */
+void *mi355_ctx_stream(mi355_ctx *ctx);
+/* Use an externally owned stream (e.g. the stream of the neighbouring element) instead. */
+int mi355_ctx_set_stream(mi355_ctx *ctx, void *hip_stream);
+int mi355_ctx_synchronize(mi355_ctx *ctx);
+
+/* Diagnostic switches (tests, A/B measurements). MI355_FLAG_FORCE_GENERIC=1 makes every element use
+ * its literal-arithmetic GENERIC kernel instead of the strength-reduced FAST one. */
+typedef enum mi355_flag { MI355_FLAG_FORCE_GENERIC = 1 } mi355_flag;
+int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
+
+void *mi355_device_alloc(mi355_ctx *ctx, size_t bytes);
+int mi355_device_free(mi355_ctx *ctx, void *dptr);
+int mi355_memcpy_h2d(mi355_ctx *ctx, void *dptr, const void *host, size_t bytes); /* synchronous */
+int mi355_memcpy_d2h(mi355_ctx *ctx, void *host, const void *dptr, size_t bytes); /* synchronous */
+
+/* ---------------------------------------------------------------- hsvfilter
+ * Replaces HsvFilter::hsv_filter + the format match of transform_frame_ip
+ * (video/hsv/src/hsvfilter/imp.rs:76-120, :323-376) and the hsvutils conversions it calls
+ * (video/hsv/src/hsvutils.rs:44-198). Settings snapshot = `Settings` (hsvfilter/imp.rs:33-39). */
+typedef struct mi355_hsv_settings {
+  float hue_shift;      /* "hue-shift"      default 0.0 */
+  float saturation_mul; /* "saturation-mul" default 1.0 */
+  float saturation_off; /* "saturation-off" default 0.0 */
+  float value_mul;      /* "value-mul"      default 1.0 */
+  float value_off;      /* "value-off"      default 0.0 */
+} mi355_hsv_settings;
+
+/* In place on plane 0 of a mapped frame in host memory. `data_len` = plane_data_mut(0).len();
+ * rows processed = data_len / stride (chunks_exact_mut drops a trailing partial row). */
+int mi355_hsvfilter_frame_ip(mi355_ctx *ctx, uint8_t *data, size_t data_len, int width, int stride,
+                             int format, const mi355_hsv_settings *settings);
+/* Same on `n_frames` device-resident frames, frame f at d_data + f*frame_pitch. Asynchronous. */
+int mi355_hsvfilter_frames_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch,
+                                  int width, int height, int stride, int format,
+                                  const mi355_hsv_settings *settings);
+
+/* ---------------------------------------------------------------- hsvdetector
+ * Replaces HsvDetector::hsv_detect + transform_frame's 6x4 format match
+ * (video/hsv/src/hsvdetector/imp.rs:100-160, :423-707). */
+typedef struct mi355_hsvdetect_settings {
+  float hue_ref, hue_var;               /* defaults 0.0, 10.0 */
+  float saturation_ref, saturation_var; /* defaults 0.0, 0.15 */
+  float value_ref, value_var;           /* defaults 0.0, 0.3  */
+} mi355_hsvdetect_settings;
+
+int mi355_hsvdetect_frame(mi355_ctx *ctx, const uint8_t *src, size_t src_len, int src_stride,
+                          int src_format, uint8_t *dst, size_t dst_len, int dst_stride,
+                          int dst_format, int width, const mi355_hsvdetect_settings *settings);
+int mi355_hsvdetect_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch,
+                                  int src_stride, int src_format, uint8_t *d_dst, size_t dst_pitch,
+                                  int dst_stride, int dst_format, int n_frames, int width,
+                                  int height, const mi355_hsvdetect_settings *settings);
+
+/* ---------------------------------------------------------------- colorlut
+ * mi355_colorlut_load replaces the `State { lut }` installed by ColorLut::start
+ * (video/colorlut/src/colorlut/imp.rs:168-194): the element keeps parsing the .cube text
+ * (video/colorlut/src/parser.rs:110-281) and hands over the parsed CubeLut:
+ *   is3d=1: `table` = Lut3D::as_flat(), size^3 cells of [r,g,b,1.0], index x + y*size + z*size^2
+ *           (parser.rs:19-53, :253-256);  is3d=0: r[size], g[size], b[size] back to back
+ *           (CubeLutKind::Lut1D, parser.rs:57-66).
+ *   domain_scale / domain_offset: CubeLut fields (parser.rs:69-75, :264-274). */
+int mi355_colorlut_load(mi355_ctx *ctx, int is3d, size_t size, const float *table,
+                        const float domain_scale[3], const float domain_offset[3]);
+/* ColorLut::stop (colorlut/imp.rs:196-199). */
+int mi355_colorlut_unload(mi355_ctx *ctx);
+/* Replaces transform_frame's body: transform_rgba / transform_rgba64::<LE>
+ * (colorlut/imp.rs:203-223 -> :226-397). format in {RGBA, RGBA64_LE, RGBA64_BE}; src and dst are
+ * plane 0 of two different frames with independent strides; rows = chunks(stride).take(height). */
+int mi355_colorlut_frame(mi355_ctx *ctx, const uint8_t *src, int src_stride, uint8_t *dst,
+                         int dst_stride, int width, int height, int format);
+int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch,
+                                 int src_stride, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
+                                 int n_frames, int width, int height, int format);
+
+/* ---------------------------------------------------------------- rsaudioecho
+ * mi355_echo_setup replaces AudioEcho::setup's RingBuffer::new(buffer_size)
+ * (audio/audiofx/src/audioecho/imp.rs:248-259, ring_buffer.rs:15-24): ring of `ring_len` f64
+ * zeros, position 0. mi355_echo_reset = stop() dropping the state (imp.rs:229-234). */
+int mi355_echo_setup(mi355_ctx *ctx, size_t ring_len);
+int mi355_echo_reset(mi355_ctx *ctx);
+/* Replaces AudioEcho::process::<f32|f64> (imp.rs:69-85) + RingBufferIter (ring_buffer.rs:37-82).
+ * `delay_samples` = delay_frames of imp.rs:74-77 (interleaved samples, after the max-delay
+ * clamp of imp.rs:207). In place on `n` interleaved samples in host memory. */
+int mi355_echo_process_f32(mi355_ctx *ctx, float *data, size_t n, size_t delay_samples,
+                           double intensity, double feedback);
+int mi355_echo_process_f64(mi355_ctx *ctx, double *data, size_t n, size_t delay_samples,
+                           double intensity, double feedback);
+int mi355_echo_process_device(mi355_ctx *ctx, void *d_data, size_t n, int is_f64,
+                              size_t delay_samples, double intensity, double feedback);
+/* Test/diagnostic access to the element state (ring contents + write position). */
+int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size_t *pos_out);
+
+/* ---------------------------------------------------------------- measurement helpers
+ * Used by bench.py: run `iters` back-to-back launches of one kernel on the context's stream
+ * bracketed by hipEvents on THAT stream and return the average milliseconds per launch. */
+int mi355_time_hsvfilter_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch,
+                                int width, int height, int stride, int format,
+                                const mi355_hsv_settings *settings, int iters, float *ms_per_launch);
+int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                               uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
+                               int width, int height, int format, int iters, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355FX_H */

@@ -1,0 +1,376 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libmi355fx.so), against the CPU oracle
+on the same seeded inputs. Bit-exact for every u8/u16 pixel result; bit-exact f32/f64 for echo.
+
+All tests here need a real MI355X: `pytest -m gpu`.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W4K, H4K = 3840, 2160
+
+
+def _mismatch_report(got, exp, limit=5):
+    bad = np.nonzero(got.reshape(-1) != exp.reshape(-1))[0]
+    return "mismatching bytes: %d, first at %s got %s exp %s" % (
+        bad.size, bad[:limit], got.reshape(-1)[bad[:limit]], exp.reshape(-1)[bad[:limit]])
+
+
+# ------------------------------------------------------------------ hsvfilter
+
+FOUR_BYTE = ["RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR"]
+
+
+@pytest.mark.parametrize("setting", ["defaults", "hue90", "mixed"])
+def test_hsvfilter_allcolors_rgba_fast(ctx, oracle, synth, setting):
+    """Every one of the 2^24 colours, FAST kernel, host entry point (H2D, kernel, D2H)."""
+    st = synth.HSV_SETTINGS[setting]
+    ac = synth.allcolors()
+    exp = ac.copy().reshape(-1)
+    oracle.hsvfilter(exp, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    got = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 4, "RGBA", st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("st", [
+    (-360.0, 1.0, 0.0, 1.0, 0.0), (360.0, 1.0, 0.0, 1.0, 0.0), (359.99997, 0.5, 0.25, 2.0, -0.5),
+    (1e-30, 1.0, 0.0, 1.0, 0.0), (-180.0, -1.0, 0.5, 0.0, 0.5), (120.5, 1e9, -1e9, 1.0, 0.0),
+    (45.0, float("nan"), 0.0, float("inf"), float("-inf")), (0.0, float("inf"), float("-inf"), 1.0, 0.0),
+])
+def test_hsvfilter_allcolors_fast_edge_settings(ctx, oracle, synth, st):
+    """FAST-path boundary settings (|hue_shift| = 360, tiny shift, NaN/inf sat/val parameters)."""
+    ac = synth.allcolors()
+    exp = ac.copy().reshape(-1)
+    oracle.hsvfilter(exp, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    got = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 4, "RGBA", st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("st", [
+    (725.5, 1.0, 0.0, 1.0, 0.0), (-1e6, 1.1, 0.0, 0.9, 0.0), (float("inf"), 1.0, 0.0, 1.0, 0.0),
+    (float("nan"), 1.0, 0.0, 1.0, 0.0), (1e-40, 1.0, 0.0, 1.0, 0.0), (3.4e38, 1.0, 0.0, 1.0, 0.0),
+])
+def test_hsvfilter_allcolors_generic_settings(ctx, oracle, synth, st):
+    """Settings outside the FAST envelope take the GENERIC (literal) kernel: huge / non-finite /
+    denormal hue-shift (SURVEY.md Appendix A1 last bullet)."""
+    ac = synth.allcolors()
+    exp = ac.copy().reshape(-1)
+    oracle.hsvfilter(exp, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    got = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 4, "RGBA", st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_hsvfilter_generic_kernel_equals_fast_kernel(ctx, oracle, synth):
+    """A/B of the two kernels on the same input (FORCE_GENERIC flag)."""
+    import mi355fx
+    st = synth.HSV_SETTINGS["mixed"]
+    ac = synth.allcolors()
+    fast = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(fast, 4096, 4096 * 4, "RGBA", st)
+    ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, 1)
+    gen = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(gen, 4096, 4096 * 4, "RGBA", st)
+    ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, 0)
+    assert (fast == gen).all(), _mismatch_report(fast, gen)
+
+
+@pytest.mark.parametrize("fmt", FOUR_BYTE + ["RGB", "BGR"])
+def test_hsvfilter_all_formats(ctx, oracle, synth, fmt):
+    """The 10 caps formats of hsvfilter (hsvfilter/imp.rs:274-312), contiguous 4-byte frames hit the
+    flat kernel, 3-byte frames the row kernel. 1920x1080 noise (config 2 shape for BGRx)."""
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    w, h = 1920, 1080
+    stride = (w * ps + 3) & ~3
+    frame = synth.noise_frame(stride, h, channels=1).reshape(-1).copy()
+    st = synth.HSV_SETTINGS["hue90"]
+    exp = frame.copy()
+    oracle.hsvfilter(exp, w, stride, ps, first, bool(bgr), st, nthreads=8)
+    got = frame.copy()
+    ctx.hsvfilter_frame_ip(got, w, stride, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("fmt,w,h,pad", [("RGBA", 37, 5, 12), ("xBGR", 1, 1, 0), ("BGRx", 3, 7, 4), ("RGB", 5, 3, 1),
+                                         ("BGR", 33, 2, 3), ("ARGB", 640, 3, 64)])
+def test_hsvfilter_ragged_and_padded(ctx, oracle, synth, fmt, w, h, pad):
+    """Row padding must come back untouched; odd sizes exercise the row kernel; a trailing partial row
+    in the plane is skipped (chunks_exact_mut)."""
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    stride = w * ps + pad
+    tail = (ps * 2) if stride > ps * 2 else 0  # partial trailing row, multiple of the pixel stride
+    rng = np.random.default_rng(11)
+    frame = rng.integers(0, 256, size=stride * h + tail, dtype=np.uint8)
+    st = synth.HSV_SETTINGS["mixed"]
+    exp = frame.copy()
+    oracle.hsvfilter(exp, w, stride, ps, first, bool(bgr), st)
+    got = frame.copy()
+    ctx.hsvfilter_frame_ip(got, w, stride, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_hsvfilter_empty_and_errors(ctx, synth):
+    import mi355fx
+    st = synth.HSV_SETTINGS["hue90"]
+    empty = np.zeros(0, np.uint8)
+    ctx.hsvfilter_frame_ip(empty, 0, 16, "RGBA", st)          # no rows: no-op
+    short = np.zeros(8, np.uint8)
+    ctx.hsvfilter_frame_ip(short, 4, 16, "RGBA", st)          # less than one row: no-op
+    assert (short == 0).all()
+    with pytest.raises(mi355fx.Mi355Error) as e:
+        ctx.hsvfilter_frame_ip(np.zeros(64, np.uint8), 8, 16, "RGBA", st)  # line_bytes > stride
+    assert e.value.status == mi355fx.ERR_INVALID_ARG
+    with pytest.raises(mi355fx.Mi355Error):
+        ctx.hsvfilter_frame_ip(np.zeros(10, np.uint8), 1, 5, "RGBA", st)   # len % pixel_stride != 0
+
+
+def test_hsvfilter_4k_batch_device_is_pure_per_pixel_function(ctx, oracle, synth):
+    """Full BASELINE size (3840x2160 RGBA, batch of 3 frames, device-resident entry point): the output
+    must equal T[input] where T is the 2^24-entry table produced by the oracle (size-independent
+    property: the element is a pure per-pixel function)."""
+    st = synth.HSV_SETTINGS["hue90"]
+    ac = synth.allcolors()
+    tab = ac.copy().reshape(-1)
+    oracle.hsvfilter(tab, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    table = tab.view(np.uint32) & np.uint32(0x00FFFFFF)       # index = r | g<<8 | b<<16
+    n = 3
+    frames = np.stack([synth.noise_frame(W4K, H4K, seed=100 + i) for i in range(n - 1)] + [synth.smooth_frame(W4K, H4K)])
+    nbytes = frames.nbytes
+    d = ctx.alloc(nbytes)
+    try:
+        ctx.h2d(d, frames)
+        ctx.hsvfilter_frames_device(d, n, W4K * H4K * 4, W4K, H4K, W4K * 4, "RGBA", st)
+        ctx.synchronize()
+        got = np.empty_like(frames)
+        ctx.d2h(got, d)
+    finally:
+        ctx.free(d)
+    inp = frames.reshape(-1).view(np.uint32)
+    exp = table[inp & np.uint32(0x00FFFFFF)] | (inp & np.uint32(0xFF000000))
+    assert (got.reshape(-1).view(np.uint32) == exp).all()
+
+
+# ------------------------------------------------------------------ colorlut
+
+def _load_cube(ctx, oracle, text):
+    cube = oracle.Cube.parse(text)
+    sc, of = cube.domain
+    ctx.colorlut_load(cube.is3d, cube.size, cube.table, sc, of)
+    return cube
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+def test_colorlut_allcolors_33(ctx, oracle, synth, force_generic):
+    """BASELINE config 3 LUT (33^3 trilinear) on every 8-bit colour: LDS kernel and generic kernel."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ac = synth.allcolors()
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
+    ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, force_generic)
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+    assert zlib.crc32(got.tobytes()) == zlib.crc32(exp.tobytes())
+
+
+@pytest.mark.parametrize("size", [2, 3, 17, 32, 33, 34, 35, 65])
+def test_colorlut_identity_is_passthrough(ctx, oracle, synth, size):
+    """SURVEY.md §8 a6 KAT: an identity LUT of any size is an exact pass-through (sizes <= 34 use the
+    LDS kernel, larger ones the gather kernel)."""
+    _load_cube(ctx, oracle, synth.cube_text_3d(size, identity=True))
+    ac = synth.allcolors()
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+    assert (got == ac).all(), _mismatch_report(got, ac)
+
+
+@pytest.mark.parametrize("size,domain", [(17, None), (33, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))), (34, None),
+                                         (5, ((0.0, 0.0, 0.0), (2.0, 0.5, 1.0))), (64, None)])
+def test_colorlut_sizes_and_domains(ctx, oracle, synth, size, domain):
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size, amp=0.07, domain=domain))
+    ac = synth.allcolors()
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_out_of_range_and_nonfinite_lut(ctx, oracle):
+    """LUT entries outside [0,1], huge, inf and nan (str::parse::<f32> accepts them): the load-time
+    check routes these to the literal kernel; results must still match the oracle."""
+    rng = np.random.default_rng(5)
+    size = 9
+    vals = rng.uniform(-0.5, 1.5, size=(size ** 3, 3))
+    lines = ["LUT_3D_SIZE %d" % size]
+    for i, v in enumerate(vals):
+        if i % 97 == 3:
+            lines.append("inf %.6f -inf" % v[1])
+        elif i % 89 == 5:
+            lines.append("%.6f nan %.6f" % (v[0], v[2]))
+        elif i % 83 == 7:
+            lines.append("3e38 -3e38 %.6f" % v[2])
+        else:
+            lines.append("%.6f %.6f %.6f" % tuple(v))
+    cube = _load_cube(ctx, oracle, "\n".join(lines) + "\n")
+    rgb = rng.integers(0, 256, size=(512, 512, 4), dtype=np.uint8).reshape(512, 2048)
+    exp = np.zeros_like(rgb)
+    oracle.colorlut_rgba8(cube, rgb, 2048, exp, 2048, 512, 512)
+    got = np.zeros_like(rgb)
+    ctx.colorlut_frame(rgb, 2048, got, 2048, 512, 512, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_1d(ctx, oracle, synth):
+    cube = _load_cube(ctx, oracle, synth.cube_text_1d(64))
+    assert not cube.is3d
+    ac = synth.allcolors()[:512]
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 512)
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 512, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("le", [True, False])
+@pytest.mark.parametrize("kind", ["3d", "1d"])
+def test_colorlut_rgba64(ctx, oracle, synth, le, kind):
+    """RGBA64_LE / RGBA64_BE arms (colorlut/imp.rs:296-397): byte order handling + raw alpha copy."""
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(17) if kind == "3d" else synth.cube_text_1d(1024))
+    rng = np.random.default_rng(9)
+    w, h = 333, 41
+    stride = w * 8 + 16
+    src = rng.integers(0, 256, size=h * stride, dtype=np.uint8)
+    exp = np.full(h * stride, 0xCD, np.uint8)
+    got = exp.copy()
+    oracle.colorlut_rgba64(cube, src, stride, exp, stride, w, h, le=le)
+    ctx.colorlut_frame(src, stride, got, stride, w, h, "RGBA64_LE" if le else "RGBA64_BE")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_independent_strides_and_untouched_padding(ctx, oracle, synth):
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    rng = np.random.default_rng(13)
+    w, h = 250, 9
+    ss, ds = w * 4 + 24, w * 4 + 8
+    src = rng.integers(0, 256, size=h * ss, dtype=np.uint8)
+    exp = np.full(h * ds, 0xEE, np.uint8)
+    got = exp.copy()
+    oracle.colorlut_rgba8(cube, src, ss, exp, ds, w, h)
+    ctx.colorlut_frame(src, ss, got, ds, w, h, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_without_lut_fails_like_reference(ctx):
+    """transform_frame without a LUT is FlowError::Error (colorlut/imp.rs:209-212)."""
+    import mi355fx
+    a = np.zeros(16, np.uint8)
+    with pytest.raises(mi355fx.Mi355Error) as e:
+        ctx.colorlut_frame(a, 16, a.copy(), 16, 4, 1, "RGBA")
+    assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+    assert "No LUT configured" in str(e.value)
+
+
+def test_colorlut_4k_batch_device_matches_table(ctx, oracle, synth):
+    """Full BASELINE size, device entry point, batch of 2 frames (noise + smooth): output == T[input]
+    with T from the oracle on all colours."""
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ac = synth.allcolors()
+    tab = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, tab, 4096 * 4, 4096, 4096, nthreads=8)
+    table = tab.reshape(-1).view(np.uint32) & np.uint32(0x00FFFFFF)
+    frames = np.stack([synth.noise_frame(W4K, H4K, seed=77), synth.smooth_frame(W4K, H4K)])
+    d_src, d_dst = ctx.alloc(frames.nbytes), ctx.alloc(frames.nbytes)
+    try:
+        ctx.h2d(d_src, frames)
+        pitch = W4K * H4K * 4
+        ctx.colorlut_frames_device(d_src, pitch, W4K * 4, d_dst, pitch, W4K * 4, 2, W4K, H4K, "RGBA")
+        ctx.synchronize()
+        got = np.empty_like(frames)
+        ctx.d2h(got, d_dst)
+    finally:
+        ctx.free(d_src)
+        ctx.free(d_dst)
+    inp = frames.reshape(-1).view(np.uint32)
+    exp = table[inp & np.uint32(0x00FFFFFF)] | (inp & np.uint32(0xFF000000))
+    assert (got.reshape(-1).view(np.uint32) == exp).all()
+
+
+def test_hsv_then_lut_chain_4k(ctx, oracle, synth):
+    """The headline chain (hsvfilter hue-shift=90 -> colorlut 33^3) on one 4K smooth frame vs the
+    oracle chain."""
+    st = synth.HSV_SETTINGS["hue90"]
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    frame = synth.smooth_frame(W4K, H4K)
+    mid = frame.copy().reshape(-1)
+    oracle.hsvfilter(mid, W4K, W4K * 4, 4, 0, False, st, nthreads=8)
+    exp = np.zeros_like(frame)
+    oracle.colorlut_rgba8(cube, mid.reshape(H4K, -1), W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
+    got_mid = frame.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(got_mid, W4K, W4K * 4, "RGBA", st)
+    got = np.zeros_like(frame)
+    ctx.colorlut_frame(got_mid, W4K * 4, got, W4K * 4, W4K, H4K, "RGBA")
+    assert (got_mid == mid).all()
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+# ------------------------------------------------------------------ rsaudioecho
+
+def _echo_pair(ctx, oracle, max_delay_ns, rate, channels):
+    e = oracle.Echo(max_delay_ns, rate, channels)
+    ctx.echo_setup(e.ring_len)
+    return e
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("delay_ms,intensity,feedback", [(250, 0.6, 0.4), (250, 0.5, 0.0), (1000, 0.9, 0.9),
+                                                         (0, 0.3, 0.2), (500000, 0.5, 0.0), (7, 1.0, 0.99)])
+def test_echo_config1(ctx, oracle, synth, dtype, delay_ms, intensity, feedback):
+    """BASELINE config 1: 48 kHz stereo sine, 10 s in ONE buffer; plus the default-parameter quirk
+    (delay 500 s clamped to max-delay 1 s), delay 0 and a short comb."""
+    rate, ch = 48000, 2
+    e = _echo_pair(ctx, oracle, 10 ** 9, rate, ch)
+    x = synth.sine_stereo_f32(480000 if feedback == 0.0 or delay_ms >= 250 or delay_ms == 0 else 48000).astype(dtype)
+    delay_ns = delay_ms * 10 ** 6
+    exp = x.copy()
+    e.process(exp, delay_ns, intensity, feedback)
+    got = x.copy()
+    d = oracle.lib().oracle_echo_delay_samples(delay_ns, 10 ** 9, rate, ch)
+    ctx.echo_process(got, d, intensity, feedback)
+    assert got.tobytes() == exp.tobytes()
+    ring, pos = ctx.echo_state(e.ring_len)
+    assert pos == e.pos
+    assert ring[: e.ring_len].tobytes() == e.ring[: e.ring_len].tobytes()
+
+
+def test_echo_streaming_many_buffers(ctx, oracle, synth):
+    """Element state carried across buffers of ragged sizes (ring position + contents)."""
+    rate, ch = 44100, 2
+    e = _echo_pair(ctx, oracle, 300 * 10 ** 6, rate, ch)
+    rng = np.random.default_rng(21)
+    delay_ns = 123456789
+    d = oracle.lib().oracle_echo_delay_samples(delay_ns, 300 * 10 ** 6, rate, ch)
+    for n in [1, 2, 4410, 0, 26460, 13, 88200, 7]:
+        x = rng.standard_normal(n).astype(np.float32)
+        exp, got = x.copy(), x.copy()
+        e.process(exp, delay_ns, 0.7, 0.5)
+        ctx.echo_process(got, d, 0.7, 0.5)
+        assert got.tobytes() == exp.tobytes()
+    ring, pos = ctx.echo_state(e.ring_len)
+    assert pos == e.pos and ring[: e.ring_len].tobytes() == e.ring[: e.ring_len].tobytes()
+
+
+def test_echo_not_negotiated(ctx):
+    """transform_ip before setup is FlowError::NotNegotiated (audioecho/imp.rs:210)."""
+    import mi355fx
+    with pytest.raises(mi355fx.Mi355Error) as e:
+        ctx.echo_process(np.zeros(4, np.float32), 1, 0.5, 0.0)
+    assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
