@@ -23,6 +23,7 @@
 #include "exact_math.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace mi355 {
@@ -147,61 +148,112 @@ __global__ __launch_bounds__(256) void colorlut_rows_kernel(const uint8_t *__res
 
 // ---------------------------------------------------------------- LDS three-pass kernel (RGBA8, 3D)
 //
-// LDS plane layout for channel c (floats): plane[x + y*S + z*S*S] = cell(x,y,z).c for the S^3 real
-// cells, followed by S*S + S + 4 zero floats. The padding lets every lane read its 8 corners at the
-// fixed offsets {0,1,S,S+1,S^2,S^2+1,S^2+S,S^2+S+1} from its base without clamping x1/y1/z1:
-// whenever the reference clamps (x0 == S-1, i.e. x == S-1 exactly) the interpolation weight is 0,
-// and a + (b - a)*0 == a for every finite b with |b - a| < inf — guaranteed by the load-time check
-// that all entries are finite with |v| <= 1e30 (a sign-of-zero difference cannot reach a non-zero
-// result and both zeros convert to byte 0).
+// Work decomposition: a block owns a tile of NT*P pixels held in VGPRs (packed pixel, LDS byte base
+// of its cell, tx, ty, tz) and makes three passes, one per output channel, with that channel's f32
+// plane staged in LDS. One 16 B load + one 16 B store per 4 pixels; the LUT never leaves LDS/L2.
 //
-// Block = NT lanes, each owning P = 4*P4 pixels held in VGPRs: packed pixel, LDS byte base, tx, ty, tz.
-// Per tile: load pixels, compute coordinates once, then for c in R,G,B: stage plane c into LDS,
-// interpolate channel c for all P pixels, insert the byte. One 16 B load + one 16 B store per 4 pixels.
+// LDS image (bytes), identical for the three passes except for the plane contents:
+//   [0, 6144)            three axis tables, 256 entries x {int32 byte offset, f32 t} per axis:
+//                        for input byte v on axis a: x = clamp(v/255*scale+offset,0,1)*(S-1) computed on
+//                        the host with the reference's IEEE operations (norm_comp, imp.rs:471-474, and
+//                        sample_3d's floor/min/sub, imp.rs:496-506); entry = {offset of floor(x), x-floor(x)}.
+//   [6144, 6144+4*S*Sz)  the plane, cell (x,y,z) at float index x + Sy*y + Sz*(S-1-z)   (z reversed).
+//   + 4*(Sy+2)           zero tail.
+// Strides Sy = 3 (mod 32) and Sz = 9 (mod 32): the LDS bank of a cell is (x + 3y + 9z) mod 32, so
+// lanes whose cells differ by any (dx,dy,dz) in {-1,0,1}^3 — the normal case for neighbouring pixels
+// of natural content — hit 27 distinct banks (a plain 33x33x33 layout has 33 = 33^2 = 1 mod 32, i.e.
+// x+1, y+1 and z+1 neighbours all collide on one bank).
+// A lane's base addresses the (x0,y0,z0+1) corner; its 8 corners sit at the fixed offsets
+// {0,4,4Sy,4Sy+4} (z0+1) and 4Sz + {0,4,4Sy,4Sy+4} (z0). No x1/y1/z1 clamping is done: whenever the
+// reference clamps (x0 == S-1 <=> x == S-1 exactly) the weight is exactly 0 and a + (b-a)*0 == a for
+// every finite b with finite b-a. The out-of-cube reads land on the next row / plane, the zero tail,
+// or — for z0 == S-1, thanks to the reversed z order — on the axis tables just below the plane
+// (small integers and t values: finite). The load-time check guarantees all entries are finite with
+// |v| <= 1e30. (A sign-of-zero difference cannot reach a non-zero result; both zeros give byte 0.)
 
-template <bool UNIT>
-__device__ __forceinline__ void lut_axis(float c8, float scale, float offset, float sm1, uint32_t &i0, float &t) {
-  float n = div255_u8(c8);
-  if constexpr (!UNIT) {
-    // finite scale/offset: inherent clamp == max-then-min (no NaN can occur)
-    n = fminf(fmaxf(n * scale + offset, 0.0f), 1.0f);
+constexpr int kAxisTableBytes = 3 * 256 * 8;
+
+struct LdsLayout {
+  int S, Sy, Sz;
+  size_t plane_floats;  // S*Sz + Sy + 2 rounded up to 256 (1 KiB)
+  size_t lds_bytes;     // kAxisTableBytes + 4*plane_floats
+};
+
+static LdsLayout lds_layout_for(int S) {
+  LdsLayout L;
+  L.S = S;
+  L.Sy = S;
+  while (L.Sy % 32 != 3) L.Sy++;
+  L.Sz = L.Sy * S;
+  while (L.Sz % 32 != 9) L.Sz++;
+  size_t pf = (size_t)S * L.Sz + L.Sy + 2;
+  L.plane_floats = (pf + 255) & ~(size_t)255;  // whole 1 KiB chunks for the async global->LDS staging
+  L.lds_bytes = kAxisTableBytes + 4 * L.plane_floats;
+  return L;
+}
+
+// round-half-away(y) for 0 <= y <= 65535: v_cvt_rpi_i32_f32 = (int)floor(y + 0.5), exact (verified
+// exhaustively on gfx950 over every float in [0,65536], tools/sem_probe.hip).
+__device__ __forceinline__ uint32_t round_half_away_nonneg(float y) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  return (uint32_t)r;
+}
+
+// Stage one channel plane into LDS with the async global->LDS path (global_load_lds_dwordx4: each
+// wave-instruction moves 1 KiB, LDS destination = wave-uniform base + lane*16, no VGPR round trip).
+template <int NT>
+__device__ __forceinline__ void stage_plane(unsigned char *lds, const float *__restrict__ plane, uint32_t plane_floats) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t chunks = plane_floats / 256;  // plane_floats is a multiple of 256 (1 KiB)
+  const char *gsrc = (const char *)plane + lane * 16;
+  for (uint32_t k = wave; k < chunks; k += NT / 64)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)k * 1024),
+                                     (__attribute__((address_space(3))) void *)(lds + kAxisTableBytes + k * 1024), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One channel pass over the P pixels a lane holds. C = output channel (byte index).
+template <int P, int C, int S_CONST>
+__device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, int Sz_rt, uint32_t (&px)[P], const uint32_t (&base)[P],
+                                         const float (&tx)[P], const float (&ty)[P], const float (&tz)[P]) {
+  // strides are compile-time for the common 33^3 case so every corner is base + immediate
+  const int Sy = S_CONST == 33 ? 35 : Sy_rt;
+  const int Sz = S_CONST == 33 ? 1161 : Sz_rt;
+  // output byte C <- value byte 0, the other three bytes kept (v_perm_b32 selector)
+  constexpr uint32_t sel = C == 0 ? 0x07060500u : (C == 1 ? 0x07060004u : 0x07000504u);
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    const float *L1 = (const float *)(lds + base[i]);  // z0+1 layer
+    const float *L0 = L1 + Sz;                         // z0 layer
+    const float a0 = L0[0], a1 = L0[1], b0 = L0[Sy], b1 = L0[Sy + 1];
+    const float c0 = L1[0], c1 = L1[1], d0 = L1[Sy], d1 = L1[Sy + 1];
+    const float c00 = lerp1(a0, a1, tx[i]), c10 = lerp1(b0, b1, tx[i]);
+    const float c01 = lerp1(c0, c1, tx[i]), c11 = lerp1(d0, d1, tx[i]);
+    const float o = lerp1(lerp1(c00, c10, ty[i]), lerp1(c01, c11, ty[i]), tz[i]);
+    // float_to_u8 (imp.rs:537-539); o is never NaN here so max-then-min == the inherent clamp
+    const uint32_t v8 = round_half_away_nonneg(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
+    px[i] = __builtin_amdgcn_perm(px[i], v8, sel);
   }
-  const float x = n * sm1;      // in [0, S-1]
-  i0 = (uint32_t)x;             // floor; never exceeds S-1 so `.min(max_idx)` is the identity
-  t = __builtin_amdgcn_fractf(x);  // x - floor(x), exact
 }
 
-template <int S_CONST>
-__device__ __forceinline__ float lut_tri_lds(const float *__restrict__ lut, uint32_t base_bytes, int S_rt, float tx,
-                                             float ty, float tz) {
-  const int S = S_CONST > 0 ? S_CONST : S_rt;
-  const float *L = (const float *)((const char *)lut + base_bytes);
-  const float a0 = L[0], a1 = L[1];
-  const float b0 = L[S], b1 = L[S + 1];
-  const float c0 = L[S * S], c1 = L[S * S + 1];
-  const float d0 = L[S * S + S], d1 = L[S * S + S + 1];
-  const float c00 = lerp1(a0, a1, tx), c10 = lerp1(b0, b1, tx);
-  const float c01 = lerp1(c0, c1, tx), c11 = lerp1(d0, d1, tx);
-  return lerp1(lerp1(c00, c10, ty), lerp1(c01, c11, ty), tz);
-}
-
-// round-half-away(clamp(v,0,1)*255) as u8 == (trunc(clamp(v,0,1)*510) + 1) >> 1 (2*RN(c*255) == RN(c*510)).
-__device__ __forceinline__ uint32_t float_to_u8_fast(float v) {
-  const float c = fminf(fmaxf(v, 0.0f), 1.0f);
-  return ((uint32_t)(c * 510.0f) + 1u) >> 1;
-}
-
-template <int NT, int P4, bool UNIT, int S_CONST>
+template <int NT, int P4, int S_CONST>
 __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                             size_t n_groups, const float *__restrict__ planar,
-                                                            uint32_t plane_floats, LutK k) {
-  extern __shared__ float lut[];
+                                                            const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
+                                                            uint32_t plane_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int P = P4 * 4;
-  const int S = S_CONST > 0 ? S_CONST : k.size;
-  const float sm1 = (float)S - 1.0f;
   const size_t tile_groups = (size_t)NT * P4;
   const size_t n_tiles = (n_groups + tile_groups - 1) / tile_groups;
 
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  __syncthreads();
+
+  // Channel order alternates R,G,B / B,G,R from tile to tile so the plane left in LDS by one tile's
+  // last pass serves the next tile's first pass: two stagings per tile instead of three.
+  bool flip = false;
+  int resident = -1;
   for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint32_t px[P];
     uint32_t base[P];
@@ -216,30 +268,32 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
     }
 #pragma unroll
     for (int i = 0; i < P; i++) {
-      uint32_t x0, y0, z0;
-      lut_axis<UNIT>((float)(px[i] & 0xffu), k.scale[0], k.offset[0], sm1, x0, tx[i]);
-      lut_axis<UNIT>((float)((px[i] >> 8) & 0xffu), k.scale[1], k.offset[1], sm1, y0, ty[i]);
-      lut_axis<UNIT>((float)((px[i] >> 16) & 0xffu), k.scale[2], k.offset[2], sm1, z0, tz[i]);
-      base[i] = (x0 + (uint32_t)S * (y0 + (uint32_t)S * z0)) * 4u;
+      const uint2 ex = *(const uint2 *)(lds + ((px[i] & 0xffu) << 3));
+      const uint2 ey = *(const uint2 *)(lds + 2048 + (((px[i] >> 8) & 0xffu) << 3));
+      const uint2 ez = *(const uint2 *)(lds + 4096 + (((px[i] >> 16) & 0xffu) << 3));
+      base[i] = ex.x + ey.x + ez.x;
+      tx[i] = __uint_as_float(ex.y);
+      ty[i] = __uint_as_float(ey.y);
+      tz[i] = __uint_as_float(ez.y);
     }
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-      __syncthreads();  // everyone is done reading the previous plane
-      {
-        const float4 *s4 = (const float4 *)(planar + (size_t)c * plane_floats);
-        float4 *d4 = (float4 *)lut;
-        const uint32_t n4 = plane_floats / 4;
-        for (uint32_t i = threadIdx.x; i < n4; i += NT) d4[i] = s4[i];
-      }
-      __syncthreads();
-      const uint32_t shift = 8u * (uint32_t)c;
-      const uint32_t keep = ~(0xffu << shift);
-#pragma unroll
-      for (int i = 0; i < P; i++) {
-        const float o = lut_tri_lds<S_CONST>(lut, base[i], S, tx[i], ty[i], tz[i]);
-        px[i] = (px[i] & keep) | (float_to_u8_fast(o) << shift);
-      }
+#define MI355_STAGE(CH)                                                              \
+  if (resident != CH) {                                                              \
+    __syncthreads(); /* everyone is done reading the previous plane */               \
+    stage_plane<NT>(lds, planar + (size_t)CH * plane_floats, plane_floats);          \
+    __syncthreads();                                                                 \
+    resident = CH;                                                                   \
+  }
+    if (!flip) {
+      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+    } else {
+      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
     }
+#undef MI355_STAGE
+    flip = !flip;
 #pragma unroll
     for (int j = 0; j < P4; j++) {
       const size_t g = g0 + (size_t)j * NT;
@@ -252,15 +306,28 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
 
 static constexpr size_t kLdsBytes = 160 * 1024;
 
-static size_t planar_plane_floats(size_t S) {
-  size_t n = S * S * S + S * S + S + 4;
-  return (n + 3) & ~(size_t)3;
-}
-
 void lut_release(mi355_ctx *ctx) {
   if (ctx->lut.d_cells) (void)hipFree(ctx->lut.d_cells);
   if (ctx->lut.d_planar) (void)hipFree(ctx->lut.d_planar);
+  if (ctx->lut.d_axis) (void)hipFree(ctx->lut.d_axis);
   ctx->lut = LutDevice{};
+}
+
+// One axis-table entry for input byte v: the reference's coordinate arithmetic, op for op
+// (this translation unit is compiled with -ffp-contract=off; host float ops are IEEE).
+static void axis_entry(int v, float scale, float offset, int S, float *t_out, int *i0_out) {
+  volatile float n = (float)v / 255.0f;            // norm_comp (imp.rs:472)
+  volatile float m = n * scale;
+  volatile float a = m + offset;
+  float cl = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);  // inherent clamp (finite domain: no NaN)
+  volatile float x = cl * ((float)S - 1.0f);       // imp.rs:438-440
+  const float fl = std::floor(x);
+  int i0 = (int)fl;
+  if (i0 > S - 1) i0 = S - 1;                       // .min(max_idx), never taken since x <= S-1
+  if (i0 < 0) i0 = 0;
+  volatile float t = x - (float)i0;                 // imp.rs:504-506
+  *t_out = t;
+  *i0_out = i0;
 }
 
 int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float scale[3],
@@ -276,16 +343,14 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
   rc = check_hip(ctx, hipMemcpy(L.d_cells, table, n_floats * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(lut cells)");
   if (rc) return rc;
 
-  L.unit_domain = true;
   bool domain_finite = true;
-  for (int c = 0; c < 3; c++) {
-    if (!(scale[c] == 1.0f && offset[c] == 0.0f)) L.unit_domain = false;
+  for (int c = 0; c < 3; c++)
     if (!std::isfinite(scale[c]) || !std::isfinite(offset[c])) domain_finite = false;
-  }
   L.lds_ok = false;
-  if (is3d && domain_finite) {
-    const size_t pf = planar_plane_floats(size);
-    if (pf * sizeof(float) <= kLdsBytes) {
+  if (is3d && domain_finite && size <= 64) {
+    const int S = (int)size;
+    const LdsLayout lay = lds_layout_for(S);
+    if (lay.lds_bytes <= kLdsBytes && (size_t)lay.Sz * 4 <= (size_t)kAxisTableBytes) {
       bool bounded = true;
       const size_t cells = size * size * size;
       for (size_t i = 0; i < cells && bounded; i++)
@@ -294,15 +359,42 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
           if (!(std::fabs(v) <= 1e30f)) { bounded = false; break; }
         }
       if (bounded) {
-        std::vector<float> planar(3 * pf, 0.0f);
+        std::vector<float> planar(3 * lay.plane_floats, 0.0f);
         for (int c = 0; c < 3; c++)
-          for (size_t i = 0; i < cells; i++) planar[(size_t)c * pf + i] = table[i * 4 + c];
+          for (int z = 0; z < S; z++)
+            for (int y = 0; y < S; y++)
+              for (int x = 0; x < S; x++)
+                planar[(size_t)c * lay.plane_floats + (size_t)x + (size_t)lay.Sy * y + (size_t)lay.Sz * (S - 1 - z)] =
+                    table[4 * ((size_t)x + (size_t)S * y + (size_t)S * S * z) + c];
+        std::vector<uint32_t> axis(3 * 256 * 2);
+        for (int a = 0; a < 3; a++)
+          for (int v = 0; v < 256; v++) {
+            float t;
+            int i0;
+            axis_entry(v, scale[a], offset[a], S, &t, &i0);
+            int off;
+            // Every offset field must stay a small non-negative integer: the z0 == S-1 pad reads
+            // interpret these dwords as floats (denormals: finite), so no negative/huge bit patterns.
+            if (a == 0) off = 4 * i0;                                       // x
+            else if (a == 1) off = 4 * lay.Sy * i0;                         // y
+            else off = kAxisTableBytes + 4 * lay.Sz * (S - 2 - i0);         // z: plane base + plane of z0+1 (reversed order)
+            axis[(size_t)(a * 256 + v) * 2 + 0] = (uint32_t)off;
+            std::memcpy(&axis[(size_t)(a * 256 + v) * 2 + 1], &t, 4);
+          }
         rc = check_hip(ctx, hipMalloc((void **)&L.d_planar, planar.size() * sizeof(float)), "hipMalloc(lut planar)");
         if (rc) return rc;
         rc = check_hip(ctx, hipMemcpy(L.d_planar, planar.data(), planar.size() * sizeof(float), hipMemcpyHostToDevice),
                        "hipMemcpy(lut planar)");
         if (rc) return rc;
-        L.planar_plane_floats = pf;
+        rc = check_hip(ctx, hipMalloc((void **)&L.d_axis, axis.size() * sizeof(uint32_t)), "hipMalloc(lut axis tables)");
+        if (rc) return rc;
+        rc = check_hip(ctx, hipMemcpy(L.d_axis, axis.data(), axis.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                       "hipMemcpy(lut axis tables)");
+        if (rc) return rc;
+        L.planar_plane_floats = lay.plane_floats;
+        L.lds_Sy = lay.Sy;
+        L.lds_Sz = lay.Sz;
+        L.lds_bytes = lay.lds_bytes;
         L.lds_ok = true;
       }
     }
@@ -311,19 +403,19 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
   return MI355_OK;
 }
 
-template <int NT, int P4, bool UNIT, int S_CONST>
-static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups, const LutK &k) {
-  auto kern = colorlut3d_lds_kernel<NT, P4, UNIT, S_CONST>;
+template <int NT, int P4, int S_CONST>
+static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups) {
+  auto kern = colorlut3d_lds_kernel<NT, P4, S_CONST>;
   const LutDevice &L = ctx->lut;
-  const size_t lds = L.planar_plane_floats * sizeof(float);
+  const size_t lds = L.lds_bytes;
   int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                      "hipFuncSetAttribute(max dynamic LDS)");
   if (rc) return rc;
   const size_t tile_groups = (size_t)NT * P4;
   size_t n_tiles = (n_groups + tile_groups - 1) / tile_groups;
   size_t grid = n_tiles < (size_t)ctx->n_cu ? n_tiles : (size_t)ctx->n_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, L.d_planar,
-                     (uint32_t)L.planar_plane_floats, k);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
+                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");
 }
 
@@ -346,13 +438,9 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
       const size_t n_groups = total_bytes / 16;
       const uint4 *s = (const uint4 *)d_src;
       uint4 *d = (uint4 *)d_dst;
-      constexpr int NT = 512, P4 = 6;
-      if (L.size == 33) {
-        return L.unit_domain ? launch_lds_variant<NT, P4, true, 33>(ctx, s, d, n_groups, k)
-                             : launch_lds_variant<NT, P4, false, 33>(ctx, s, d, n_groups, k);
-      }
-      return L.unit_domain ? launch_lds_variant<NT, P4, true, 0>(ctx, s, d, n_groups, k)
-                           : launch_lds_variant<NT, P4, false, 0>(ctx, s, d, n_groups, k);
+      constexpr int NT = 1024, P4 = 3;
+      if (L.size == 33) return launch_lds_variant<NT, P4, 33>(ctx, s, d, n_groups);
+      return launch_lds_variant<NT, P4, 0>(ctx, s, d, n_groups);
     }
   }
 

@@ -15,10 +15,12 @@ struct LutDevice {
   float scale[3] = {1, 1, 1};
   float offset[3] = {0, 0, 0};
   float *d_cells = nullptr;   // 3D: [size^3][4] as the reference stores it; 1D: r|g|b planes
-  float *d_planar = nullptr;  // 3D only: three channel planes padded for the LDS kernel (see colorlut_kernels.hip)
+  float *d_planar = nullptr;  // 3D only: three channel planes in the LDS image layout (see colorlut_kernels.hip)
+  uint32_t *d_axis = nullptr; // 3D only: per-axis {offset, t} tables, 3 x 256 x 2 dwords
   size_t planar_plane_floats = 0;  // floats per padded plane
+  int lds_Sy = 0, lds_Sz = 0;      // LDS row / plane strides (floats)
+  size_t lds_bytes = 0;            // dynamic LDS per block
   bool lds_ok = false;        // LDS fast path legal for this LUT (fits, finite, bounded)
-  bool unit_domain = false;   // scale == 1 && offset == 0 on all channels
   bool loaded = false;
 };
 
