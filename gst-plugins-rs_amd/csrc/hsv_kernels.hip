@@ -158,25 +158,156 @@ __device__ __forceinline__ uint32_t hsvfilter_px(uint32_t p, const HsvK &k, cons
   }
 }
 
+// ---------------------------------------------------------------- FAST path, two pixels per call
+//
+// Measured gfx950 VALU issue costs (tools/valu_bench.hip, cycles per wave64 instruction per SIMD):
+// v_add/sub/mul_f32 and v_ashrrev ~2.6; every other VALU op (v_fma, v_cndmask, v_cmp, v_cvt_*, v_perm,
+// v_min/max, bit ops) ~4.3; v_pk_mul/add/fma_f32 ~4.8 for two results; v_rcp_f32 ~8.5. The filter is
+// VALU-bound, so this version minimises the "slow" class:
+//   * the max channel is rotated to byte 0 with one v_perm_b32 (selector picked by two SDWA byte
+//     compares), which also delivers the hue sector constant (0/2/4) as byte 3 — no float selects;
+//   * fused multiply-adds are issued pairwise over the two pixels (v_pk_fma_f32);
+//   * sign fix-ups use v_ashrrev + v_and + v_add instead of compare+select;
+//   * the sextant index is floor(h/60) (not ceil): at integer h/60 both neighbouring sextants give
+//     identical triples (x == c or x == 0 there), so one v_cvt_u32 feeds the LDS selector lookup;
+//   * the three output bytes are converted straight into their byte lanes (SDWA v_cvt_u32_f32);
+//   * hue-shift sign and identity saturation/value settings are compile-time variants.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+
+enum HsvShiftClass { HSV_SHIFT_ZERO = 0, HSV_SHIFT_POS = 1, HSV_SHIFT_NEG = 2 };
+
+// selector table indexed by floor(h/60) in 0..6 (see hsv_sel_entry for the byte codes):
+//   0:(A,B,C) 1:(B,A,C) 2:(C,A,B) 3:(C,B,A) 4:(B,C,A) 5,6:(A,C,B)
+__host__ __device__ constexpr uint32_t hsv_sel_entry_floor(int k, int rpos, int gpos, int bpos, int npos) {
+  return hsv_sel_entry(k < 6 ? k + 1 : 6, rpos, gpos, bpos, npos);
+}
+
+// x + 360 if x < 0 else x, without compare/select: (bits(x) >>s 31) & bits(360.0f).
+__device__ __forceinline__ float add360_if_negative(float x) {
+  const int m = __float_as_int(x) >> 31;
+  return x + __int_as_float(m & 0x43b40000);
+}
+
+__device__ __forceinline__ void cvt_u8_into(uint32_t &packed, float v, int byte) {
+  // `as u8` of a value known to lie in [0,255.0001]: truncating convert written into one byte lane
+  if (byte == 0) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(packed) : "v"(v));
+  else if (byte == 1) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(packed) : "v"(v));
+  else asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(packed) : "v"(v));
+}
+
+template <int RPOS, int GPOS, int BPOS, int NPOS, int SHIFT, bool SV_IDENT>
+__device__ __forceinline__ void hsvfilter_px2_fast(uint32_t &p0, uint32_t &p1, const HsvK &k, const uint32_t *sel_tab) {
+  // ---- from_rgb / from_bgr (hsvutils.rs:44-128): rotate so that byte0 = max channel M, bytes 1,2 =
+  // the other two in the cyclic order the hue formula subtracts them, byte3 = 0/2/4.
+  constexpr uint32_t SEL_R = (uint32_t)RPOS | ((uint32_t)GPOS << 8) | ((uint32_t)BPOS << 16) | (4u << 24);
+  constexpr uint32_t SEL_G = (uint32_t)GPOS | ((uint32_t)BPOS << 8) | ((uint32_t)RPOS << 16) | (5u << 24);
+  constexpr uint32_t SEL_B = (uint32_t)BPOS | ((uint32_t)RPOS << 8) | ((uint32_t)GPOS << 16) | (6u << 24);
+  uint32_t rot[2];
+  {
+    const uint32_t p[2] = {p0, p1};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t r = (p[j] >> (8 * RPOS)) & 0xffu, g = (p[j] >> (8 * GPOS)) & 0xffu, b = (p[j] >> (8 * BPOS)) & 0xffu;
+      // first of R,G,B equal to the max (hsvutils.rs:63-68)
+      const uint32_t sel = (r >= g && r >= b) ? SEL_R : (g >= b ? SEL_G : SEL_B);
+      rot[j] = __builtin_amdgcn_perm(0x00040200u, p[j], sel);
+    }
+  }
+  const f2 M8 = {(float)(rot[0] & 0xffu), (float)(rot[1] & 0xffu)};
+  const f2 a8 = {(float)((rot[0] >> 8) & 0xffu), (float)((rot[1] >> 8) & 0xffu)};
+  const f2 b8 = {(float)((rot[0] >> 16) & 0xffu), (float)((rot[1] >> 16) & 0xffu)};
+  const f2 add = {(float)(rot[0] >> 24), (float)(rot[1] >> 24)};
+  const f2 hi = splat2(MI355_INV255_HI), lo = splat2(MI355_INV255_LO);
+  const f2 value = fma2(M8, hi, M8 * lo);  // RN(n/255), see div255_u8
+  const f2 af = fma2(a8, hi, a8 * lo);
+  const f2 bf = fma2(b8, hi, b8 * lo);
+  const f2 minv = {fminf(af.x, bf.x), fminf(af.y, bf.y)};
+  const f2 chroma = value - minv;
+  const f2 num = af - bf;
+  // q = num/chroma, sat = chroma/value: hardware reciprocal + one residual step (div_rcp_refine),
+  // the four fmas issued as two packed ones. Zero denominators only occur with zero numerators.
+  const f2 dq = {fmaxf(chroma.x, 1e-30f), fmaxf(chroma.y, 1e-30f)};
+  const f2 ds = {fmaxf(value.x, 1e-30f), fmaxf(value.y, 1e-30f)};
+  const f2 yq = {__builtin_amdgcn_rcpf(dq.x), __builtin_amdgcn_rcpf(dq.y)};
+  const f2 ys = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
+  f2 q = num * yq;
+  f2 sat = chroma * ys;
+  q = fma2(fma2(-q, dq, num), yq, q);
+  sat = fma2(fma2(-sat, ds, chroma), ys, sat);
+  f2 h = splat2(60.0f) * (add + q);
+  h.x = add360_if_negative(h.x);
+  h.y = add360_if_negative(h.y);
+  // ---- filter (hsvfilter/imp.rs:102-115)
+  f2 t = h;
+  if constexpr (SHIFT == HSV_SHIFT_POS) {
+    // t in [0, 720): subtract 360 exactly when t >= 360 (bit-select on the sign of t-360)
+    t = h + splat2(k.hue_shift);
+    const f2 u = t - splat2(360.0f);
+    const int mx = __float_as_int(u.x) >> 31, my = __float_as_int(u.y) >> 31;
+    t.x = __int_as_float((__float_as_int(t.x) & mx) | (__float_as_int(u.x) & ~mx));
+    t.y = __int_as_float((__float_as_int(t.y) & my) | (__float_as_int(u.y) & ~my));
+  } else if constexpr (SHIFT == HSV_SHIFT_NEG) {
+    // t in [-360, 360): fmod is the identity (t == -360 -> +0 instead of -0, indistinguishable),
+    // then `if h < 0 { h += 360 }`
+    t = h + splat2(k.hue_shift);
+    t.x = add360_if_negative(t.x);
+    t.y = add360_if_negative(t.y);
+  }
+  f2 s = sat, v = value;
+  if constexpr (!SV_IDENT) {
+    const f2 s1 = splat2(k.sat_mul) * sat + splat2(k.sat_off);
+    const f2 v1 = splat2(k.val_mul) * value + splat2(k.val_off);
+    s = f2{fminf(fmaxf(s1.x, 0.0f), 1.0f), fminf(fmaxf(s1.y, 0.0f), 1.0f)};
+    v = f2{fminf(fmaxf(v1.x, 0.0f), 1.0f), fminf(fmaxf(v1.y, 0.0f), 1.0f)};
+  }
+  // ---- to_rgb / to_bgr (hsvutils.rs:132-198)
+  const f2 c = v * s;
+  const f2 hp = fma2(t, splat2(MI355_INV60_HI), t * splat2(MI355_INV60_LO));  // RN(t/60), see div60_hue
+  const f2 hh = hp * splat2(0.5f);
+  const f2 fr = {__builtin_amdgcn_fractf(hh.x), __builtin_amdgcn_fractf(hh.y)};
+  const f2 w = fma2(splat2(2.0f), fr, splat2(-1.0f));
+  const f2 x = c * (splat2(1.0f) - f2{fabsf(w.x), fabsf(w.y)});
+  const f2 m = v - c;
+  const f2 A = (c + m) * splat2(255.0f), B = (x + m) * splat2(255.0f), C = m * splat2(255.0f);
+  uint32_t pk0 = 0, pk1 = 0;
+  cvt_u8_into(pk0, A.x, 0); cvt_u8_into(pk0, B.x, 1); cvt_u8_into(pk0, C.x, 2);
+  cvt_u8_into(pk1, A.y, 0); cvt_u8_into(pk1, B.y, 1); cvt_u8_into(pk1, C.y, 2);
+  const uint32_t sel0 = sel_tab[(uint32_t)hp.x];
+  const uint32_t sel1 = sel_tab[(uint32_t)hp.y];
+  p0 = __builtin_amdgcn_perm(p0, pk0, sel0);
+  p1 = __builtin_amdgcn_perm(p1, pk1, sel1);
+}
+
 // ---------------------------------------------------------------- hsvfilter kernels
 
 // Flat streaming kernel for 4-byte formats on contiguous storage (stride == width*4 and frames
 // back to back): each lane owns 16 B (4 pixels) per iteration -> global_load/store_dwordx4.
-template <bool FAST, int FIRST, bool BGR>
+// VARIANT: -1 = GENERIC arithmetic; otherwise FAST with SHIFT = VARIANT & 3, SV_IDENT = VARIANT >> 2.
+template <int VARIANT, int FIRST, bool BGR>
 __global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__ data, size_t n_vec,
                                                              HsvK k) {
   constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
   constexpr int NPOS = FIRST == 0 ? 3 : 0;
+  constexpr bool FAST = VARIANT >= 0;
   __shared__ uint32_t sel_tab[8];
-  if (threadIdx.x < 7) sel_tab[threadIdx.x] = hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
+  if (threadIdx.x < 7)
+    sel_tab[threadIdx.x] = FAST ? hsv_sel_entry_floor(threadIdx.x, RPOS, GPOS, BPOS, NPOS)
+                                : hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     uint4 p = data[i];
-    p.x = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.x, k, sel_tab);
-    p.y = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.y, k, sel_tab);
-    p.z = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.z, k, sel_tab);
-    p.w = hsvfilter_px<FAST, RPOS, GPOS, BPOS, NPOS>(p.w, k, sel_tab);
+    if constexpr (FAST) {
+      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p.x, p.y, k, sel_tab);
+      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p.z, p.w, k, sel_tab);
+    } else {
+      p.x = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.x, k, sel_tab);
+      p.y = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.y, k, sel_tab);
+      p.z = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.z, k, sel_tab);
+      p.w = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.w, k, sel_tab);
+    }
     data[i] = p;
   }
 }
@@ -224,13 +355,13 @@ static int grid_for(mi355_ctx *ctx, size_t work_items, int block, int blocks_per
   return (int)blocks;
 }
 
-template <bool FAST>
+template <int VARIANT>
 static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, int first, int bgr, int grid) {
   dim3 g(grid), b(256);
-  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 0, false>), g, b, 0, ctx->stream, d, n_vec, k);
-  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 0, true>), g, b, 0, ctx->stream, d, n_vec, k);
-  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 1, false>), g, b, 0, ctx->stream, d, n_vec, k);
-  else hipLaunchKernelGGL((hsvfilter_flat_kernel<FAST, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
+  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, false>), g, b, 0, ctx->stream, d, n_vec, k);
+  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, true>), g, b, 0, ctx->stream, d, n_vec, k);
+  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, false>), g, b, 0, ctx->stream, d, n_vec, k);
+  else hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
 }
 
 int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
@@ -245,8 +376,22 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   if (contiguous && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
     const size_t n_vec = total_bytes / 16;
     const int grid = grid_for(ctx, n_vec, 256, 8);
-    if (fast) launch_flat<true>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
-    else launch_flat<false>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
+    if (!fast) {
+      launch_flat<-1>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
+    } else {
+      // x*1+0 == x exactly for the x in [0,1] the conversion produces: identity settings skip the affine step
+      const bool sv_ident = s.saturation_mul == 1.0f && s.saturation_off == 0.0f && s.value_mul == 1.0f && s.value_off == 0.0f;
+      const int shift = s.hue_shift == 0.0f ? HSV_SHIFT_ZERO : (s.hue_shift > 0.0f ? HSV_SHIFT_POS : HSV_SHIFT_NEG);
+      uint4 *d = (uint4 *)d_data;
+      switch (shift | (sv_ident ? 4 : 0)) {
+        case 0: launch_flat<0>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+        case 1: launch_flat<1>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+        case 2: launch_flat<2>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+        case 4: launch_flat<4>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+        case 5: launch_flat<5>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+        default: launch_flat<6>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+      }
+    }
   } else {
     const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
     const int grid = grid_for(ctx, total, 256, 8);
