@@ -39,10 +39,12 @@ __device__ __forceinline__ float div60_hue(float h) {
 
 // a / b for |a| <= 1, 2^-9 < b <= 1 via hardware reciprocal (1 ulp) + one residual correction.
 // q0 = a*y carries <= ~1.5 ulp error; r = a - q0*b is exact in the fma; q0 + r*y then rounds to
-// RN(a/b) unless a/b lies within ~2^-46 relative of a rounding boundary. For the operand set the
-// HSV conversion produces (chroma, value and channel differences of u8/255 quotients) this is
-// verified exhaustively on the device by the all-colours parity test; kernels keep an IEEE
-// variant (template flag) as the fallback.
+// RN(a/b) unless a/b lies within ~2^-46 relative of a rounding boundary. With a correctly rounded
+// reciprocal the sequence is exact for every operand pair the HSV conversion produces (CPU replay,
+// tests/test_exact_math.py); with a reciprocal a full ulp off it mis-rounds ~60 of the 2^24 colours.
+// gfx950's v_rcp_f32 is exact enough on this operand set: the all-colours GPU parity tests compare
+// every (chroma, value, channel-difference) combination the filter can ever see against the oracle.
+// The GENERIC kernels use the IEEE `/` sequence instead.
 __device__ __forceinline__ float div_rcp_refine(float a, float b) {
   float y = __builtin_amdgcn_rcpf(b);
   float q = a * y;

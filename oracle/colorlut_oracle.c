@@ -482,3 +482,19 @@ void oracle_colorlut_rgba64(const oracle_cube *lut, const uint8_t *src, int src_
     }
   }
 }
+
+/* CPU-baseline helper: `n_streams` independent 4-byte-pixel frames, each pushed through
+ * hsvfilter (in place, RGBx layout) then colorlut (RGBA8) by ONE thread — the reference's only scaling
+ * axis is more independent pipelines, each with a single streaming thread. */
+void oracle_hsvfilter_frame(uint8_t *data, size_t data_len, int width, int stride, int pixel_stride,
+                            int first, int bgr, const float settings[5]);
+void oracle_chain_streams(const oracle_cube *lut, uint8_t *frames, uint8_t *outs, int n_streams, int width,
+                          int height, const float settings[5], int nthreads) {
+  const size_t fb = (size_t)width * 4 * (size_t)height;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+  for (int s = 0; s < n_streams; s++) {
+    oracle_hsvfilter_frame(frames + (size_t)s * fb, fb, width, width * 4, 4, 0, 0, settings);
+    oracle_colorlut_rgba8(lut, frames + (size_t)s * fb, width * 4, outs + (size_t)s * fb, width * 4, width, height);
+  }
+}

@@ -48,6 +48,7 @@ def lib():
     L.oracle_colorlut_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.oracle_colorlut_rgba8_mt.argtypes = L.oracle_colorlut_rgba8.argtypes + [C.c_int]
     L.oracle_colorlut_rgba64.argtypes = L.oracle_colorlut_rgba8.argtypes + [C.c_int]
+    L.oracle_chain_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
     L.oracle_echo_ring_len.restype = C.c_size_t
     L.oracle_echo_ring_len.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.oracle_echo_delay_samples.restype = C.c_size_t
@@ -165,6 +166,13 @@ def colorlut_rgba8(cube, src, src_stride, dst, dst_stride, width, height, nthrea
 def colorlut_rgba64(cube, src, src_stride, dst, dst_stride, width, height, le=True):
     lib().oracle_colorlut_rgba64(cube.h, src.ctypes.data, src_stride, dst.ctypes.data, dst_stride, width, height, int(le))
     return dst
+
+
+def chain_streams(cube, frames, outs, n_streams, width, height, settings, nthreads):
+    """n_streams independent frames through hsvfilter (in place) then colorlut, one thread per stream."""
+    st = _f32(settings)
+    lib().oracle_chain_streams(cube.h, frames.ctypes.data, outs.ctypes.data, n_streams, width, height, _fp(st), nthreads)
+    return outs
 
 
 # ---- echo ----
