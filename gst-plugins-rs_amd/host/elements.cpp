@@ -1,0 +1,523 @@
+// elements.cpp — see elements.hpp. Property tables transcribe docs/plugins/gst_plugins_cache.json
+// (hsvfilter :6532, hsvdetector :6418, colorlut :2979, rsaudioecho :11757).
+#include "elements.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "mi355fx_host.h"
+
+namespace mi355host {
+
+// ------------------------------------------------------------------ Element
+
+Element::Element(int device) {
+  int st = 0;
+  ctx_ = mi355_ctx_create(device, &st);
+  if (!ctx_) last_error_ = std::string("cannot create device context: ") + mi355_status_string(st);
+}
+
+Element::~Element() {
+  if (ctx_) mi355_ctx_destroy(ctx_);
+}
+
+const ParamSpec *Element::find_spec(const std::string &name) const {
+  for (const auto &p : properties())
+    if (p.name == name) return &p;
+  return nullptr;
+}
+
+bool Element::set_property(const std::string &name, double v) {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || (ps->type != PropType::Float && ps->type != PropType::Double)) {
+    last_error_ = "no numeric property '" + name + "'";
+    return false;
+  }
+  // g_param_value_validate clamps to [min,max] and g_object_set rejects (with a warning) any value the
+  // clamp changed — that covers out-of-range numbers, infinities and NaN (NaN != NaN after the clamp).
+  if (ps->type == PropType::Float && std::isfinite(v) && std::fabs(v) > (double)FLT_MAX) v = std::copysign(INFINITY, v);
+  if (!(v >= ps->min_num && v <= ps->max_num)) {
+    last_error_ = "value out of range for property '" + name + "'";
+    return false;
+  }
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return store_number(name, v);
+}
+
+bool Element::set_property_u64(const std::string &name, uint64_t v) {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || ps->type != PropType::UInt64) {
+    last_error_ = "no guint64 property '" + name + "'";
+    return false;
+  }
+  if (v == UINT64_MAX) {  // maximum(u64::MAX - 1)
+    last_error_ = "value out of range for property '" + name + "'";
+    return false;
+  }
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return store_u64(name, v);
+}
+
+bool Element::get_property_u64(const std::string &name, uint64_t *v) const {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || ps->type != PropType::UInt64) return false;
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return load_u64(name, v);
+}
+
+bool Element::set_property(const std::string &name, const std::string &v) {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || ps->type != PropType::String) {
+    last_error_ = "no string property '" + name + "'";
+    return false;
+  }
+  // mutable_ready properties cannot change once the element has left READY
+  if (ps->mutability == Mutability::Ready && started_) {
+    last_error_ = "property '" + name + "' can only be changed in NULL or READY state";
+    return false;
+  }
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return store_string(name, v);
+}
+
+bool Element::get_property(const std::string &name, double *v) const {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || (ps->type != PropType::Float && ps->type != PropType::Double)) return false;
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return load_number(name, v);
+}
+
+bool Element::get_property(const std::string &name, std::string *v) const {
+  const ParamSpec *ps = find_spec(name);
+  if (!ps || ps->type != PropType::String) return false;
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return load_string(name, v);
+}
+
+FlowReturn Element::flow_from_status(int status) {
+  if (status == MI355_OK) return FlowReturn::Ok;
+  last_error_ = ctx_ ? mi355_ctx_last_error(ctx_) : "no device context";
+  if (status == MI355_ERR_NOT_CONFIGURED && std::strcmp(factory_name(), "rsaudioecho") == 0) return FlowReturn::NotNegotiated;
+  return FlowReturn::Error;
+}
+
+static ParamSpec float_spec(const char *name, const char *nick, const char *blurb, double def, double lo, double hi,
+                            Mutability m) {
+  ParamSpec p;
+  p.name = name; p.nick = nick; p.blurb = blurb; p.type = PropType::Float;
+  p.def_num = def; p.min_num = lo; p.max_num = hi; p.mutability = m;
+  return p;
+}
+
+// ------------------------------------------------------------------ HsvFilter
+
+HsvFilter::HsvFilter(int device) : Element(device) {}
+
+const ElementMetadata &HsvFilter::metadata() const {
+  static const ElementMetadata m{"HSV filter", "Filter/Effect/Converter/Video",
+                                 "Works within the HSV colorspace to apply transformations to incoming frames",
+                                 "Julien Bardagi <julien.bardagi@gmail.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &HsvFilter::properties() const {
+  static const std::vector<ParamSpec> p = {
+      float_spec("hue-shift", "Hue shift", "Hue shifting in degrees", 0.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+      float_spec("saturation-mul", "Saturation multiplier", "Saturation multiplier to apply to the saturation value (before offset)", 1.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+      float_spec("saturation-off", "Saturation offset", "Saturation offset to add to the saturation value (after multiplier)", 0.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+      float_spec("value-mul", "Value multiplier", "Value multiplier to apply to the value (before offset)", 1.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+      float_spec("value-off", "Value offset", "Value offset to add to the value (after multiplier)", 0.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+  };
+  return p;
+}
+
+std::vector<int> HsvFilter::sink_formats() const {
+  return {MI355_FMT_RGBX, MI355_FMT_XRGB, MI355_FMT_BGRX, MI355_FMT_XBGR, MI355_FMT_RGBA,
+          MI355_FMT_ARGB, MI355_FMT_BGRA, MI355_FMT_ABGR, MI355_FMT_RGB, MI355_FMT_BGR};
+}
+
+bool HsvFilter::store_number(const std::string &n, double v) {
+  const float f = (float)v;
+  if (n == "hue-shift") settings_.hue_shift = f;
+  else if (n == "saturation-mul") settings_.saturation_mul = f;
+  else if (n == "saturation-off") settings_.saturation_off = f;
+  else if (n == "value-mul") settings_.value_mul = f;
+  else if (n == "value-off") settings_.value_off = f;
+  else return false;
+  return true;
+}
+
+bool HsvFilter::load_number(const std::string &n, double *v) const {
+  if (n == "hue-shift") *v = settings_.hue_shift;
+  else if (n == "saturation-mul") *v = settings_.saturation_mul;
+  else if (n == "saturation-off") *v = settings_.saturation_off;
+  else if (n == "value-mul") *v = settings_.value_mul;
+  else if (n == "value-off") *v = settings_.value_off;
+  else return false;
+  return true;
+}
+
+FlowReturn HsvFilter::transform_frame_ip(VideoFrame &frame) {
+  if (!ctx_) return FlowReturn::Error;
+  bool ok = false;
+  for (int f : sink_formats()) ok |= (f == frame.format);
+  if (!ok) {  // `_ => unreachable!()` in the reference: negotiation guarantees a template format
+    last_error_ = "hsvfilter: format not in the pad template";
+    return FlowReturn::NotNegotiated;
+  }
+  mi355_hsv_settings snap;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);  // `let settings = *self.settings.lock().unwrap();`
+    snap = settings_;
+  }
+  return flow_from_status(mi355_hsvfilter_frame_ip(ctx_, frame.data, frame.size, frame.width, frame.stride, frame.format, &snap));
+}
+
+// ------------------------------------------------------------------ HsvDetector
+
+HsvDetector::HsvDetector(int device) : Element(device) {}
+
+const ElementMetadata &HsvDetector::metadata() const {
+  static const ElementMetadata m{"HSV detector", "Filter/Effect/Converter/Video",
+                                 "Works within the HSV colorspace to mark positive pixels",
+                                 "Julien Bardagi <julien.bardagi@gmail.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &HsvDetector::properties() const {
+  static const std::vector<ParamSpec> p = {
+      float_spec("hue-ref", "Hue reference", "Hue reference in degrees", 0.0, -FLT_MAX, FLT_MAX, Mutability::Playing),
+      float_spec("hue-var", "Hue variation", "Allowed hue variation from the reference hue angle, in degrees", 10.0, 0.0, 180.0, Mutability::Playing),
+      float_spec("saturation-ref", "Saturation reference", "Reference saturation value", 0.0, 0.0, 1.0, Mutability::Playing),
+      float_spec("saturation-var", "Saturation variation", "Allowed saturation variation from the reference value", 0.15, 0.0, 1.0, Mutability::Playing),
+      float_spec("value-ref", "Value reference", "Reference value value", 0.0, 0.0, 1.0, Mutability::Playing),
+      float_spec("value-var", "Value variation", "Allowed value variation from the reference value", 0.3, 0.0, 1.0, Mutability::Playing),
+  };
+  return p;
+}
+
+std::vector<int> HsvDetector::sink_formats() const {
+  return {MI355_FMT_RGBX, MI355_FMT_XRGB, MI355_FMT_BGRX, MI355_FMT_XBGR, MI355_FMT_RGB, MI355_FMT_BGR};
+}
+std::vector<int> HsvDetector::src_formats() const { return {MI355_FMT_RGBA, MI355_FMT_ARGB, MI355_FMT_BGRA, MI355_FMT_ABGR}; }
+
+bool HsvDetector::store_number(const std::string &n, double v) {
+  const float f = (float)v;
+  if (n == "hue-ref") settings_.hue_ref = f;
+  else if (n == "hue-var") settings_.hue_var = f;
+  else if (n == "saturation-ref") settings_.saturation_ref = f;
+  else if (n == "saturation-var") settings_.saturation_var = f;
+  else if (n == "value-ref") settings_.value_ref = f;
+  else if (n == "value-var") settings_.value_var = f;
+  else return false;
+  return true;
+}
+
+bool HsvDetector::load_number(const std::string &n, double *v) const {
+  if (n == "hue-ref") *v = settings_.hue_ref;
+  else if (n == "hue-var") *v = settings_.hue_var;
+  else if (n == "saturation-ref") *v = settings_.saturation_ref;
+  else if (n == "saturation-var") *v = settings_.saturation_var;
+  else if (n == "value-ref") *v = settings_.value_ref;
+  else if (n == "value-var") *v = settings_.value_var;
+  else return false;
+  return true;
+}
+
+FlowReturn HsvDetector::transform_frame(const VideoFrame &in, VideoFrame &out) {
+  if (!ctx_) return FlowReturn::Error;
+  mi355_hsvdetect_settings snap;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    snap = settings_;
+  }
+  return flow_from_status(mi355_hsvdetect_frame(ctx_, in.data, in.size, in.stride, in.format, out.data, out.size, out.stride,
+                                                out.format, in.width, &snap));
+}
+
+// ------------------------------------------------------------------ ColorLut
+
+ColorLut::ColorLut(int device) : Element(device) {}
+
+const ElementMetadata &ColorLut::metadata() const {
+  static const ElementMetadata m{"Color LUT", "Filter/Effect/Video", "Apply color lookup table",
+                                 "Seungha Yang <seungha@centricular.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &ColorLut::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    ParamSpec s;
+    s.name = "location"; s.nick = "Location"; s.blurb = "Location of the LUT file to read from";
+    s.type = PropType::String; s.mutability = Mutability::Ready;
+    return std::vector<ParamSpec>{s};
+  }();
+  return p;
+}
+
+std::vector<int> ColorLut::sink_formats() const { return {MI355_FMT_RGBA64_LE, MI355_FMT_RGBA64_BE, MI355_FMT_RGBA}; }
+
+bool ColorLut::store_string(const std::string &n, const std::string &v) {
+  if (n != "location") return false;
+  location_ = v;
+  have_location_ = true;
+  return true;
+}
+bool ColorLut::load_string(const std::string &n, std::string *v) const {
+  if (n != "location" || !have_location_) return false;
+  *v = location_;
+  return true;
+}
+
+bool ColorLut::start() {
+  if (!ctx_) return false;
+  std::string loc;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    if (!have_location_) {  // ResourceError::Settings (colorlut/imp.rs:175-180)
+      last_error_ = "LUT file location is not configured";
+      return false;
+    }
+    loc = location_;
+  }
+  char err[512] = {0};
+  mi355h_cube *cube = mi355h_cube_parse_file(loc.c_str(), err, sizeof err);
+  if (!cube) {  // ResourceError::Read (colorlut/imp.rs:182-187)
+    last_error_ = "Failed to parse LUT file " + loc + ": " + err;
+    return false;
+  }
+  float scale[3], offset[3];
+  mi355h_cube_domain(cube, scale, offset);
+  const int rc = mi355_colorlut_load(ctx_, mi355h_cube_is3d(cube), mi355h_cube_size(cube), mi355h_cube_table(cube), scale, offset);
+  mi355h_cube_free(cube);
+  if (rc != MI355_OK) {
+    last_error_ = mi355_ctx_last_error(ctx_);
+    return false;
+  }
+  started_ = true;
+  return true;
+}
+
+bool ColorLut::stop() {
+  if (ctx_) mi355_colorlut_unload(ctx_);
+  started_ = false;
+  return true;
+}
+
+FlowReturn ColorLut::transform_frame(const VideoFrame &in, VideoFrame &out) {
+  if (!ctx_) return FlowReturn::Error;
+  if (in.format != out.format || in.width != out.width || in.height != out.height) {
+    last_error_ = "colorlut: input and output caps differ";
+    return FlowReturn::NotNegotiated;
+  }
+  return flow_from_status(mi355_colorlut_frame(ctx_, in.data, in.stride, out.data, out.stride, in.width, in.height, in.format));
+}
+
+// ------------------------------------------------------------------ AudioEcho
+
+AudioEcho::AudioEcho(int device) : Element(device) {}
+
+const ElementMetadata &AudioEcho::metadata() const {
+  static const ElementMetadata m{"Audio echo", "Filter/Effect/Audio", "Adds an echo or reverb effect to an audio stream",
+                                 "Sebastian Dröge <sebastian@centricular.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &AudioEcho::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    auto u64 = [](const char *n, const char *nick, const char *blurb, double def) {
+      ParamSpec s;
+      s.name = n; s.nick = nick; s.blurb = blurb; s.type = PropType::UInt64;
+      s.def_num = def; s.min_num = 0; s.max_num = 18446744073709551614.0; s.mutability = Mutability::Ready;
+      return s;
+    };
+    auto dbl = [](const char *n, const char *nick, const char *blurb, double def) {
+      ParamSpec s;
+      s.name = n; s.nick = nick; s.blurb = blurb; s.type = PropType::Double;
+      s.def_num = def; s.min_num = 0.0; s.max_num = 1.0; s.mutability = Mutability::Ready;
+      return s;
+    };
+    return std::vector<ParamSpec>{
+        u64("max-delay", "Maximum Delay", "Maximum delay of the echo in nanoseconds (can't be changed in PLAYING or PAUSED state)", 1e9),
+        u64("delay", "Delay", "Delay of the echo in nanoseconds", 5e11),
+        dbl("intensity", "Intensity", "Intensity of the echo", 0.5),
+        dbl("feedback", "Feedback", "Amount of feedback", 0.0),
+    };
+  }();
+  return p;
+}
+
+bool AudioEcho::store_number(const std::string &n, double v) {
+  if (n == "intensity") intensity_ = v;
+  else if (n == "feedback") feedback_ = v;
+  else return false;
+  return true;
+}
+bool AudioEcho::load_number(const std::string &n, double *v) const {
+  if (n == "intensity") *v = intensity_;
+  else if (n == "feedback") *v = feedback_;
+  else return false;
+  return true;
+}
+bool AudioEcho::store_u64(const std::string &n, uint64_t v) {
+  if (n == "max-delay") {
+    if (!have_state_) max_delay_ns_ = v;  // only while there is no state (audioecho/imp.rs:137-142)
+  } else if (n == "delay") {
+    delay_ns_ = v;
+  } else {
+    return false;
+  }
+  return true;
+}
+bool AudioEcho::load_u64(const std::string &n, uint64_t *v) const {
+  if (n == "max-delay") *v = max_delay_ns_;
+  else if (n == "delay") *v = delay_ns_;
+  else return false;
+  return true;
+}
+
+bool AudioEcho::setup(const AudioInfo &info) {
+  if (!ctx_) return false;
+  uint64_t max_delay;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    max_delay = max_delay_ns_;
+  }
+  // size = (max_delay * rate).seconds(); buffer_size = size * channels (audioecho/imp.rs:250-251)
+  const uint64_t size = (max_delay * (uint64_t)info.rate) / 1000000000ull;
+  const size_t ring_len = (size_t)size * (size_t)info.channels;
+  if (mi355_echo_setup(ctx_, ring_len) != MI355_OK) {
+    last_error_ = mi355_ctx_last_error(ctx_);
+    return false;
+  }
+  info_ = info;
+  have_state_ = true;
+  return true;
+}
+
+FlowReturn AudioEcho::transform_ip(void *data, size_t nbytes) {
+  if (!ctx_) return FlowReturn::Error;
+  uint64_t delay, max_delay;
+  double intensity, feedback;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    delay = delay_ns_; max_delay = max_delay_ns_; intensity = intensity_; feedback = feedback_;
+  }
+  if (delay > max_delay) delay = max_delay;  // cmp::min(settings.max_delay, settings.delay) (imp.rs:207)
+  if (!have_state_) {                         // ok_or(FlowError::NotNegotiated) (imp.rs:210)
+    last_error_ = "rsaudioecho: not negotiated";
+    return FlowReturn::NotNegotiated;
+  }
+  // delay_frames = (delay * channels * rate).seconds() (imp.rs:74-77)
+  const size_t delay_samples = (size_t)((delay * (uint64_t)info_.channels * (uint64_t)info_.rate) / 1000000000ull);
+  int rc;
+  if (info_.f64) rc = mi355_echo_process_f64(ctx_, (double *)data, nbytes / sizeof(double), delay_samples, intensity, feedback);
+  else rc = mi355_echo_process_f32(ctx_, (float *)data, nbytes / sizeof(float), delay_samples, intensity, feedback);
+  return flow_from_status(rc);
+}
+
+bool AudioEcho::stop() {
+  if (ctx_) mi355_echo_reset(ctx_);
+  have_state_ = false;
+  started_ = false;
+  return true;
+}
+
+// ------------------------------------------------------------------ registry
+
+std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho"}; }
+
+std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error) {
+  std::unique_ptr<Element> e;
+  if (factory == "hsvfilter") e.reset(new HsvFilter(device));
+  else if (factory == "hsvdetector") e.reset(new HsvDetector(device));
+  else if (factory == "colorlut") e.reset(new ColorLut(device));
+  else if (factory == "rsaudioecho") e.reset(new AudioEcho(device));
+  else {
+    if (error) *error = "no such element factory: " + factory;
+    return nullptr;
+  }
+  if (!e->last_error().empty()) {  // context creation failed: no device, no element (no CPU fallback)
+    if (error) *error = e->last_error();
+    return nullptr;
+  }
+  return e;
+}
+
+}  // namespace mi355host
+
+// ------------------------------------------------------------------ flat C API over the element objects
+// (what the Python tests and the compile-gated GStreamer shim call)
+using namespace mi355host;
+
+struct mi355el { std::unique_ptr<Element> e; std::string err; };
+
+extern "C" {
+
+mi355el *mi355el_factory_make(const char *factory, int device, char *err, size_t errlen) {
+  std::string msg;
+  auto e = element_factory_make(factory ? factory : "", device, &msg);
+  if (!e) {
+    if (err && errlen) { std::strncpy(err, msg.c_str(), errlen - 1); err[errlen - 1] = 0; }
+    return nullptr;
+  }
+  auto *h = new mi355el();
+  h->e = std::move(e);
+  return h;
+}
+void mi355el_free(mi355el *h) { delete h; }
+const char *mi355el_last_error(const mi355el *h) { return h ? h->e->last_error().c_str() : "null element"; }
+const char *mi355el_type_name(const mi355el *h) { return h->e->type_name(); }
+const char *mi355el_factory_name(const mi355el *h) { return h->e->factory_name(); }
+const char *mi355el_klass(const mi355el *h) { return h->e->metadata().klass.c_str(); }
+const char *mi355el_long_name(const mi355el *h) { return h->e->metadata().long_name.c_str(); }
+int mi355el_n_properties(const mi355el *h) { return (int)h->e->properties().size(); }
+const char *mi355el_property_name(const mi355el *h, int i) { return h->e->properties().at((size_t)i).name.c_str(); }
+int mi355el_property_info(const mi355el *h, int i, int *type, double *def, double *lo, double *hi, int *mutable_playing) {
+  const ParamSpec &p = h->e->properties().at((size_t)i);
+  *type = (int)p.type; *def = p.def_num; *lo = p.min_num; *hi = p.max_num; *mutable_playing = p.mutability == Mutability::Playing;
+  return 0;
+}
+int mi355el_n_formats(const mi355el *h, int src) { return (int)(src ? h->e->src_formats() : h->e->sink_formats()).size(); }
+int mi355el_format(const mi355el *h, int src, int i) { return (src ? h->e->src_formats() : h->e->sink_formats()).at((size_t)i); }
+int mi355el_set_double(mi355el *h, const char *name, double v) { return h->e->set_property(name, v) ? 0 : -1; }
+int mi355el_get_double(const mi355el *h, const char *name, double *v) { return h->e->get_property(name, v) ? 0 : -1; }
+int mi355el_set_u64(mi355el *h, const char *name, uint64_t v) { return h->e->set_property_u64(name, v) ? 0 : -1; }
+int mi355el_get_u64(const mi355el *h, const char *name, uint64_t *v) { return h->e->get_property_u64(name, v) ? 0 : -1; }
+int mi355el_set_string(mi355el *h, const char *name, const char *v) { return h->e->set_property(name, std::string(v ? v : "")) ? 0 : -1; }
+int mi355el_start(mi355el *h) { return h->e->start() ? 0 : -1; }
+int mi355el_stop(mi355el *h) { return h->e->stop() ? 0 : -1; }
+
+int mi355el_transform_frame_ip(mi355el *h, int format, int width, int height, int stride, uint8_t *data, size_t size) {
+  auto *f = dynamic_cast<HsvFilter *>(h->e.get());
+  if (!f) return (int)FlowReturn::Error;
+  VideoFrame fr;
+  fr.format = format; fr.width = width; fr.height = height; fr.stride = stride; fr.data = data; fr.size = size;
+  return (int)f->transform_frame_ip(fr);
+}
+
+int mi355el_transform_frame(mi355el *h, int in_format, int width, int height, int in_stride, const uint8_t *in, size_t in_size,
+                            int out_format, int out_stride, uint8_t *out, size_t out_size) {
+  VideoFrame a, b;
+  a.format = in_format; a.width = width; a.height = height; a.stride = in_stride; a.data = const_cast<uint8_t *>(in); a.size = in_size;
+  b.format = out_format; b.width = width; b.height = height; b.stride = out_stride; b.data = out; b.size = out_size;
+  if (auto *c = dynamic_cast<ColorLut *>(h->e.get())) return (int)c->transform_frame(a, b);
+  if (auto *d = dynamic_cast<HsvDetector *>(h->e.get())) return (int)d->transform_frame(a, b);
+  return (int)FlowReturn::Error;
+}
+
+int mi355el_audio_setup(mi355el *h, int rate, int channels, int f64) {
+  auto *e = dynamic_cast<AudioEcho *>(h->e.get());
+  if (!e) return -1;
+  AudioInfo info;
+  info.rate = rate; info.channels = channels; info.f64 = f64 != 0;
+  return e->setup(info) ? 0 : -1;
+}
+int mi355el_audio_transform_ip(mi355el *h, void *data, size_t nbytes) {
+  auto *e = dynamic_cast<AudioEcho *>(h->e.get());
+  if (!e) return (int)FlowReturn::Error;
+  return (int)e->transform_ip(data, nbytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// elements.hpp — host-side mirror of the reference elements' operator interface for the hot path.
+//
+// The reference elements are Rust GObject subclasses on gstreamer-rs; neither Rust nor the
+// GStreamer/GLib headers exist in this image, so the element layer above the C ABI is restated here in
+// C++ with the same names, property surface (docs/plugins/gst_plugins_cache.json), vfunc names,
+// argument meaning and error behaviour:
+//   HsvFilter    video/hsv/src/hsvfilter/imp.rs      (VideoFilter, AlwaysInPlace: transform_frame_ip)
+//   HsvDetector  video/hsv/src/hsvdetector/imp.rs    (VideoFilter, NeverInPlace: transform_frame)
+//   ColorLut     video/colorlut/src/colorlut/imp.rs  (VideoFilter, NeverInPlace: start/stop/transform_frame)
+//   AudioEcho    audio/audiofx/src/audioecho/imp.rs  (AudioFilter, AlwaysInPlace: setup/transform_ip/stop)
+// Each object owns one mi355_ctx (include/mi355fx.h) and forwards its per-buffer vfunc to the C ABI,
+// exactly where the Rust element would call its inner loop. The GStreamer shim (gst/) wraps these.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355fx.h"
+
+namespace mi355host {
+
+// GstFlowReturn values (gst/gstpad.h)
+enum class FlowReturn : int { Ok = 0, Eos = -3, NotNegotiated = -4, Error = -5 };
+
+enum class PropType { Float, Double, UInt64, String };
+enum class Mutability { Ready, Playing };  // mutable_ready / mutable_playing
+
+struct ParamSpec {
+  std::string name, nick, blurb;
+  PropType type;
+  double def_num = 0, min_num = 0, max_num = 0;  // numeric types
+  Mutability mutability = Mutability::Ready;
+};
+
+struct ElementMetadata {
+  std::string long_name, klass, description, author;
+};
+
+// GstVideoFrame restricted to what the hot path reads: plane 0 of a packed-RGB frame.
+struct VideoFrame {
+  int format = MI355_FMT_RGBA;  // mi355_video_format
+  int width = 0, height = 0;
+  int stride = 0;               // plane_stride()[0]
+  uint8_t *data = nullptr;      // plane_data(0)
+  size_t size = 0;              // plane_data(0).len()
+};
+
+struct AudioInfo {
+  int rate = 0, channels = 0;
+  bool f64 = false;  // AUDIO_FORMAT_F64 vs AUDIO_FORMAT_F32 (interleaved)
+};
+
+class Element {
+ public:
+  virtual ~Element();
+  virtual const char *factory_name() const = 0;   // "hsvfilter", ...
+  virtual const char *type_name() const = 0;      // GType name "GstHsvFilter", ...
+  virtual const ElementMetadata &metadata() const = 0;
+  virtual const std::vector<ParamSpec> &properties() const = 0;
+  virtual std::vector<int> sink_formats() const = 0;  // pad template caps (video formats / audio: F32,F64)
+  virtual std::vector<int> src_formats() const = 0;
+
+  // g_object_set / g_object_get for the element's own properties. Out-of-range values are rejected
+  // (GLib warns and leaves the property unchanged); unknown names are an error.
+  bool set_property(const std::string &name, double v);
+  bool set_property(const std::string &name, const std::string &v);
+  bool set_property_u64(const std::string &name, uint64_t v);
+  bool get_property_u64(const std::string &name, uint64_t *v) const;
+  bool get_property(const std::string &name, double *v) const;
+  bool get_property(const std::string &name, std::string *v) const;
+
+  // BaseTransform::start / stop (state change READY<->PAUSED)
+  virtual bool start() { started_ = true; return true; }
+  virtual bool stop() { started_ = false; return true; }
+  bool started() const { return started_; }
+
+  const std::string &last_error() const { return last_error_; }
+
+ protected:
+  explicit Element(int device);
+  const ParamSpec *find_spec(const std::string &name) const;
+  virtual bool store_number(const std::string &name, double v) = 0;
+  virtual bool load_number(const std::string &name, double *v) const = 0;
+  virtual bool store_u64(const std::string &, uint64_t) { return false; }
+  virtual bool load_u64(const std::string &, uint64_t *) const { return false; }
+  virtual bool store_string(const std::string &, const std::string &) { return false; }
+  virtual bool load_string(const std::string &, std::string *) const { return false; }
+  FlowReturn flow_from_status(int status);
+  mi355_ctx *ctx_ = nullptr;
+  mutable std::mutex settings_mutex_;  // settings behind a Mutex, snapshotted once per buffer
+  bool started_ = false;
+  std::string last_error_;
+};
+
+class HsvFilter final : public Element {
+ public:
+  explicit HsvFilter(int device);
+  const char *factory_name() const override { return "hsvfilter"; }
+  const char *type_name() const override { return "GstHsvFilter"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override;
+  std::vector<int> src_formats() const override { return sink_formats(); }
+  // VideoFilterImpl::transform_frame_ip (hsvfilter/imp.rs:323-376)
+  FlowReturn transform_frame_ip(VideoFrame &frame);
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  mi355_hsv_settings settings_{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};  // hsvfilter/imp.rs:25-29
+};
+
+class HsvDetector final : public Element {
+ public:
+  explicit HsvDetector(int device);
+  const char *factory_name() const override { return "hsvdetector"; }
+  const char *type_name() const override { return "GstHsvDetector"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override;
+  std::vector<int> src_formats() const override;
+  // VideoFilterImpl::transform_frame (hsvdetector/imp.rs:423-707)
+  FlowReturn transform_frame(const VideoFrame &in, VideoFrame &out);
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  mi355_hsvdetect_settings settings_{0.0f, 10.0f, 0.0f, 0.15f, 0.0f, 0.3f};  // hsvdetector/imp.rs:25-30
+};
+
+class ColorLut final : public Element {
+ public:
+  explicit ColorLut(int device);
+  const char *factory_name() const override { return "colorlut"; }
+  const char *type_name() const override { return "GstColorLut"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override;
+  std::vector<int> src_formats() const override { return sink_formats(); }
+  bool start() override;  // parse `location`, install the LUT (colorlut/imp.rs:168-194)
+  bool stop() override;   // drop the LUT (colorlut/imp.rs:196-199)
+  // VideoFilterImpl::transform_frame (colorlut/imp.rs:203-223)
+  FlowReturn transform_frame(const VideoFrame &in, VideoFrame &out);
+
+ private:
+  bool store_number(const std::string &, double) override { return false; }
+  bool load_number(const std::string &, double *) const override { return false; }
+  bool store_string(const std::string &name, const std::string &v) override;
+  bool load_string(const std::string &name, std::string *v) const override;
+  bool have_location_ = false;
+  std::string location_;
+};
+
+class AudioEcho final : public Element {
+ public:
+  explicit AudioEcho(int device);
+  const char *factory_name() const override { return "rsaudioecho"; }
+  const char *type_name() const override { return "GstRsAudioEcho"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {0, 1}; }  // F32, F64 interleaved
+  std::vector<int> src_formats() const override { return {0, 1}; }
+  // AudioFilterImpl::setup (audioecho/imp.rs:248-259)
+  bool setup(const AudioInfo &info);
+  // BaseTransformImpl::transform_ip (audioecho/imp.rs:205-227): `data` = the mapped buffer bytes
+  FlowReturn transform_ip(void *data, size_t nbytes);
+  bool stop() override;  // drops the state (audioecho/imp.rs:229-234)
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  bool store_u64(const std::string &name, uint64_t v) override;
+  bool load_u64(const std::string &name, uint64_t *v) const override;
+  // audioecho/imp.rs:31-34
+  uint64_t max_delay_ns_ = 1000000000ull, delay_ns_ = 500ull * 1000000000ull;
+  double intensity_ = 0.5, feedback_ = 0.0;
+  bool have_state_ = false;
+  AudioInfo info_;
+};
+
+// gst_element_factory_make(): nullptr for an unknown factory name or when no device context can be made.
+std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error);
+// Names registered by the plugins (video/hsv/src/lib.rs:23-27, video/colorlut/src/lib.rs, audio/audiofx/src/lib.rs)
+std::vector<std::string> registered_factories();
+
+}  // namespace mi355host

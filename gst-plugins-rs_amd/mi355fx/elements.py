@@ -1,0 +1,143 @@
+"""ctypes binding of the host-side element layer (gst-plugins-rs_amd/host/elements.cpp): the C++ mirror
+of the reference elements' GObject/BaseTransform surface. Tests drive the hot path through it the way
+gst_check::Harness drives the real elements (audio/hrtf/tests/hrtfrender.rs:58-92)."""
+import ctypes as C
+
+import numpy as np
+
+from . import FMT
+from .cube import load_host_library
+
+FLOW_OK, FLOW_EOS, FLOW_NOT_NEGOTIATED, FLOW_ERROR = 0, -3, -4, -5
+PROP_FLOAT, PROP_DOUBLE, PROP_UINT64, PROP_STRING = 0, 1, 2, 3
+FMT_NAME = {v: k for k, v in FMT.items()}
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = load_host_library()
+    if not _bound:
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        sig = {
+            "mi355el_factory_make": (vp, [C.c_char_p, i, C.c_char_p, sz]),
+            "mi355el_free": (None, [vp]),
+            "mi355el_last_error": (C.c_char_p, [vp]),
+            "mi355el_type_name": (C.c_char_p, [vp]),
+            "mi355el_factory_name": (C.c_char_p, [vp]),
+            "mi355el_klass": (C.c_char_p, [vp]),
+            "mi355el_long_name": (C.c_char_p, [vp]),
+            "mi355el_n_properties": (i, [vp]),
+            "mi355el_property_name": (C.c_char_p, [vp, i]),
+            "mi355el_property_info": (i, [vp, i, C.POINTER(i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i)]),
+            "mi355el_n_formats": (i, [vp, i]),
+            "mi355el_format": (i, [vp, i, i]),
+            "mi355el_set_double": (i, [vp, C.c_char_p, C.c_double]),
+            "mi355el_get_double": (i, [vp, C.c_char_p, C.POINTER(C.c_double)]),
+            "mi355el_set_u64": (i, [vp, C.c_char_p, C.c_uint64]),
+            "mi355el_get_u64": (i, [vp, C.c_char_p, C.POINTER(C.c_uint64)]),
+            "mi355el_set_string": (i, [vp, C.c_char_p, C.c_char_p]),
+            "mi355el_start": (i, [vp]),
+            "mi355el_stop": (i, [vp]),
+            "mi355el_transform_frame_ip": (i, [vp, i, i, i, i, vp, sz]),
+            "mi355el_transform_frame": (i, [vp, i, i, i, i, vp, sz, i, i, vp, sz]),
+            "mi355el_audio_setup": (i, [vp, i, i, i]),
+            "mi355el_audio_transform_ip": (i, [vp, vp, sz]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _bound = True
+    return L
+
+
+class ElementError(RuntimeError):
+    pass
+
+
+class Element:
+    """gst::ElementFactory::make(factory) on the mirror layer."""
+
+    def __init__(self, factory, device=0):
+        L = _lib()
+        err = C.create_string_buffer(512)
+        self.h = L.mi355el_factory_make(factory.encode(), device, err, 512)
+        if not self.h:
+            raise ElementError(err.value.decode("utf-8", "replace"))
+        self.L = L
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi355el_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- introspection (gst-inspect surface)
+    @property
+    def type_name(self):
+        return self.L.mi355el_type_name(self.h).decode()
+
+    @property
+    def klass(self):
+        return self.L.mi355el_klass(self.h).decode()
+
+    @property
+    def last_error(self):
+        return self.L.mi355el_last_error(self.h).decode("utf-8", "replace")
+
+    def properties(self):
+        out = {}
+        for k in range(self.L.mi355el_n_properties(self.h)):
+            t, m = C.c_int(), C.c_int()
+            d, lo, hi = C.c_double(), C.c_double(), C.c_double()
+            self.L.mi355el_property_info(self.h, k, C.byref(t), C.byref(d), C.byref(lo), C.byref(hi), C.byref(m))
+            out[self.L.mi355el_property_name(self.h, k).decode()] = dict(type=t.value, default=d.value, min=lo.value, max=hi.value,
+                                                                         mutable="playing" if m.value else "ready")
+        return out
+
+    def formats(self, src=False):
+        return [FMT_NAME.get(self.L.mi355el_format(self.h, int(src), k)) for k in range(self.L.mi355el_n_formats(self.h, int(src)))]
+
+    # ---- g_object_set / get
+    def set_property(self, name, value):
+        n = name.encode()
+        if isinstance(value, str):
+            rc = self.L.mi355el_set_string(self.h, n, value.encode())
+        elif isinstance(value, int) and not isinstance(value, bool) and self.properties().get(name, {}).get("type") == PROP_UINT64:
+            rc = self.L.mi355el_set_u64(self.h, n, value)
+        else:
+            rc = self.L.mi355el_set_double(self.h, n, float(value))
+        return rc == 0
+
+    def get_property(self, name):
+        n = name.encode()
+        if self.properties()[name]["type"] == PROP_UINT64:
+            v = C.c_uint64()
+            assert self.L.mi355el_get_u64(self.h, n, C.byref(v)) == 0
+            return v.value
+        v = C.c_double()
+        assert self.L.mi355el_get_double(self.h, n, C.byref(v)) == 0
+        return v.value
+
+    # ---- vfuncs
+    def start(self):
+        return self.L.mi355el_start(self.h) == 0
+
+    def stop(self):
+        return self.L.mi355el_stop(self.h) == 0
+
+    def transform_frame_ip(self, fmt, width, height, stride, data):
+        return self.L.mi355el_transform_frame_ip(self.h, FMT[fmt], width, height, stride, data.ctypes.data, data.nbytes)
+
+    def transform_frame(self, in_fmt, width, height, in_stride, src, out_fmt, out_stride, dst):
+        return self.L.mi355el_transform_frame(self.h, FMT[in_fmt], width, height, in_stride, src.ctypes.data, src.nbytes,
+                                              FMT[out_fmt], out_stride, dst.ctypes.data, dst.nbytes)
+
+    def audio_setup(self, rate, channels, f64=False):
+        return self.L.mi355el_audio_setup(self.h, rate, channels, int(f64)) == 0
+
+    def audio_transform_ip(self, data):
+        assert isinstance(data, np.ndarray) and data.flags.c_contiguous
+        return self.L.mi355el_audio_transform_ip(self.h, data.ctypes.data, data.nbytes)

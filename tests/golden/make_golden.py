@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerates the fixtures in tests/golden/.
+  surface : element_surface.json from /root/reference/docs/plugins/gst_plugins_cache.json (introspection DATA)
+  crc     : pixel_crc.json — CRC-32 of the oracle's outputs on the seeded synthetic inputs
+"""
+import json
+import os
+import re
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gst-plugins-rs_amd"))
+
+
+def surface():
+    d = json.load(open("/root/reference/docs/plugins/gst_plugins_cache.json"))
+    out = {}
+    for plug, els in (("hsv", ["hsvfilter", "hsvdetector"]), ("colorlut", ["colorlut"]), ("rsaudiofx", ["rsaudioecho"])):
+        for e in els:
+            el = d[plug]["elements"][e]
+            props = {n: {k: p[k] for k in ("type", "default", "min", "max", "mutable") if k in p}
+                     for n, p in el["properties"].items() if n not in ("name", "parent", "qos")}
+            spec = {"type_name": el["hierarchy"][0], "klass": el["klass"], "properties": props}
+            if plug != "rsaudiofx":
+                def fmts(caps):
+                    return [t.strip() for t in re.search(r"format:\s*\{([^}]*)\}", caps).group(1).split(",")]
+                spec["sink_formats"] = fmts(el["pad-templates"]["sink"]["caps"])
+                spec["src_formats"] = fmts(el["pad-templates"]["src"]["caps"])
+            out[e] = spec
+    json.dump(out, open(os.path.join(HERE, "element_surface.json"), "w"), indent=1, sort_keys=True)
+
+
+def crc_cases():
+    """name -> bytes of the oracle output. Shared with tests/test_golden.py."""
+    import numpy as np
+    from oracle import oracle as O
+    from mi355fx import synth
+    ac = synth.allcolors()
+    out = {}
+    for name, st in synth.HSV_SETTINGS.items():
+        buf = ac.copy().reshape(-1)
+        O.hsvfilter(buf, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+        out["hsvfilter_allcolors_rgba_" + name] = buf.tobytes()
+    buf = ac.copy().reshape(-1)
+    O.hsvfilter(buf, 4096, 4096 * 4, 4, 1, True, synth.HSV_SETTINGS["mixed"], nthreads=8)
+    out["hsvfilter_allcolors_xbgr_mixed"] = buf.tobytes()
+    for tag, text in (("lut33", synth.cube_text_3d(33)), ("lut17_domain", synth.cube_text_3d(17, amp=0.07, domain=((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9)))),
+                      ("lut1d64", synth.cube_text_1d(64))):
+        dst = np.zeros_like(ac)
+        O.colorlut_rgba8(O.Cube.parse(text), ac, 4096 * 4, dst, 4096 * 4, 4096, 4096, nthreads=8)
+        out["colorlut_allcolors_" + tag] = dst.tobytes()
+    e = O.Echo(10 ** 9, 48000, 2)
+    x = synth.sine_stereo_f32()
+    e.process(x, 250 * 10 ** 6, 0.6, 0.4)
+    out["echo_config1_f32"] = x.tobytes()
+    return out
+
+
+def crc():
+    vals = {k: zlib.crc32(v) for k, v in crc_cases().items()}
+    json.dump(vals, open(os.path.join(HERE, "pixel_crc.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("surface", "all") and os.path.exists("/root/reference"):
+        surface()
+    if what in ("crc", "all"):
+        crc()

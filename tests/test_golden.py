@@ -1,0 +1,46 @@
+"""Golden fixtures: the oracle must keep producing the committed CRCs (CPU), and the HIP path must
+produce the same CRCs (GPU) — a checksum-of-checksums tie between the two test tiers."""
+import importlib.util
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "pixel_crc.json")))
+
+
+def test_oracle_reproduces_committed_crcs():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    got = {k: zlib.crc32(v) for k, v in mg.crc_cases().items()}
+    assert got == GOLDEN
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_committed_crcs(ctx, synth):
+    from mi355fx.cube import parse_cube
+    ac = synth.allcolors()
+    got = {}
+    for name, st in synth.HSV_SETTINGS.items():
+        buf = ac.copy().reshape(-1)
+        ctx.hsvfilter_frame_ip(buf, 4096, 4096 * 4, "RGBA", st)
+        got["hsvfilter_allcolors_rgba_" + name] = zlib.crc32(buf.tobytes())
+    buf = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(buf, 4096, 4096 * 4, "xBGR", synth.HSV_SETTINGS["mixed"])
+    got["hsvfilter_allcolors_xbgr_mixed"] = zlib.crc32(buf.tobytes())
+    for tag, text in (("lut33", synth.cube_text_3d(33)), ("lut17_domain", synth.cube_text_3d(17, amp=0.07, domain=((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9)))),
+                      ("lut1d64", synth.cube_text_1d(64))):
+        lut = parse_cube(text)
+        ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+        dst = np.zeros_like(ac)
+        ctx.colorlut_frame(ac, 4096 * 4, dst, 4096 * 4, 4096, 4096, "RGBA")
+        got["colorlut_allcolors_" + tag] = zlib.crc32(dst.tobytes())
+    ctx.echo_setup(96000)
+    x = synth.sine_stereo_f32()
+    ctx.echo_process(x, 24000, 0.6, 0.4)
+    got["echo_config1_f32"] = zlib.crc32(x.tobytes())
+    assert got == GOLDEN
