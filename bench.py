@@ -179,6 +179,17 @@ def main():
         else:
             dom, dom_ms = "hsvfilter_flat_kernel", hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM bytes/launch of the dominant kernel from the last committed rocprofv3 --pmc passes
+        # (tools/collect_profiles.sh + tools/summarize_profiles.py); counters cannot be read from inside
+        # the process, so this is the profile's per-launch figure for the same batch size, or null.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            for kname, rec in pmc.get("kernels", {}).items():
+                if kname.startswith(dom.split("<")[0]) and args.batch == 8:
+                    traffic = rec["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         chain_gbs = 2 * per_launch_bytes / ((hsv_ms + lut_ms) * 1e-3) / 1e9
         out = {
             "metric": "4K RGBA frames/sec through hsvfilter+colorlut at 1 GPU; % HBM roofline",
@@ -189,7 +200,7 @@ def main():
                        "frames_per_step": args.batch, "ring_batches": args.ring, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms},
             "kernels": {"hsvfilter_ms_per_launch": hsv_ms, "colorlut_ms_per_launch": lut_ms,
                         "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,

@@ -96,7 +96,9 @@ def test_hsvdetector_element(oracle, synth):
     assert not e.set_property("hue-var", 181.0) and not e.set_property("value-ref", -0.1)   # bounded ranges
     st = (120.0, 40.0, np.float32(0.8), 0.5, np.float32(0.7), np.float32(0.6))
     rng = np.random.default_rng(17)
-    w, h = 97, 13
+    # h is a multiple of 3: the reference asserts plane_len % pixel_stride == 0 (hsvdetector/imp.rs:124),
+    # so a padded 3-byte-pixel plane whose length is not a multiple of 3 is a panic there (an error here)
+    w, h = 97, 12
     for in_fmt in ("RGBx", "xRGB", "BGRx", "xBGR", "RGB", "BGR"):
         ps, first, bgr = FMT_LAYOUT[in_fmt]
         ss = (w * ps + 3) & ~3

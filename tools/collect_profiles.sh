@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/collect_profiles.sh <tag> — run ON THE GPU BOX (via gpurun). Collects, for the default bench.py
+# workload: (1) rocprofv3 --kernel-trace --stats, (2) FETCH_SIZE and (3) WRITE_SIZE in separate --pmc
+# passes (TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 do not fit one pass; MI355X_MICROARCH.md §PMC slots).
+# Outputs land in gpurun_out/profiles_<tag>/ ; tools/summarize_profiles.py condenses them into profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > "$OUT/pmc_fetch.log" 2>&1; echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > "$OUT/pmc_write.log" 2>&1; echo "write rc=$?"
+grep -h '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
+python3 $R/bench.py --steps 50 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+cat "$OUT/bench.json"

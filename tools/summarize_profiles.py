@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""tools/summarize_profiles.py <tag> — condense gpurun_out/profiles_<tag>/ into tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_pmc.json           per-kernel FETCH_SIZE / WRITE_SIZE averages and corrected HBM bytes/launch
+  profiles/<tag>_bench.json         the bench.py line of the same run
+  profiles/pmc_latest.json          copy of <tag>_pmc.json that bench.py reads for roofline.traffic
+gfx950 corrections (MI355X_MICROARCH.md §HBM): counters are in KiB; FETCH_SIZE reports exactly half the
+bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is used as is (it matches the
+algorithmic store bytes of the streaming kernels to 0.0%).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def avg_counter(path, counter):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row.get("Counter_Name") == counter:
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    fetch = glob.glob(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)
+    write = glob.glob(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"), recursive=True)
+    out = {"tag": tag, "units": "bytes per launch", "fetch_correction": "FETCH_SIZE(KiB) * 1024 * 2", "kernels": {}}
+    if fetch and write:
+        f, w = avg_counter(fetch[0], "FETCH_SIZE"), avg_counter(write[0], "WRITE_SIZE")
+        for k in f:
+            if "mi355::" not in k:
+                continue
+            short = k.split("mi355::")[1].split("(")[0]
+            fb = f[k][0] * 1024 * 2
+            wb = w.get(k, (0.0, 0))[0] * 1024
+            out["kernels"][short] = {"fetch_size_kib_raw": f[k][0], "write_size_kib_raw": w.get(k, (0.0, 0))[0],
+                                     "hbm_read_bytes": fb, "hbm_write_bytes": wb, "hbm_bytes": fb + wb, "launches_sampled": f[k][1]}
+    json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    shutil.copy(os.path.join(dst, tag + "_pmc.json"), os.path.join(dst, "pmc_latest.json"))
+    b = os.path.join(src, "bench.json")
+    if os.path.exists(b) and os.path.getsize(b):
+        shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
