@@ -375,7 +375,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
   if (contiguous && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
     const size_t n_vec = total_bytes / 16;
-    const int grid = grid_for(ctx, n_vec, 256, 8);
+    const int grid = grid_for(ctx, n_vec, 256, ctx->hsv_blocks_per_cu);
     if (!fast) {
       launch_flat<-1>(ctx, (uint4 *)d_data, n_vec, k, fmt.first, fmt.bgr, grid);
     } else {
@@ -394,7 +394,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
     }
   } else {
     const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
-    const int grid = grid_for(ctx, total, 256, 8);
+    const int grid = grid_for(ctx, total, 256, 32);
     if (fast)
       hipLaunchKernelGGL((hsvfilter_rows_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_data, n_frames,
                          frame_pitch, width, height, stride, fmt.pixel_stride, fmt.first, fmt.bgr, k);
@@ -453,7 +453,7 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
   const HsvDetK k{s.hue_ref, s.hue_var, s.saturation_ref, s.saturation_var, s.value_ref, s.value_var};
   const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
-  const int grid = grid_for(ctx, total, 256, 8);
+  const int grid = grid_for(ctx, total, 256, 32);
   hipLaunchKernelGGL(hsvdetect_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_src, src_pitch, src_stride,
                      sfmt.pixel_stride, sfmt.first, sfmt.bgr, d_dst, dst_pitch, dst_stride, dst_alpha_first, dst_bgr,
                      n_frames, width, height, k);

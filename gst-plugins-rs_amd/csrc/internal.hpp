@@ -44,6 +44,7 @@ struct mi355_ctx {
   mi355::LutDevice lut;
   mi355::EchoDevice echo;
   bool force_generic = false;
+  int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };
 

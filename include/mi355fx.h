@@ -79,7 +79,10 @@ int mi355_ctx_synchronize(mi355_ctx *ctx);
 
 /* Diagnostic switches (tests, A/B measurements). MI355_FLAG_FORCE_GENERIC=1 makes every element use
  * its literal-arithmetic GENERIC kernel instead of the strength-reduced FAST one. */
-typedef enum mi355_flag { MI355_FLAG_FORCE_GENERIC = 1 } mi355_flag;
+typedef enum mi355_flag {
+  MI355_FLAG_FORCE_GENERIC = 1,
+  MI355_FLAG_HSV_BLOCKS_PER_CU = 2 /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
+} mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 
 void *mi355_device_alloc(mi355_ctx *ctx, size_t bytes);

@@ -316,6 +316,89 @@ static float run3(const char *name, const uint4 *src, uint4 *dst, size_t n_group
   return ms;
 }
 
+
+// ---- Option Q: one launch per channel, plane resident for the whole launch, streaming waves.
+template <int NT, int C, bool FINAL>
+__global__ __launch_bounds__(NT) void kq(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t *__restrict__ planeC,
+                                         const uint32_t *__restrict__ planeR, const uint32_t *__restrict__ planeG, size_t n_groups,
+                                         const float *__restrict__ planar, const uint32_t *__restrict__ axis_tab, uint32_t plane_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int Sy = 35, Sz = 1161;
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  refill_dma<NT>(lds, planar + (size_t)C * plane_floats, plane_floats);
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * NT;
+  size_t g = (size_t)blockIdx.x * NT + threadIdx.x;
+  uint4 nxt = make_uint4(0, 0, 0, 0), nxt2 = make_uint4(0, 0, 0, 0);
+  uint32_t nr = 0, ng = 0, nr2 = 0, ng2 = 0;
+  if (g < n_groups) { nxt = src[g]; if (FINAL) { nr = planeR[g]; ng = planeG[g]; } }
+  if (g + stride < n_groups) { nxt2 = src[g + stride]; if (FINAL) { nr2 = planeR[g + stride]; ng2 = planeG[g + stride]; } }
+  for (; g < n_groups; g += stride) {
+    const uint4 v = nxt;
+    const uint32_t cr = nr, cg = ng;
+    nxt = nxt2; nr = nr2; ng = ng2;
+    if (g + 2 * stride < n_groups) { nxt2 = src[g + 2 * stride]; if (FINAL) { nr2 = planeR[g + 2 * stride]; ng2 = planeG[g + 2 * stride]; } }
+    const uint32_t px[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out4 = 0;
+    uint32_t res[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint2 ex = *(const uint2 *)(lds + ((px[i] & 0xffu) << 3));
+      const uint2 ey = *(const uint2 *)(lds + 2048 + (((px[i] >> 8) & 0xffu) << 3));
+      const uint2 ez = *(const uint2 *)(lds + 4096 + (((px[i] >> 16) & 0xffu) << 3));
+      const uint32_t base = ex.x + ey.x + ez.x;
+      const float tx = __uint_as_float(ex.y), ty = __uint_as_float(ey.y), tz = __uint_as_float(ez.y);
+      const float *L1 = (const float *)(lds + base);
+      const float *L0 = L1 + Sz;
+      const float a0 = L0[0], a1 = L0[1], b0 = L0[Sy], b1 = L0[Sy + 1];
+      const float c0 = L1[0], c1 = L1[1], d0 = L1[Sy], d1 = L1[Sy + 1];
+      const float c00 = lerp1(a0, a1, tx), c10 = lerp1(b0, b1, tx);
+      const float c01 = lerp1(c0, c1, tx), c11 = lerp1(d0, d1, tx);
+      const float o = lerp1(lerp1(c00, c10, ty), lerp1(c01, c11, ty), tz);
+      res[i] = rha(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
+    }
+    if (!FINAL) {
+      out4 = res[0] | (res[1] << 8) | (res[2] << 16) | (res[3] << 24);
+      planeC[g] = out4;
+    } else {
+      const uint32_t r4 = cr, g4 = cg;
+      uint4 o;
+      o.x = (px[0] & 0xff000000u) | (r4 & 0xff) | ((g4 & 0xff) << 8) | (res[0] << 16);
+      o.y = (px[1] & 0xff000000u) | ((r4 >> 8) & 0xff) | (((g4 >> 8) & 0xff) << 8) | (res[1] << 16);
+      o.z = (px[2] & 0xff000000u) | ((r4 >> 16) & 0xff) | (((g4 >> 16) & 0xff) << 8) | (res[2] << 16);
+      o.w = (px[3] & 0xff000000u) | (r4 >> 24) | ((g4 >> 24) << 8) | (res[3] << 16);
+      dst[g] = o;
+    }
+  }
+}
+
+template <int NT>
+static float runq(const char *name, const uint4 *src, uint4 *dst, uint32_t *pr, uint32_t *pg, size_t n_groups, int frames_per_group, int n_frames,
+                  const float *planar, const uint32_t *axis, uint32_t pf, int grid, size_t lds) {
+  auto k0 = kq<NT, 0, false>; auto k1 = kq<NT, 1, false>; auto k2 = kq<NT, 2, true>;
+  CK(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const size_t gpf = n_groups / n_frames;  // groups per frame
+  auto once = [&]() {
+    for (int f0 = 0; f0 < n_frames; f0 += frames_per_group) {
+      const size_t off = gpf * f0, n = gpf * frames_per_group;
+      hipLaunchKernelGGL(k0, dim3(grid), dim3(NT), lds, 0, src + off, dst + off, pr + off, nullptr, nullptr, n, planar, axis, pf);
+      hipLaunchKernelGGL(k1, dim3(grid), dim3(NT), lds, 0, src + off, dst + off, pg + off, nullptr, nullptr, n, planar, axis, pf);
+      hipLaunchKernelGGL(k2, dim3(grid), dim3(NT), lds, 0, src + off, dst + off, nullptr, pr + off, pg + off, n, planar, axis, pf);
+    }
+  };
+  once(); once();
+  CK(hipEventRecord(e0));
+  const int it = 10;
+  for (int w = 0; w < it; w++) once();
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+  printf("  kq %-24s NT=%d frames/group=%d  %.4f ms  (%.0f GB/s algorithmic)\n", name, NT, frames_per_group, ms, n_groups * 32.0 / ms / 1e6);
+  return ms;
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint32_t xr() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
 
@@ -372,19 +455,16 @@ int main(int argc, char **argv) {
     printf("%s content, batch of %d 4K frames, lds=%zu B\n", content ? "noise" : "smooth", B, lds);
     run2<1024, 3, 0, true>("alt order (compiler sched)", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
     {
-      // correctness cross-check of k3 against k2 on this content
       std::vector<uint32_t> ref(npx), got(npx);
       CK(hipMemcpy(ref.data(), d_dst, npx * 4, hipMemcpyDeviceToHost));
-      run3<1024, 3>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
+      uint32_t *pr, *pg; CK(hipMalloc(&pr, npx)); CK(hipMalloc(&pg, npx));
+      for (int fpg : {8, 4, 2, 1}) runq<1024>("3 launches/channel", d_src, d_dst, pr, pg, n_groups, fpg, B, d_planar, d_axis, (uint32_t)pf, grid, lds);
       CK(hipMemcpy(got.data(), d_dst, npx * 4, hipMemcpyDeviceToHost));
       size_t bad = 0; for (size_t i = 0; i < npx; i++) bad += ref[i] != got[i];
-      printf("  k3 vs k2 mismatching pixels: %zu\n", bad);
+      printf("  kq vs k2 mismatching pixels: %zu\n", bad);
+      for (int fpg : {8, 2}) runq<512>("3 launches/channel", d_src, d_dst, pr, pg, n_groups, fpg, B, d_planar, d_axis, (uint32_t)pf, grid, lds);
+      CK(hipFree(pr)); CK(hipFree(pg));
     }
-    run3<1024, 4>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
-    run3<768, 5>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
-    run3<768, 6>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
-    run3<512, 8>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
-    run3<512, 10>("pipelined asm", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
   }
   return 0;
 }
