@@ -245,7 +245,14 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int P = P4 * 4;
   const size_t tile_groups = (size_t)NT * P4;
-  const size_t n_tiles = (n_groups + tile_groups - 1) / tile_groups;
+  // Work split: `full_rounds` rounds of whole tiles (tile t -> block t % grid), then the remaining
+  // groups are cut into gridDim.x equal chunks so the last round keeps every CU busy instead of
+  // leaving most of them idle behind a few whole tiles.
+  const size_t full_rounds = (n_groups / tile_groups) / gridDim.x;
+  const size_t full_tiles = full_rounds * gridDim.x;
+  const size_t rem_start = full_tiles * tile_groups;
+  const size_t rem_chunk = (n_groups - rem_start + gridDim.x - 1) / gridDim.x;  // <= tile_groups (+ rounding), see launcher
+  const size_t my_rounds = full_rounds + (rem_chunk > 0 ? 1 : 0);
 
   for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
   __syncthreads();
@@ -254,16 +261,26 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   // last pass serves the next tile's first pass: two stagings per tile instead of three.
   bool flip = false;
   int resident = -1;
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (size_t round = 0; round < my_rounds; round++) {
+    size_t t_begin, t_end;
+    if (round < full_rounds) {
+      t_begin = (round * gridDim.x + blockIdx.x) * tile_groups;
+      t_end = t_begin + tile_groups;
+    } else {
+      t_begin = rem_start + (size_t)blockIdx.x * rem_chunk;
+      t_end = t_begin + rem_chunk;
+      if (t_end > n_groups) t_end = n_groups;
+      if (t_begin >= t_end) break;  // block-uniform: nothing left for this block
+    }
     uint32_t px[P];
     uint32_t base[P];
     float tx[P], ty[P], tz[P];
-    const size_t g0 = tile * tile_groups + threadIdx.x;
+    const size_t g0 = t_begin + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < P4; j++) {
       const size_t g = g0 + (size_t)j * NT;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (g < n_groups) v = src[g];
+      if (g < t_end) v = src[g];
       px[4 * j + 0] = v.x; px[4 * j + 1] = v.y; px[4 * j + 2] = v.z; px[4 * j + 3] = v.w;
     }
 #pragma unroll
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
 #pragma unroll
     for (int j = 0; j < P4; j++) {
       const size_t g = g0 + (size_t)j * NT;
-      if (g < n_groups) dst[g] = make_uint4(px[4 * j + 0], px[4 * j + 1], px[4 * j + 2], px[4 * j + 3]);
+      if (g < t_end) dst[g] = make_uint4(px[4 * j + 0], px[4 * j + 1], px[4 * j + 2], px[4 * j + 3]);
     }
   }
 }
@@ -411,9 +428,12 @@ static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size
   int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                      "hipFuncSetAttribute(max dynamic LDS)");
   if (rc) return rc;
-  const size_t tile_groups = (size_t)NT * P4;
-  size_t n_tiles = (n_groups + tile_groups - 1) / tile_groups;
-  size_t grid = n_tiles < (size_t)ctx->n_cu ? n_tiles : (size_t)ctx->n_cu;
+  // one block per CU (the plane takes the CU's whole LDS); small inputs use fewer blocks so that a
+  // block always has at least 1024 pixels to amortise its plane stagings
+  size_t grid = (size_t)ctx->n_cu;
+  const size_t min_blocks = (n_groups + 255) / 256;
+  if (grid > min_blocks) grid = min_blocks;
+  if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
                      (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");

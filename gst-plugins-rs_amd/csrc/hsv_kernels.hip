@@ -197,10 +197,11 @@ __device__ __forceinline__ void cvt_u8_into(uint32_t &packed, float v, int byte)
   else asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(packed) : "v"(v));
 }
 
-template <int RPOS, int GPOS, int BPOS, int NPOS, int SHIFT, bool SV_IDENT>
-__device__ __forceinline__ void hsvfilter_px2_fast(uint32_t &p0, uint32_t &p1, const HsvK &k, const uint32_t *sel_tab) {
-  // ---- from_rgb / from_bgr (hsvutils.rs:44-128): rotate so that byte0 = max channel M, bytes 1,2 =
-  // the other two in the cyclic order the hue formula subtracts them, byte3 = 0/2/4.
+// from_rgb / from_bgr (hsvutils.rs:44-128) for two pixels: hue in [0,360), saturation, value.
+template <int RPOS, int GPOS, int BPOS>
+__device__ __forceinline__ void hsv_from_rgb_pair_fast(uint32_t p0, uint32_t p1, f2 &h, f2 &sat, f2 &value) {
+  // rotate so that byte0 = max channel M, bytes 1,2 = the other two in the cyclic order the hue
+  // formula subtracts them, byte3 = 0/2/4
   constexpr uint32_t SEL_R = (uint32_t)RPOS | ((uint32_t)GPOS << 8) | ((uint32_t)BPOS << 16) | (4u << 24);
   constexpr uint32_t SEL_G = (uint32_t)GPOS | ((uint32_t)BPOS << 8) | ((uint32_t)RPOS << 16) | (5u << 24);
   constexpr uint32_t SEL_B = (uint32_t)BPOS | ((uint32_t)RPOS << 8) | ((uint32_t)GPOS << 16) | (6u << 24);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void hsvfilter_px2_fast(uint32_t &p0, uint32_t &p1, c
   const f2 b8 = {(float)((rot[0] >> 16) & 0xffu), (float)((rot[1] >> 16) & 0xffu)};
   const f2 add = {(float)(rot[0] >> 24), (float)(rot[1] >> 24)};
   const f2 hi = splat2(MI355_INV255_HI), lo = splat2(MI355_INV255_LO);
-  const f2 value = fma2(M8, hi, M8 * lo);  // RN(n/255), see div255_u8
+  value = fma2(M8, hi, M8 * lo);  // RN(n/255), see div255_u8
   const f2 af = fma2(a8, hi, a8 * lo);
   const f2 bf = fma2(b8, hi, b8 * lo);
   const f2 minv = {fminf(af.x, bf.x), fminf(af.y, bf.y)};
@@ -233,12 +234,18 @@ __device__ __forceinline__ void hsvfilter_px2_fast(uint32_t &p0, uint32_t &p1, c
   const f2 yq = {__builtin_amdgcn_rcpf(dq.x), __builtin_amdgcn_rcpf(dq.y)};
   const f2 ys = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
   f2 q = num * yq;
-  f2 sat = chroma * ys;
+  sat = chroma * ys;
   q = fma2(fma2(-q, dq, num), yq, q);
   sat = fma2(fma2(-sat, ds, chroma), ys, sat);
-  f2 h = splat2(60.0f) * (add + q);
+  h = splat2(60.0f) * (add + q);
   h.x = add360_if_negative(h.x);
   h.y = add360_if_negative(h.y);
+}
+
+template <int RPOS, int GPOS, int BPOS, int NPOS, int SHIFT, bool SV_IDENT>
+__device__ __forceinline__ void hsvfilter_px2_fast(uint32_t &p0, uint32_t &p1, const HsvK &k, const uint32_t *sel_tab) {
+  f2 h, sat, value;
+  hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS>(p0, p1, h, sat, value);
   // ---- filter (hsvfilter/imp.rs:102-115)
   f2 t = h;
   if constexpr (SHIFT == HSV_SHIFT_POS) {
@@ -456,6 +463,39 @@ __global__ __launch_bounds__(256) void hsvdetect_rows_kernel(const uint8_t *__re
     if (out_bgr) { c[0] = (uint8_t)b8; c[1] = (uint8_t)g8; c[2] = (uint8_t)r8; }
     else { c[0] = (uint8_t)r8; c[1] = (uint8_t)g8; c[2] = (uint8_t)b8; }
     op[out_alpha_first ? 0 : 3] = alpha;
+  }
+}
+
+// FAST detector kernel: 4-byte input formats on contiguous storage, 4 pixels per lane. Valid for
+// hue_ref in [-180,180] (finite): shifted = hue + (180 - hue_ref) lies in [0,720), so the reference's
+// `if shifted < 0` never fires and `% 360` is one conditional exact subtraction.
+template <int IN_FIRST, bool IN_BGR>
+__global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec,
+                                                             HsvDetK k, uint32_t out_sel) {
+  constexpr int RPOS = IN_FIRST + (IN_BGR ? 2 : 0), GPOS = IN_FIRST + 1, BPOS = IN_FIRST + (IN_BGR ? 0 : 2);
+  const float off = 180.0f - k.hue_ref;  // ref_hue_offset (hsvdetector/imp.rs:140)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const uint4 p = src[i];
+    const uint32_t in[4] = {p.x, p.y, p.z, p.w};
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      f2 h, s, v;
+      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS>(in[j], in[j + 1], h, s, v);
+      f2 sh = h + splat2(off);
+      const f2 u = sh - splat2(360.0f);
+      sh.x = (u.x >= 0.0f) ? u.x : sh.x;
+      sh.y = (u.y >= 0.0f) ? u.y : sh.y;
+      const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = v - splat2(k.val_ref);
+      const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
+      const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;
+      // out_sel picks the colour bytes from the input pixel (selector 4..7) and the alpha byte from the
+      // second operand (selector 0)
+      out[j] = __builtin_amdgcn_perm(in[j], hit0 ? 255u : 0u, out_sel);
+      out[j + 1] = __builtin_amdgcn_perm(in[j + 1], hit1 ? 255u : 0u, out_sel);
+    }
+    dst[i] = make_uint4(out[0], out[1], out[2], out[3]);
   }
 }
 

@@ -374,3 +374,30 @@ def test_echo_not_negotiated(ctx):
     with pytest.raises(mi355fx.Mi355Error) as e:
         ctx.echo_process(np.zeros(4, np.float32), 1, 0.5, 0.0)
     assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+
+
+# ------------------------------------------------------------------ hsvdetector
+
+@pytest.mark.parametrize("st", [
+    (0.0, 10.0, 0.0, 0.15, 0.0, 0.3),            # defaults (hsvdetector/imp.rs:25-30)
+    (120.0, 40.0, 0.8, 0.5, 0.7, 0.6),
+    (-180.0, 180.0, 0.5, 0.5, 0.5, 0.5), (180.0, 1.0, 1.0, 0.25, 1.0, 0.25), (-0.0, 0.0, 0.0, 1.0, 0.0, 1.0),
+    (359.0, 15.0, 0.5, 0.4, 0.5, 0.4), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5),   # outside [-180,180]: literal kernel
+])
+@pytest.mark.parametrize("in_fmt,out_fmt", [("RGBx", "RGBA"), ("xBGR", "ARGB"), ("BGRx", "ABGR"), ("xRGB", "BGRA")])
+def test_hsvdetect_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
+    """hsvdetector on every colour (vectorised FAST kernel for hue-ref in [-180,180], literal otherwise)."""
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[in_fmt]
+    af, obgr = {"RGBA": (0, 0), "ARGB": (1, 0), "BGRA": (0, 1), "ABGR": (1, 1)}[out_fmt]
+    ac = synth.allcolors()
+    if first == 1:   # put the colour triple at bytes 1..3
+        ac = np.roll(ac.reshape(-1, 4), 1, axis=1).reshape(4096, -1).copy()
+    if bgr:
+        v = ac.reshape(-1, 4)
+        v[:, first:first + 3] = v[:, first:first + 3][:, ::-1].copy()
+    exp = np.zeros_like(ac)
+    oracle.hsvdetect(ac, 4096 * 4, ps, first, bool(bgr), exp, 4096 * 4, bool(af), bool(obgr), 4096, st)
+    got = np.zeros_like(ac)
+    ctx.hsvdetect_frame(ac, 4096 * 4, in_fmt, got, 4096 * 4, out_fmt, 4096, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)

@@ -399,6 +399,93 @@ static float runq(const char *name, const uint4 *src, uint4 *dst, uint32_t *pr, 
   return ms;
 }
 
+
+// ---- k4: k2 (alt order, DMA staging) + software prefetch of the next tile's pixels during the passes.
+template <int NT, int P4>
+__global__ __launch_bounds__(NT) void k4(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_groups,
+                                         const float *__restrict__ planar, const uint32_t *__restrict__ axis_tab, uint32_t plane_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int P = P4 * 4;
+  const size_t tile_groups = (size_t)NT * P4;
+  const size_t n_tiles = (n_groups + tile_groups - 1) / tile_groups;
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  __syncthreads();
+  bool flip = false;
+  int resident = -1;
+  uint4 nxt[P4];
+  {
+    const size_t g0 = (size_t)blockIdx.x * tile_groups + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P4; j++) { const size_t g = g0 + (size_t)j * NT; nxt[j] = make_uint4(0, 0, 0, 0); if (blockIdx.x < n_tiles && g < n_groups) nxt[j] = src[g]; }
+  }
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t px[P], base[P];
+    float tx[P], ty[P], tz[P];
+    const size_t g0 = tile * tile_groups + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P4; j++) { px[4 * j + 0] = nxt[j].x; px[4 * j + 1] = nxt[j].y; px[4 * j + 2] = nxt[j].z; px[4 * j + 3] = nxt[j].w; }
+    // prefetch the next tile now: the loads fly during the three passes below
+    {
+      const size_t nt = tile + gridDim.x;
+      const size_t h0 = nt * tile_groups + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < P4; j++) { const size_t g = h0 + (size_t)j * NT; if (nt < n_tiles && g < n_groups) nxt[j] = src[g]; }
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const uint2 ex = *(const uint2 *)(lds + ((px[i] & 0xffu) << 3));
+      const uint2 ey = *(const uint2 *)(lds + 2048 + (((px[i] >> 8) & 0xffu) << 3));
+      const uint2 ez = *(const uint2 *)(lds + 4096 + (((px[i] >> 16) & 0xffu) << 3));
+      base[i] = ex.x + ey.x + ez.x;
+      tx[i] = __uint_as_float(ex.y); ty[i] = __uint_as_float(ey.y); tz[i] = __uint_as_float(ez.y);
+    }
+#define STAGE4(CH)                                                                  \
+    if (resident != CH) {                                                           \
+      __syncthreads();                                                              \
+      {                                                                             \
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
+        const uint32_t chunks = plane_floats / 256;                                 \
+        const char *gsrc = (const char *)(planar + (size_t)CH * plane_floats) + lane * 16; \
+        for (uint32_t kk = wave; kk < chunks; kk += NT / 64)                        \
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)kk * 1024), \
+                                           (__attribute__((address_space(3))) void *)(lds + kAxisTableBytes + kk * 1024), 16, 0, 0); \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P4) : "memory"); /* leave the pixel prefetches in flight */ \
+      }                                                                             \
+      __syncthreads();                                                              \
+      resident = CH;                                                                \
+    }
+    if (!flip) {
+      STAGE4(0) pass<P, 0, 0>(lds, px, base, tx, ty, tz);
+      STAGE4(1) pass<P, 0, 1>(lds, px, base, tx, ty, tz);
+      STAGE4(2) pass<P, 0, 2>(lds, px, base, tx, ty, tz);
+    } else {
+      STAGE4(2) pass<P, 0, 2>(lds, px, base, tx, ty, tz);
+      STAGE4(1) pass<P, 0, 1>(lds, px, base, tx, ty, tz);
+      STAGE4(0) pass<P, 0, 0>(lds, px, base, tx, ty, tz);
+    }
+    flip = !flip;
+#pragma unroll
+    for (int j = 0; j < P4; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      if (g < n_groups) dst[g] = make_uint4(px[4 * j + 0], px[4 * j + 1], px[4 * j + 2], px[4 * j + 3]);
+    }
+  }
+}
+template <int NT, int P4>
+static float run4(const char *name, const uint4 *src, uint4 *dst, size_t n_groups, const float *planar, const uint32_t *axis, uint32_t pf, int grid, size_t lds) {
+  auto kern = k4<NT, P4>;
+  CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, 0, src, dst, n_groups, planar, axis, pf);
+  CK(hipEventRecord(e0));
+  const int it = 10;
+  for (int w = 0; w < it; w++) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, 0, src, dst, n_groups, planar, axis, pf);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+  printf("  k4 %-31s NT=%d P4=%d  %.4f ms  (%.0f GB/s algorithmic)\n", name, NT, P4, ms, n_groups * 32.0 / ms / 1e6);
+  return ms;
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint32_t xr() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
 
@@ -457,14 +544,15 @@ int main(int argc, char **argv) {
     {
       std::vector<uint32_t> ref(npx), got(npx);
       CK(hipMemcpy(ref.data(), d_dst, npx * 4, hipMemcpyDeviceToHost));
-      uint32_t *pr, *pg; CK(hipMalloc(&pr, npx)); CK(hipMalloc(&pg, npx));
-      for (int fpg : {8, 4, 2, 1}) runq<1024>("3 launches/channel", d_src, d_dst, pr, pg, n_groups, fpg, B, d_planar, d_axis, (uint32_t)pf, grid, lds);
+      run4<1024, 2>("prefetch next tile", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
       CK(hipMemcpy(got.data(), d_dst, npx * 4, hipMemcpyDeviceToHost));
       size_t bad = 0; for (size_t i = 0; i < npx; i++) bad += ref[i] != got[i];
-      printf("  kq vs k2 mismatching pixels: %zu\n", bad);
-      for (int fpg : {8, 2}) runq<512>("3 launches/channel", d_src, d_dst, pr, pg, n_groups, fpg, B, d_planar, d_axis, (uint32_t)pf, grid, lds);
-      CK(hipFree(pr)); CK(hipFree(pg));
+      printf("  k4 vs k2 mismatching pixels: %zu\n", bad);
     }
+    run4<1024, 3>("prefetch next tile", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
+    run2<1024, 2, 0, true>("alt order (compiler sched)", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
+    run4<768, 4>("prefetch next tile", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
+    run4<512, 6>("prefetch next tile", d_src, d_dst, n_groups, d_planar, d_axis, (uint32_t)pf, grid, lds);
   }
   return 0;
 }
