@@ -319,6 +319,40 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   }
 }
 
+// ---------------------------------------------------------------- 1D LUT, RGBA8, tables in LDS
+//
+// transform_rgba_1d / apply_1d / sample_1d (imp.rs:237-265,399-414,482-490). LDS image: the three
+// axis tables {byte offset of lut_c[x0], t} (same construction as the 3D kernel) followed by the three
+// channel tables, each `size`+1 floats (one zero pad so x1 = x0+1 needs no clamp: when the reference
+// clamps, t == 0). One lane = 4 pixels per iteration, 8 B/pixel of HBM traffic, everything else in LDS.
+template <int NT>
+__global__ __launch_bounds__(NT) void colorlut1d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec,
+                                                            const uint32_t *__restrict__ lds_image, uint32_t image_dwords) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  for (uint32_t i = threadIdx.x; i < image_dwords; i += NT) ((uint32_t *)lds)[i] = lds_image[i];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * NT;
+  for (size_t g = (size_t)blockIdx.x * NT + threadIdx.x; g < n_vec; g += stride) {
+    const uint4 v = src[g];
+    uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t out = px[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const uint2 e = *(const uint2 *)(lds + c * 2048 + (((px[i] >> (8 * c)) & 0xffu) << 3));
+        const float *L = (const float *)(lds + e.x);
+        const float o = lerp1(L[0], L[1], __uint_as_float(e.y));
+        const uint32_t v8 = round_half_away_nonneg(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
+        const uint32_t sel = c == 0 ? 0x07060500u : (c == 1 ? 0x07060004u : 0x07000504u);
+        out = __builtin_amdgcn_perm(out, v8, sel);
+      }
+      px[i] = out;
+    }
+    dst[g] = make_uint4(px[0], px[1], px[2], px[3]);
+  }
+}
+
 // ---------------------------------------------------------------- host side: LUT upload + dispatch
 
 static constexpr size_t kLdsBytes = 160 * 1024;
@@ -416,6 +450,33 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
       }
     }
   }
+  if (!is3d && domain_finite) {
+    const size_t plane = size + 1;
+    const size_t bytes = kAxisTableBytes + 3 * plane * sizeof(float);
+    bool bounded = true;
+    for (size_t i = 0; i < 3 * size && bounded; i++)
+      if (!(std::fabs(table[i]) <= 1e30f)) bounded = false;
+    if (bytes <= kLdsBytes && bounded) {
+      std::vector<uint32_t> image((bytes + 3) / 4, 0u);
+      for (int a = 0; a < 3; a++) {
+        for (int v = 0; v < 256; v++) {
+          float t;
+          int i0;
+          axis_entry(v, scale[a], offset[a], (int)size, &t, &i0);
+          image[(size_t)(a * 256 + v) * 2 + 0] = (uint32_t)(kAxisTableBytes + (a * plane + (size_t)i0) * sizeof(float));
+          std::memcpy(&image[(size_t)(a * 256 + v) * 2 + 1], &t, 4);
+        }
+        std::memcpy(&image[kAxisTableBytes / 4 + a * plane], table + (size_t)a * size, size * sizeof(float));
+      }
+      rc = check_hip(ctx, hipMalloc((void **)&L.d_axis, image.size() * sizeof(uint32_t)), "hipMalloc(1D LUT LDS image)");
+      if (rc) return rc;
+      rc = check_hip(ctx, hipMemcpy(L.d_axis, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                     "hipMemcpy(1D LUT LDS image)");
+      if (rc) return rc;
+      L.lds_bytes = image.size() * sizeof(uint32_t);
+      L.lds_ok = true;
+    }
+  }
   L.loaded = true;
   return MI355_OK;
 }
@@ -449,6 +510,30 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   k.size = L.size;
 
   const bool rgba8 = (format == MI355_FMT_RGBA);
+  if (rgba8 && !L.is3d && L.lds_ok && !ctx->force_generic) {
+    const size_t row_bytes = (size_t)width * 4;
+    const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                            (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+    const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+    if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
+      constexpr int NT = 512;
+      auto kern = colorlut1d_lds_kernel<NT>;
+      int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes),
+                         "hipFuncSetAttribute(max dynamic LDS)");
+      if (rc) return rc;
+      const size_t n_vec = total_bytes / 16;
+      // blocks per CU limited by the LDS image; a few hundred pixels per lane amortise the table staging
+      size_t per_cu = kLdsBytes / (L.lds_bytes ? L.lds_bytes : 1);
+      if (per_cu < 1) per_cu = 1;
+      if (per_cu > 4) per_cu = 4;
+      size_t grid = (size_t)ctx->n_cu * per_cu;
+      const size_t max_blocks = (n_vec + NT - 1) / NT;
+      if (grid > max_blocks) grid = max_blocks;
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), L.lds_bytes, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_vec,
+                         (const uint32_t *)L.d_axis, (uint32_t)(L.lds_bytes / 4));
+      return check_hip(ctx, hipGetLastError(), "colorlut1d_lds kernel launch");
+    }
+  }
   if (rgba8 && L.is3d && L.lds_ok && !ctx->force_generic) {
     const size_t row_bytes = (size_t)width * 4;
     const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&

@@ -506,6 +506,30 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
   const HsvDetK k{s.hue_ref, s.hue_var, s.saturation_ref, s.saturation_var, s.value_ref, s.value_var};
   const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
+  const size_t row_bytes = (size_t)width * 4;
+  const bool contiguous = sfmt.pixel_stride == 4 && (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                          (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+  const bool fast = !ctx->force_generic && s.hue_ref >= -180.0f && s.hue_ref <= 180.0f;
+  if (fast && contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && ((total * 4) % 16 == 0)) {
+    // output byte j: colour channel c sits at input byte in_pos(c); alpha comes from operand 1 byte 0
+    const int in_pos[3] = {sfmt.first + (sfmt.bgr ? 2 : 0), sfmt.first + 1, sfmt.first + (sfmt.bgr ? 0 : 2)};  // R,G,B
+    const int cbase = dst_alpha_first ? 1 : 0;
+    uint32_t sel = 0;  // alpha byte selector stays 0 (= byte 0 of the 0/255 operand)
+    for (int c = 0; c < 3; c++) {
+      const int out_byte = cbase + (dst_bgr ? 2 - c : c);
+      sel |= (uint32_t)(4 + in_pos[c]) << (8 * out_byte);
+    }
+    const size_t n_vec = total / 4;
+    const int fgrid = grid_for(ctx, n_vec, 256, 64);
+    dim3 g(fgrid), b(256);
+    const uint4 *sp = (const uint4 *)d_src;
+    uint4 *dp = (uint4 *)d_dst;
+    if (sfmt.first == 0 && !sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<0, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
+    else if (sfmt.first == 0 && sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<0, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
+    else if (sfmt.first == 1 && !sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<1, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
+    else hipLaunchKernelGGL((hsvdetect_flat_kernel<1, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
+    return check_hip(ctx, hipGetLastError(), "hsvdetect flat kernel launch");
+  }
   const int grid = grid_for(ctx, total, 256, 32);
   hipLaunchKernelGGL(hsvdetect_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_src, src_pitch, src_stride,
                      sfmt.pixel_stride, sfmt.first, sfmt.bgr, d_dst, dst_pitch, dst_stride, dst_alpha_first, dst_bgr,

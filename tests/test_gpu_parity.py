@@ -401,3 +401,18 @@ def test_hsvdetect_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
     got = np.zeros_like(ac)
     ctx.hsvdetect_frame(ac, 4096 * 4, in_fmt, got, 4096 * 4, out_fmt, 4096, st)
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("size,force_generic", [(2, 0), (64, 0), (64, 1), (1024, 0), (12000, 0), (65536, 0)])
+def test_colorlut_1d_allcolors(ctx, oracle, synth, size, force_generic):
+    """1D LUTs on every colour: LDS kernel for sizes whose three tables fit LDS, literal kernel otherwise."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_1d(size, gamma=0.45))
+    ac = synth.allcolors()
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
+    ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, force_generic)
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+    ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, 0)
+    assert (got == exp).all(), _mismatch_report(got, exp)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""tools/bench_elements.py — per-element device-resident kernel rates for the non-headline configs of
+BASELINE.json and the secondary kernels (wall clock around N async launches + one synchronize)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gst-plugins-rs_amd"))
+import mi355fx
+from mi355fx import FMT, HsvDetectSettings, synth
+from mi355fx.cube import parse_cube
+
+ctx = mi355fx.Context(0)
+
+
+def timeit(fn, n=30, warm=3):
+    for _ in range(warm):
+        fn()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def report(name, secs, nbytes, frames):
+    print("%-58s %8.3f ms  %7.0f GB/s (%.1f%% of 8 TB/s)  %9.0f frames/s" % (name, secs * 1e3, nbytes / secs / 1e9, nbytes / secs / 8e12 * 100, frames / secs))
+
+
+# config 2: hsvfilter hue-shift on 1920x1080 BGRx, batch 32
+W, H, B = 1920, 1080, 32
+fr = np.stack([synth.smooth_frame(W, H)] * B)
+d = ctx.alloc(fr.nbytes); ctx.h2d(d, fr)
+st = synth.HSV_SETTINGS["hue90"]
+report("hsvfilter 1080p BGRx hue-shift=90 (config 2), batch 32", timeit(lambda: ctx.hsvfilter_frames_device(d, B, W * H * 4, W, H, W * 4, "BGRx", st)), 2 * fr.nbytes, B)
+report("hsvfilter 1080p BGRx mixed settings, batch 32", timeit(lambda: ctx.hsvfilter_frames_device(d, B, W * H * 4, W, H, W * 4, "BGRx", synth.HSV_SETTINGS["mixed"])), 2 * fr.nbytes, B)
+mi355fx_flag = mi355fx.FLAG_FORCE_GENERIC
+ctx.set_flag(mi355fx_flag, 1)
+report("hsvfilter 1080p BGRx GENERIC (literal) kernel, batch 32", timeit(lambda: ctx.hsvfilter_frames_device(d, B, W * H * 4, W, H, W * 4, "BGRx", st), n=5), 2 * fr.nbytes, B)
+ctx.set_flag(mi355fx_flag, 0)
+# 3-byte format row kernel
+fr3 = np.stack([synth.noise_frame(W * 3, H, channels=1)] * 8)
+d3 = ctx.alloc(fr3.nbytes); ctx.h2d(d3, fr3)
+report("hsvfilter 1080p RGB (3 B/px row kernel), batch 8", timeit(lambda: ctx.hsvfilter_frames_device(d3, 8, W * H * 3, W, H, W * 3, "RGB", st), n=10), 2 * fr3.nbytes, 8)
+
+# hsvdetector 4K RGBx -> RGBA
+W, H, B = 3840, 2160, 8
+fr = np.stack([synth.smooth_frame(W, H)] * B)
+ds, dd = ctx.alloc(fr.nbytes), ctx.alloc(fr.nbytes); ctx.h2d(ds, fr)
+s = HsvDetectSettings(120.0, 40.0, 0.8, 0.5, 0.7, 0.6)
+L = ctx.L
+report("hsvdetector 4K RGBx->RGBA, batch 8", timeit(lambda: L.mi355_hsvdetect_frames_device(ctx.h, ds, W * H * 4, W * 4, FMT["RGBx"], dd, W * H * 4, W * 4, FMT["RGBA"], B, W, H, C.byref(s))), 2 * fr.nbytes, B)
+
+# colorlut variants on 4K RGBA batch 8
+for name, text in (("colorlut 33^3 LDS (config 3)", synth.cube_text_3d(33)), ("colorlut 17^3 LDS", synth.cube_text_3d(17)),
+                   ("colorlut 65^3 gather kernel", synth.cube_text_3d(65)), ("colorlut 1D 1024 LDS", synth.cube_text_1d(1024))):
+    lut = parse_cube(text)
+    ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+    report(name + ", 4K RGBA batch 8", timeit(lambda: ctx.colorlut_frames_device(ds, W * H * 4, W * 4, dd, W * H * 4, W * 4, B, W, H, "RGBA"), n=10), 2 * fr.nbytes, B)
+
+# rsaudioecho config 1 (device resident): 10 s stereo 48 kHz f32
+x = synth.sine_stereo_f32()
+dx = ctx.alloc(x.nbytes); ctx.h2d(dx, x)
+ctx.echo_setup(96000)
+for fb in (0.4, 0.0):
+    secs = timeit(lambda: L.mi355_echo_process_device(ctx.h, dx, x.size, 0, 24000, 0.6, fb), n=20)
+    print("%-58s %8.3f ms  -> %.0fx real time (10 s buffer), %.1f Msamples/s" % ("rsaudioecho config 1 feedback=%.1f" % fb, secs * 1e3, 10.0 / secs, x.size / secs / 1e6))
