@@ -175,6 +175,7 @@ constexpr int kAxisTableBytes = 3 * 256 * 8;
 
 struct LdsLayout {
   int S, Sy, Sz;
+  bool all_resident;    // all three planes fit LDS at once
   size_t plane_floats;  // S*Sz + Sy + 2 rounded up to 256 (1 KiB)
   size_t lds_bytes;     // kAxisTableBytes + 4*plane_floats
 };
@@ -189,6 +190,8 @@ static LdsLayout lds_layout_for(int S) {
   size_t pf = (size_t)S * L.Sz + L.Sy + 2;
   L.plane_floats = (pf + 255) & ~(size_t)255;  // whole 1 KiB chunks for the async global->LDS staging
   L.lds_bytes = kAxisTableBytes + 4 * L.plane_floats;
+  L.all_resident = kAxisTableBytes + 3 * 4 * L.plane_floats <= 160 * 1024;
+  if (L.all_resident) L.lds_bytes = kAxisTableBytes + 3 * 4 * L.plane_floats;
   return L;
 }
 
@@ -215,8 +218,8 @@ __device__ __forceinline__ void stage_plane(unsigned char *lds, const float *__r
 
 // One channel pass over the P pixels a lane holds. C = output channel (byte index).
 template <int P, int C, int S_CONST>
-__device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, int Sz_rt, uint32_t (&px)[P], const uint32_t (&base)[P],
-                                         const float (&tx)[P], const float (&ty)[P], const float (&tz)[P]) {
+__device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, int Sz_rt, uint32_t plane_off, uint32_t (&px)[P],
+                                         const uint32_t (&base)[P], const float (&tx)[P], const float (&ty)[P], const float (&tz)[P]) {
   // strides are compile-time for the common 33^3 case so every corner is base + immediate
   const int Sy = S_CONST == 33 ? 35 : Sy_rt;
   const int Sz = S_CONST == 33 ? 1161 : Sz_rt;
@@ -224,7 +227,7 @@ __device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, in
   constexpr uint32_t sel = C == 0 ? 0x07060500u : (C == 1 ? 0x07060004u : 0x07000504u);
 #pragma unroll
   for (int i = 0; i < P; i++) {
-    const float *L1 = (const float *)(lds + base[i]);  // z0+1 layer
+    const float *L1 = (const float *)(lds + base[i] + plane_off);  // z0+1 layer (plane_off != 0 only when all planes are resident)
     const float *L0 = L1 + Sz;                         // z0 layer
     const float a0 = L0[0], a1 = L0[1], b0 = L0[Sy], b1 = L0[Sy + 1];
     const float c0 = L1[0], c1 = L1[1], d0 = L1[Sy], d1 = L1[Sy + 1];
@@ -241,7 +244,7 @@ template <int NT, int P4, int S_CONST>
 __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                             size_t n_groups, const float *__restrict__ planar,
                                                             const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
-                                                            uint32_t plane_floats) {
+                                                            uint32_t plane_floats, int all_resident) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int P = P4 * 4;
   const size_t tile_groups = (size_t)NT * P4;
@@ -255,12 +258,17 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   const size_t my_rounds = full_rounds + (rem_chunk > 0 ? 1 : 0);
 
   for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  // Small LUTs (size <= 18): all three planes fit LDS together and are staged once per block.
+  const uint32_t plane_bytes = all_resident ? plane_floats * 4u : 0u;
+  if (all_resident) {
+    for (int c = 0; c < 3; c++) stage_plane<NT>(lds + (size_t)c * plane_bytes, planar + (size_t)c * plane_floats, plane_floats);
+  }
   __syncthreads();
 
   // Channel order alternates R,G,B / B,G,R from tile to tile so the plane left in LDS by one tile's
   // last pass serves the next tile's first pass: two stagings per tile instead of three.
   bool flip = false;
-  int resident = -1;
+  int resident = all_resident ? 3 : -1;  // 3 = "every plane"
   for (size_t round = 0; round < my_rounds; round++) {
     size_t t_begin, t_end;
     if (round < full_rounds) {
@@ -294,20 +302,20 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
       tz[i] = __uint_as_float(ez.y);
     }
 #define MI355_STAGE(CH)                                                              \
-  if (resident != CH) {                                                              \
+  if (resident != CH && resident != 3) {                                             \
     __syncthreads(); /* everyone is done reading the previous plane */               \
     stage_plane<NT>(lds, planar + (size_t)CH * plane_floats, plane_floats);          \
     __syncthreads();                                                                 \
     resident = CH;                                                                   \
   }
     if (!flip) {
-      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
-      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
-      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, px, base, tx, ty, tz);
     } else {
-      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
-      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
-      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, px, base, tx, ty, tz);
+      MI355_STAGE(2) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE(1) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE(0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, px, base, tx, ty, tz);
     }
 #undef MI355_STAGE
     flip = !flip;
@@ -446,6 +454,7 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
         L.lds_Sy = lay.Sy;
         L.lds_Sz = lay.Sz;
         L.lds_bytes = lay.lds_bytes;
+        L.lds_all_resident = lay.all_resident;
         L.lds_ok = true;
       }
     }
@@ -496,7 +505,7 @@ static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size
   if (grid > min_blocks) grid = min_blocks;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
-                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats);
+                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");
 }
 

@@ -20,6 +20,7 @@ struct LutDevice {
   size_t planar_plane_floats = 0;  // floats per padded plane
   int lds_Sy = 0, lds_Sz = 0;      // LDS row / plane strides (floats)
   size_t lds_bytes = 0;            // dynamic LDS per block
+  bool lds_all_resident = false;   // all three planes staged once (small LUTs)
   bool lds_ok = false;        // LDS fast path legal for this LUT (fits, finite, bounded)
   bool loaded = false;
 };
