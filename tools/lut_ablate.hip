@@ -424,13 +424,6 @@ __global__ __launch_bounds__(NT) void k4(const uint4 *__restrict__ src, uint4 *_
     const size_t g0 = tile * tile_groups + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < P4; j++) { px[4 * j + 0] = nxt[j].x; px[4 * j + 1] = nxt[j].y; px[4 * j + 2] = nxt[j].z; px[4 * j + 3] = nxt[j].w; }
-    // prefetch the next tile now: the loads fly during the three passes below
-    {
-      const size_t nt = tile + gridDim.x;
-      const size_t h0 = nt * tile_groups + threadIdx.x;
-#pragma unroll
-      for (int j = 0; j < P4; j++) { const size_t g = h0 + (size_t)j * NT; if (nt < n_tiles && g < n_groups) nxt[j] = src[g]; }
-    }
 #pragma unroll
     for (int i = 0; i < P; i++) {
       const uint2 ex = *(const uint2 *)(lds + ((px[i] & 0xffu) << 3));
@@ -449,19 +442,25 @@ __global__ __launch_bounds__(NT) void k4(const uint4 *__restrict__ src, uint4 *_
         for (uint32_t kk = wave; kk < chunks; kk += NT / 64)                        \
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)kk * 1024), \
                                            (__attribute__((address_space(3))) void *)(lds + kAxisTableBytes + kk * 1024), 16, 0, 0); \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P4) : "memory"); /* leave the pixel prefetches in flight */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
       }                                                                             \
       __syncthreads();                                                              \
       resident = CH;                                                                \
     }
+#define PREFETCH4()                                                               \
+    {                                                                               \
+      const size_t nt = tile + gridDim.x;                                           \
+      const size_t h0 = nt * tile_groups + threadIdx.x;                             \
+      _Pragma("unroll") for (int j = 0; j < P4; j++) { const size_t g = h0 + (size_t)j * NT; if (nt < n_tiles && g < n_groups) nxt[j] = src[g]; } \
+    }
     if (!flip) {
       STAGE4(0) pass<P, 0, 0>(lds, px, base, tx, ty, tz);
       STAGE4(1) pass<P, 0, 1>(lds, px, base, tx, ty, tz);
-      STAGE4(2) pass<P, 0, 2>(lds, px, base, tx, ty, tz);
+      STAGE4(2) PREFETCH4() pass<P, 0, 2>(lds, px, base, tx, ty, tz);
     } else {
       STAGE4(2) pass<P, 0, 2>(lds, px, base, tx, ty, tz);
       STAGE4(1) pass<P, 0, 1>(lds, px, base, tx, ty, tz);
-      STAGE4(0) pass<P, 0, 0>(lds, px, base, tx, ty, tz);
+      STAGE4(0) PREFETCH4() pass<P, 0, 0>(lds, px, base, tx, ty, tz);
     }
     flip = !flip;
 #pragma unroll
