@@ -140,6 +140,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   lut_release(ctx);
+  ebur128_release(ctx);
   if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
   for (int i = 0; i < 2; i++)
     if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -476,6 +477,43 @@ int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size
   }
   return MI355_OK;
 }
+
+/* ------------------------------------------------------------------ ebur128 (loudness meter) */
+
+int mi355_ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_setup(ctx, channels, rate, mode, channel_class);
+}
+int mi355_ebur128_reset(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_reset(ctx);
+}
+int mi355_ebur128_teardown(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  ebur128_release(ctx);
+  return MI355_OK;
+}
+int mi355_ebur128_add_frames(mi355_ctx *ctx, const void *data, size_t frames, int sample_format) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_add_frames(ctx, data, nullptr, frames, sample_format);
+}
+int mi355_ebur128_add_frames_planar(mi355_ctx *ctx, const void *const *planes, size_t frames, int sample_format) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_add_frames(ctx, nullptr, planes, frames, sample_format);
+}
+int mi355_ebur128_loudness_momentary(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 0, out); }
+int mi355_ebur128_loudness_shortterm(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 1, out); }
+int mi355_ebur128_loudness_global(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 2, out); }
+int mi355_ebur128_relative_threshold(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 3, out); }
+int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 4, out); }
+int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 0, channel, out); }
+int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 1, channel, out); }
 
 /* ------------------------------------------------------------------ measurement helpers */
 

@@ -44,6 +44,7 @@ struct mi355_ctx {
   size_t d_stage_bytes[2] = {0, 0};
   mi355::LutDevice lut;
   mi355::EchoDevice echo;
+  void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
   bool force_generic = false;
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
@@ -78,5 +79,11 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
 void lut_release(mi355_ctx *ctx);
 int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay, double intensity,
                 double feedback);
+int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+int ebur128_reset(mi355_ctx *ctx);
+void ebur128_release(mi355_ctx *ctx);
+int ebur128_add_frames(mi355_ctx *ctx, const void *data, const void *const *planes, size_t frames, int fmt);
+int ebur128_query(mi355_ctx *ctx, int what, double *out);
+int ebur128_peak(mi355_ctx *ctx, int true_peak, unsigned channel, double *out);
 
 }  // namespace mi355

@@ -83,6 +83,18 @@ def load_library():
         "mi355_echo_process_f64": (i, [vp, vp, sz, sz, C.c_double, C.c_double]),
         "mi355_echo_process_device": (i, [vp, vp, sz, i, sz, C.c_double, C.c_double]),
         "mi355_echo_get_state": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "mi355_ebur128_setup": (i, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
+        "mi355_ebur128_reset": (i, [vp]),
+        "mi355_ebur128_teardown": (i, [vp]),
+        "mi355_ebur128_add_frames": (i, [vp, vp, sz, i]),
+        "mi355_ebur128_add_frames_planar": (i, [vp, C.POINTER(vp), sz, i]),
+        "mi355_ebur128_loudness_momentary": (i, [vp, C.POINTER(C.c_double)]),
+        "mi355_ebur128_loudness_shortterm": (i, [vp, C.POINTER(C.c_double)]),
+        "mi355_ebur128_loudness_global": (i, [vp, C.POINTER(C.c_double)]),
+        "mi355_ebur128_relative_threshold": (i, [vp, C.POINTER(C.c_double)]),
+        "mi355_ebur128_loudness_range": (i, [vp, C.POINTER(C.c_double)]),
+        "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_time_hsvfilter_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
         "mi355_time_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i, i, f32p]),
     }
@@ -234,3 +246,57 @@ class Context:
         pos = C.c_size_t(0)
         self._ck(self.L.mi355_echo_get_state(self.h, ring.ctypes.data, ring_len, C.byref(pos)))
         return ring, pos.value
+
+
+    # ---- ebur128 (loudness meter)
+    _EB_FMT = {np.dtype(np.int16): 0, np.dtype(np.int32): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+
+    def ebur128_setup(self, channels, rate, mode=63, channel_class=None):
+        cc = None
+        if channel_class is not None:
+            cc = (C.c_int * channels)(*[int(v) for v in channel_class])
+        self._ck(self.L.mi355_ebur128_setup(self.h, channels, rate, mode, cc))
+        self._eb_channels = channels
+
+    def ebur128_reset(self):
+        self._ck(self.L.mi355_ebur128_reset(self.h))
+
+    def ebur128_add_frames(self, data, planar=False):
+        a = np.ascontiguousarray(data)
+        fmt = self._EB_FMT[a.dtype]
+        if planar:
+            frames = a.shape[1]
+            ptrs = (C.c_void_p * a.shape[0])(*[a[c].ctypes.data for c in range(a.shape[0])])
+            self._ck(self.L.mi355_ebur128_add_frames_planar(self.h, ptrs, frames, fmt))
+        else:
+            self._ck(self.L.mi355_ebur128_add_frames(self.h, a.ctypes.data, a.size // self._eb_channels, fmt))
+
+    def _eb_get(self, name):
+        v = C.c_double(0)
+        self._ck(getattr(self.L, name)(self.h, C.byref(v)))
+        return v.value
+
+    def ebur128_loudness_momentary(self):
+        return self._eb_get("mi355_ebur128_loudness_momentary")
+
+    def ebur128_loudness_shortterm(self):
+        return self._eb_get("mi355_ebur128_loudness_shortterm")
+
+    def ebur128_loudness_global(self):
+        return self._eb_get("mi355_ebur128_loudness_global")
+
+    def ebur128_relative_threshold(self):
+        return self._eb_get("mi355_ebur128_relative_threshold")
+
+    def ebur128_loudness_range(self):
+        return self._eb_get("mi355_ebur128_loudness_range")
+
+    def ebur128_sample_peak(self, c):
+        v = C.c_double(0)
+        self._ck(self.L.mi355_ebur128_sample_peak(self.h, c, C.byref(v)))
+        return v.value
+
+    def ebur128_true_peak(self, c):
+        v = C.c_double(0)
+        self._ck(self.L.mi355_ebur128_true_peak(self.h, c, C.byref(v)))
+        return v.value

@@ -167,6 +167,37 @@ int mi355_echo_process_device(mi355_ctx *ctx, void *d_data, size_t n, int is_f64
 /* Test/diagnostic access to the element state (ring contents + write position). */
 int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size_t *pos_out);
 
+/* ---------------------------------------------------------------- ebur128 (loudness meter)
+ * Replaces the `ebur128::EbuR128` object (third-party crate ebur128 0.1.10, Cargo.lock:3685-3686) that
+ * `ebur128level` feeds and queries: EbuR128::new(channels, rate, mode) + set_channel_map
+ * (audio/audiofx/src/ebur128level/imp.rs:518-595), reset() (:329), add_frames_{i16,i32,f32,f64}[_planar]
+ * (:690-739), loudness_momentary / loudness_shortterm / loudness_global / relative_threshold /
+ * loudness_range / sample_peak / true_peak (:378-452). The crate's source is not vendored: this is the
+ * published BS.1770-4 / EBU R128 algorithm in libebur128's formulation (histogram mode, as the element
+ * always requests, imp.rs:55-56); parity with the crate is unpinned.
+ *   mode: bit 0 momentary, 1 short-term, 2 global (integrated + relative threshold), 3 loudness range,
+ *         4 sample peak, 5 true peak  (== GstEbuR128LevelMode, imp.rs:34-51).
+ *   channel_class[c]: 0 unused (LFE / unknown position), 1 weight 1.0 (L, R, C, ...), 2 weight 1.41
+ *         (surround: +-110/+-90/+-60 degrees), 3 dual mono (weight 2.0); NULL = libebur128's default map.
+ *   sample_format: 0 S16, 1 S32, 2 F32, 3 F64 (native endian), interleaved or planar.
+ * Loudness values are LUFS / LU as f64; "no signal above the gate" is -inf (global) / -70 (threshold). */
+typedef enum mi355_ebur128_mode {
+  MI355_EBUR128_MOMENTARY = 1, MI355_EBUR128_SHORT_TERM = 2, MI355_EBUR128_GLOBAL = 4,
+  MI355_EBUR128_LOUDNESS_RANGE = 8, MI355_EBUR128_SAMPLE_PEAK = 16, MI355_EBUR128_TRUE_PEAK = 32
+} mi355_ebur128_mode;
+int mi355_ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+int mi355_ebur128_reset(mi355_ctx *ctx);
+int mi355_ebur128_teardown(mi355_ctx *ctx);
+int mi355_ebur128_add_frames(mi355_ctx *ctx, const void *data, size_t frames, int sample_format);
+int mi355_ebur128_add_frames_planar(mi355_ctx *ctx, const void *const *planes, size_t frames, int sample_format);
+int mi355_ebur128_loudness_momentary(mi355_ctx *ctx, double *out);
+int mi355_ebur128_loudness_shortterm(mi355_ctx *ctx, double *out);
+int mi355_ebur128_loudness_global(mi355_ctx *ctx, double *out);
+int mi355_ebur128_relative_threshold(mi355_ctx *ctx, double *out);
+int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out);
+int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out);
+int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out);
+
 /* ---------------------------------------------------------------- measurement helpers
  * Used by bench.py: run `iters` back-to-back launches of one kernel on the context's stream
  * bracketed by hipEvents on THAT stream and return the average milliseconds per launch. */

@@ -62,6 +62,22 @@ def lib():
     L.oracle_echo_pos.argtypes = [C.c_void_p]
     L.oracle_echo_process_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
     L.oracle_echo_process_f64.argtypes = L.oracle_echo_process_f32.argtypes
+    f64p2 = C.POINTER(C.c_double)
+    L.oracle_ebur128_new.restype = C.c_void_p
+    L.oracle_ebur128_new.argtypes = [C.c_uint, C.c_ulong, C.c_uint]
+    L.oracle_ebur128_free.argtypes = [C.c_void_p]
+    L.oracle_ebur128_reset.argtypes = [C.c_void_p]
+    L.oracle_ebur128_set_channel_class.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+    L.oracle_ebur128_add_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+    for name in ("momentary", "shortterm", "global", "range"):
+        fn = getattr(L, "oracle_ebur128_loudness_" + name)
+        fn.argtypes = [C.c_void_p, f64p2]
+    L.oracle_ebur128_relative_threshold.argtypes = [C.c_void_p, f64p2]
+    L.oracle_ebur128_sample_peak.restype = C.c_double
+    L.oracle_ebur128_sample_peak.argtypes = [C.c_void_p, C.c_uint]
+    L.oracle_ebur128_true_peak.restype = C.c_double
+    L.oracle_ebur128_true_peak.argtypes = [C.c_void_p, C.c_uint]
+    L.oracle_ebur128_filter_coeffs.argtypes = [C.c_void_p, f64p2, f64p2]
     _LIB = L
     return L
 
@@ -201,4 +217,82 @@ class Echo:
     def __del__(self):
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.oracle_echo_free(self.h)
+            self.h = None
+
+
+# ---- ebur128 ----
+EB_M, EB_S, EB_I, EB_LRA, EB_SAMPLE_PEAK, EB_TRUE_PEAK = 1, 2, 4, 8, 16, 32
+EB_ALL = 63
+CH_UNUSED, CH_NORMAL, CH_SURROUND, CH_DUAL_MONO = 0, 1, 2, 3
+
+
+class EbuR128:
+    """Serial f64 restatement of the BS.1770 / EBU R128 meter (libebur128 formulation)."""
+
+    def __init__(self, channels, rate, mode=EB_ALL, channel_classes=None):
+        self.channels, self.rate, self.mode = channels, rate, mode
+        self.h = lib().oracle_ebur128_new(channels, rate, mode)
+        if not self.h:
+            raise ValueError("bad ebur128 configuration")
+        if channel_classes is not None:
+            for c, cls in enumerate(channel_classes):
+                lib().oracle_ebur128_set_channel_class(self.h, c, cls)
+
+    def reset(self):
+        lib().oracle_ebur128_reset(self.h)
+
+    def add_frames(self, data, planar=False):
+        """data: interleaved (frames*channels,) or planar (channels, frames); int16/int32/float32/float64."""
+        a = np.asarray(data)
+        if a.dtype == np.int16:
+            d = a.astype(np.float64) / 32768.0
+        elif a.dtype == np.int32:
+            d = a.astype(np.float64) / 2147483648.0
+        else:
+            d = a.astype(np.float64)
+        d = np.ascontiguousarray(d)
+        if planar:
+            frames = d.shape[1]
+            lib().oracle_ebur128_add_frames(self.h, d.ctypes.data, frames, 1, frames)
+        else:
+            frames = d.size // self.channels
+            lib().oracle_ebur128_add_frames(self.h, d.ctypes.data, frames, self.channels, 1)
+
+    def _get(self, name):
+        v = C.c_double(0)
+        rc = getattr(lib(), name)(self.h, C.byref(v))
+        if rc != 0:
+            raise RuntimeError(name + " failed")
+        return v.value
+
+    def loudness_momentary(self):
+        return self._get("oracle_ebur128_loudness_momentary")
+
+    def loudness_shortterm(self):
+        return self._get("oracle_ebur128_loudness_shortterm")
+
+    def loudness_global(self):
+        return self._get("oracle_ebur128_loudness_global")
+
+    def relative_threshold(self):
+        return self._get("oracle_ebur128_relative_threshold")
+
+    def loudness_range(self):
+        return self._get("oracle_ebur128_loudness_range")
+
+    def sample_peak(self, c):
+        return lib().oracle_ebur128_sample_peak(self.h, c)
+
+    def true_peak(self, c):
+        return lib().oracle_ebur128_true_peak(self.h, c)
+
+    def filter_coeffs(self):
+        b, a = np.zeros(5), np.zeros(5)
+        dp = C.POINTER(C.c_double)
+        lib().oracle_ebur128_filter_coeffs(self.h, b.ctypes.data_as(dp), a.ctypes.data_as(dp))
+        return b, a
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_ebur128_free(self.h)
             self.h = None
