@@ -8,10 +8,8 @@
 // oracle/ebur128_oracle.c (serial f64) with a tolerance, and against the EBU Tech 3341/3342 readings.
 //
 // GPU mapping
-//   * K-weighting (4th-order IIR, direct form II, f64) is a linear recurrence: each lane owns a chunk of
-//     the 100/400 ms segment, runs it from a zero state, lane 0 chains the boundary states with A^L
-//     (s_{k+1} = A^L s_k + z_k), then every lane re-runs its chunk from its true start state with exactly
-//     the serial arithmetic. Results differ from a serial run only by the rounding of the chained states.
+//   * K-weighting (4th-order IIR, direct form II, f64): one lane per channel runs the literal recurrence
+//     (bit-identical to a serial CPU run); parallelism is across channels (and across streams/contexts).
 //   * Gating-block / short-term energies: per-channel sum of squares over the ring window, wave shuffle
 //     (__shfl_down, 64 lanes) + LDS reduction, channel weights applied at the end.
 //   * Sample peak / true peak: max|x| reductions; the true-peak interpolator is the 49-tap Hann-windowed
@@ -43,111 +41,62 @@ template <> __device__ __forceinline__ double eb_to_double<int32_t>(int32_t v) {
 template <> __device__ __forceinline__ double eb_to_double<float>(float v) { return (double)v; }
 template <> __device__ __forceinline__ double eb_to_double<double>(double v) { return v; }
 
-__device__ __forceinline__ void mat4_mul(const double *A, const double *B, double *C) {  // C = A*B, row-major 4x4
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      double s = 0.0;
-      for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
-      C[i * 4 + j] = s;
-    }
-}
-
-// One block per channel. src element (i,c) at src[i*stride_f + c*stride_c] (interleaved: stride_f=C, stride_c=1;
-// planar staging: stride_f=1, stride_c=plane_len). Writes the filtered samples to ring[(ring_frame0+i)*C + c],
-// updates vstate[c][0..3] (v1..v4) and, if peak != nullptr, atomically maxes |x| into peak[c] (as u64 bits).
+// K-weighting + sample peak, one lane per channel (one wave handles up to 64 channels). The 4th-order
+// recurrence is serial per channel by nature; a chunked parallel scan was
+// implemented and rejected: superposing zero-state and homogeneous responses through A^L loses ~7 digits
+// because the direct-form-II state of the high-pass stage is ~1e4 times larger than its output
+// (1e-9 LU deviations). Running the literal recurrence keeps the filtered samples bit-identical to a
+// serial CPU run; with interleaved input the wave's loads and ring stores are coalesced across
+// channels, and the loop is unrolled so the loads of the next frames are in flight while the dependent
+// chain of the current frame retires. src element (i,c) at src[i*stride_f + c*stride_c].
 template <typename T>
-__global__ __launch_bounds__(kEbNT) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
-                                                          double *__restrict__ ring, size_t ring_frame0, unsigned channels,
-                                                          const int *__restrict__ channel_class, double *__restrict__ vstate,
-                                                          unsigned long long *__restrict__ peak, EbFilterK k) {
-  const unsigned c = blockIdx.x;
-  const unsigned t = threadIdx.x;
-  __shared__ double z_end[kEbNT][4];
-  __shared__ double s_start[kEbNT + 1][4];
-  __shared__ double powL[16], powR[16];
-  __shared__ double wave_max[kEbNT / 64];
-
-  const size_t L = (n + kEbNT - 1) / kEbNT;
-  const size_t i0 = (size_t)t * L;
-  const size_t i1 = i0 + L < n ? i0 + L : n;
-  const size_t cnt = i0 < n ? i1 - i0 : 0;
+__global__ __launch_bounds__(64) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
+                                                       double *__restrict__ ring, size_t ring_frame0, unsigned channels,
+                                                       const int *__restrict__ channel_class, double *__restrict__ vstate,
+                                                       unsigned long long *__restrict__ peak, EbFilterK k) {
+  const unsigned c = threadIdx.x;
+  if (c >= channels) return;
   const T *sp = src + (size_t)c * stride_c;
-
-  // sample peak (raw input, before weighting) — exact: max is order independent
-  if (peak) {
-    double mx = 0.0;
-    for (size_t i = i0; i < i0 + cnt; i++) {
-      const double x = eb_to_double<T>(sp[i * stride_f]);
-      const double ax = x < 0.0 ? -x : x;
+  const bool used = channel_class[c] != 0;
+  double v1 = vstate[c * 4 + 0], v2 = vstate[c * 4 + 1], v3 = vstate[c * 4 + 2], v4 = vstate[c * 4 + 3];
+  double mx = 0.0;
+  double *dst = ring + ring_frame0 * channels + c;
+  constexpr int U = 8;
+  size_t i = 0;
+  for (; i + U <= n; i += U) {
+    double x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) x[u] = eb_to_double<T>(sp[(i + u) * stride_f]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const double ax = x[u] < 0.0 ? -x[u] : x[u];
       if (ax > mx) mx = ax;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double o = __shfl_down(mx, off, 64);
-      if (o > mx) mx = o;
-    }
-    if ((t & 63) == 0) wave_max[t >> 6] = mx;
-    __syncthreads();
-    if (t == 0) {
-      double m = wave_max[0];
-      for (int w = 1; w < kEbNT / 64; w++) if (wave_max[w] > m) m = wave_max[w];
-      atomicMax(&peak[c], (unsigned long long)__double_as_longlong(m));  // non-negative doubles order like their bits
-    }
-  }
-  if (channel_class[c] == 0) return;  // unused channel: no filtering (block-uniform)
-
-  // pass 1: zero-state response end state of this lane's chunk
-  {
-    double v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
-    for (size_t i = i0; i < i0 + cnt; i++) {
-      const double x = eb_to_double<T>(sp[i * stride_f]);
-      const double v0 = x - k.a[1] * v1 - k.a[2] * v2 - k.a[3] * v3 - k.a[4] * v4;
-      v4 = v3; v3 = v2; v2 = v1; v1 = v0;
-    }
-    z_end[t][0] = v1; z_end[t][1] = v2; z_end[t][2] = v3; z_end[t][3] = v4;
-  }
-  __syncthreads();
-  // chain the boundary states: s_{k+1} = A^{len_k} s_k + z_k  (A = companion matrix of the denominator)
-  if (t == 0) {
-    const double A[16] = {-k.a[1], -k.a[2], -k.a[3], -k.a[4], 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    double P[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Q[16];
-    const size_t full = n / L;           // lanes with exactly L samples
-    const size_t rem = n - full * L;     // samples of lane `full` (0 <= rem < L)
-    for (size_t m = 0; m < L; m++) {
-      if (m == rem) for (int q = 0; q < 16; q++) powR[q] = P[q];
-      mat4_mul(A, P, Q);
-      for (int q = 0; q < 16; q++) P[q] = Q[q];
-    }
-    for (int q = 0; q < 16; q++) powL[q] = P[q];
-    for (int q = 0; q < 4; q++) s_start[0][q] = vstate[c * 4 + q];
-    for (unsigned kx = 0; kx < kEbNT; kx++) {
-      const size_t len = kx < full ? L : (kx == full ? rem : 0);
-      if (len == 0) {
-        for (int q = 0; q < 4; q++) s_start[kx + 1][q] = s_start[kx][q];
-      } else {
-        const double *M = (len == L) ? powL : powR;
-        for (int q = 0; q < 4; q++)
-          s_start[kx + 1][q] = M[q * 4 + 0] * s_start[kx][0] + M[q * 4 + 1] * s_start[kx][1] + M[q * 4 + 2] * s_start[kx][2] +
-                               M[q * 4 + 3] * s_start[kx][3] + z_end[kx][q];
+      if (used) {
+        const double v0 = x[u] - k.a[1] * v1 - k.a[2] * v2 - k.a[3] * v3 - k.a[4] * v4;
+        dst[(i + u) * channels] = k.b[0] * v0 + k.b[1] * v1 + k.b[2] * v2 + k.b[3] * v3 + k.b[4] * v4;
+        v4 = v3; v3 = v2; v2 = v1; v1 = v0;
       }
     }
-    // carried state for the next segment, with libebur128's denormal flush
-    for (int q = 0; q < 4; q++) {
-      double v = s_start[kEbNT][q];
-      if (fabs(v) < DBL_MIN) v = 0.0;
-      vstate[c * 4 + q] = v;
-    }
   }
-  __syncthreads();
-  // pass 2: the real run from the true start state — same operation order as the serial filter
-  {
-    double v1 = s_start[t][0], v2 = s_start[t][1], v3 = s_start[t][2], v4 = s_start[t][3];
-    double *dst = ring + ring_frame0 * channels + c;
-    for (size_t i = i0; i < i0 + cnt; i++) {
-      const double x = eb_to_double<T>(sp[i * stride_f]);
+  for (; i < n; i++) {
+    const double x = eb_to_double<T>(sp[i * stride_f]);
+    const double ax = x < 0.0 ? -x : x;
+    if (ax > mx) mx = ax;
+    if (used) {
       const double v0 = x - k.a[1] * v1 - k.a[2] * v2 - k.a[3] * v3 - k.a[4] * v4;
       dst[i * channels] = k.b[0] * v0 + k.b[1] * v1 + k.b[2] * v2 + k.b[3] * v3 + k.b[4] * v4;
       v4 = v3; v3 = v2; v2 = v1; v1 = v0;
     }
+  }
+  if (used) {  // libebur128 flushes denormal state at the end of every filtered segment
+    vstate[c * 4 + 0] = fabs(v1) < DBL_MIN ? 0.0 : v1;
+    vstate[c * 4 + 1] = fabs(v2) < DBL_MIN ? 0.0 : v2;
+    vstate[c * 4 + 2] = fabs(v3) < DBL_MIN ? 0.0 : v3;
+    vstate[c * 4 + 3] = fabs(v4) < DBL_MIN ? 0.0 : v4;
+  }
+  if (peak) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);  // non-negative doubles order like their bits
+    if (bits > peak[c]) peak[c] = bits;
   }
 }
 
@@ -415,7 +364,7 @@ static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, 
   if (st->have_interp)
     hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_tail,
                        st->d_peak + st->channels, st->ik);
-  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(st->channels), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
+  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
                      st->index_frames, st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk);
 }
 

@@ -26,7 +26,7 @@ namespace mi355host {
 // GstFlowReturn values (gst/gstpad.h)
 enum class FlowReturn : int { Ok = 0, Eos = -3, NotNegotiated = -4, Error = -5 };
 
-enum class PropType { Float, Double, UInt64, String };
+enum class PropType { Float, Double, UInt64, String, Flags, Boolean };
 enum class Mutability { Ready, Playing };  // mutable_ready / mutable_playing
 
 struct ParamSpec {
@@ -180,6 +180,50 @@ class AudioEcho final : public Element {
   double intensity_ = 0.5, feedback_ = 0.0;
   bool have_state_ = false;
   AudioInfo info_;
+};
+
+// ebur128level (audio/audiofx/src/ebur128level/imp.rs): AudioFilter in passthrough mode; chops the
+// buffers at `interval` boundaries, feeds the loudness meter and queues one "ebur128-level" message per
+// full interval (imp.rs:296-486).
+struct EbuR128LevelMessage {
+  uint64_t timestamp = 0;  // ns: the time until which measurements are included (imp.rs:353-361)
+  unsigned fields = 0;     // bit set of present fields == the mode bits
+  double momentary_loudness = 0, shortterm_loudness = 0, global_loudness = 0, relative_threshold = 0, loudness_range = 0;
+  std::vector<double> sample_peak, true_peak;
+};
+
+class EbuR128Level final : public Element {
+ public:
+  explicit EbuR128Level(int device);
+  const char *factory_name() const override { return "ebur128level"; }
+  const char *type_name() const override { return "GstEbuR128Level"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {0, 1, 2, 3}; }  // S16, S32, F32, F64 (x interleaved / planar)
+  std::vector<int> src_formats() const override { return {0, 1, 2, 3}; }
+  // AudioFilterImpl::setup (imp.rs:513-613). sample_format 0..3; channel_class as mi355_ebur128_setup
+  // (nullptr = no channel positions: every channel weighted like Center, imp.rs:589-595)
+  bool setup(int rate, int channels, int sample_format, bool planar, const int *channel_class);
+  // BaseTransformImpl::transform_ip_passthrough (imp.rs:296-486)
+  FlowReturn transform_ip_passthrough(const void *data, const void *const *planes, size_t frames, uint64_t pts_ns);
+  void reset_signal() { reset_requested_ = true; }  // the `reset` action signal (imp.rs:124-139)
+  bool pop_message(EbuR128LevelMessage *out);
+  bool stop() override;
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  bool store_u64(const std::string &name, uint64_t v) override;
+  bool load_u64(const std::string &name, uint64_t *v) const override;
+  unsigned mode_ = 63;             // DEFAULT_MODE = Mode::all() (imp.rs:80)
+  bool post_messages_ = true;      // imp.rs:81
+  uint64_t interval_ns_ = 1000000000ull;  // imp.rs:82
+  bool have_state_ = false, reset_requested_ = false;
+  int rate_ = 0, channels_ = 0, format_ = 2;
+  bool planar_ = false;
+  unsigned state_mode_ = 0;
+  uint64_t num_frames_ = 0, interval_frames_ = 0, interval_frames_remaining_ = 0;
+  std::vector<EbuR128LevelMessage> queue_;
 };
 
 // gst_element_factory_make(): nullptr for an unknown factory name or when no device context can be made.

@@ -44,6 +44,11 @@ def _lib():
             "mi355el_transform_frame": (i, [vp, i, i, i, i, vp, sz, i, i, vp, sz]),
             "mi355el_audio_setup": (i, [vp, i, i, i]),
             "mi355el_audio_transform_ip": (i, [vp, vp, sz]),
+            "mi355el_ebur128_setup": (i, [vp, i, i, i, i, C.POINTER(i)]),
+            "mi355el_ebur128_push": (i, [vp, vp, C.POINTER(vp), sz, C.c_uint64]),
+            "mi355el_ebur128_reset_signal": (None, [vp]),
+            "mi355el_ebur128_pop_message": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                C.POINTER(C.c_double), i, C.POINTER(i)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -103,6 +108,8 @@ class Element:
     # ---- g_object_set / get
     def set_property(self, name, value):
         n = name.encode()
+        if isinstance(value, bool):
+            value = 1.0 if value else 0.0
         if isinstance(value, str):
             rc = self.L.mi355el_set_string(self.h, n, value.encode())
         elif isinstance(value, int) and not isinstance(value, bool) and self.properties().get(name, {}).get("type") == PROP_UINT64:
@@ -141,3 +148,46 @@ class Element:
     def audio_transform_ip(self, data):
         assert isinstance(data, np.ndarray) and data.flags.c_contiguous
         return self.L.mi355el_audio_transform_ip(self.h, data.ctypes.data, data.nbytes)
+
+    # ---- ebur128level
+    _EB_FMT = {np.dtype(np.int16): 0, np.dtype(np.int32): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+
+    def ebur128_setup(self, rate, channels, dtype, planar=False, channel_class=None):
+        cc = (C.c_int * channels)(*channel_class) if channel_class is not None else None
+        self._eb_channels = channels
+        return self.L.mi355el_ebur128_setup(self.h, rate, channels, self._EB_FMT[np.dtype(dtype)], int(planar), cc) == 0
+
+    def ebur128_push(self, data, pts_ns, planar=False):
+        a = np.ascontiguousarray(data)
+        if planar:
+            ptrs = (C.c_void_p * a.shape[0])(*[a[c].ctypes.data for c in range(a.shape[0])])
+            return self.L.mi355el_ebur128_push(self.h, None, ptrs, a.shape[1], pts_ns)
+        ch = self._eb_channels
+        return self.L.mi355el_ebur128_push(self.h, a.ctypes.data, None, a.size // ch, pts_ns)
+
+    def ebur128_reset_signal(self):
+        self.L.mi355el_ebur128_reset_signal(self.h)
+
+    def ebur128_pop_messages(self):
+        out = []
+        while True:
+            ts, fields, nch = C.c_uint64(), C.c_uint(), C.c_int()
+            sc = (C.c_double * 5)()
+            sp, tp = (C.c_double * 64)(), (C.c_double * 64)()
+            if not self.L.mi355el_ebur128_pop_message(self.h, C.byref(ts), C.byref(fields), sc, sp, tp, 64, C.byref(nch)):
+                return out
+            m = {"timestamp": ts.value}
+            f = fields.value
+            if f & 1:
+                m["momentary-loudness"] = sc[0]
+            if f & 2:
+                m["shortterm-loudness"] = sc[1]
+            if f & 4:
+                m["global-loudness"], m["relative-threshold"] = sc[2], sc[3]
+            if f & 8:
+                m["loudness-range"] = sc[4]
+            if f & 16:
+                m["sample-peak"] = [sp[c] for c in range(nch.value)]
+            if f & 32:
+                m["true-peak"] = [tp[c] for c in range(nch.value)]
+            out.append(m)

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "gst-plugins-rs_amd"))
 def surface():
     d = json.load(open("/root/reference/docs/plugins/gst_plugins_cache.json"))
     out = {}
-    for plug, els in (("hsv", ["hsvfilter", "hsvdetector"]), ("colorlut", ["colorlut"]), ("rsaudiofx", ["rsaudioecho"])):
+    for plug, els in (("hsv", ["hsvfilter", "hsvdetector"]), ("colorlut", ["colorlut"]), ("rsaudiofx", ["rsaudioecho", "ebur128level"])):
         for e in els:
             el = d[plug]["elements"][e]
             props = {n: {k: p[k] for k in ("type", "default", "min", "max", "mutable") if k in p}

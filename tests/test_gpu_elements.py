@@ -140,3 +140,57 @@ def test_unknown_factory():
     from mi355fx.elements import Element, ElementError
     with pytest.raises(ElementError):
         Element("agingradio")
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.float32, np.float64])
+@pytest.mark.parametrize("planar", [False, True])
+def test_ebur128level_element_like_the_reference_test(oracle, dtype, planar):
+    """Replays audio/audiofx/tests/ebur128level.rs:93-153 on the element mirror: 5 one-second buffers of a
+    440 Hz test tone (audiotestsrc default: sine, volume 0.8), 2 channels 48 kHz, interval=500 ms ->
+    exactly 10 `ebur128-level` messages with timestamps k*500 ms carrying every field; in addition the
+    values must equal the oracle's readings at the same instants."""
+    from mi355fx.elements import Element, FLOW_OK
+    rate, ch = 48000, 2
+    e = Element("ebur128level")
+    assert e.set_property("interval", 500_000_000)
+    assert e.get_property("interval") == 500_000_000 and e.get_property("mode") == 63 and e.get_property("post-messages") == 1.0
+    assert e.ebur128_setup(rate, ch, dtype, planar)
+    ref = oracle.EbuR128(ch, rate, 63, [1, 1])   # no channel positions -> Center weighting for all (imp.rs:589-595)
+    t = np.arange(5 * rate) / rate
+    tone = 0.8 * np.sin(2 * np.pi * 440.0 * t)
+    if dtype == np.int16:
+        x = np.round(tone * 32767).astype(np.int16)
+    elif dtype == np.int32:
+        x = np.round(tone * 2147483647).astype(np.int32)
+    else:
+        x = tone.astype(dtype)
+    x = np.repeat(x[:, None], ch, axis=1)
+    msgs, expected = [], []
+    for b in range(5):
+        buf = x[b * rate:(b + 1) * rate]
+        data = np.ascontiguousarray(buf.T) if planar else buf.reshape(-1)
+        assert e.ebur128_push(data, b * 10 ** 9, planar) == FLOW_OK
+        msgs += e.ebur128_pop_messages()
+        for half in range(2):
+            part = buf[half * rate // 2:(half + 1) * rate // 2]
+            ref.add_frames(np.ascontiguousarray(part.T) if planar else part.reshape(-1), planar=planar)
+            expected.append((ref.loudness_momentary(), ref.loudness_shortterm(), ref.loudness_global(), ref.relative_threshold(),
+                             ref.loudness_range(), [ref.sample_peak(c) for c in range(ch)], [ref.true_peak(c) for c in range(ch)]))
+    assert len(msgs) == 10
+    for k, (m, ex) in enumerate(zip(msgs, expected), start=1):
+        assert m["timestamp"] == k * 500_000_000
+        for field in ("momentary-loudness", "shortterm-loudness", "global-loudness", "relative-threshold", "loudness-range"):
+            assert isinstance(m[field], float)
+        assert len(m["sample-peak"]) == 2 and len(m["true-peak"]) == 2
+        got = (m["momentary-loudness"], m["shortterm-loudness"], m["global-loudness"], m["relative-threshold"], m["loudness-range"])
+        for g, w in zip(got, ex[:5]):
+            assert (g == w) or abs(g - w) <= 1e-9
+        assert m["sample-peak"] == ex[5] and m["true-peak"] == ex[6]
+    # post-messages=false is honoured per buffer (mutable in PLAYING); the `reset` action restarts the interval
+    assert e.set_property("post-messages", False)
+    assert e.ebur128_push(x[:rate].reshape(-1) if not planar else np.ascontiguousarray(x[:rate].T), 5 * 10 ** 9, planar) == FLOW_OK
+    assert e.ebur128_pop_messages() == []
+    assert e.stop()
+    from mi355fx.elements import FLOW_NOT_NEGOTIATED
+    assert e.ebur128_push(x[:10].reshape(-1) if not planar else np.ascontiguousarray(x[:10].T), 0, planar) == FLOW_NOT_NEGOTIATED
+    e.close()
