@@ -332,6 +332,46 @@ __global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__
   }
 }
 
+// 3-byte formats (RGB / BGR) on contiguous storage: one lane = 12 B = 4 pixels. The three dwords are
+// split into four pixel words with v_alignbit-style shifts, filtered by the same pair routine as the
+// 4-byte formats (byte 3 of each word is scratch) and re-packed.
+struct Rgb24x4 { uint32_t d0, d1, d2; };
+template <int VARIANT, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_rgb24_kernel(Rgb24x4 *__restrict__ data, size_t n_grp, HsvK k) {
+  constexpr int RPOS = BGR ? 2 : 0, GPOS = 1, BPOS = BGR ? 0 : 2, NPOS = 3;
+  constexpr bool FAST = VARIANT >= 0;
+  __shared__ uint32_t sel_tab[8];
+  if (threadIdx.x < 7)
+    sel_tab[threadIdx.x] = FAST ? hsv_sel_entry_floor(threadIdx.x, RPOS, GPOS, BPOS, NPOS)
+                                : hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grp; i += stride) {
+    const Rgb24x4 v = data[i];
+    uint32_t p0 = v.d0, p1 = (v.d0 >> 24) | (v.d1 << 8), p2 = (v.d1 >> 16) | (v.d2 << 16), p3 = v.d2 >> 8;
+    if constexpr (FAST) {
+      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p0, p1, k, sel_tab);
+      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p2, p3, k, sel_tab);
+    } else {
+      p0 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p0, k, sel_tab);
+      p1 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p1, k, sel_tab);
+      p2 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p2, k, sel_tab);
+      p3 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p3, k, sel_tab);
+    }
+    Rgb24x4 o;
+    o.d0 = (p0 & 0x00ffffffu) | (p1 << 24);
+    o.d1 = ((p1 >> 8) & 0x0000ffffu) | (p2 << 16);
+    o.d2 = ((p2 >> 16) & 0x000000ffu) | (p3 << 8);
+    data[i] = o;
+  }
+}
+
+template <int VARIANT>
+static void launch_rgb24(mi355_ctx *ctx, Rgb24x4 *d, size_t n_grp, const HsvK &k, int bgr, int grid) {
+  if (bgr) hipLaunchKernelGGL((hsvfilter_rgb24_kernel<VARIANT, true>), dim3(grid), dim3(256), 0, ctx->stream, d, n_grp, k);
+  else hipLaunchKernelGGL((hsvfilter_rgb24_kernel<VARIANT, false>), dim3(grid), dim3(256), 0, ctx->stream, d, n_grp, k);
+}
+
 // General kernel: any stride / pixel stride (3 or 4) / triple offset, one pixel per lane, byte
 // accesses. Only `line[..width*pixel_stride]` of each row is touched (hsvfilter/imp.rs:94-97).
 template <bool FAST>
@@ -410,6 +450,25 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
         case 4: launch_flat<4>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
         case 5: launch_flat<5>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
         default: launch_flat<6>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
+      }
+    }
+  } else if (fmt.pixel_stride == 3 && fmt.first == 0 && (size_t)stride == row_bytes &&
+             (n_frames == 1 || frame_pitch == row_bytes * (size_t)height) && ((uintptr_t)d_data % 4 == 0) && (total_bytes % 12 == 0)) {
+    const size_t n_grp = total_bytes / 12;
+    const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
+    Rgb24x4 *d = (Rgb24x4 *)d_data;
+    if (!fast) {
+      launch_rgb24<-1>(ctx, d, n_grp, k, fmt.bgr, grid);
+    } else {
+      const bool sv_ident = s.saturation_mul == 1.0f && s.saturation_off == 0.0f && s.value_mul == 1.0f && s.value_off == 0.0f;
+      const int shift = s.hue_shift == 0.0f ? HSV_SHIFT_ZERO : (s.hue_shift > 0.0f ? HSV_SHIFT_POS : HSV_SHIFT_NEG);
+      switch (shift | (sv_ident ? 4 : 0)) {
+        case 0: launch_rgb24<0>(ctx, d, n_grp, k, fmt.bgr, grid); break;
+        case 1: launch_rgb24<1>(ctx, d, n_grp, k, fmt.bgr, grid); break;
+        case 2: launch_rgb24<2>(ctx, d, n_grp, k, fmt.bgr, grid); break;
+        case 4: launch_rgb24<4>(ctx, d, n_grp, k, fmt.bgr, grid); break;
+        case 5: launch_rgb24<5>(ctx, d, n_grp, k, fmt.bgr, grid); break;
+        default: launch_rgb24<6>(ctx, d, n_grp, k, fmt.bgr, grid); break;
       }
     }
   } else {

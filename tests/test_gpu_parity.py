@@ -416,3 +416,20 @@ def test_colorlut_1d_allcolors(ctx, oracle, synth, size, force_generic):
     ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
     ctx.set_flag(mi355fx.FLAG_FORCE_GENERIC, 0)
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("setting", ["hue90", "mixed", "generic"])
+def test_hsvfilter_rgb24_allcolors(ctx, oracle, synth, fmt, setting):
+    """3-byte formats on contiguous storage take the 12-byte (4 pixel) vector kernel: every colour, FAST and
+    GENERIC arithmetic."""
+    st = synth.HSV_SETTINGS.get(setting) or (1234.5, 0.7, 0.1, 1.3, -0.1)
+    ac = synth.allcolors().reshape(-1, 4)[:, :3]
+    if fmt == "BGR":
+        ac = ac[:, ::-1]
+    frame = np.ascontiguousarray(ac).reshape(-1)          # 4096x4096 RGB, stride 12288
+    exp = frame.copy()
+    oracle.hsvfilter(exp, 4096, 4096 * 3, 3, 0, fmt == "BGR", st, nthreads=8)
+    got = frame.copy()
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 3, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
