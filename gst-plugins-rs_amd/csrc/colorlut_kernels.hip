@@ -327,6 +327,120 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   }
 }
 
+// ---------------------------------------------------------------- LDS three-pass kernel, RGBA64 (3D)
+//
+// transform_rgba64_3d::<LE> (imp.rs:348-397): same plane layout, staging and pass structure as the
+// RGBA8 kernel; a pixel is two dwords (r16|g16, b16|a16, byte order per LE), the coordinates are
+// computed with VALU (65536 input levels do not fit an LDS axis table): norm_comp_u16 = v/65535 via the
+// exact two-operation quotient (div65535_u16), scale/offset, clamp, *(S-1), floor/fract.
+// Output: float_to_u16 = round-half-away(clamp(v)*65535) (v_cvt_rpi, exact on [0,65536]).
+struct Lut64K {
+  float scale[3], offset[3];
+  float sm1;
+  uint32_t sy4, sz4;  // byte strides 4*Sy, 4*Sz
+  uint32_t plane_base;  // kAxisTableBytes
+  int S;
+};
+
+__device__ __forceinline__ uint32_t swap16(uint32_t v) { return ((v >> 8) & 0xffu) | ((v & 0xffu) << 8); }
+
+template <int NT, int P2, bool LE>
+__global__ __launch_bounds__(NT) void colorlut3d_lds64_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_groups,
+                                                              const float *__restrict__ planar, const uint32_t *__restrict__ axis_tab,
+                                                              uint32_t plane_floats, Lut64K k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int P = P2 * 2;  // pixels per lane (one uint4 = 2 pixels)
+  const size_t tile_groups = (size_t)NT * P2;
+  const size_t full_rounds = (n_groups / tile_groups) / gridDim.x;
+  const size_t rem_start = full_rounds * gridDim.x * tile_groups;
+  const size_t rem_chunk = (n_groups - rem_start + gridDim.x - 1) / gridDim.x;
+  const size_t my_rounds = full_rounds + (rem_chunk > 0 ? 1 : 0);
+  // the axis-table region is staged too: the z0 == S-1 pad reads land there (finite values)
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  __syncthreads();
+  const int Sy = (int)(k.sy4 / 4), Sz = (int)(k.sz4 / 4);
+  bool flip = false;
+  int resident = -1;
+  for (size_t round = 0; round < my_rounds; round++) {
+    size_t t_begin, t_end;
+    if (round < full_rounds) {
+      t_begin = (round * gridDim.x + blockIdx.x) * tile_groups;
+      t_end = t_begin + tile_groups;
+    } else {
+      t_begin = rem_start + (size_t)blockIdx.x * rem_chunk;
+      t_end = t_begin + rem_chunk;
+      if (t_end > n_groups) t_end = n_groups;
+      if (t_begin >= t_end) break;
+    }
+    uint32_t lo[P], hi[P], base[P];
+    float tx[P], ty[P], tz[P];
+    const size_t g0 = t_begin + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P2; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g < t_end) v = src[g];
+      lo[2 * j] = v.x; hi[2 * j] = v.y; lo[2 * j + 1] = v.z; hi[2 * j + 1] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      uint32_t c16[3] = {lo[i] & 0xffffu, lo[i] >> 16, hi[i] & 0xffffu};
+      uint32_t idx[3];
+      float t[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const uint32_t v = LE ? c16[a] : swap16(c16[a]);
+        float n = div65535_u16((float)v);
+        n = fminf(fmaxf(n * k.scale[a] + k.offset[a], 0.0f), 1.0f);  // finite domain: == inherent clamp
+        const float x = n * k.sm1;
+        idx[a] = (uint32_t)x;
+        t[a] = __builtin_amdgcn_fractf(x);
+      }
+      base[i] = k.plane_base + 4u * idx[0] + k.sy4 * idx[1] + k.sz4 * (uint32_t)(k.S - 2 - (int)idx[2]);
+      tx[i] = t[0]; ty[i] = t[1]; tz[i] = t[2];
+    }
+#define MI355_STAGE64(CH)                                                            \
+  if (resident != CH) {                                                              \
+    __syncthreads();                                                                 \
+    stage_plane<NT>(lds, planar + (size_t)CH * plane_floats, plane_floats);          \
+    __syncthreads();                                                                 \
+    resident = CH;                                                                   \
+  }
+#define MI355_PASS64(CH)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < P; i++) {                                                            \
+    const float *L1 = (const float *)(lds + base[i]);                                                        \
+    const float *L0 = L1 + Sz;                                                                               \
+    const float a0 = L0[0], a1 = L0[1], b0 = L0[Sy], b1 = L0[Sy + 1];                                        \
+    const float c0 = L1[0], c1 = L1[1], d0 = L1[Sy], d1 = L1[Sy + 1];                                        \
+    const float c00 = lerp1(a0, a1, tx[i]), c10 = lerp1(b0, b1, tx[i]);                                      \
+    const float c01 = lerp1(c0, c1, tx[i]), c11 = lerp1(d0, d1, tx[i]);                                      \
+    const float o = lerp1(lerp1(c00, c10, ty[i]), lerp1(c01, c11, ty[i]), tz[i]);                            \
+    uint32_t v16 = round_half_away_nonneg(fminf(fmaxf(o, 0.0f), 1.0f) * 65535.0f);                           \
+    if (!LE) v16 = swap16(v16);                                                                              \
+    if (CH == 0) lo[i] = (lo[i] & 0xffff0000u) | v16;                                                        \
+    else if (CH == 1) lo[i] = (lo[i] & 0x0000ffffu) | (v16 << 16);                                           \
+    else hi[i] = (hi[i] & 0xffff0000u) | v16;                                                                \
+  }
+    if (!flip) {
+      MI355_STAGE64(0) MI355_PASS64(0)
+      MI355_STAGE64(1) MI355_PASS64(1)
+      MI355_STAGE64(2) MI355_PASS64(2)
+    } else {
+      MI355_STAGE64(2) MI355_PASS64(2)
+      MI355_STAGE64(1) MI355_PASS64(1)
+      MI355_STAGE64(0) MI355_PASS64(0)
+    }
+#undef MI355_STAGE64
+#undef MI355_PASS64
+    flip = !flip;
+#pragma unroll
+    for (int j = 0; j < P2; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      if (g < t_end) dst[g] = make_uint4(lo[2 * j], hi[2 * j], lo[2 * j + 1], hi[2 * j + 1]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- 1D LUT, RGBA8, tables in LDS
 //
 // transform_rgba_1d / apply_1d / sample_1d (imp.rs:237-265,399-414,482-490). LDS image: the three
@@ -555,6 +669,37 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
       constexpr int NT = 1024, P4 = 3;
       if (L.size == 33) return launch_lds_variant<NT, P4, 33>(ctx, s, d, n_groups);
       return launch_lds_variant<NT, P4, 0>(ctx, s, d, n_groups);
+    }
+  }
+
+  if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && L.is3d && L.lds_ok && !L.lds_all_resident && !ctx->force_generic) {
+    const size_t row_bytes = (size_t)width * 8;
+    const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                            (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+    const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+    if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
+      constexpr int NT = 1024, P2 = 4;
+      Lut64K k64;
+      for (int c = 0; c < 3; c++) { k64.scale[c] = L.scale[c]; k64.offset[c] = L.offset[c]; }
+      k64.sm1 = (float)L.size - 1.0f;
+      k64.sy4 = 4u * (uint32_t)L.lds_Sy; k64.sz4 = 4u * (uint32_t)L.lds_Sz; k64.plane_base = kAxisTableBytes; k64.S = L.size;
+      const size_t n_groups = total_bytes / 16;
+      size_t grid = (size_t)ctx->n_cu;
+      const size_t min_blocks = (n_groups + 255) / 256;
+      if (grid > min_blocks) grid = min_blocks;
+      if (grid < 1) grid = 1;
+      const size_t lds = kAxisTableBytes + 4 * L.planar_plane_floats;
+      const bool le = format == MI355_FMT_RGBA64_LE;
+      auto kle = colorlut3d_lds64_kernel<NT, P2, true>;
+      auto kbe = colorlut3d_lds64_kernel<NT, P2, false>;
+      int rc = check_hip(ctx, hipFuncSetAttribute(le ? (const void *)kle : (const void *)kbe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                         "hipFuncSetAttribute(max dynamic LDS)");
+      if (rc) return rc;
+      if (le) hipLaunchKernelGGL(kle, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_groups,
+                                 (const float *)L.d_planar, (const uint32_t *)L.d_axis, (uint32_t)L.planar_plane_floats, k64);
+      else hipLaunchKernelGGL(kbe, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_groups,
+                              (const float *)L.d_planar, (const uint32_t *)L.d_axis, (uint32_t)L.planar_plane_floats, k64);
+      return check_hip(ctx, hipGetLastError(), "colorlut3d_lds64 kernel launch");
     }
   }
 

@@ -21,6 +21,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace mi355 {
@@ -206,12 +207,12 @@ struct Ebur128State {
 };
 
 static double g_hist_energy[kHistBins], g_hist_bound[kHistBins + 1];
-static bool g_hist_ready = false;
+static std::once_flag g_hist_once;
 static void hist_tables() {
-  if (g_hist_ready) return;
-  for (int i = 0; i < kHistBins; i++) g_hist_energy[i] = std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0);
-  for (int i = 0; i <= kHistBins; i++) g_hist_bound[i] = std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0);
-  g_hist_ready = true;
+  std::call_once(g_hist_once, [] {
+    for (int i = 0; i < kHistBins; i++) g_hist_energy[i] = std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0);
+    for (int i = 0; i <= kHistBins; i++) g_hist_bound[i] = std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0);
+  });
 }
 static size_t hist_index(double e) {
   size_t lo = 0, hi = kHistBins;

@@ -433,3 +433,65 @@ def test_hsvfilter_rgb24_allcolors(ctx, oracle, synth, fmt, setting):
     got = frame.copy()
     ctx.hsvfilter_frame_ip(got, 4096, 4096 * 3, fmt, st)
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_independent_contexts_are_concurrent_safe(oracle, synth, mi355lib):
+    """Many element instances on one GPU, each driven by its own streaming thread (SURVEY.md section 8b
+    'Threading'): four contexts in four Python threads, different settings/LUTs, results must match the
+    oracle for every stream."""
+    import threading
+    import mi355fx
+    from mi355fx.cube import parse_cube
+    w, h = 1280, 720
+    frames = [synth.noise_frame(w, h, seed=500 + i) for i in range(4)]
+    settings = [(90.0, 1.0, 0.0, 1.0, 0.0), (-45.0, 1.2, -0.05, 0.9, 0.02), (0.0, 0.5, 0.25, 1.0, 0.0), (200.0, 1.0, 0.0, 1.1, -0.1)]
+    texts = [synth.cube_text_3d(33), synth.cube_text_3d(17, amp=0.07), synth.cube_text_3d(33, identity=True), synth.cube_text_1d(256)]
+    results, errors = [None] * 4, []
+
+    def worker(i):
+        try:
+            with mi355fx.Context(0) as c:
+                lut = parse_cube(texts[i])
+                c.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+                out = None
+                for _ in range(5):
+                    mid = frames[i].copy().reshape(-1)
+                    c.hsvfilter_frame_ip(mid, w, w * 4, "RGBA", settings[i])
+                    out = np.zeros_like(frames[i])
+                    c.colorlut_frame(mid, w * 4, out, w * 4, w, h, "RGBA")
+                results[i] = out
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        mid = frames[i].copy().reshape(-1)
+        oracle.hsvfilter(mid, w, w * 4, 4, 0, False, settings[i])
+        exp = np.zeros_like(frames[i])
+        oracle.colorlut_rgba8(oracle.Cube.parse(texts[i]), mid, w * 4, exp, w * 4, w, h)
+        assert (results[i] == exp).all(), "stream %d" % i
+
+
+@pytest.mark.parametrize("le", [True, False])
+@pytest.mark.parametrize("domain", [None, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))])
+def test_colorlut_rgba64_lds_kernel(ctx, oracle, synth, le, domain):
+    """RGBA64 + 33^3 LUT on contiguous frames takes the LDS three-pass kernel (VALU coordinates, exact
+    /65535): random 16-bit pixels plus every channel value 0..65535 on the diagonal."""
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33, amp=0.06, domain=domain))
+    rng = np.random.default_rng(23)
+    w, h = 1024, 320
+    px = rng.integers(0, 65536, size=(h * w, 4), dtype=np.uint16)
+    ramp = np.arange(65536, dtype=np.uint16)
+    px[:65536, 0] = ramp; px[:65536, 1] = ramp[::-1]; px[:65536, 2] = (ramp * 3) & 0xffff
+    px[65536:131072, :3] = ramp[:, None]
+    src = (px if le else px.byteswap()).reshape(-1).view(np.uint8).copy()
+    exp = np.zeros_like(src)
+    oracle.colorlut_rgba64(cube, src, w * 8, exp, w * 8, w, h, le=le)
+    got = np.zeros_like(src)
+    ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, "RGBA64_LE" if le else "RGBA64_BE")
+    assert (got == exp).all(), _mismatch_report(got, exp)
