@@ -160,7 +160,42 @@ def main():
             del srcs, dsts
             return dt, hsv_ms, lut_ms
 
+        def measure_fused(content, steps, warmup):
+            """Same chain as ONE launch per batch (mi355_hsv_colorlut_frames_device): SURVEY §8(d) 'fused' accounting."""
+            srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
+            dsts = [torch.empty_like(s) for s in srcs]
+            pitch = FRAME_BYTES
+
+            def region(n, record):
+                evs = []
+                for k in range(n):
+                    s_, d_ = srcs[k % len(srcs)], dsts[k % len(dsts)]
+                    if record:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    ctx.hsv_colorlut_frames_device(s_.data_ptr(), pitch, W * 4, d_.data_ptr(), pitch, W * 4, args.batch, W, H, settings)
+                    if record:
+                        e1.record()
+                        evs.append((e0, e1))
+                return evs
+
+            region(warmup, False)
+            evs = []
+            dtf = sharding.timed_region(lambda: evs.extend(region(steps, True)), dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            del srcs, dsts
+            return dtf, ms
+
         dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
+        fused = None
+        if not args.no_extra:
+            dtf, fused_ms = measure_fused(args.content, args.steps, args.warmup)
+            fused_fps = sharding.aggregate_throughput(args.steps * args.batch, world, dtf)
+            fb = BYTES_PER_FRAME_PER_KERNEL * args.batch
+            fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms, "kernel": "colorlut3d_lds_kernel<HSV>",
+                     "algorithmic_bytes_per_launch": fb, "GBps": fb / (fused_ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": fb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "one launch per batch, 8 B/px algorithmic (SURVEY 8d fused accounting); bit-identical to the two-kernel chain"}
         extra = None
         if not args.no_extra and rank == 0 and world == 1:
             other = "noise" if args.content == "smooth" else "smooth"
@@ -207,6 +242,8 @@ def main():
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS},
         }
+        if fused:
+            out["fused_chain"] = fused
         if extra:
             out["other_content"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -20,6 +20,7 @@
 // Algorithmic traffic of both: 4 B read + 4 B written per pixel (RGBA8); the LUT is a
 // cache/LDS-resident constant.
 #include "internal.hpp"
+#include "hsv_device.hpp"
 #include "exact_math.hpp"
 
 #include <cmath>
@@ -240,12 +241,21 @@ __device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, in
   }
 }
 
-template <int NT, int P4, int S_CONST>
+// HSV: kNoHsv = plain colorlut. Otherwise the kernel is the fused hsvfilter -> colorlut chain on RGBA: the pixels
+// are run through the hsvfilter arithmetic (variant as in hsv_kernels.hip: -1 GENERIC, 0..6 FAST) in registers
+// right after the load, so the chain costs one read and one write per pixel instead of two of each.
+constexpr int kNoHsv = -2;
+template <int NT, int P4, int S_CONST, int HSV>
 __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                             size_t n_groups, const float *__restrict__ planar,
                                                             const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
-                                                            uint32_t plane_floats, int all_resident) {
+                                                            uint32_t plane_floats, int all_resident, HsvK hk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ uint32_t hsv_sel[HSV == kNoHsv ? 1 : 8];
+  if constexpr (HSV != kNoHsv) {
+    if (threadIdx.x < 7)
+      hsv_sel[threadIdx.x] = HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3);
+  }
   constexpr int P = P4 * 4;
   const size_t tile_groups = (size_t)NT * P4;
   // Work split: `full_rounds` rounds of whole tiles (tile t -> block t % grid), then the remaining
@@ -290,6 +300,14 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
       uint4 v = make_uint4(0, 0, 0, 0);
       if (g < t_end) v = src[g];
       px[4 * j + 0] = v.x; px[4 * j + 1] = v.y; px[4 * j + 2] = v.z; px[4 * j + 3] = v.w;
+    }
+    if constexpr (HSV >= 0) {
+#pragma unroll
+      for (int i = 0; i < P; i += 2)
+        hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(px[i], px[i + 1], hk, hsv_sel);
+    } else if constexpr (HSV == -1) {
+#pragma unroll
+      for (int i = 0; i < P; i++) px[i] = hsvfilter_px<false, 0, 1, 2, 3>(px[i], hk, hsv_sel);
     }
 #pragma unroll
     for (int i = 0; i < P; i++) {
@@ -604,9 +622,9 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
   return MI355_OK;
 }
 
-template <int NT, int P4, int S_CONST>
-static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups) {
-  auto kern = colorlut3d_lds_kernel<NT, P4, S_CONST>;
+template <int NT, int P4, int S_CONST, int HSV = kNoHsv>
+static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups, const HsvK &hk = HsvK{}) {
+  auto kern = colorlut3d_lds_kernel<NT, P4, S_CONST, HSV>;
   const LutDevice &L = ctx->lut;
   const size_t lds = L.lds_bytes;
   int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -619,8 +637,68 @@ static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size
   if (grid > min_blocks) grid = min_blocks;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
-                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0);
+                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0, hk);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");
+}
+
+// Is the RGBA8 3D LDS kernel applicable to this geometry? (contiguous rows and frames, 16 B aligned)
+static bool lds3d_rgba_applicable(const mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst,
+                                  size_t dst_pitch, int dst_stride, int n_frames, int width, int height, size_t *n_groups) {
+  const LutDevice &L = ctx->lut;
+  if (!(L.is3d && L.lds_ok) || ctx->force_generic) return false;
+  const size_t row_bytes = (size_t)width * 4;
+  const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                          (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+  const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+  if (!(contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0))) return false;
+  *n_groups = total_bytes / 16;
+  return true;
+}
+
+template <int HSV>
+static int launch_fused_variant(mi355_ctx *ctx, const uint4 *s, uint4 *d, size_t n_groups, const HsvK &hk) {
+  constexpr int NT = 1024, P4 = 3;
+  if (ctx->lut.size == 33) return launch_lds_variant<NT, P4, 33, HSV>(ctx, s, d, n_groups, hk);
+  return launch_lds_variant<NT, P4, 0, HSV>(ctx, s, d, n_groups, hk);
+}
+
+// hsvfilter followed by colorlut on RGBA frames. One fused launch when the 3D LDS kernel applies; otherwise the
+// two element kernels back to back (copy src -> dst, hsvfilter in place on dst, colorlut dst -> dst; every colorlut
+// kernel reads a pixel before it writes the same pixel, so in-place is safe).
+int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                        size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
+                        const mi355_hsv_settings &hs) {
+  const LutDevice &L = ctx->lut;
+  if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
+  size_t n_groups = 0;
+  if (lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups)) {
+    const HsvK hk{hs.hue_shift, hs.saturation_mul, hs.saturation_off, hs.value_mul, hs.value_off};
+    const uint4 *s = (const uint4 *)d_src;
+    uint4 *d = (uint4 *)d_dst;
+    switch (hsv_variant_for(hs, false)) {
+      case -1: return launch_fused_variant<-1>(ctx, s, d, n_groups, hk);
+      case 0: return launch_fused_variant<0>(ctx, s, d, n_groups, hk);
+      case 1: return launch_fused_variant<1>(ctx, s, d, n_groups, hk);
+      case 2: return launch_fused_variant<2>(ctx, s, d, n_groups, hk);
+      case 4: return launch_fused_variant<4>(ctx, s, d, n_groups, hk);
+      case 5: return launch_fused_variant<5>(ctx, s, d, n_groups, hk);
+      default: return launch_fused_variant<6>(ctx, s, d, n_groups, hk);
+    }
+  }
+  PixFmt fmt;
+  pixfmt_of(MI355_FMT_RGBA, &fmt);
+  if (d_src != d_dst) {
+    for (int f = 0; f < n_frames; f++) {
+      int rc = check_hip(ctx, hipMemcpy2DAsync(d_dst + (size_t)f * dst_pitch, (size_t)dst_stride, d_src + (size_t)f * src_pitch, (size_t)src_stride,
+                                               (size_t)width * 4, (size_t)height, hipMemcpyDeviceToDevice, ctx->stream),
+                         "hsv+colorlut: device copy");
+      if (rc) return rc;
+    }
+  }
+  int rc = launch_hsvfilter(ctx, d_dst, n_frames, dst_pitch, width, height, dst_stride, fmt, hs);
+  if (rc) return rc;
+  return launch_colorlut(ctx, d_dst, dst_pitch, dst_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, MI355_FMT_RGBA);
 }
 
 int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
@@ -657,13 +735,9 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
       return check_hip(ctx, hipGetLastError(), "colorlut1d_lds kernel launch");
     }
   }
-  if (rgba8 && L.is3d && L.lds_ok && !ctx->force_generic) {
-    const size_t row_bytes = (size_t)width * 4;
-    const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
-                            (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
-    const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
-    if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
-      const size_t n_groups = total_bytes / 16;
+  {
+    size_t n_groups = 0;
+    if (rgba8 && lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups)) {
       const uint4 *s = (const uint4 *)d_src;
       uint4 *d = (uint4 *)d_dst;
       constexpr int NT = 1024, P4 = 3;

@@ -367,6 +367,21 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
   return launch_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
 }
 
+int mi355_hsv_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                                     size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
+                                     const mi355_hsv_settings *settings) {
+  REQUIRE_CTX(ctx);
+  if (!settings) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: null settings");
+  if (!ctx->lut.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (n_frames < 0 || width < 0 || height < 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: negative size");
+  if (n_frames == 0 || width == 0 || height == 0) return MI355_OK;
+  if (!d_src || !d_dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: null data");
+  if ((size_t)src_stride < (size_t)width * 4 || (size_t)dst_stride < (size_t)width * 4)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: stride smaller than row bytes");
+  BIND_DEVICE(ctx);
+  return launch_hsv_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, *settings);
+}
+
 int mi355_colorlut_frame(mi355_ctx *ctx, const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width,
                          int height, int format) {
   REQUIRE_CTX(ctx);
@@ -523,6 +538,16 @@ int mi355_time_hsvfilter_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, s
   BIND_DEVICE(ctx);
   return time_launches(ctx, iters, ms_per_launch, [&]() {
     return mi355_hsvfilter_frames_device(ctx, d_data, n_frames, frame_pitch, width, height, stride, format, settings);
+  });
+}
+
+int mi355_time_hsv_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                                   size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
+                                   const mi355_hsv_settings *settings, int iters, float *ms_per_launch) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return time_launches(ctx, iters, ms_per_launch, [&]() {
+    return mi355_hsv_colorlut_frames_device(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, settings);
   });
 }
 

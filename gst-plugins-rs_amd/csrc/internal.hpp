@@ -74,6 +74,9 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
 int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                     uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames, int width,
                     int height, int format);
+int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                        uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames, int width,
+                        int height, const mi355_hsv_settings &hs);
 int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float scale[3],
                const float offset[3]);
 void lut_release(mi355_ctx *ctx);

@@ -77,6 +77,7 @@ def load_library():
         "mi355_colorlut_unload": (i, [vp]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
+        "mi355_hsv_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_echo_setup": (i, [vp, sz]),
         "mi355_echo_reset": (i, [vp]),
         "mi355_echo_process_f32": (i, [vp, vp, sz, sz, C.c_double, C.c_double]),
@@ -96,6 +97,7 @@ def load_library():
         "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_time_hsvfilter_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
+        "mi355_time_hsv_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
         "mi355_time_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i, i, f32p]),
     }
     for name, (res, args) in sig.items():
@@ -226,6 +228,17 @@ class Context:
     def time_colorlut_device(self, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, fmt, iters):
         ms = C.c_float(0)
         self._ck(self.L.mi355_time_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, FMT[fmt], iters, C.byref(ms)))
+        return ms.value
+
+    # ---- hsvfilter ! colorlut as one pass (RGBA)
+    def hsv_colorlut_frames_device(self, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, settings):
+        s = HsvSettings(*[float(v) for v in settings])
+        self._ck(self.L.mi355_hsv_colorlut_frames_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s)))
+
+    def time_hsv_colorlut_device(self, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, settings, iters):
+        s = HsvSettings(*[float(v) for v in settings])
+        ms = C.c_float(0)
+        self._ck(self.L.mi355_time_hsv_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s), iters, C.byref(ms)))
         return ms.value
 
     # ---- rsaudioecho

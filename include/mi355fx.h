@@ -149,6 +149,17 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
                                  int src_stride, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                                  int n_frames, int width, int height, int format);
 
+/* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
+ * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and
+ * colorlut/imp.rs:125-137) as ONE pass: every pixel goes through hsv_filter's body (hsvfilter/imp.rs:96-118) and
+ * then transform_rgba's body (colorlut/imp.rs:226-294) in registers. Output is bit-identical to
+ * mi355_hsvfilter_frames_device followed by mi355_colorlut_frames_device; src is left untouched (src == dst
+ * allowed). Needs a loaded LUT; 1D LUTs and non-contiguous frames run as the two element kernels. */
+int mi355_hsv_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch,
+                                     int src_stride, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
+                                     int n_frames, int width, int height,
+                                     const mi355_hsv_settings *settings);
+
 /* ---------------------------------------------------------------- rsaudioecho
  * mi355_echo_setup replaces AudioEcho::setup's RingBuffer::new(buffer_size)
  * (audio/audiofx/src/audioecho/imp.rs:248-259, ring_buffer.rs:15-24): ring of `ring_len` f64
@@ -204,6 +215,9 @@ int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out);
 int mi355_time_hsvfilter_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch,
                                 int width, int height, int stride, int format,
                                 const mi355_hsv_settings *settings, int iters, float *ms_per_launch);
+int mi355_time_hsv_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
+                                   uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames, int width,
+                                   int height, const mi355_hsv_settings *settings, int iters, float *ms_per_launch);
 int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                                uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
                                int width, int height, int format, int iters, float *ms_per_launch);

@@ -495,3 +495,119 @@ def test_colorlut_rgba64_lds_kernel(ctx, oracle, synth, le, domain):
     got = np.zeros_like(src)
     ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, "RGBA64_LE" if le else "RGBA64_BE")
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+# ------------------------------------------------------------------ hsvfilter ! colorlut, one pass
+
+def _fused_device(ctx, frames, w, h, st, src_stride=None, dst_stride=None, in_place=False):
+    """Run mi355_hsv_colorlut_frames_device on host frames (n, h, stride) -> host result."""
+    n = frames.shape[0]
+    sstride = w * 4 if src_stride is None else src_stride
+    dstride = w * 4 if dst_stride is None else dst_stride
+    src = np.ascontiguousarray(frames).reshape(-1)
+    out = np.full(n * h * dstride, 0x5A, np.uint8)
+    d_src = ctx.alloc(src.nbytes)
+    d_dst = d_src if in_place else ctx.alloc(out.nbytes)
+    try:
+        ctx.h2d(d_src, src)
+        if not in_place:
+            ctx.h2d(d_dst, out)
+        ctx.hsv_colorlut_frames_device(d_src, h * sstride, sstride, d_dst, h * dstride, dstride, n, w, h, st)
+        ctx.synchronize()
+        ctx.d2h(out, d_dst)
+        src_after = np.zeros_like(src)
+        ctx.d2h(src_after, d_src)
+    finally:
+        ctx.free(d_src)
+        if not in_place:
+            ctx.free(d_dst)
+    return out, src_after
+
+
+def _oracle_chain(oracle, cube, frame_bytes, w, h, st):
+    mid = frame_bytes.copy().reshape(-1)
+    oracle.hsvfilter(mid, w, w * 4, 4, 0, False, st, nthreads=8)
+    exp = np.zeros_like(mid)
+    oracle.colorlut_rgba8(cube, mid, w * 4, exp, w * 4, w, h, nthreads=8)
+    return exp
+
+
+@pytest.mark.parametrize("setting", ["defaults", "hue90", "mixed", "neg", "nonfinite"])
+def test_fused_chain_allcolors(ctx, oracle, synth, setting):
+    """One-pass hsvfilter+colorlut over every 8-bit colour == oracle hsvfilter then oracle colorlut, for each
+    arithmetic variant of the hsv stage (identity, +shift, -shift with affine s/v, generic/non-finite)."""
+    st = {"neg": (-77.5, 1.0, 0.0, 1.0, 0.0), "nonfinite": (float("inf"), 1.3, -0.1, 0.9, 0.05)}.get(setting) or synth.HSV_SETTINGS[setting]
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ac = synth.allcolors()
+    exp = _oracle_chain(oracle, cube, ac, 4096, 4096, st)
+    got, src_after = _fused_device(ctx, ac.reshape(1, 4096, 4096 * 4), 4096, 4096, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+    assert (src_after == ac.reshape(-1)).all(), "fused chain must not modify its source"
+
+
+@pytest.mark.parametrize("size", [2, 17, 33, 40])
+def test_fused_chain_lut_sizes_and_in_place(ctx, oracle, synth, size):
+    """All-resident small LUTs, the 33^3 fast path and a LUT too large for LDS (two-kernel route), in place."""
+    st = synth.HSV_SETTINGS["mixed"]
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size))
+    w, h, n = 1920, 540, 3
+    frames = np.stack([synth.noise_frame(w, h, seed=11 + i) for i in range(n)])
+    exp = np.concatenate([_oracle_chain(oracle, cube, frames[i], w, h, st) for i in range(n)])
+    got, _ = _fused_device(ctx, frames, w, h, st, in_place=True)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_fused_chain_padded_rows_and_1d_lut_take_two_kernel_route(ctx, oracle, synth):
+    """Row padding (stride > width*4) and 1D LUTs are not eligible for the fused kernel: same results through
+    the element kernels, padding bytes of dst untouched, src untouched."""
+    st = synth.HSV_SETTINGS["hue90"]
+    w, h = 333, 37
+    sstride, dstride = w * 4 + 12, w * 4 + 20
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (1, h, sstride), dtype=np.uint8)
+    for text in (synth.cube_text_3d(33), synth.cube_text_1d(64)):
+        cube = _load_cube(ctx, oracle, text)
+        tight = np.ascontiguousarray(src[0, :, : w * 4])
+        exp = _oracle_chain(oracle, cube, tight, w, h, st).reshape(h, w * 4)
+        got, src_after = _fused_device(ctx, src, w, h, st, src_stride=sstride, dst_stride=dstride)
+        got = got.reshape(h, dstride)
+        assert (got[:, : w * 4] == exp).all()
+        assert (got[:, w * 4:] == 0x5A).all()
+        assert (src_after == src.reshape(-1)).all()
+
+
+def test_fused_chain_4k_batch_equals_two_element_launches(ctx, oracle, synth):
+    """BASELINE headline shape (8 x 4K RGBA, hue-shift=90, 33^3): fused launch == hsvfilter launch then colorlut
+    launch on the device, and both equal the oracle chain on the first frame."""
+    st = synth.HSV_SETTINGS["hue90"]
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    n = 8
+    frames = np.stack([synth.smooth_frame(W4K, H4K, seed=100 + i) if i % 2 == 0 else synth.noise_frame(W4K, H4K, seed=100 + i) for i in range(n)])
+    fused, _ = _fused_device(ctx, frames, W4K, H4K, st)
+    nbytes = frames.nbytes
+    d_a, d_b = ctx.alloc(nbytes), ctx.alloc(nbytes)
+    two = np.zeros(nbytes, np.uint8)
+    try:
+        ctx.h2d(d_a, frames.reshape(-1))
+        ctx.hsvfilter_frames_device(d_a, n, H4K * W4K * 4, W4K, H4K, W4K * 4, "RGBA", st)
+        ctx.colorlut_frames_device(d_a, H4K * W4K * 4, W4K * 4, d_b, H4K * W4K * 4, W4K * 4, n, W4K, H4K, "RGBA")
+        ctx.synchronize()
+        ctx.d2h(two, d_b)
+    finally:
+        ctx.free(d_a)
+        ctx.free(d_b)
+    assert (fused == two).all(), _mismatch_report(fused, two)
+    exp0 = _oracle_chain(oracle, cube, frames[0], W4K, H4K, st)
+    assert (fused[: exp0.size] == exp0).all()
+
+
+def test_fused_chain_errors(ctx, synth):
+    import mi355fx
+    ctx.colorlut_unload()
+    d = ctx.alloc(64)
+    try:
+        with pytest.raises(mi355fx.Mi355Error) as e:
+            ctx.hsv_colorlut_frames_device(d, 64, 16, d, 64, 16, 1, 4, 4, synth.HSV_SETTINGS["defaults"])
+        assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+    finally:
+        ctx.free(d)
