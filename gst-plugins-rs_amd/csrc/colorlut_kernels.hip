@@ -345,6 +345,160 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   }
 }
 
+// ---------------------------------------------------------------- fused hsvfilter -> colorlut, software pipelined
+// Same three-pass structure, but the hsvfilter arithmetic of tile n+1 (pure VALU, ~100 instructions per pixel)
+// runs inside the two plane-staging windows of tile n, where the CU otherwise only waits for the L2->LDS DMA:
+//   setup(n) | issue loads(n+1) | pass A | [DMA B || hsv(first half of n+1)] | pass B | [DMA C || hsv(second half)] | pass C | store(n)
+// Vector-memory results return in issue order, so the loads of tile n+1 (issued before DMA B) have landed once
+// DMA B's own counter position is reached: for the 33^3 layout every wave issues exactly kDma33 DMA
+// instructions (compile-time), which lets the compiler place `s_waitcnt vmcnt(kDma33)` in front of the hsv code
+// instead of a full drain.
+constexpr int kPlaneChunks33 = (33 * 1161 * 4 + 1023) / 1024;  // 150 KiB-chunks of the padded 33^3 plane
+
+template <int NT, int S_CONST>
+__device__ __forceinline__ void stage_plane_issue(unsigned char *lds, const float *__restrict__ plane, uint32_t plane_floats) {
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const char *gsrc = (const char *)plane + lane * 16;
+  if constexpr (S_CONST == 33) {
+    constexpr uint32_t per_wave = (kPlaneChunks33 + NT / 64 - 1) / (NT / 64);
+#pragma unroll
+    for (uint32_t i = 0; i < per_wave; i++) {
+      uint32_t k = wave + i * (NT / 64);
+      k = k < (uint32_t)kPlaneChunks33 ? k : (uint32_t)kPlaneChunks33 - 1;  // surplus slots re-copy the last chunk (same bytes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)k * 1024),
+                                       (__attribute__((address_space(3))) void *)(lds + kAxisTableBytes + k * 1024), 16, 0, 0);
+    }
+  } else {
+    const uint32_t chunks = plane_floats / 256;
+    for (uint32_t k = wave; k < chunks; k += NT / 64)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)k * 1024),
+                                       (__attribute__((address_space(3))) void *)(lds + kAxisTableBytes + k * 1024), 16, 0, 0);
+  }
+}
+
+template <int HSV, int I0, int I1, int P>
+__device__ __forceinline__ void hsv_range(uint32_t (&nx)[P], const HsvK &hk, const uint32_t *hsv_sel) {
+  if constexpr (HSV >= 0) {
+#pragma unroll
+    for (int i = I0; i < I1; i += 2) hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(nx[i], nx[i + 1], hk, hsv_sel);
+  } else {
+#pragma unroll
+    for (int i = I0; i < I1; i++) nx[i] = hsvfilter_px<false, 0, 1, 2, 3>(nx[i], hk, hsv_sel);
+  }
+}
+
+template <int NT, int P4, int S_CONST, int HSV>
+__global__ __launch_bounds__(NT) void hsv_colorlut3d_pipe_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                                 size_t n_groups, const float *__restrict__ planar,
+                                                                 const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
+                                                                 uint32_t plane_floats, int all_resident, HsvK hk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ uint32_t hsv_sel[8];
+  constexpr int P = P4 * 4;
+  static_assert(P % 4 == 0, "pixel pairs are split in two halves");
+  constexpr int PH = (P / 2 + 1) & ~1;  // first half, even
+  const size_t tile_groups = (size_t)NT * P4;
+  const size_t full_rounds = (n_groups / tile_groups) / gridDim.x;
+  const size_t full_tiles = full_rounds * gridDim.x;
+  const size_t rem_start = full_tiles * tile_groups;
+  const size_t rem_chunk = (n_groups - rem_start + gridDim.x - 1) / gridDim.x;
+  const size_t my_rounds = full_rounds + (rem_chunk > 0 ? 1 : 0);
+  // [t_begin, t_end) of this block's tile in `round`; false when there is none (block-uniform)
+  auto tile_range = [&](size_t round, size_t &t_begin, size_t &t_end) -> bool {
+    if (round >= my_rounds) return false;
+    if (round < full_rounds) {
+      t_begin = (round * gridDim.x + blockIdx.x) * tile_groups;
+      t_end = t_begin + tile_groups;
+      return true;
+    }
+    t_begin = rem_start + (size_t)blockIdx.x * rem_chunk;
+    t_end = t_begin + rem_chunk;
+    if (t_end > n_groups) t_end = n_groups;
+    return t_begin < t_end;
+  };
+
+  if (threadIdx.x < 7)
+    hsv_sel[threadIdx.x] = HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3);
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  const uint32_t plane_bytes = all_resident ? plane_floats * 4u : 0u;
+  if (all_resident) {
+    for (int c = 0; c < 3; c++) stage_plane<NT>(lds + (size_t)c * plane_bytes, planar + (size_t)c * plane_floats, plane_floats);
+  }
+  __syncthreads();
+
+  uint32_t nx[P];
+  auto load_tile = [&](size_t t_begin, size_t t_end) {
+    const size_t g0 = t_begin + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P4; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g < t_end) v = src[g];
+      nx[4 * j + 0] = v.x; nx[4 * j + 1] = v.y; nx[4 * j + 2] = v.z; nx[4 * j + 3] = v.w;
+    }
+  };
+
+  size_t t_begin = 0, t_end = 0;
+  bool have = tile_range(0, t_begin, t_end);
+  if (have) {
+    load_tile(t_begin, t_end);
+    hsv_range<HSV, 0, P>(nx, hk, hsv_sel);
+  }
+  bool flip = false;
+  int resident = all_resident ? 3 : -1;
+  for (size_t round = 0; have; round++) {
+    uint32_t px[P], base[P];
+    float tx[P], ty[P], tz[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      px[i] = nx[i];
+      const uint2 ex = *(const uint2 *)(lds + ((px[i] & 0xffu) << 3));
+      const uint2 ey = *(const uint2 *)(lds + 2048 + (((px[i] >> 8) & 0xffu) << 3));
+      const uint2 ez = *(const uint2 *)(lds + 4096 + (((px[i] >> 16) & 0xffu) << 3));
+      base[i] = ex.x + ey.x + ez.x;
+      tx[i] = __uint_as_float(ex.y);
+      ty[i] = __uint_as_float(ey.y);
+      tz[i] = __uint_as_float(ez.y);
+    }
+    size_t n_begin = 0, n_end = 0;
+    const bool have_next = tile_range(round + 1, n_begin, n_end);
+    if (have_next) load_tile(n_begin, n_end);
+    // stage plane CH if needed, running the hsv stage of pixels [I0, I1) of the next tile under the DMA
+#define MI355_STAGE_HSV(CH, I0, I1)                                                             \
+  {                                                                                             \
+    const bool need = resident != CH && resident != 3;                                          \
+    if (need) {                                                                                 \
+      __syncthreads(); /* everyone is done reading the previous plane */                        \
+      stage_plane_issue<NT, S_CONST>(lds, planar + (size_t)CH * plane_floats, plane_floats);    \
+    }                                                                                           \
+    if (have_next) hsv_range<HSV, I0, I1>(nx, hk, hsv_sel);                                     \
+    if (need) {                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+      __syncthreads();                                                                          \
+      resident = CH;                                                                            \
+    }                                                                                           \
+  }
+    if (!flip) {
+      MI355_STAGE_HSV(0, 0, 0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE_HSV(1, 0, PH) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE_HSV(2, PH, P) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, px, base, tx, ty, tz);
+    } else {
+      MI355_STAGE_HSV(2, 0, 0) lut_pass<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE_HSV(1, 0, PH) lut_pass<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, px, base, tx, ty, tz);
+      MI355_STAGE_HSV(0, PH, P) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, px, base, tx, ty, tz);
+    }
+#undef MI355_STAGE_HSV
+    flip = !flip;
+    const size_t g0 = t_begin + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P4; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      if (g < t_end) dst[g] = make_uint4(px[4 * j + 0], px[4 * j + 1], px[4 * j + 2], px[4 * j + 3]);
+    }
+    t_begin = n_begin; t_end = n_end; have = have_next;
+  }
+}
+
 // ---------------------------------------------------------------- LDS three-pass kernel, RGBA64 (3D)
 //
 // transform_rgba64_3d::<LE> (imp.rs:348-397): same plane layout, staging and pass structure as the
@@ -655,11 +809,32 @@ static bool lds3d_rgba_applicable(const mi355_ctx *ctx, const uint8_t *d_src, si
   return true;
 }
 
+template <int NT, int P4, int S_CONST, int HSV>
+static int launch_pipe_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups, const HsvK &hk) {
+  auto kern = hsv_colorlut3d_pipe_kernel<NT, P4, S_CONST, HSV>;
+  const LutDevice &L = ctx->lut;
+  const size_t lds = L.lds_bytes;
+  int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                     "hipFuncSetAttribute(max dynamic LDS)");
+  if (rc) return rc;
+  size_t grid = (size_t)ctx->n_cu;
+  const size_t min_blocks = (n_groups + 255) / 256;
+  if (grid > min_blocks) grid = min_blocks;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
+                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0, hk);
+  return check_hip(ctx, hipGetLastError(), "hsv_colorlut3d_pipe kernel launch");
+}
+
 template <int HSV>
 static int launch_fused_variant(mi355_ctx *ctx, const uint4 *s, uint4 *d, size_t n_groups, const HsvK &hk) {
-  constexpr int NT = 1024, P4 = 3;
-  if (ctx->lut.size == 33) return launch_lds_variant<NT, P4, 33, HSV>(ctx, s, d, n_groups, hk);
-  return launch_lds_variant<NT, P4, 0, HSV>(ctx, s, d, n_groups, hk);
+  const bool s33 = ctx->lut.size == 33;
+  // MI355_FLAG_FUSED_VARIANT 1: software-pipelined kernel (hsv of the next tile under the plane DMA). Measured on
+  // 8x4K: 0.316 ms smooth / 0.476 ms noise at 1024x2 vs 0.330 / 0.435 ms for the inline kernel at 1024x3; the
+  // 1024x3 pipelined tiling spills at the 128-VGPR cap (0.49 ms), so the inline kernel stays the default.
+  if (ctx->fused_variant == 1)
+    return s33 ? launch_pipe_variant<1024, 2, 33, HSV>(ctx, s, d, n_groups, hk) : launch_pipe_variant<1024, 2, 0, HSV>(ctx, s, d, n_groups, hk);
+  return s33 ? launch_lds_variant<1024, 3, 33, HSV>(ctx, s, d, n_groups, hk) : launch_lds_variant<1024, 3, 0, HSV>(ctx, s, d, n_groups, hk);
 }
 
 // hsvfilter followed by colorlut on RGBA frames. One fused launch when the 3D LDS kernel applies; otherwise the

@@ -46,6 +46,7 @@ struct mi355_ctx {
   mi355::EchoDevice echo;
   void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
   bool force_generic = false;
+  int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

@@ -23,6 +23,8 @@ FMT_LAYOUT = {"RGBx": (4, 0, 0), "RGBA": (4, 0, 0), "RGB": (3, 0, 0), "xRGB": (4
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_OOM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 FLAG_FORCE_GENERIC = 1
+FLAG_HSV_BLOCKS_PER_CU = 2
+FLAG_FUSED_VARIANT = 3
 
 
 class HsvSettings(C.Structure):

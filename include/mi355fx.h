@@ -81,7 +81,8 @@ int mi355_ctx_synchronize(mi355_ctx *ctx);
  * its literal-arithmetic GENERIC kernel instead of the strength-reduced FAST one. */
 typedef enum mi355_flag {
   MI355_FLAG_FORCE_GENERIC = 1,
-  MI355_FLAG_HSV_BLOCKS_PER_CU = 2 /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
+  MI355_FLAG_HSV_BLOCKS_PER_CU = 2, /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
+  MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 

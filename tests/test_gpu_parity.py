@@ -532,11 +532,14 @@ def _oracle_chain(oracle, cube, frame_bytes, w, h, st):
     return exp
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("setting", ["defaults", "hue90", "mixed", "neg", "nonfinite"])
-def test_fused_chain_allcolors(ctx, oracle, synth, setting):
+def test_fused_chain_allcolors(ctx, oracle, synth, setting, variant):
     """One-pass hsvfilter+colorlut over every 8-bit colour == oracle hsvfilter then oracle colorlut, for each
     arithmetic variant of the hsv stage (identity, +shift, -shift with affine s/v, generic/non-finite)."""
     st = {"neg": (-77.5, 1.0, 0.0, 1.0, 0.0), "nonfinite": (float("inf"), 1.3, -0.1, 0.9, 0.05)}.get(setting) or synth.HSV_SETTINGS[setting]
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_FUSED_VARIANT, variant)
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
     ac = synth.allcolors()
     exp = _oracle_chain(oracle, cube, ac, 4096, 4096, st)
@@ -545,9 +548,13 @@ def test_fused_chain_allcolors(ctx, oracle, synth, setting):
     assert (src_after == ac.reshape(-1)).all(), "fused chain must not modify its source"
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("size", [2, 17, 33, 40])
-def test_fused_chain_lut_sizes_and_in_place(ctx, oracle, synth, size):
-    """All-resident small LUTs, the 33^3 fast path and a LUT too large for LDS (two-kernel route), in place."""
+def test_fused_chain_lut_sizes_and_in_place(ctx, oracle, synth, size, variant):
+    """All-resident small LUTs, the 33^3 fast path and a LUT too large for LDS (two-kernel route), in place; both
+    fused kernels (inline hsv stage / software-pipelined)."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_FUSED_VARIANT, variant)
     st = synth.HSV_SETTINGS["mixed"]
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(size))
     w, h, n = 1920, 540, 3
