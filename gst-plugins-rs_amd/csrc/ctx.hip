@@ -141,6 +141,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   lut_release(ctx);
   ebur128_release(ctx);
+  hrtf_release(ctx);
   if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
   for (int i = 0; i < 2; i++)
     if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -530,6 +531,44 @@ int mi355_ebur128_relative_threshold(mi355_ctx *ctx, double *out) { REQUIRE_CTX(
 int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 4, out); }
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 0, channel, out); }
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 1, channel, out); }
+
+/* ------------------------------------------------------------------ hrtfrender */
+
+int mi355_hrtf_load_sphere(mi355_ctx *ctx, const void *bytes, size_t len, uint32_t device_rate) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return hrtf_load_sphere(ctx, (const unsigned char *)bytes, len, device_rate);
+}
+int mi355_hrtf_setup(mi355_ctx *ctx, int channels, int block_length, int interpolation_steps) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return hrtf_setup(ctx, channels, block_length, interpolation_steps);
+}
+int mi355_hrtf_reset(mi355_ctx *ctx) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return hrtf_reset(ctx); }
+int mi355_hrtf_teardown(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  hrtf_release(ctx);
+  return MI355_OK;
+}
+int mi355_hrtf_process_block(mi355_ctx *ctx, const float *in, float *out, const float *positions_xyz, const float *distance_gains) {
+  REQUIRE_CTX(ctx);
+  if (!in || !out || !positions_xyz || !distance_gains) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: null argument");
+  BIND_DEVICE(ctx);
+  return hrtf_process_block_host(ctx, in, out, positions_xyz, distance_gains);
+}
+int mi355_hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, const float *positions_xyz, const float *distance_gains) {
+  REQUIRE_CTX(ctx);
+  if (!d_in || !d_out || !positions_xyz || !distance_gains) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: null argument");
+  BIND_DEVICE(ctx);
+  return hrtf_process_block_device(ctx, d_in, d_out, positions_xyz, distance_gains);
+}
+int mi355_hrtf_sphere_info(mi355_ctx *ctx, uint32_t *hrir_len, uint32_t *n_vertices, uint32_t *n_faces) {
+  REQUIRE_CTX(ctx);
+  return hrtf_info(ctx, hrir_len, n_vertices, n_faces);
+}
+int mi355_hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return hrtf_last_lookup(ctx, faces, uvw); }
 
 /* ------------------------------------------------------------------ measurement helpers */
 

@@ -45,6 +45,7 @@ struct mi355_ctx {
   mi355::LutDevice lut;
   mi355::EchoDevice echo;
   void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
+  void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
@@ -86,6 +87,14 @@ int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay
 int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
 int ebur128_reset(mi355_ctx *ctx);
 void ebur128_release(mi355_ctx *ctx);
+int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
+int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);
+int hrtf_reset(mi355_ctx *ctx);
+void hrtf_release(mi355_ctx *ctx);
+int hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, const float *positions, const float *gains);
+int hrtf_process_block_host(mi355_ctx *ctx, const float *in, float *out, const float *positions, const float *gains);
+int hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw);
+int hrtf_info(mi355_ctx *ctx, uint32_t *len, uint32_t *vertices, uint32_t *faces);
 int ebur128_add_frames(mi355_ctx *ctx, const void *data, const void *const *planes, size_t frames, int fmt);
 int ebur128_query(mi355_ctx *ctx, int what, double *out);
 int ebur128_peak(mi355_ctx *ctx, int true_peak, unsigned channel, double *out);

@@ -98,6 +98,14 @@ def load_library():
         "mi355_ebur128_loudness_range": (i, [vp, C.POINTER(C.c_double)]),
         "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_hrtf_load_sphere": (i, [vp, vp, sz, C.c_uint32]),
+        "mi355_hrtf_setup": (i, [vp, i, i, i]),
+        "mi355_hrtf_reset": (i, [vp]),
+        "mi355_hrtf_teardown": (i, [vp]),
+        "mi355_hrtf_process_block": (i, [vp, f32p, f32p, f32p, f32p]),
+        "mi355_hrtf_process_block_device": (i, [vp, vp, vp, f32p, f32p]),
+        "mi355_hrtf_sphere_info": (i, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "mi355_hrtf_last_lookup": (i, [vp, C.POINTER(C.c_int), f32p]),
         "mi355_time_hsvfilter_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
         "mi355_time_hsv_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings), i, f32p]),
         "mi355_time_colorlut_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i, i, f32p]),
@@ -242,6 +250,52 @@ class Context:
         ms = C.c_float(0)
         self._ck(self.L.mi355_time_hsv_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s), iters, C.byref(ms)))
         return ms.value
+
+    # ---- hrtfrender
+    def hrtf_load_sphere(self, data, rate):
+        b = bytes(data)
+        buf = (C.c_uint8 * len(b)).from_buffer_copy(b)
+        self._ck(self.L.mi355_hrtf_load_sphere(self.h, C.cast(buf, C.c_void_p), len(b), rate))
+
+    def hrtf_setup(self, channels, block_length=512, interpolation_steps=8):
+        self._ck(self.L.mi355_hrtf_setup(self.h, channels, block_length, interpolation_steps))
+        self._hrtf_shape = (channels, block_length * interpolation_steps, interpolation_steps)
+
+    def hrtf_reset(self):
+        self._ck(self.L.mi355_hrtf_reset(self.h))
+
+    def hrtf_teardown(self):
+        self._ck(self.L.mi355_hrtf_teardown(self.h))
+
+    def hrtf_sphere_info(self):
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.L.mi355_hrtf_sphere_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def hrtf_process_block(self, inp, positions, gains):
+        channels, frames, _ = self._hrtf_shape
+        fp = C.POINTER(C.c_float)
+        x = np.ascontiguousarray(inp, dtype=np.float32).reshape(-1)
+        assert x.size == frames * channels, "one block = block_length*interpolation_steps frames"
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1)
+        g = np.ascontiguousarray(gains, dtype=np.float32).reshape(-1)
+        assert pos.size == 3 * channels and g.size == channels
+        out = np.zeros(frames * 2, np.float32)
+        self._ck(self.L.mi355_hrtf_process_block(self.h, x.ctypes.data_as(fp), out.ctypes.data_as(fp), pos.ctypes.data_as(fp), g.ctypes.data_as(fp)))
+        return out
+
+    def hrtf_process_block_device(self, d_in, d_out, positions, gains):
+        fp = C.POINTER(C.c_float)
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1)
+        g = np.ascontiguousarray(gains, dtype=np.float32).reshape(-1)
+        self._ck(self.L.mi355_hrtf_process_block_device(self.h, d_in, d_out, pos.ctypes.data_as(fp), g.ctypes.data_as(fp)))
+
+    def hrtf_last_lookup(self):
+        channels, _, steps = self._hrtf_shape
+        faces = np.zeros(channels * steps, np.int32)
+        uvw = np.zeros(channels * steps * 3, np.float32)
+        self._ck(self.L.mi355_hrtf_last_lookup(self.h, faces.ctypes.data_as(C.POINTER(C.c_int)), uvw.ctypes.data_as(C.POINTER(C.c_float))))
+        return faces.reshape(channels, steps), uvw.reshape(channels, steps, 3)
 
     # ---- rsaudioecho
     def echo_setup(self, ring_len):

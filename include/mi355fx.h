@@ -210,6 +210,33 @@ int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out);
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out);
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out);
 
+/* ---------------------------------------------------------------- hrtfrender
+ * Replaces the per-block body of HrtfRender::process (audio/hrtf/src/hrtf/imp.rs:164-278) including the calls
+ * into the `hrtf` crate (HrirSphere::new, HrtfProcessor::new, process_samples).
+ *   mi355_hrtf_load_sphere : Settings::sphere(rate) -> HrirSphere::new(bytes, rate) (imp.rs:84-94). `bytes` is the
+ *       crate's file format ("HRIR", u32 rate, u32 len, u32 n_vertices, u32 n_indices, indices, vertices). A sphere
+ *       whose rate differs from `device_rate` returns MI355_ERR_UNSUPPORTED (the crate resamples it with rubato).
+ *   mi355_hrtf_setup       : the ChannelProcessor vector of set_caps (imp.rs:662-680): one HrtfProcessor per input
+ *       channel, zeroed tails, no previous vector/gain.
+ *   mi355_hrtf_reset       : State::reset_processors (imp.rs:124-129).
+ *   mi355_hrtf_process_block : one block of block_length*interpolation_steps frames (imp.rs:196-271): `in` is
+ *       interleaved f32 [frames][channels], `out` interleaved stereo f32 [frames][2], overwritten.
+ *       positions[c] = Settings::position(c) (already `.to_right_handed()`, imp.rs:64-73), gains[c] =
+ *       Settings::distance_gain(c). The adapter / drain logic around it (imp.rs:281-420) stays in the element. */
+int mi355_hrtf_load_sphere(mi355_ctx *ctx, const void *bytes, size_t len, uint32_t device_rate);
+int mi355_hrtf_setup(mi355_ctx *ctx, int channels, int block_length, int interpolation_steps);
+int mi355_hrtf_reset(mi355_ctx *ctx);
+int mi355_hrtf_teardown(mi355_ctx *ctx);
+int mi355_hrtf_process_block(mi355_ctx *ctx, const float *in, float *out, const float *positions_xyz,
+                             const float *distance_gains);
+/* Same with device-resident input/output (asynchronous on the context stream). */
+int mi355_hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out,
+                                    const float *positions_xyz, const float *distance_gains);
+/* Sphere geometry as loaded: HRIR length, vertices, faces. */
+int mi355_hrtf_sphere_info(mi355_ctx *ctx, uint32_t *hrir_len, uint32_t *n_vertices, uint32_t *n_faces);
+/* Diagnostics: mesh face (or -1) and barycentric weights chosen per [channel][step] in the last block. */
+int mi355_hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw);
+
 /* ---------------------------------------------------------------- measurement helpers
  * Used by bench.py: run `iters` back-to-back launches of one kernel on the context's stream
  * bracketed by hipEvents on THAT stream and return the average milliseconds per launch. */

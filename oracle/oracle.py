@@ -78,6 +78,19 @@ def lib():
     L.oracle_ebur128_true_peak.restype = C.c_double
     L.oracle_ebur128_true_peak.argtypes = [C.c_void_p, C.c_uint]
     L.oracle_ebur128_filter_coeffs.argtypes = [C.c_void_p, f64p2, f64p2]
+    L.oracle_hrir_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.oracle_hrir_free.argtypes = [C.c_void_p]
+    for name in ("len", "vertices", "faces"):
+        fn = getattr(L, "oracle_hrir_" + name)
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_uint32
+    L.oracle_hrir_sample.argtypes = [C.c_void_p, f32p, f32p]
+    L.oracle_hrtf_new.restype = C.c_void_p
+    L.oracle_hrtf_new.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.oracle_hrtf_free.argtypes = [C.c_void_p]
+    L.oracle_hrtf_reset.argtypes = [C.c_void_p]
+    L.oracle_hrtf_process_block.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p]
+    L.oracle_hrtf_block_exact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f64p, f32p, f32p, f32p, f32p, f64p, f64p]
     _LIB = L
     return L
 
@@ -296,3 +309,83 @@ class EbuR128:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.oracle_ebur128_free(self.h)
             self.h = None
+
+
+class HrirSphere:
+    """Parsed IRCAM-style HRIR sphere (hrtf crate file format)."""
+
+    def __init__(self, data, rate):
+        self._bytes = bytes(data)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * len(self._bytes)).from_buffer_copy(self._bytes)
+        rc = lib().oracle_hrir_parse(buf, len(self._bytes), rate, C.byref(h))
+        if rc != 0:
+            raise ValueError("hrir parse failed: %d" % rc)
+        self.h = h
+        self.rate = rate
+
+    len = property(lambda self: lib().oracle_hrir_len(self.h))
+    vertices = property(lambda self: lib().oracle_hrir_vertices(self.h))
+    faces = property(lambda self: lib().oracle_hrir_faces(self.h))
+
+    def sample(self, direction):
+        d = np.ascontiguousarray(direction, dtype=np.float32)
+        uvw = np.zeros(3, np.float32)
+        face = lib().oracle_hrir_sample(self.h, _fp(d), _fp(uvw))
+        return face, uvw
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_hrir_free(self.h)
+            self.h = None
+
+
+class HrtfRender:
+    """Per-channel HrtfProcessor bank + the element's mixing (audio/hrtf/src/hrtf/imp.rs:164-278), FFT overlap-save in f32."""
+
+    def __init__(self, sphere, channels, steps=8, block_len=512):
+        self.sphere, self.channels, self.steps, self.block_len = sphere, channels, steps, block_len
+        self.h = lib().oracle_hrtf_new(sphere.h, channels, steps, block_len)
+
+    def reset(self):
+        lib().oracle_hrtf_reset(self.h)
+
+    def process_block(self, inp, positions, gains):
+        frames = self.steps * self.block_len
+        x = np.ascontiguousarray(inp, dtype=np.float32).reshape(frames * self.channels)
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(self.channels * 3)
+        g = np.ascontiguousarray(gains, dtype=np.float32).reshape(self.channels)
+        out = np.zeros(frames * 2, np.float32)
+        lib().oracle_hrtf_process_block(self.h, _fp(x), _fp(out), _fp(pos), _fp(g))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_hrtf_free(self.h)
+            self.h = None
+
+
+class HrtfExact:
+    """f64 time-domain evaluation of the same mathematical result (streaming convolution), carrying its own state."""
+
+    def __init__(self, sphere, channels, steps=8, block_len=512):
+        self.sphere, self.channels, self.steps, self.block_len = sphere, channels, steps, block_len
+        pad = max(sphere.len - 1, 1)
+        self.hist = np.zeros(channels * pad, np.float64)
+        self.taps = np.zeros(channels * 2 * sphere.len, np.float64)
+        self.prev_pos = None
+        self.prev_gain = None
+
+    def process_block(self, inp, positions, gains):
+        frames = self.steps * self.block_len
+        x = np.ascontiguousarray(inp, dtype=np.float32).reshape(frames * self.channels)
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(self.channels * 3)
+        g = np.ascontiguousarray(gains, dtype=np.float32).reshape(self.channels)
+        pp = pos if self.prev_pos is None else self.prev_pos
+        pg = g if self.prev_gain is None else self.prev_gain
+        out = np.zeros(frames * 2, np.float64)
+        dp = C.POINTER(C.c_double)
+        lib().oracle_hrtf_block_exact(self.sphere.h, self.channels, self.steps, self.block_len, _fp(x), out.ctypes.data_as(dp),
+                                      _fp(pp), _fp(pg), _fp(pos), _fp(g), self.hist.ctypes.data_as(dp), self.taps.ctypes.data_as(dp))
+        self.prev_pos, self.prev_gain = pos.copy(), g.copy()
+        return out
