@@ -586,9 +586,245 @@ FlowReturn EbuR128Level::transform_ip_passthrough(const void *data, const void *
   return FlowReturn::Ok;
 }
 
+// ------------------------------------------------------------------ HrtfRender
+
+HrtfRender::HrtfRender(int device) : Element(device) {}
+
+const ElementMetadata &HrtfRender::metadata() const {
+  static const ElementMetadata m{"Head-Related Transfer Function (HRTF) renderer", "Filter/Effect/Audio",
+                                 "Renders spatial sounds to a given position", "Tomasz Andrzejak <andreiltd@gmail.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &HrtfRender::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    auto u64 = [](const char *n, const char *nick, const char *blurb, double def) {
+      ParamSpec s;
+      s.name = n; s.nick = nick; s.blurb = blurb; s.type = PropType::UInt64;
+      s.def_num = def; s.min_num = 0; s.max_num = 18446744073709551614.0; s.mutability = Mutability::Ready;
+      return s;
+    };
+    ParamSpec file;
+    file.name = "hrir-file"; file.nick = "Head Transform Impulse Response";
+    file.blurb = "Head Transform Impulse Response file location to read from"; file.type = PropType::String; file.mutability = Mutability::Ready;
+    ParamSpec rayon;
+    rayon.name = "use-rayon"; rayon.nick = "Use Rayon"; rayon.blurb = "Use Rayon to process input channels in parallel";
+    rayon.type = PropType::Boolean; rayon.def_num = 0; rayon.min_num = 0; rayon.max_num = 1; rayon.mutability = Mutability::Ready;
+    return std::vector<ParamSpec>{
+        file,
+        u64("interpolation-steps", "Interpolation Steps", "Interpolation Steps is the amount of slices to cut source to", 8),
+        u64("block-length", "Block Length", "Block Length is the length of each slice", 512),
+        rayon,
+    };
+  }();
+  return p;
+}
+
+bool HrtfRender::store_number(const std::string &n, double v) {
+  if (n != "use-rayon") return false;
+  use_rayon_ = v != 0.0;  // kept for the property surface; channels are always processed in parallel on the device
+  return true;
+}
+bool HrtfRender::load_number(const std::string &n, double *v) const {
+  if (n != "use-rayon") return false;
+  *v = use_rayon_ ? 1.0 : 0.0;
+  return true;
+}
+bool HrtfRender::store_u64(const std::string &n, uint64_t v) {
+  if (n == "interpolation-steps") interpolation_steps_ = v;
+  else if (n == "block-length") block_length_ = v;
+  else return false;
+  return true;
+}
+bool HrtfRender::load_u64(const std::string &n, uint64_t *v) const {
+  if (n == "interpolation-steps") *v = interpolation_steps_;
+  else if (n == "block-length") *v = block_length_;
+  else return false;
+  return true;
+}
+bool HrtfRender::store_string(const std::string &n, const std::string &v) {
+  if (n != "hrir-file") return false;
+  hrir_file_ = v;
+  have_hrir_file_ = true;
+  return true;
+}
+bool HrtfRender::load_string(const std::string &n, std::string *v) const {
+  if (n != "hrir-file") return false;
+  *v = hrir_file_;
+  return true;
+}
+
+void HrtfRender::set_hrir_raw(const void *bytes, size_t len) {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  hrir_raw_.assign((const unsigned char *)bytes, (const unsigned char *)bytes + len);
+  have_hrir_raw_ = true;
+}
+
+bool HrtfRender::set_spatial_objects(const std::vector<SpatialObject> &objs) {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  if (have_state_ && (int)objs.size() != channels_) {  // imp.rs:440-451: warning, property unchanged
+    last_error_ = "Could not update spatial objects, expected " + std::to_string(channels_) + " channels, got " + std::to_string(objs.size());
+    return false;
+  }
+  objects_ = objs;
+  have_objects_ = !objs.empty();  // an empty array unsets the property (imp.rs:453)
+  return true;
+}
+
+std::vector<SpatialObject> HrtfRender::spatial_objects() const {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  return have_objects_ ? objects_ : std::vector<SpatialObject>();
+}
+
+// TryFrom<AudioChannelPosition> for SpatialObject (spatial.rs:177-222); GstAudioChannelPosition numbering
+static bool object_from_position(int pos, SpatialObject *o) {
+  struct P { int pos; float x, y, z; };
+  static const P table[] = {
+      {-2 /*Mono*/, 0.0f, 0.0f, 2.5f}, {0 /*FrontLeft*/, -1.45f, 0.0f, 2.5f}, {1 /*FrontRight*/, 1.45f, 0.0f, 2.5f},
+      {2 /*FrontCenter*/, 0.0f, 0.0f, 2.5f}, {3 /*Lfe1*/, 0.0f, 0.0f, 0.0f}, {4 /*RearLeft*/, -1.45f, 0.0f, -2.5f},
+      {5 /*RearRight*/, 1.45f, 0.0f, -2.5f}, {6 /*FrontLeftOfCenter*/, -0.72f, 0.0f, 2.5f}, {7 /*FrontRightOfCenter*/, 0.72f, 0.0f, 2.5f},
+      {8 /*RearCenter*/, 0.0f, 0.0f, -2.5f}, {9 /*Lfe2*/, 0.0f, 0.0f, 0.0f}, {10 /*SideLeft*/, -2.5f, 0.0f, -0.44f},
+      {11 /*SideRight*/, 2.5f, 0.0f, -0.44f}, {12 /*TopFrontLeft*/, -0.72f, 2.5f, 1.25f}, {13 /*TopFrontRight*/, 0.72f, 2.5f, 1.25f},
+      {14 /*TopFrontCenter*/, 0.0f, 2.5f, 1.25f}, {15 /*TopCenter*/, 0.0f, 2.5f, 0.0f}, {16 /*TopRearLeft*/, -0.72f, 2.5f, -1.25f},
+      {17 /*TopRearRight*/, 0.72f, 2.5f, -1.25f}, {18 /*TopSideLeft*/, -1.25f, 2.5f, -0.22f}, {19 /*TopSideRight*/, 1.25f, 2.5f, -0.22f},
+      {20 /*TopRearCenter*/, 0.0f, 2.5f, -1.25f}, {21 /*BottomFrontCenter*/, 0.0f, -2.5f, 1.25f}, {22 /*BottomFrontLeft*/, -0.72f, -2.5f, 1.25f},
+      {23 /*BottomFrontRight*/, 0.72f, -2.5f, 1.25f}, {24 /*WideLeft*/, -2.5f, 0.0f, 1.45f}, {25 /*WideRight*/, 2.5f, 0.0f, 1.45f},
+      {26 /*SurroundLeft*/, -2.5f, 0.0f, -1.45f}, {27 /*SurroundRight*/, 2.5f, 0.0f, -1.45f}};
+  for (const P &p : table)
+    if (p.pos == pos) {
+      o->coordinate_system = 1;  // Position::LeftHanded
+      o->x = p.x; o->y = p.y; o->z = p.z;
+      o->distance_gain = 1.0f;
+      return true;
+    }
+  return false;  // FlowError::NotSupported -> "Unsupported channel position"
+}
+
+// Position::to_right_handed().to_vec3() (spatial.rs:58-66)
+static void to_right_handed(const SpatialObject &o, float out[3]) {
+  if (o.coordinate_system == 0) { out[0] = -o.y; out[1] = o.z; out[2] = -o.x; }        // Cartesian
+  else if (o.coordinate_system == 1) { out[0] = o.x; out[1] = o.y; out[2] = -o.z; }    // LeftHanded
+  else { out[0] = o.x; out[1] = o.y; out[2] = o.z; }                                    // RightHanded
+}
+
+bool HrtfRender::set_caps(int rate, int channels, const int *positions) {
+  if (!ctx_) return false;
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  have_state_ = false;
+  if (channels < 1 || channels > 64 || rate <= 0) { last_error_ = "Failed to parse input caps"; return false; }
+  if (!have_objects_) {
+    if (!positions) { last_error_ = "Cannot infer object positions"; return false; }
+    std::vector<SpatialObject> objs((size_t)channels);
+    for (int c = 0; c < channels; c++)
+      if (!object_from_position(positions[c], &objs[(size_t)c])) { last_error_ = "Unsupported channel position"; return false; }
+    objects_ = objs;
+    have_objects_ = true;
+  }
+  if ((int)objects_.size() != channels) { last_error_ = "Wrong number of spatial objects"; return false; }
+  // Settings::sphere (imp.rs:84-94): raw bytes win over the file location
+  std::vector<unsigned char> bytes;
+  if (have_hrir_raw_) {
+    bytes = hrir_raw_;
+  } else if (have_hrir_file_) {
+    FILE *f = std::fopen(hrir_file_.c_str(), "rb");
+    if (!f) { last_error_ = "Failed to load sphere: cannot open " + hrir_file_; return false; }
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + n);
+    std::fclose(f);
+  } else {
+    last_error_ = "Failed to load sphere: Impulse response not set";
+    return false;
+  }
+  if (mi355_hrtf_load_sphere(ctx_, bytes.data(), bytes.size(), (uint32_t)rate) != MI355_OK) {
+    last_error_ = std::string("Failed to load sphere: ") + mi355_ctx_last_error(ctx_);
+    return false;
+  }
+  // block_samples = blklen.checked_mul(steps) (imp.rs:655-657)
+  unsigned long long bs = 0;
+  if (__builtin_umulll_overflow(block_length_, interpolation_steps_, &bs) || bs == 0 || bs > (1ull << 24)) {
+    last_error_ = "Not enough memory for frame allocation";
+    return false;
+  }
+  if (mi355_hrtf_setup(ctx_, channels, (int)block_length_, (int)interpolation_steps_) != MI355_OK) {
+    last_error_ = mi355_ctx_last_error(ctx_);
+    return false;
+  }
+  rate_ = rate; channels_ = channels; block_samples_ = (size_t)bs;
+  adapter_.clear();
+  have_state_ = true;
+  return true;
+}
+
+size_t HrtfRender::transform_size(size_t in_bytes) const {
+  if (!have_state_) return 0;
+  const size_t inblk = block_samples_ * (size_t)channels_ * 4, outblk = block_samples_ * 8;
+  return ((in_bytes + adapter_.size() * 4) / inblk) * outblk;
+}
+
+FlowReturn HrtfRender::process_available(std::vector<float> *out) {
+  const size_t blk = block_samples_ * (size_t)channels_;
+  std::vector<float> pos((size_t)channels_ * 3), gains((size_t)channels_);
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);  // settings snapshot for this buffer
+    if (!have_objects_ || (int)objects_.size() != channels_) return FlowReturn::NotNegotiated;
+    for (int c = 0; c < channels_; c++) {
+      to_right_handed(objects_[(size_t)c], &pos[(size_t)c * 3]);
+      gains[(size_t)c] = objects_[(size_t)c].distance_gain;
+    }
+  }
+  size_t done = 0;
+  while (adapter_.size() - done >= blk) {
+    const size_t o = out->size();
+    out->resize(o + block_samples_ * 2);
+    const int rc = mi355_hrtf_process_block(ctx_, adapter_.data() + done, out->data() + o, pos.data(), gains.data());
+    if (rc != MI355_OK) return flow_from_status(rc);
+    done += blk;
+  }
+  adapter_.erase(adapter_.begin(), adapter_.begin() + (std::ptrdiff_t)done);
+  return FlowReturn::Ok;
+}
+
+FlowReturn HrtfRender::transform(const float *in, size_t in_bytes, std::vector<float> *out) {
+  if (!ctx_) return FlowReturn::Error;
+  if (!have_state_) { last_error_ = "hrtfrender: not negotiated"; return FlowReturn::NotNegotiated; }
+  out->clear();
+  adapter_.insert(adapter_.end(), in, in + in_bytes / 4);
+  return process_available(out);
+}
+
+FlowReturn HrtfRender::drain(std::vector<float> *out) {
+  if (!ctx_) return FlowReturn::Error;
+  if (!have_state_) return FlowReturn::NotNegotiated;
+  out->clear();
+  const size_t avail = adapter_.size();  // samples
+  if (avail == 0) return FlowReturn::Ok;
+  const size_t blk = block_samples_ * (size_t)channels_;
+  const size_t out_frames = avail / (size_t)channels_;  // outputsz = avail / inbpf * outbpf (imp.rs:303)
+  adapter_.resize(blk, 0.0f);                            // zero input of inblksz - avail bytes (imp.rs:305-318)
+  const FlowReturn r = process_available(out);
+  if (r != FlowReturn::Ok) return r;
+  out->resize(out_frames * 2);                           // outbuf.set_size(outputsz)
+  mi355_hrtf_reset(ctx_);                                // state.reset_processors()
+  return FlowReturn::Ok;
+}
+
+void HrtfRender::flush_stop() {
+  adapter_.clear();
+  if (ctx_ && have_state_) mi355_hrtf_reset(ctx_);
+}
+
+bool HrtfRender::stop() {
+  if (ctx_) mi355_hrtf_teardown(ctx_);
+  have_state_ = false;
+  adapter_.clear();
+  started_ = false;
+  return true;
+}
+
 // ------------------------------------------------------------------ registry
 
-std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level"}; }
+std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender"}; }
 
 std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error) {
   std::unique_ptr<Element> e;
@@ -597,6 +833,7 @@ std::unique_ptr<Element> element_factory_make(const std::string &factory, int de
   else if (factory == "colorlut") e.reset(new ColorLut(device));
   else if (factory == "rsaudioecho") e.reset(new AudioEcho(device));
   else if (factory == "ebur128level") e.reset(new EbuR128Level(device));
+  else if (factory == "hrtfrender") e.reset(new HrtfRender(device));
   else {
     if (error) *error = "no such element factory: " + factory;
     return nullptr;
@@ -711,6 +948,74 @@ int mi355el_ebur128_pop_message(mi355el *h, uint64_t *timestamp, unsigned *field
   for (int c = 0; c < max_ch && c < (int)m.sample_peak.size(); c++) sample_peak[c] = m.sample_peak[(size_t)c];
   for (int c = 0; c < max_ch && c < (int)m.true_peak.size(); c++) true_peak[c] = m.true_peak[(size_t)c];
   return 1;
+}
+
+
+// ---- hrtfrender
+static HrtfRender *as_hrtf(mi355el *h) { return h ? dynamic_cast<HrtfRender *>(h->e.get()) : nullptr; }
+
+int mi355el_hrtf_set_hrir_raw(mi355el *h, const void *bytes, size_t len) {
+  auto *e = as_hrtf(h);
+  if (!e) return -1;
+  e->set_hrir_raw(bytes, len);
+  return 0;
+}
+// objects: n x {x, y, z, distance_gain}; coordinate_system[n] (GstHrtfCoordinateSystem)
+int mi355el_hrtf_set_objects(mi355el *h, int n, const float *xyzg, const int *coordinate_system) {
+  auto *e = as_hrtf(h);
+  if (!e || n < 0) return -1;
+  std::vector<SpatialObject> objs((size_t)n);
+  for (int i = 0; i < n; i++) {
+    objs[(size_t)i].x = xyzg[4 * i]; objs[(size_t)i].y = xyzg[4 * i + 1]; objs[(size_t)i].z = xyzg[4 * i + 2];
+    objs[(size_t)i].distance_gain = xyzg[4 * i + 3];
+    objs[(size_t)i].coordinate_system = coordinate_system ? coordinate_system[i] : 1;
+  }
+  return e->set_spatial_objects(objs) ? 0 : -1;
+}
+int mi355el_hrtf_get_objects(mi355el *h, int max, float *xyzg, int *coordinate_system) {
+  auto *e = as_hrtf(h);
+  if (!e) return -1;
+  const auto objs = e->spatial_objects();
+  for (int i = 0; i < (int)objs.size() && i < max; i++) {
+    xyzg[4 * i] = objs[(size_t)i].x; xyzg[4 * i + 1] = objs[(size_t)i].y; xyzg[4 * i + 2] = objs[(size_t)i].z;
+    xyzg[4 * i + 3] = objs[(size_t)i].distance_gain;
+    if (coordinate_system) coordinate_system[i] = objs[(size_t)i].coordinate_system;
+  }
+  return (int)objs.size();
+}
+int mi355el_hrtf_set_caps(mi355el *h, int rate, int channels, const int *positions) {
+  auto *e = as_hrtf(h);
+  if (!e) return -1;
+  return e->set_caps(rate, channels, positions) ? 0 : -1;
+}
+size_t mi355el_hrtf_transform_size(mi355el *h, size_t in_bytes) {
+  auto *e = as_hrtf(h);
+  return e ? e->transform_size(in_bytes) : 0;
+}
+// returns the GstFlowReturn value; *out_bytes = bytes written to `out` (never more than out_capacity)
+int mi355el_hrtf_transform(mi355el *h, const float *in, size_t in_bytes, float *out, size_t out_capacity, size_t *out_bytes) {
+  auto *e = as_hrtf(h);
+  if (!e) return (int)FlowReturn::Error;
+  std::vector<float> o;
+  const FlowReturn r = e->transform(in, in_bytes, &o);
+  const size_t n = o.size() * 4 < out_capacity ? o.size() * 4 : out_capacity;
+  if (n) std::memcpy(out, o.data(), n);
+  if (out_bytes) *out_bytes = o.size() * 4;
+  return (int)r;
+}
+int mi355el_hrtf_drain(mi355el *h, float *out, size_t out_capacity, size_t *out_bytes) {
+  auto *e = as_hrtf(h);
+  if (!e) return (int)FlowReturn::Error;
+  std::vector<float> o;
+  const FlowReturn r = e->drain(&o);
+  const size_t n = o.size() * 4 < out_capacity ? o.size() * 4 : out_capacity;
+  if (n) std::memcpy(out, o.data(), n);
+  if (out_bytes) *out_bytes = o.size() * 4;
+  return (int)r;
+}
+void mi355el_hrtf_flush_stop(mi355el *h) {
+  auto *e = as_hrtf(h);
+  if (e) e->flush_stop();
 }
 
 }  // extern "C"

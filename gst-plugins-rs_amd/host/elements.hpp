@@ -8,6 +8,7 @@
 //   HsvDetector  video/hsv/src/hsvdetector/imp.rs    (VideoFilter, NeverInPlace: transform_frame)
 //   ColorLut     video/colorlut/src/colorlut/imp.rs  (VideoFilter, NeverInPlace: start/stop/transform_frame)
 //   AudioEcho    audio/audiofx/src/audioecho/imp.rs  (AudioFilter, AlwaysInPlace: setup/transform_ip/stop)
+//   HrtfRender   audio/hrtf/src/hrtf/imp.rs          (BaseTransform, NeverInPlace: set_caps/transform/drain/stop)
 // Each object owns one mi355_ctx (include/mi355fx.h) and forwards its per-buffer vfunc to the C ABI,
 // exactly where the Rust element would call its inner loop. The GStreamer shim (gst/) wraps these.
 #pragma once
@@ -224,6 +225,62 @@ class EbuR128Level final : public Element {
   unsigned state_mode_ = 0;
   uint64_t num_frames_ = 0, interval_frames_ = 0, interval_frames_remaining_ = 0;
   std::vector<EbuR128LevelMessage> queue_;
+};
+
+// hrtfrender (audio/hrtf/src/hrtf/imp.rs): BaseTransform, NeverInPlace; input goes through an adapter and is
+// rendered in blocks of block-length * interpolation-steps frames; EOS drains the rest zero-padded.
+struct SpatialObject {      // audio/hrtf/src/spatial.rs:118-137
+  int coordinate_system = 1;  // GstHrtfCoordinateSystem: 0 cartesian, 1 left-handed (default), 2 right-handed
+  float x = 0, y = 0, z = 0;
+  float distance_gain = 1.0f;
+};
+
+class HrtfRender final : public Element {
+ public:
+  explicit HrtfRender(int device);
+  const char *factory_name() const override { return "hrtfrender"; }
+  const char *type_name() const override { return "GstHrtfRender"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {0}; }  // F32 interleaved, 1..=64 channels
+  std::vector<int> src_formats() const override { return {0}; }   // F32 interleaved, 2 channels
+  // "hrir-raw" (glib::Bytes) and "spatial-objects" (GstValueArray of GstStructure) have no scalar spelling
+  void set_hrir_raw(const void *bytes, size_t len);
+  bool set_spatial_objects(const std::vector<SpatialObject> &objs);  // ignored with a warning on a channel-count mismatch once negotiated
+  std::vector<SpatialObject> spatial_objects() const;
+  // BaseTransformImpl::set_caps (imp.rs:628-693). positions: GstAudioChannelPosition per channel, or nullptr
+  // (unpositioned caps: spatial-objects must have been set)
+  bool set_caps(int rate, int channels, const int *positions);
+  // transform_size (imp.rs:574-599): output bytes for `in_bytes` more input
+  size_t transform_size(size_t in_bytes) const;
+  // transform (imp.rs:547-572): push into the adapter, render every complete block; `out` receives
+  // transform_size(in_bytes) bytes of interleaved stereo
+  FlowReturn transform(const float *in, size_t in_bytes, std::vector<float> *out);
+  // sink_event(Eos) -> drain (imp.rs:281-352): the remainder zero-padded to a block, output truncated to the
+  // real frame count; tails are reset afterwards
+  FlowReturn drain(std::vector<float> *out);
+  void flush_stop();  // sink_event(FlushStop) (imp.rs:710-718)
+  bool stop() override;
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  bool store_u64(const std::string &name, uint64_t v) override;
+  bool load_u64(const std::string &name, uint64_t *v) const override;
+  bool store_string(const std::string &name, const std::string &v) override;
+  bool load_string(const std::string &name, std::string *v) const override;
+  FlowReturn process_available(std::vector<float> *out);
+  uint64_t interpolation_steps_ = 8, block_length_ = 512;  // imp.rs:36-37
+  bool use_rayon_ = false;
+  std::vector<SpatialObject> objects_;
+  bool have_objects_ = false;
+  std::vector<unsigned char> hrir_raw_;
+  bool have_hrir_raw_ = false, have_hrir_file_ = false;
+  std::string hrir_file_;
+  bool have_state_ = false;
+  int rate_ = 0, channels_ = 0;
+  size_t block_samples_ = 0;
+  std::vector<float> adapter_;
 };
 
 // gst_element_factory_make(): nullptr for an unknown factory name or when no device context can be made.

@@ -49,6 +49,14 @@ def _lib():
             "mi355el_ebur128_reset_signal": (None, [vp]),
             "mi355el_ebur128_pop_message": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double), i, C.POINTER(i)]),
+            "mi355el_hrtf_set_hrir_raw": (i, [vp, vp, sz]),
+            "mi355el_hrtf_set_objects": (i, [vp, i, C.POINTER(C.c_float), C.POINTER(i)]),
+            "mi355el_hrtf_get_objects": (i, [vp, i, C.POINTER(C.c_float), C.POINTER(i)]),
+            "mi355el_hrtf_set_caps": (i, [vp, i, i, C.POINTER(i)]),
+            "mi355el_hrtf_transform_size": (sz, [vp, sz]),
+            "mi355el_hrtf_transform": (i, [vp, vp, sz, vp, sz, C.POINTER(sz)]),
+            "mi355el_hrtf_drain": (i, [vp, vp, sz, C.POINTER(sz)]),
+            "mi355el_hrtf_flush_stop": (None, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -191,3 +199,56 @@ class Element:
             if f & 32:
                 m["true-peak"] = [tp[c] for c in range(nch.value)]
             out.append(m)
+
+
+    # ---- hrtfrender
+    COORD = {"cartesian": 0, "left-handed": 1, "right-handed": 2}
+
+    def hrtf_set_hrir_raw(self, data):
+        b = bytes(data)
+        buf = (C.c_uint8 * len(b)).from_buffer_copy(b)
+        return self.L.mi355el_hrtf_set_hrir_raw(self.h, C.cast(buf, C.c_void_p), len(b)) == 0
+
+    def hrtf_set_spatial_objects(self, objs):
+        """objs: list of dicts {x, y, z, distance-gain (default 1.0), coordinate-system (default left-handed)}"""
+        n = len(objs)
+        arr = (C.c_float * (4 * max(n, 1)))()
+        cs = (C.c_int * max(n, 1))()
+        for k, o in enumerate(objs):
+            arr[4 * k], arr[4 * k + 1], arr[4 * k + 2] = o["x"], o["y"], o["z"]
+            arr[4 * k + 3] = o.get("distance-gain", 1.0)
+            cs[k] = self.COORD[o.get("coordinate-system", "left-handed")]
+        return self.L.mi355el_hrtf_set_objects(self.h, n, arr, cs) == 0
+
+    def hrtf_spatial_objects(self):
+        arr = (C.c_float * 256)()
+        cs = (C.c_int * 64)()
+        n = self.L.mi355el_hrtf_get_objects(self.h, 64, arr, cs)
+        names = {v: k for k, v in self.COORD.items()}
+        return [{"x": arr[4 * k], "y": arr[4 * k + 1], "z": arr[4 * k + 2], "distance-gain": arr[4 * k + 3],
+                 "coordinate-system": names[cs[k]]} for k in range(n)]
+
+    def hrtf_set_caps(self, rate, channels, positions=None):
+        p = (C.c_int * channels)(*positions) if positions is not None else None
+        return self.L.mi355el_hrtf_set_caps(self.h, rate, channels, p) == 0
+
+    def hrtf_transform_size(self, in_bytes):
+        return self.L.mi355el_hrtf_transform_size(self.h, in_bytes)
+
+    def hrtf_transform(self, data):
+        """Push one input buffer (interleaved f32); returns (flow, stereo f32 output of every block completed)."""
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        cap = self.hrtf_transform_size(a.nbytes)
+        out = np.zeros(max(cap // 4, 1), np.float32)
+        nb = C.c_size_t(0)
+        flow = self.L.mi355el_hrtf_transform(self.h, a.ctypes.data, a.nbytes, out.ctypes.data, cap, C.byref(nb))
+        return flow, out[: nb.value // 4]
+
+    def hrtf_drain(self, max_frames=1 << 20):
+        out = np.zeros(max_frames * 2, np.float32)
+        nb = C.c_size_t(0)
+        flow = self.L.mi355el_hrtf_drain(self.h, out.ctypes.data, out.nbytes, C.byref(nb))
+        return flow, out[: nb.value // 4]
+
+    def hrtf_flush_stop(self):
+        self.L.mi355el_hrtf_flush_stop(self.h)

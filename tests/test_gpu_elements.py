@@ -194,3 +194,128 @@ def test_ebur128level_element_like_the_reference_test(oracle, dtype, planar):
     from mi355fx.elements import FLOW_NOT_NEGOTIATED
     assert e.ebur128_push(x[:10].reshape(-1) if not planar else np.ascontiguousarray(x[:10].T), 0, planar) == FLOW_NOT_NEGOTIATED
     e.close()
+
+
+# ------------------------------------------------------------------ hrtfrender (audio/hrtf/tests/hrtfrender.rs)
+
+HRIR_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test.hrir")
+FLOW_OK, FLOW_NOT_NEGOTIATED = 0, -4
+
+
+def _hrtf_element(channels, positions=None, objects=None, rate=44100, hrir=None):
+    from mi355fx.elements import Element
+    e = Element("hrtfrender")
+    assert e.hrtf_set_hrir_raw(open(HRIR_FIXTURE, "rb").read() if hrir is None else hrir)
+    if objects is not None:
+        assert e.hrtf_set_spatial_objects(objects)
+    return e, e.hrtf_set_caps(rate, channels, positions)
+
+
+def test_hrtfrender_samples_in_samples_out():
+    """test_hrtfrender_samples_in_samples_out: one full block + 20 frames in -> one full block out, the 20-frame
+    residue comes out at EOS (drain), zero-padded internally and truncated to 20 frames."""
+    e, ok = _hrtf_element(1, positions=[2])  # channel-mask 0x1... FRONT_LEFT in the reference; any positioned mono works
+    assert ok, e.last_error
+    full_block = 512 * 8
+    buf = np.zeros(full_block + 20, np.float32)
+    assert e.hrtf_transform_size(buf.nbytes) == full_block * 8
+    flow, out = e.hrtf_transform(buf)
+    assert flow == FLOW_OK and out.nbytes == full_block * 8
+    flow, out = e.hrtf_drain()
+    assert flow == FLOW_OK and out.nbytes == 20 * 8
+    flow, out = e.hrtf_drain()          # adapter empty: nothing more
+    assert flow == FLOW_OK and out.size == 0
+
+
+def test_hrtfrender_implicit_spatial_objects():
+    """8 channels, channel-mask 0xc3f (FL FR FC LFE RL RR SL SR): objects are inferred from the positions."""
+    e, ok = _hrtf_element(8, positions=[0, 1, 2, 3, 4, 5, 10, 11])
+    assert ok, e.last_error
+    objs = e.hrtf_spatial_objects()
+    assert len(objs) == 8
+    assert (objs[0]["x"], objs[0]["y"], objs[0]["z"]) == (pytest.approx(-1.45), 0.0, 2.5)   # FrontLeft (spatial.rs:184)
+    assert (objs[3]["x"], objs[3]["y"], objs[3]["z"]) == (0.0, 0.0, 0.0)                    # Lfe1
+    assert objs[6]["x"] == -2.5 and objs[6]["z"] == pytest.approx(-0.44)                    # SideLeft
+    assert all(o["coordinate-system"] == "left-handed" and o["distance-gain"] == 1.0 for o in objs)
+
+
+def test_hrtfrender_explicit_spatial_objects():
+    objs = [{"x": -1.0 + x / 8.0, "y": 0.0, "z": 1.0, "distance-gain": 0.1} for x in range(8)]
+    e, ok = _hrtf_element(8, objects=objs)   # unpositioned caps are fine once objects are set
+    assert ok, e.last_error
+    got = e.hrtf_spatial_objects()
+    assert len(got) == 8 and got[7]["x"] == pytest.approx(-0.125) and got[0]["distance-gain"] == pytest.approx(0.1)
+
+
+def test_hrtfrender_caps_negotiation_fail():
+    """6 input channels but 2 spatial objects: set_caps fails ("Wrong number of spatial objects") and pushing a
+    buffer returns NotNegotiated."""
+    objs = [{"x": 0.0, "y": 0.0, "z": 1.0, "distance-gain": 0.1} for _ in range(2)]
+    e, ok = _hrtf_element(6, objects=objs)
+    assert not ok and "Wrong number of spatial objects" in e.last_error
+    flow, out = e.hrtf_transform(np.zeros(512, np.float32))
+    assert flow == FLOW_NOT_NEGOTIATED and out.size == 0
+
+
+def test_hrtfrender_errors_like_the_reference():
+    from mi355fx.elements import Element
+    e = Element("hrtfrender")
+    assert not e.hrtf_set_caps(44100, 1, [2]) and "Impulse response not set" in e.last_error
+    e, ok = _hrtf_element(2, positions=None)
+    assert not ok and "Cannot infer object positions" in e.last_error
+    e, ok = _hrtf_element(1, positions=[-1])                      # GST_AUDIO_CHANNEL_POSITION_INVALID
+    assert not ok and "Unsupported channel position" in e.last_error
+    e, ok = _hrtf_element(1, positions=[2], rate=48000)           # sphere is 44.1 kHz: resampling unsupported
+    assert not ok and "Failed to load sphere" in e.last_error
+    # once negotiated, a spatial-objects update with the wrong count is ignored with a warning (imp.rs:440-451)
+    e, ok = _hrtf_element(2, positions=[0, 1])
+    assert ok
+    assert not e.hrtf_set_spatial_objects([{"x": 0.0, "y": 0.0, "z": 1.0}])
+    assert len(e.hrtf_spatial_objects()) == 2
+    assert e.properties()["interpolation-steps"]["default"] == 8 and e.properties()["block-length"]["default"] == 512
+    assert e.get_property("use-rayon") == 0.0
+
+
+def test_hrtfrender_element_stream_matches_oracle(oracle, synth):
+    """Arbitrary buffer sizes through the adapter, moving objects between buffers, EOS drain: the element's output
+    stream equals the oracle fed block by block (tolerance as tests/test_gpu_hrtf.py)."""
+    mesh = open(HRIR_FIXTURE, "rb").read()
+    data = synth.hrir_sphere_bytes(mesh, 64)
+    C, steps, bl = 3, 4, 128
+    from mi355fx.elements import Element
+    e = Element("hrtfrender")
+    e.hrtf_set_hrir_raw(data)
+    assert e.set_property("interpolation-steps", steps) and e.set_property("block-length", bl)
+    objs = [{"x": 1.0, "y": 0.2, "z": 0.5, "coordinate-system": "cartesian"}, {"x": -0.3, "y": 0.1, "z": 1.0, "distance-gain": 0.7},
+            {"x": 0.4, "y": -0.9, "z": -0.2, "coordinate-system": "right-handed", "distance-gain": 0.5}]
+    assert e.hrtf_set_spatial_objects(objs)
+    assert e.hrtf_set_caps(44100, C), e.last_error
+    sphere = oracle.HrirSphere(data, 44100)
+    ref = oracle.HrtfRender(sphere, C, steps, bl)
+
+    def rh(o):  # Position::to_right_handed (spatial.rs:58-66)
+        cs = o.get("coordinate-system", "left-handed")
+        x, y, z = o["x"], o["y"], o["z"]
+        return {"cartesian": (-y, z, -x), "left-handed": (x, y, -z), "right-handed": (x, y, z)}[cs]
+
+    rng = np.random.default_rng(12)
+    blk = steps * bl
+    total = 3 * blk + 57
+    x = rng.uniform(-1, 1, (total, C)).astype(np.float32)
+    got = []
+    fed = 0
+    for n in (100, blk, 2 * blk - 100 + 30, total - (100 + blk + 2 * blk - 100 + 30)):
+        flow, out = e.hrtf_transform(x[fed: fed + n])
+        assert flow == FLOW_OK
+        got.append(out)
+        fed += n
+    flow, out = e.hrtf_drain()
+    assert flow == FLOW_OK and out.size == 57 * 2
+    got.append(out)
+    got = np.concatenate(got)
+    pos = np.array([rh(o) for o in objs], np.float32)
+    gains = np.array([o.get("distance-gain", 1.0) for o in objs], np.float32)
+    xp = np.concatenate([x, np.zeros((4 * blk - total, C), np.float32)])
+    exp = np.concatenate([ref.process_block(xp[k * blk: (k + 1) * blk], pos, gains) for k in range(4)])[: total * 2]
+    assert got.size == exp.size
+    assert np.abs(got - exp).max() <= 4e-5 * max(1.0, np.abs(exp).max())
