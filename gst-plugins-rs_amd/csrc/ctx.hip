@@ -532,6 +532,57 @@ int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx)
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 0, channel, out); }
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 1, channel, out); }
 
+/* ------------------------------------------------------------------ videocompare */
+
+static int videocompare_channels(mi355_ctx *ctx, int format, int algo, int *channels) {
+  if (algo < MI355_HASH_MEAN || algo > MI355_HASH_DSSIM) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: unknown hash-algo");
+  if (algo != MI355_HASH_BLOCKHASH)
+    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: only hash-algo=blockhash is implemented on the device");
+  if (format == MI355_FMT_RGBA) *channels = 4;
+  else if (format == MI355_FMT_RGB) *channels = 3;
+  else return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: format must be RGB or RGBA");  // pad template caps (imp.rs:167-172)
+  return MI355_OK;
+}
+
+int mi355_videocompare_hash_frames_device(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames,
+                                          int width, int height, int format, int algo, uint64_t *hashes) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = videocompare_channels(ctx, format, algo, &channels);
+  if (rc) return rc;
+  if (n_frames < 0 || width <= 0 || height <= 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: bad frame size");
+  if (n_frames == 0) return MI355_OK;
+  if (!d_frames || !hashes) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: null data");
+  if ((size_t)stride < (size_t)width * channels) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: stride smaller than row bytes");
+  BIND_DEVICE(ctx);
+  return launch_blockhash(ctx, d_frames, frame_pitch, stride, n_frames, width, height, channels, (unsigned long long *)hashes);
+}
+
+int mi355_videocompare_hash_frame(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height, int format, int algo,
+                                  uint64_t *hash) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = videocompare_channels(ctx, format, algo, &channels);
+  if (rc) return rc;
+  if (width <= 0 || height <= 0 || !data || !hash) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: bad frame");
+  if ((size_t)stride < (size_t)width * channels) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: stride smaller than row bytes");
+  BIND_DEVICE(ctx);
+  // pack while copying: only the first width*channels bytes of every row travel (tightly_packed_framebuffer)
+  const size_t row = (size_t)width * channels, pitch = (row + 15) & ~(size_t)15;
+  rc = ensure_stage(ctx, 0, pitch * (size_t)height);
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpy2DAsync(ctx->d_stage[0], pitch, data, (size_t)stride, row, (size_t)height, hipMemcpyHostToDevice, ctx->stream),
+                 "videocompare H2D");
+  if (rc) return rc;
+  return launch_blockhash(ctx, (const uint8_t *)ctx->d_stage[0], pitch * (size_t)height, (int)pitch, 1, width, height, channels,
+                          (unsigned long long *)hash);
+}
+
+double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t frame_hash) {
+  if (algo != MI355_HASH_BLOCKHASH) return -1.0;
+  return (double)__builtin_popcountll(reference_hash ^ frame_hash);
+}
+
 /* ------------------------------------------------------------------ hrtfrender */
 
 int mi355_hrtf_load_sphere(mi355_ctx *ctx, const void *bytes, size_t len, uint32_t device_rate) {

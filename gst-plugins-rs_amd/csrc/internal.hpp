@@ -87,6 +87,8 @@ int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay
 int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
 int ebur128_reset(mi355_ctx *ctx);
 void ebur128_release(mi355_ctx *ctx);
+int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
+                     int channels, unsigned long long *hashes);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
 int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);
 int hrtf_reset(mi355_ctx *ctx);

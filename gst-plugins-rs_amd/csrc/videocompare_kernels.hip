@@ -1,0 +1,218 @@
+// videocompare_kernels.hip — gfx950 kernels for videocompare's default hash (BASELINE config 5 shape:
+// many concurrent 4K streams, one comparison per stream per frame).
+//
+// Reference path replaced: HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79)
+// with HashAlgorithm::Blockhash, the element default (videocompare/imp.rs:31) -> crate image_hasher 3.1.1
+// `blockhash` (sources not in the reference tree; algorithm restated in oracle/videocompare_oracle.c):
+//   64 u32 block sums over (width/8) x (height/8) pixel blocks of sum_px (r+g+b; RGBA with a == 0 counts 765),
+//   two bands of 32 blocks, upper median per band, bit = block > median || (block == median && median > half scale),
+//   distance = Hamming distance of the 64-bit hashes.
+// The frame is read once (4 B/px RGBA, 3 B/px RGB) and nothing but 64 counters is written: a pure HBM-bound
+// reduction. Lanes of a wavefront that fall into the same hash block (the common case: a block is hundreds of
+// pixels wide) are combined with a cross-lane shuffle reduction before one LDS atomic; the 64 LDS counters of
+// a workgroup are flushed with one global atomic each. Integer adds: the result is order-independent, bit-exact.
+#include "internal.hpp"
+
+namespace mi355 {
+
+__device__ __forceinline__ uint32_t sum_px_rgba(uint32_t p) {
+  const uint32_t s = (p & 0xffu) + ((p >> 8) & 0xffu) + ((p >> 16) & 0xffu);
+  return (p >> 24) == 0u ? 765u : s;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// add `v` to LDS counter `bin`; lanes of the wave sharing one bin are reduced first
+__device__ __forceinline__ void bin_add(uint32_t *s_bins, int bin, uint32_t v) {
+  const int first = __shfl(bin, 0);
+  if (__all(bin == first)) {
+    const uint32_t t = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && bin >= 0) atomicAdd(&s_bins[bin], t);
+  } else if (bin >= 0) {
+    atomicAdd(&s_bins[bin], v);
+  }
+}
+
+// per-lane add (no wave-collective part): used for the rare second block column of a straddling pixel group
+__device__ __forceinline__ void bin_add_lane(uint32_t *s_bins, int bin, uint32_t v) {
+  if (bin >= 0 && v) atomicAdd(&s_bins[bin], v);
+}
+
+// RGBA, rows 16 B aligned, width % 4 == 0, block width >= 4: one lane owns a 4-pixel column group (uint4) over a
+// group of kRowGroup rows, so its pixels stay in the same hash-block column; the row loop keeps several independent
+// 16 B loads in flight and the cross-lane reduction happens once per row group instead of once per row.
+// Work item = (frame, row group, 1024-pixel segment).
+constexpr int kRowGroup = 32;
+__global__ __launch_bounds__(256) void blockhash_rgba_kernel(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
+                                                             int n_frames, int width, int height, uint32_t *__restrict__ sums) {
+  __shared__ uint32_t s_bins[64];
+  const int bw = width / 8, bh = height / 8;
+  const int segs = (width + 1023) / 1024;
+  const int groups = (height + kRowGroup - 1) / kRowGroup;
+  const size_t items_per_frame = (size_t)groups * segs;
+  const size_t total = items_per_frame * (size_t)n_frames;
+  // contiguous range of items per workgroup so that it flushes its LDS counters once per frame it touches
+  const size_t per_wg = (total + gridDim.x - 1) / gridDim.x;
+  size_t it = (size_t)blockIdx.x * per_wg;
+  const size_t it_end = it + per_wg < total ? it + per_wg : total;
+  int cur_frame = -1;
+  if (threadIdx.x < 64) s_bins[threadIdx.x] = 0;
+  __syncthreads();
+  for (; it < it_end; it++) {
+    const int f = (int)(it / items_per_frame);
+    if (f != cur_frame) {
+      if (cur_frame >= 0) {
+        __syncthreads();
+        if (threadIdx.x < 64) { const uint32_t v = s_bins[threadIdx.x]; if (v) atomicAdd(&sums[(size_t)cur_frame * 64 + threadIdx.x], v); s_bins[threadIdx.x] = 0; }
+        __syncthreads();
+      }
+      cur_frame = f;
+    }
+    const size_t r = it - (size_t)f * items_per_frame;
+    const int g = (int)(r / segs), seg = (int)(r - (size_t)g * segs);
+    const int x0 = seg * 1024 + (int)threadIdx.x * 4;
+    const bool live = x0 < width;
+    // the 4 pixels cover at most two block columns (bw >= 4): column of pixel 0 and of pixel 3
+    const int bxa = live ? x0 / bw : 0, bxb = live ? (x0 + 3) / bw : 0;
+    const int split = (bxa + 1) * bw - x0;  // pixels [0, split) belong to bxa (split >= 4 when bxa == bxb)
+    const uint8_t *col = frames + (size_t)f * frame_pitch + (size_t)x0 * 4;
+    const int y0 = g * kRowGroup, y1 = y0 + kRowGroup < height ? y0 + kRowGroup : height;
+    uint32_t acca = 0, accb = 0;
+    int by = y0 / bh;
+    for (int yb = y0; yb < y1; yb += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        v[k] = make_uint4(0xff000000u, 0xff000000u, 0xff000000u, 0xff000000u);  // opaque black: adds 0
+        if (live && yb + k < y1) v[k] = *(const uint4 *)(col + (size_t)(yb + k) * (size_t)stride);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int y = yb + k;
+        if (y < y1 && y / bh != by) {  // row group crosses a block-row edge: flush (wave-uniform condition)
+          bin_add(s_bins, live ? by * 8 + bxa : -1, acca);
+          if (bxb != bxa) bin_add_lane(s_bins, live ? by * 8 + bxb : -1, accb);
+          acca = accb = 0;
+          by = y / bh;
+        }
+        const uint32_t s0 = sum_px_rgba(v[k].x), s1 = sum_px_rgba(v[k].y), s2 = sum_px_rgba(v[k].z), s3 = sum_px_rgba(v[k].w);
+        acca += s0 + (split > 1 ? s1 : 0u) + (split > 2 ? s2 : 0u) + (split > 3 ? s3 : 0u);
+        accb += (split > 1 ? 0u : s1) + (split > 2 ? 0u : s2) + (split > 3 ? 0u : s3);
+      }
+    }
+    bin_add(s_bins, live ? by * 8 + bxa : -1, acca);
+    if (bxb != bxa) bin_add_lane(s_bins, live ? by * 8 + bxb : -1, accb);
+  }
+  __syncthreads();
+  if (cur_frame >= 0 && threadIdx.x < 64) { const uint32_t v = s_bins[threadIdx.x]; if (v) atomicAdd(&sums[(size_t)cur_frame * 64 + threadIdx.x], v); }
+}
+
+// Any packed layout (RGB, unaligned RGBA): one lane = one pixel, byte loads.
+__global__ __launch_bounds__(256) void blockhash_bytes_kernel(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride,
+                                                              int n_frames, int width, int height, int channels,
+                                                              uint32_t *__restrict__ sums) {
+  __shared__ uint32_t s_bins[64];
+  const int bw = width / 8, bh = height / 8;
+  const int segs = (width + 255) / 256;
+  const size_t items_per_frame = (size_t)height * segs;
+  const size_t total = items_per_frame * (size_t)n_frames;
+  const size_t per_wg = (total + gridDim.x - 1) / gridDim.x;
+  size_t it = (size_t)blockIdx.x * per_wg;
+  const size_t it_end = it + per_wg < total ? it + per_wg : total;
+  int cur_frame = -1;
+  if (threadIdx.x < 64) s_bins[threadIdx.x] = 0;
+  __syncthreads();
+  for (; it < it_end; it++) {
+    const int f = (int)(it / items_per_frame);
+    if (f != cur_frame) {
+      if (cur_frame >= 0) {
+        __syncthreads();
+        if (threadIdx.x < 64) { const uint32_t v = s_bins[threadIdx.x]; if (v) atomicAdd(&sums[(size_t)cur_frame * 64 + threadIdx.x], v); s_bins[threadIdx.x] = 0; }
+        __syncthreads();
+      }
+      cur_frame = f;
+    }
+    const size_t r = it - (size_t)f * items_per_frame;
+    const int y = (int)(r / segs), seg = (int)(r - (size_t)y * segs);
+    const int x = seg * 256 + (int)threadIdx.x;
+    uint32_t acc = 0;
+    int bin = -1;
+    if (x < width) {
+      const uint8_t *p = frames + (size_t)f * frame_pitch + (size_t)y * (size_t)stride + (size_t)x * channels;
+      acc = (uint32_t)p[0] + p[1] + p[2];
+      if (channels == 4 && p[3] == 0) acc = 765u;
+      bin = (y / bh) * 8 + x / bw;
+    }
+    bin_add(s_bins, bin, acc);
+  }
+  __syncthreads();
+  if (cur_frame >= 0 && threadIdx.x < 64) { const uint32_t v = s_bins[threadIdx.x]; if (v) atomicAdd(&sums[(size_t)cur_frame * 64 + threadIdx.x], v); }
+}
+
+// one wave per frame: lanes 0..31 own band 0, 32..63 band 1; rank-based upper median, then the bits
+__global__ __launch_bounds__(64) void blockhash_finish_kernel(const uint32_t *__restrict__ sums, int n_frames, uint32_t cmp_factor,
+                                                              unsigned long long *__restrict__ hashes) {
+  const int f = blockIdx.x;
+  if (f >= n_frames) return;
+  const int lane = threadIdx.x, band = lane >> 5;
+  const uint32_t v = sums[(size_t)f * 64 + lane];
+  // rank = number of band elements smaller than v (ties broken by lane) -> the element of rank 16 is sorted[16]
+  int rank = 0;
+  for (int j = 0; j < 32; j++) {
+    const int src = band * 32 + j;
+    const uint32_t o = __shfl(v, src);
+    rank += (o < v) || (o == v && src < lane);
+  }
+  const unsigned long long is_med = __ballot(rank == 16);
+  const int med_lane0 = __ffsll((long long)(is_med & 0xffffffffull)) - 1;
+  const int med_lane1 = __ffsll((long long)(is_med >> 32)) - 1 + 32;
+  const uint32_t median = __shfl(v, band ? med_lane1 : med_lane0);
+  const bool bit = v > median || (v == median && median > cmp_factor);
+  const unsigned long long h = __ballot(bit);
+  if (lane == 0) hashes[f] = h;
+}
+
+// Hashes `n_frames` device-resident frames; `hashes` is a HOST array of n_frames u64.
+int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
+                     int channels, unsigned long long *hashes) {
+  if (width % 8 != 0 || height % 8 != 0)
+    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: blockhash needs width and height divisible by 8 (the crate's floating-point path is not ported)");
+  // scratch: [n_frames][64] u32 sums + [n_frames] u64 hashes in staging slot 1 (slot 0 holds the host entry's frame)
+  const size_t need = (size_t)n_frames * (64 * 4 + 8);
+  if (ctx->d_stage_bytes[1] < need) {
+    if (ctx->d_stage[1]) (void)hipFree(ctx->d_stage[1]);
+    ctx->d_stage[1] = nullptr;
+    ctx->d_stage_bytes[1] = 0;
+    int rc = check_hip(ctx, hipMalloc(&ctx->d_stage[1], need), "hipMalloc(blockhash scratch)");
+    if (rc) return rc;
+    ctx->d_stage_bytes[1] = need;
+  }
+  unsigned long long *d_hashes = (unsigned long long *)ctx->d_stage[1];
+  uint32_t *d_sums = (uint32_t *)(d_hashes + n_frames);
+  int rc = check_hip(ctx, hipMemsetAsync(d_sums, 0, (size_t)n_frames * 64 * 4, ctx->stream), "hipMemset(blockhash sums)");
+  if (rc) return rc;
+  const bool vec = channels == 4 && stride % 16 == 0 && frame_pitch % 16 == 0 && ((uintptr_t)d_frames % 16 == 0) && width >= 32;
+  const size_t seg_px = vec ? 1024 : 256;
+  const size_t rows = vec ? ((size_t)height + kRowGroup - 1) / kRowGroup : (size_t)height;
+  const size_t items = (size_t)n_frames * rows * (((size_t)width + seg_px - 1) / seg_px);
+  size_t grid = (size_t)ctx->n_cu * 8;
+  if (grid > items) grid = items;
+  if (grid < 1) grid = 1;
+  if (vec)
+    hipLaunchKernelGGL(blockhash_rgba_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_frames, frame_pitch, stride, n_frames, width, height, d_sums);
+  else
+    hipLaunchKernelGGL(blockhash_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_frames, frame_pitch, stride, n_frames, width, height, channels, d_sums);
+  const uint32_t cmp_factor = 765u * (uint32_t)((width / 8) * (height / 8)) / 2u;
+  hipLaunchKernelGGL(blockhash_finish_kernel, dim3(n_frames), dim3(64), 0, ctx->stream, (const uint32_t *)d_sums, n_frames, cmp_factor, d_hashes);
+  rc = check_hip(ctx, hipGetLastError(), "blockhash kernel launch");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpyAsync(hashes, d_hashes, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream), "blockhash D2H");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "blockhash sync");
+}
+
+}  // namespace mi355

@@ -98,6 +98,9 @@ def load_library():
         "mi355_ebur128_loudness_range": (i, [vp, C.POINTER(C.c_double)]),
         "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_videocompare_hash_frame": (i, [vp, u8p, i, i, i, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_videocompare_hash_frames_device": (i, [vp, u8p, sz, i, i, i, i, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_videocompare_distance": (C.c_double, [i, C.c_uint64, C.c_uint64]),
         "mi355_hrtf_load_sphere": (i, [vp, vp, sz, C.c_uint32]),
         "mi355_hrtf_setup": (i, [vp, i, i, i]),
         "mi355_hrtf_reset": (i, [vp]),
@@ -250,6 +253,23 @@ class Context:
         ms = C.c_float(0)
         self._ck(self.L.mi355_time_hsv_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s), iters, C.byref(ms)))
         return ms.value
+
+    # ---- videocompare
+    HASH_ALGO = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}
+
+    def videocompare_hash_frame(self, frame, stride, width, height, fmt="RGBA", algo="blockhash"):
+        h = C.c_uint64(0)
+        self._ck(self.L.mi355_videocompare_hash_frame(self.h, _ptr(frame), stride, width, height, FMT[fmt], self.HASH_ALGO[algo], C.byref(h)))
+        return h.value
+
+    def videocompare_hash_frames_device(self, d_frames, frame_pitch, stride, n_frames, width, height, fmt="RGBA", algo="blockhash"):
+        hs = (C.c_uint64 * max(n_frames, 1))()
+        self._ck(self.L.mi355_videocompare_hash_frames_device(self.h, d_frames, frame_pitch, stride, n_frames, width, height, FMT[fmt],
+                                                              self.HASH_ALGO[algo], hs))
+        return [hs[k] for k in range(n_frames)]
+
+    def videocompare_distance(self, a, b, algo="blockhash"):
+        return self.L.mi355_videocompare_distance(self.HASH_ALGO[algo], a, b)
 
     # ---- hrtfrender
     def hrtf_load_sphere(self, data, rate):

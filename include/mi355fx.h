@@ -210,6 +210,25 @@ int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out);
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out);
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out);
 
+/* ---------------------------------------------------------------- videocompare
+ * Replaces HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79) for
+ * HashAlgorithm::Blockhash, the element default (videocompare/imp.rs:31): image_hasher 3.1.1 blockhash, 8x8 bits, on
+ * the packed RGB / RGBA frame (rows addressed by `stride`, which covers tightly_packed_framebuffer :110-130).
+ * `algo` takes GstVideoCompareHashAlgorithm values (videocompare/mod.rs:60-100); every other algorithm and frame
+ * sizes not divisible by 8 return MI355_ERR_UNSUPPORTED. A hash is the 64 block bits, bit i = block i row-major. */
+typedef enum mi355_hash_algo {
+  MI355_HASH_MEAN = 0, MI355_HASH_GRADIENT = 1, MI355_HASH_VERTGRADIENT = 2, MI355_HASH_DOUBLEGRADIENT = 3,
+  MI355_HASH_BLOCKHASH = 4, MI355_HASH_DSSIM = 5
+} mi355_hash_algo;
+int mi355_videocompare_hash_frame(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height,
+                                  int format, int algo, uint64_t *hash);
+/* `n_frames` device-resident frames (frame f at d_frames + f*frame_pitch); `hashes` is a host array. Synchronous. */
+int mi355_videocompare_hash_frames_device(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch,
+                                          int stride, int n_frames, int width, int height, int format,
+                                          int algo, uint64_t *hashes);
+/* ImageHash::dist as f64 (hashed_image.rs:64): Hamming distance. Negative for an unsupported `algo`. */
+double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t frame_hash);
+
 /* ---------------------------------------------------------------- hrtfrender
  * Replaces the per-block body of HrtfRender::process (audio/hrtf/src/hrtf/imp.rs:164-278) including the calls
  * into the `hrtf` crate (HrirSphere::new, HrtfProcessor::new, process_samples).

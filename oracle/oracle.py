@@ -91,6 +91,9 @@ def lib():
     L.oracle_hrtf_reset.argtypes = [C.c_void_p]
     L.oracle_hrtf_process_block.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p]
     L.oracle_hrtf_block_exact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f64p, f32p, f32p, f32p, f32p, f64p, f64p]
+    L.oracle_blockhash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.oracle_hash_distance.restype = C.c_double
+    L.oracle_hash_distance.argtypes = [C.c_uint64, C.c_uint64]
     _LIB = L
     return L
 
@@ -389,3 +392,16 @@ class HrtfExact:
                                       _fp(pp), _fp(pg), _fp(pos), _fp(g), self.hist.ctypes.data_as(dp), self.taps.ctypes.data_as(dp))
         self.prev_pos, self.prev_gain = pos.copy(), g.copy()
         return out
+
+
+def blockhash(frame, width, height, stride, channels):
+    """image_hasher Blockhash (8x8) of a packed RGB/RGBA frame; ValueError when the integer fast path does not apply."""
+    a = np.ascontiguousarray(frame, dtype=np.uint8)
+    h = C.c_uint64(0)
+    if lib().oracle_blockhash(a.ctypes.data, width, height, stride, channels, C.byref(h)) != 0:
+        raise ValueError("blockhash fast path needs width and height divisible by 8")
+    return h.value
+
+
+def hash_distance(a, b):
+    return lib().oracle_hash_distance(a, b)

@@ -1,0 +1,82 @@
+"""GPU parity tests for videocompare's Blockhash path through the C ABI: bit-exact 64-bit hashes and distances
+against the oracle (integer arithmetic), including the BASELINE config-5 shape (a batch of concurrent 4K streams)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(rng, n, w, h, c):
+    return rng.integers(0, 256, (n, h, w * c), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("w,h,c", [(64, 64, 4), (320, 240, 4), (1920, 1080, 4), (3840, 2160, 4), (40, 48, 3), (1280, 720, 3), (8, 8, 4), (24, 16, 4)])
+def test_hash_frame_matches_oracle(ctx, oracle, w, h, c):
+    rng = np.random.default_rng(w * 7 + h + c)
+    f = _frames(rng, 1, w, h, c)[0]
+    if c == 4:
+        f[:, 3::4] = np.where(rng.random((h, w)) < 0.1, 0, 255)   # some fully transparent pixels (count as 765)
+    # give the blocks structure so that the medians separate them
+    f[: h // 2] //= 3
+    fmt = "RGBA" if c == 4 else "RGB"
+    assert ctx.videocompare_hash_frame(f, w * c, w, h, fmt) == oracle.blockhash(f, w, h, w * c, c)
+
+
+def test_padded_rows_and_solid_frames(ctx, oracle):
+    rng = np.random.default_rng(2)
+    w, h = 200, 104
+    f = np.zeros((h, w * 4 + 36), np.uint8)
+    f[:, : w * 4] = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
+    f[:, w * 4:] = 0xEE   # padding must not be hashed
+    assert ctx.videocompare_hash_frame(f, w * 4 + 36, w, h, "RGBA") == oracle.blockhash(f, w, h, w * 4 + 36, 4)
+    red = np.zeros((240, 320 * 4), np.uint8); red[:, 0::4] = 255; red[:, 3::4] = 255
+    hr = ctx.videocompare_hash_frame(red, 1280, 320, 240, "RGBA")
+    assert hr == oracle.blockhash(red, 320, 240, 1280, 4)
+    assert ctx.videocompare_distance(hr, ctx.videocompare_hash_frame(red.copy(), 1280, 320, 240, "RGBA")) == 0.0   # reference test 1
+    snow = rng.integers(0, 256, (240, 320), dtype=np.uint8).repeat(4, axis=1); snow[:, 3::4] = 255
+    assert ctx.videocompare_distance(hr, ctx.videocompare_hash_frame(snow, 1280, 320, 240, "RGBA")) > 0                # reference test 2
+    white = np.full((64, 256), 255, np.uint8)
+    assert ctx.videocompare_hash_frame(white, 256, 64, 64, "RGBA") == 0xFFFFFFFFFFFFFFFF
+
+
+def test_config5_batch_of_4k_streams_on_device(ctx, oracle):
+    """32 streams per GPU, one comparison per stream per frame: 16 reference + 16 secondary 4K RGBA frames hashed in one
+    launch; distances equal the oracle's; identical pairs give exactly 0.0."""
+    rng = np.random.default_rng(9)
+    n, w, h = 16, 3840, 2160
+    ref = np.zeros((n, h, w * 4), np.uint8)
+    for k in range(n):
+        base = rng.integers(0, 256, (h // 40, w // 40, 4), dtype=np.uint8).repeat(40, axis=0).repeat(40, axis=1)
+        ref[k] = base.reshape(h, w * 4)
+    sec = ref.copy()
+    for k in range(0, n, 2):    # every other stream differs in one quadrant
+        sec[k, : h // 2, : w * 2] = 255 - sec[k, : h // 2, : w * 2]
+    both = np.concatenate([ref, sec]).reshape(-1)
+    d = ctx.alloc(both.nbytes)
+    try:
+        ctx.h2d(d, both)
+        hashes = ctx.videocompare_hash_frames_device(d, h * w * 4, w * 4, 2 * n, w, h, "RGBA")
+    finally:
+        ctx.free(d)
+    for k in range(n):
+        er, es = oracle.blockhash(ref[k], w, h, w * 4, 4), oracle.blockhash(sec[k], w, h, w * 4, 4)
+        assert hashes[k] == er and hashes[n + k] == es
+        dist = ctx.videocompare_distance(hashes[k], hashes[n + k])
+        assert dist == oracle.hash_distance(er, es)
+        assert (dist == 0.0) == (k % 2 == 1)
+
+
+def test_unsupported_and_errors(ctx):
+    import mi355fx
+    f = np.zeros((16, 64), np.uint8)
+    for algo in ("mean", "gradient", "vertgradient", "doublegradient", "dssim"):
+        with pytest.raises(mi355fx.Mi355Error) as e:
+            ctx.videocompare_hash_frame(f, 64, 16, 16, "RGBA", algo)
+        assert e.value.status == mi355fx.ERR_UNSUPPORTED
+    with pytest.raises(mi355fx.Mi355Error) as e:      # fast path only
+        ctx.videocompare_hash_frame(np.zeros((16, 60), np.uint8), 60, 15, 16, "RGBA")
+    assert e.value.status == mi355fx.ERR_UNSUPPORTED
+    with pytest.raises(mi355fx.Mi355Error) as e:      # pad template: RGB / RGBA only
+        ctx.videocompare_hash_frame(f, 64, 16, 16, "BGRx")
+    assert e.value.status == mi355fx.ERR_INVALID_ARG
+    assert ctx.videocompare_distance(1, 2, "dssim") < 0

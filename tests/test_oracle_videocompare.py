@@ -1,0 +1,56 @@
+"""CPU tests of the videocompare oracle (image_hasher Blockhash restatement; parity unpinned for arbitrary content,
+see oracle/videocompare_oracle.c). Pinned here: the properties the reference's own tests assert
+(video/videofx/tests/videocompare.rs) and the algorithm's defining cases."""
+import numpy as np
+import pytest
+
+
+def _solid(w, h, rgba):
+    f = np.zeros((h, w * 4), np.uint8)
+    for c in range(4):
+        f[:, c::4] = rgba[c]
+    return f
+
+
+def test_identical_frames_have_distance_zero(oracle):
+    """test_can_find_similar_frames: videotestsrc pattern=red on both pads -> distance <= 0.0."""
+    red = _solid(320, 240, (255, 0, 0, 255))
+    h = oracle.blockhash(red, 320, 240, 320 * 4, 4)
+    assert oracle.hash_distance(h, oracle.blockhash(red.copy(), 320, 240, 320 * 4, 4)) == 0.0
+
+
+def test_snow_is_far_from_red(oracle):
+    """test_do_not_send_message_when_image_not_found: snow vs red -> distance > 0 (no message at threshold 0)."""
+    red = _solid(320, 240, (255, 0, 0, 255))
+    snow = np.random.default_rng(1).integers(0, 256, (240, 320), dtype=np.uint8).repeat(4, axis=1)
+    snow[:, 3::4] = 255
+    assert oracle.hash_distance(oracle.blockhash(red, 320, 240, 1280, 4), oracle.blockhash(snow, 320, 240, 1280, 4)) > 0
+
+
+def test_uniform_frames_tie_rule(oracle):
+    """All blocks equal the median: bits are set only when the median is above half scale (765*area/2)."""
+    assert oracle.blockhash(_solid(64, 64, (255, 255, 255, 255)), 64, 64, 256, 4) == 0xFFFFFFFFFFFFFFFF
+    assert oracle.blockhash(_solid(64, 64, (10, 10, 10, 255)), 64, 64, 256, 4) == 0
+    # transparent pixels count as white (sum_px: a == 0 -> 765)
+    assert oracle.blockhash(_solid(64, 64, (0, 0, 0, 0)), 64, 64, 256, 4) == 0xFFFFFFFFFFFFFFFF
+
+
+def test_known_pattern_bits(oracle):
+    """Left half bright, right half dark: in every row of blocks the 4 left blocks exceed the band median."""
+    f = _solid(64, 64, (0, 0, 0, 255))
+    f[:, : 32 * 4] = 200
+    f[:, 3::4] = 255
+    h = oracle.blockhash(f, 64, 64, 256, 4)
+    # upper median of 16 bright + 16 dark values is a bright value: nothing is strictly greater, and the tie rule
+    # (median > half scale) decides: bright = 600*64 = 38400 > 765*64/2 = 24480 -> bright bits set
+    assert h == 0x0F0F0F0F0F0F0F0F  # bit index = block_row*8 + block_col: columns 0..3 of every row
+
+
+def test_rgb_and_stride(oracle):
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (48, 40 * 3), dtype=np.uint8)
+    padded = np.zeros((48, 40 * 3 + 13), np.uint8)
+    padded[:, : 120] = rgb
+    assert oracle.blockhash(rgb, 40, 48, 120, 3) == oracle.blockhash(padded, 40, 48, 133, 3)
+    with pytest.raises(ValueError):
+        oracle.blockhash(rgb, 39, 48, 120, 3)
