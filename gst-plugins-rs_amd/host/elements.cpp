@@ -822,9 +822,98 @@ bool HrtfRender::stop() {
   return true;
 }
 
+// ------------------------------------------------------------------ VideoCompare
+
+VideoCompare::VideoCompare(int device) : Element(device) {}
+
+const ElementMetadata &VideoCompare::metadata() const {
+  static const ElementMetadata m{"Image comparison", "Filter/Video", "Compare similarity of video frames",
+                                 "Rafael Caricio <rafael@caricio.com>"};
+  return m;
+}
+
+static const char *const kHashAlgoNicks[] = {"mean", "gradient", "vertgradient", "doublegradient", "blockhash", "dssim"};
+
+const std::vector<ParamSpec> &VideoCompare::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    ParamSpec algo;
+    algo.name = "hash-algo"; algo.nick = "Hashing Algorithm"; algo.blurb = "Which hashing algorithm to use for image comparisons";
+    algo.type = PropType::String; algo.def_num = MI355_HASH_BLOCKHASH; algo.mutability = Mutability::Ready;  // GEnum, set by nick
+    ParamSpec thr;
+    thr.name = "max-dist-threshold"; thr.nick = "Maximum Distance Threshold";
+    thr.blurb = "Maximum distance threshold to emit messages when an image is detected, by default emits only on exact match";
+    thr.type = PropType::Double; thr.def_num = 0.0; thr.min_num = 0.0; thr.max_num = DBL_MAX; thr.mutability = Mutability::Ready;
+    return std::vector<ParamSpec>{algo, thr};
+  }();
+  return p;
+}
+
+bool VideoCompare::store_number(const std::string &n, double v) {
+  if (n != "max-dist-threshold") return false;
+  max_dist_threshold_ = v;
+  return true;
+}
+bool VideoCompare::load_number(const std::string &n, double *v) const {
+  if (n != "max-dist-threshold") return false;
+  *v = max_dist_threshold_;
+  return true;
+}
+bool VideoCompare::store_string(const std::string &n, const std::string &v) {
+  if (n != "hash-algo") return false;
+  for (int i = 0; i < 6; i++)
+    if (v == kHashAlgoNicks[i]) { hash_algo_ = i; return true; }  // state.hasher = hash_algo.into() (imp.rs:112)
+  last_error_ = "hash-algo: unknown nick " + v;
+  return false;
+}
+bool VideoCompare::load_string(const std::string &n, std::string *v) const {
+  if (n != "hash-algo") return false;
+  *v = kHashAlgoNicks[hash_algo_];
+  return true;
+}
+
+FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames, bool have_running_time, uint64_t running_time,
+                                          VideoCompareMessage *msg, bool *posted) {
+  *posted = false;
+  if (!ctx_) return FlowReturn::Error;
+  if (frames.empty()) { last_error_ = "No reference sink pad exists"; return FlowReturn::Eos; }  // imp.rs:275-278
+  int algo;
+  double threshold;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    algo = hash_algo_; threshold = max_dist_threshold_;
+  }
+  const VideoFrame &ref = frames[0];
+  if (!ref.data) return FlowReturn::Ok;  // reference pad has not produced a buffer: nothing to compare (imp.rs:283-296)
+  VideoCompareMessage m;
+  m.have_running_time = have_running_time;
+  m.running_time = running_time;
+  uint64_t ref_hash = 0;
+  int rc = mi355_videocompare_hash_frame(ctx_, ref.data, ref.stride, ref.width, ref.height, ref.format, algo, &ref_hash);
+  if (rc != MI355_OK) return flow_from_status(rc);
+  for (size_t k = 1; k < frames.size(); k++) {
+    const VideoFrame &f = frames[k];
+    if (!f.data) return FlowReturn::Ok;  // pad without a prepared frame: skip this round (imp.rs:331-334)
+    if (f.width != ref.width || f.height != ref.height) {  // imp.rs:337-347
+      last_error_ = "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)";
+      return FlowReturn::NotNegotiated;
+    }
+    uint64_t h = 0;
+    rc = mi355_videocompare_hash_frame(ctx_, f.data, f.stride, f.width, f.height, f.format, algo, &h);
+    if (rc != MI355_OK) return flow_from_status(rc);
+    VideoCompareMessage::PadDistance pd;
+    pd.pad = "sink_" + std::to_string(k);
+    pd.distance = mi355_videocompare_distance(algo, ref_hash, h);
+    m.pad_distances.push_back(pd);
+  }
+  bool any = false;
+  for (const auto &pd : m.pad_distances) any = any || pd.distance <= threshold;  // imp.rs:361-364
+  if (any) { *msg = m; *posted = true; }
+  return FlowReturn::Ok;
+}
+
 // ------------------------------------------------------------------ registry
 
-std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender"}; }
+std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender", "videocompare"}; }
 
 std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error) {
   std::unique_ptr<Element> e;
@@ -834,6 +923,7 @@ std::unique_ptr<Element> element_factory_make(const std::string &factory, int de
   else if (factory == "rsaudioecho") e.reset(new AudioEcho(device));
   else if (factory == "ebur128level") e.reset(new EbuR128Level(device));
   else if (factory == "hrtfrender") e.reset(new HrtfRender(device));
+  else if (factory == "videocompare") e.reset(new VideoCompare(device));
   else {
     if (error) *error = "no such element factory: " + factory;
     return nullptr;
@@ -1016,6 +1106,27 @@ int mi355el_hrtf_drain(mi355el *h, float *out, size_t out_capacity, size_t *out_
 void mi355el_hrtf_flush_stop(mi355el *h) {
   auto *e = as_hrtf(h);
   if (e) e->flush_stop();
+}
+
+
+// ---- videocompare: n frames of identical layout (frame 0 = reference pad). Returns the GstFlowReturn value;
+// *posted = 1 when a message would be posted, distances[k-1] = distance of pad sink_k.
+int mi355el_videocompare_aggregate(mi355el *h, int n_frames, const uint8_t *const *frames, int format, int width, int height,
+                                   int stride, uint64_t running_time, int *posted, double *distances, int max_distances) {
+  auto *e = h ? dynamic_cast<VideoCompare *>(h->e.get()) : nullptr;
+  if (!e) return (int)FlowReturn::Error;
+  std::vector<VideoFrame> fs((size_t)(n_frames > 0 ? n_frames : 0));
+  for (int k = 0; k < n_frames; k++) {
+    fs[(size_t)k].format = format; fs[(size_t)k].width = width; fs[(size_t)k].height = height; fs[(size_t)k].stride = stride;
+    fs[(size_t)k].data = const_cast<uint8_t *>(frames[k]);
+    fs[(size_t)k].size = (size_t)stride * (size_t)height;
+  }
+  VideoCompareMessage msg;
+  bool p = false;
+  const FlowReturn r = e->aggregate_frames(fs, true, running_time, &msg, &p);
+  if (posted) *posted = p ? 1 : 0;
+  for (int k = 0; p && k < (int)msg.pad_distances.size() && k < max_distances; k++) distances[k] = msg.pad_distances[(size_t)k].distance;
+  return (int)r;
 }
 
 }  // extern "C"

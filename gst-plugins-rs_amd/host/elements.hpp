@@ -9,6 +9,7 @@
 //   ColorLut     video/colorlut/src/colorlut/imp.rs  (VideoFilter, NeverInPlace: start/stop/transform_frame)
 //   AudioEcho    audio/audiofx/src/audioecho/imp.rs  (AudioFilter, AlwaysInPlace: setup/transform_ip/stop)
 //   HrtfRender   audio/hrtf/src/hrtf/imp.rs          (BaseTransform, NeverInPlace: set_caps/transform/drain/stop)
+//   VideoCompare video/videofx/src/videocompare/imp.rs (VideoAggregator: aggregate_frames)
 // Each object owns one mi355_ctx (include/mi355fx.h) and forwards its per-buffer vfunc to the C ABI,
 // exactly where the Rust element would call its inner loop. The GStreamer shim (gst/) wraps these.
 #pragma once
@@ -281,6 +282,39 @@ class HrtfRender final : public Element {
   int rate_ = 0, channels_ = 0;
   size_t block_samples_ = 0;
   std::vector<float> adapter_;
+};
+
+// videocompare (video/videofx/src/videocompare/imp.rs): VideoAggregator; the first sink pad is the reference, every
+// other pad's current frame is hashed and compared with it; one "videocompare" message is posted when any pad is
+// within max-dist-threshold.
+struct VideoCompareMessage {   // videocompare/mod.rs:104-170
+  struct PadDistance { std::string pad; double distance = 0; };
+  std::vector<PadDistance> pad_distances;
+  bool have_running_time = false;
+  uint64_t running_time = 0;
+};
+
+class VideoCompare final : public Element {
+ public:
+  explicit VideoCompare(int device);
+  const char *factory_name() const override { return "videocompare"; }
+  const char *type_name() const override { return "GstVideoCompare"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {MI355_FMT_RGB, MI355_FMT_RGBA}; }
+  std::vector<int> src_formats() const override { return {MI355_FMT_RGB, MI355_FMT_RGBA}; }
+  // VideoAggregatorImpl::aggregate_frames (imp.rs:259-390). frames[0] is the reference pad's prepared frame,
+  // frames[k] the one of pad "sink_k". Returns Ok with *posted == true and *msg filled when a message is posted.
+  FlowReturn aggregate_frames(const std::vector<VideoFrame> &frames, bool have_running_time, uint64_t running_time,
+                              VideoCompareMessage *msg, bool *posted);
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  bool store_string(const std::string &name, const std::string &v) override;   // "hash-algo" by nick
+  bool load_string(const std::string &name, std::string *v) const override;
+  int hash_algo_ = MI355_HASH_BLOCKHASH;  // DEFAULT_HASH_ALGO (imp.rs:31)
+  double max_dist_threshold_ = 0.0;       // imp.rs:32
 };
 
 // gst_element_factory_make(): nullptr for an unknown factory name or when no device context can be made.

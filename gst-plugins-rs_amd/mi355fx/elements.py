@@ -49,6 +49,7 @@ def _lib():
             "mi355el_ebur128_reset_signal": (None, [vp]),
             "mi355el_ebur128_pop_message": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double), i, C.POINTER(i)]),
+            "mi355el_videocompare_aggregate": (i, [vp, i, C.POINTER(vp), i, i, i, i, C.c_uint64, C.POINTER(i), C.POINTER(C.c_double), i]),
             "mi355el_hrtf_set_hrir_raw": (i, [vp, vp, sz]),
             "mi355el_hrtf_set_objects": (i, [vp, i, C.POINTER(C.c_float), C.POINTER(i)]),
             "mi355el_hrtf_get_objects": (i, [vp, i, C.POINTER(C.c_float), C.POINTER(i)]),
@@ -252,3 +253,14 @@ class Element:
 
     def hrtf_flush_stop(self):
         self.L.mi355el_hrtf_flush_stop(self.h)
+
+    # ---- videocompare
+    def videocompare_aggregate(self, frames, fmt, width, height, stride, running_time=0):
+        """frames[0] = reference pad; returns (flow, posted, [distance of sink_1, ...])."""
+        arrs = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        posted = C.c_int(0)
+        dist = (C.c_double * 64)()
+        flow = self.L.mi355el_videocompare_aggregate(self.h, len(arrs), ptrs, FMT[fmt], width, height, stride, running_time,
+                                                     C.byref(posted), dist, 64)
+        return flow, bool(posted.value), [dist[k] for k in range(max(len(arrs) - 1, 0))] if posted.value else []

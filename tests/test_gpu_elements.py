@@ -319,3 +319,54 @@ def test_hrtfrender_element_stream_matches_oracle(oracle, synth):
     exp = np.concatenate([ref.process_block(xp[k * blk: (k + 1) * blk], pos, gains) for k in range(4)])[: total * 2]
     assert got.size == exp.size
     assert np.abs(got - exp).max() <= 4e-5 * max(1.0, np.abs(exp).max())
+
+
+# ------------------------------------------------------------------ videocompare (video/videofx/tests/videocompare.rs)
+
+def _solid_rgba(w, h, rgb):
+    f = np.zeros((h, w * 4), np.uint8)
+    f[:, 0::4], f[:, 1::4], f[:, 2::4], f[:, 3::4] = rgb[0], rgb[1], rgb[2], 255
+    return f
+
+
+def test_videocompare_can_find_similar_frames():
+    """pattern=red on both pads, max-dist-threshold 0, Blockhash: a message is posted and sink_1's distance is <= 0."""
+    from mi355fx.elements import Element
+    e = Element("videocompare")
+    assert e.set_property("max-dist-threshold", 0.0) and e.set_property("hash-algo", "blockhash")
+    red = _solid_rgba(320, 240, (255, 0, 0))
+    flow, posted, dist = e.videocompare_aggregate([red, red.copy()], "RGBA", 320, 240, 1280)
+    assert flow == 0 and posted and dist == [0.0]
+
+
+def test_videocompare_do_not_send_message_when_image_not_found():
+    """reference = snow, secondary = red: no message at threshold 0."""
+    from mi355fx.elements import Element
+    e = Element("videocompare")
+    snow = np.random.default_rng(3).integers(0, 256, (240, 320), dtype=np.uint8).repeat(4, axis=1)
+    snow[:, 3::4] = 255
+    flow, posted, dist = e.videocompare_aggregate([snow, _solid_rgba(320, 240, (255, 0, 0))], "RGBA", 320, 240, 1280)
+    assert flow == 0 and not posted
+    # with a generous threshold the same pair does post, carrying the real distance
+    assert e.set_property("max-dist-threshold", 64.0)
+    flow, posted, dist = e.videocompare_aggregate([snow, _solid_rgba(320, 240, (255, 0, 0))], "RGBA", 320, 240, 1280)
+    assert posted and 0 < dist[0] <= 64
+
+
+def test_videocompare_several_pads_and_unsupported_algo(oracle):
+    from mi355fx.elements import Element
+    e = Element("videocompare")
+    assert e.set_property("max-dist-threshold", 3.0)
+    rng = np.random.default_rng(8)
+    ref = rng.integers(0, 256, (64, 96 * 4), dtype=np.uint8)
+    near = ref.copy(); near[:8, :48] ^= 0x80
+    far = rng.integers(0, 256, (64, 96 * 4), dtype=np.uint8)
+    flow, posted, dist = e.videocompare_aggregate([ref, far, near, ref], "RGBA", 96, 64, 384)
+    assert flow == 0 and posted and len(dist) == 3 and dist[2] == 0.0
+    exp = [oracle.hash_distance(oracle.blockhash(ref, 96, 64, 384, 4), oracle.blockhash(x, 96, 64, 384, 4)) for x in (far, near, ref)]
+    assert dist == exp
+    assert e.get_property("max-dist-threshold") == 3.0
+    assert e.set_property("hash-algo", "dssim")               # accepted as a property value ...
+    flow, posted, _ = e.videocompare_aggregate([ref, ref], "RGBA", 96, 64, 384)
+    assert flow == -5 and not posted and "blockhash" in e.last_error   # ... but not implemented on the device: loud error, no fallback
+    assert not e.set_property("hash-algo", "nonsense")
