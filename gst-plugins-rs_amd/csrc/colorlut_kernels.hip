@@ -378,7 +378,9 @@ __device__ __forceinline__ void stage_plane_issue(unsigned char *lds, const floa
 
 template <int HSV, int I0, int I1, int P>
 __device__ __forceinline__ void hsv_range(uint32_t (&nx)[P], const HsvK &hk, const uint32_t *hsv_sel) {
-  if constexpr (HSV >= 0) {
+  if constexpr (HSV == kNoHsv) {
+    // plain colorlut: nothing to do between load and setup
+  } else if constexpr (HSV >= 0) {
 #pragma unroll
     for (int i = I0; i < I1; i += 2) hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(nx[i], nx[i + 1], hk, hsv_sel);
   } else {
@@ -387,7 +389,11 @@ __device__ __forceinline__ void hsv_range(uint32_t (&nx)[P], const HsvK &hk, con
   }
 }
 
-template <int NT, int P4, int S_CONST, int HSV>
+// LATE_LOAD: issue the next tile's loads before the LAST pass of the tile instead of before the first one. The CU's
+// vector-memory pipe returns in order, so loads issued ahead of a plane DMA hold that DMA back; issued after the
+// tile's last DMA they only have the stores behind them and fly during the last pass and the next tile's first one.
+// Used for plain colorlut (HSV == kNoHsv), where nothing has to happen to the pixels between load and setup.
+template <int NT, int P4, int S_CONST, int HSV, bool LATE_LOAD = false>
 __global__ __launch_bounds__(NT) void hsv_colorlut3d_pipe_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                                  size_t n_groups, const float *__restrict__ planar,
                                                                  const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(NT) void hsv_colorlut3d_pipe_kernel(const uint4 *__
     }
     size_t n_begin = 0, n_end = 0;
     const bool have_next = tile_range(round + 1, n_begin, n_end);
-    if (have_next) load_tile(n_begin, n_end);
+    if (!LATE_LOAD && have_next) load_tile(n_begin, n_end);
     // stage plane CH if needed, running the hsv stage of pixels [I0, I1) of the next tile under the DMA
 #define MI355_STAGE_HSV(CH, I0, I1)                                                             \
   {                                                                                             \
@@ -471,12 +477,13 @@ __global__ __launch_bounds__(NT) void hsv_colorlut3d_pipe_kernel(const uint4 *__
       __syncthreads(); /* everyone is done reading the previous plane */                        \
       stage_plane_issue<NT, S_CONST>(lds, planar + (size_t)CH * plane_floats, plane_floats);    \
     }                                                                                           \
-    if (have_next) hsv_range<HSV, I0, I1>(nx, hk, hsv_sel);                                     \
+    if (!LATE_LOAD && have_next) hsv_range<HSV, I0, I1>(nx, hk, hsv_sel);                       \
     if (need) {                                                                                 \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
       __syncthreads();                                                                          \
       resident = CH;                                                                            \
     }                                                                                           \
+    if (LATE_LOAD && (I1) == P && have_next) load_tile(n_begin, n_end); /* after the tile's last DMA */ \
   }
     if (!flip) {
       MI355_STAGE_HSV(0, 0, 0) lut_pass<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, px, base, tx, ty, tz);
@@ -809,9 +816,9 @@ static bool lds3d_rgba_applicable(const mi355_ctx *ctx, const uint8_t *d_src, si
   return true;
 }
 
-template <int NT, int P4, int S_CONST, int HSV>
+template <int NT, int P4, int S_CONST, int HSV, bool LATE_LOAD = false>
 static int launch_pipe_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups, const HsvK &hk) {
-  auto kern = hsv_colorlut3d_pipe_kernel<NT, P4, S_CONST, HSV>;
+  auto kern = hsv_colorlut3d_pipe_kernel<NT, P4, S_CONST, HSV, LATE_LOAD>;
   const LutDevice &L = ctx->lut;
   const size_t lds = L.lds_bytes;
   int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -916,6 +923,9 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
       const uint4 *s = (const uint4 *)d_src;
       uint4 *d = (uint4 *)d_dst;
       constexpr int NT = 1024, P4 = 3;
+      if (ctx->lut_variant == 1)  // MI355_FLAG_LUT_VARIANT: next tile's pixels prefetched before the last pass
+        return L.size == 33 ? launch_pipe_variant<NT, P4, 33, kNoHsv, true>(ctx, s, d, n_groups, HsvK{})
+                            : launch_pipe_variant<NT, P4, 0, kNoHsv, true>(ctx, s, d, n_groups, HsvK{});
       if (L.size == 33) return launch_lds_variant<NT, P4, 33>(ctx, s, d, n_groups);
       return launch_lds_variant<NT, P4, 0>(ctx, s, d, n_groups);
     }

@@ -48,6 +48,7 @@ struct mi355_ctx {
   void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
+  int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

@@ -25,6 +25,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_OOM, ERR_UN
 FLAG_FORCE_GENERIC = 1
 FLAG_HSV_BLOCKS_PER_CU = 2
 FLAG_FUSED_VARIANT = 3
+FLAG_LUT_VARIANT = 4
 
 
 class HsvSettings(C.Structure):
@@ -98,6 +99,15 @@ def load_library():
         "mi355_ebur128_loudness_range": (i, [vp, C.POINTER(C.c_double)]),
         "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_host_alloc": (vp, [vp, sz]),
+        "mi355_host_free": (i, [vp, vp]),
+        "mi355_pipe_create": (vp, [vp, i, sz]),
+        "mi355_pipe_destroy": (None, [vp]),
+        "mi355_pipe_submit_hsvfilter": (i, [vp, u8p, sz, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
+        "mi355_pipe_submit_colorlut": (i, [vp, u8p, i, u8p, i, i, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_pipe_submit_hsv_colorlut": (i, [vp, u8p, i, u8p, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
+        "mi355_pipe_wait": (i, [vp, C.c_uint64]),
+        "mi355_pipe_wait_all": (i, [vp]),
         "mi355_videocompare_hash_frame": (i, [vp, u8p, i, i, i, i, i, C.POINTER(C.c_uint64)]),
         "mi355_videocompare_hash_frames_device": (i, [vp, u8p, sz, i, i, i, i, i, i, C.POINTER(C.c_uint64)]),
         "mi355_videocompare_distance": (C.c_double, [i, C.c_uint64, C.c_uint64]),
@@ -253,6 +263,53 @@ class Context:
         ms = C.c_float(0)
         self._ck(self.L.mi355_time_hsv_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s), iters, C.byref(ms)))
         return ms.value
+
+    # ---- pinned host memory + asynchronous host-buffer pipeline
+    def host_array(self, nbytes):
+        """A page-locked uint8 numpy array of `nbytes` (mi355_host_alloc); free with host_free(arr)."""
+        p = self.L.mi355_host_alloc(self.h, nbytes)
+        if not p:
+            raise Mi355Error(ERR_OOM, self.L.mi355_ctx_last_error(self.h).decode("utf-8", "replace"))
+        arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._ck(self.L.mi355_host_free(self.h, p))
+
+    def pipe_create(self, depth, max_frame_bytes):
+        p = self.L.mi355_pipe_create(self.h, depth, max_frame_bytes)
+        if not p:
+            raise Mi355Error(ERR_INVALID_ARG, self.L.mi355_ctx_last_error(self.h).decode("utf-8", "replace"))
+        return p
+
+    def pipe_destroy(self, pipe):
+        self.L.mi355_pipe_destroy(pipe)
+
+    def pipe_submit_hsvfilter(self, pipe, data, width, stride, fmt, settings):
+        s = HsvSettings(*[float(v) for v in settings])
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_pipe_submit_hsvfilter(pipe, _ptr(data), data.nbytes, width, stride, FMT[fmt], C.byref(s), C.byref(t)))
+        return t.value
+
+    def pipe_submit_colorlut(self, pipe, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_pipe_submit_colorlut(pipe, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt], C.byref(t)))
+        return t.value
+
+    def pipe_submit_hsv_colorlut(self, pipe, src, src_stride, dst, dst_stride, width, height, settings):
+        s = HsvSettings(*[float(v) for v in settings])
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_pipe_submit_hsv_colorlut(pipe, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, C.byref(s), C.byref(t)))
+        return t.value
+
+    def pipe_wait(self, pipe, ticket):
+        self._ck(self.L.mi355_pipe_wait(pipe, ticket))
+
+    def pipe_wait_all(self, pipe):
+        self._ck(self.L.mi355_pipe_wait_all(pipe))
 
     # ---- videocompare
     HASH_ALGO = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}

@@ -82,6 +82,7 @@ int mi355_ctx_synchronize(mi355_ctx *ctx);
 typedef enum mi355_flag {
   MI355_FLAG_FORCE_GENERIC = 1,
   MI355_FLAG_HSV_BLOCKS_PER_CU = 2, /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
+  MI355_FLAG_LUT_VARIANT = 4,  /* colorlut 3D LDS kernel: 0 = default; 1 = next tile prefetched before the last pass */
   MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
@@ -255,6 +256,29 @@ int mi355_hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_
 int mi355_hrtf_sphere_info(mi355_ctx *ctx, uint32_t *hrir_len, uint32_t *n_vertices, uint32_t *n_faces);
 /* Diagnostics: mesh face (or -1) and barycentric weights chosen per [channel][step] in the last block. */
 int mi355_hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw);
+
+/* ---------------------------------------------------------------- pinned memory + asynchronous host-buffer pipeline
+ * For the GStreamer shim (precedent video/colorlut/src/d3d12colorlut/imp.rs:385-492 and
+ * audio/audiofx/src/audiornnoise/imp.rs:323-348): mi355_host_alloc backs a GstAllocator / buffer pool offered in
+ * propose_allocation so that mapped GstBuffer payloads are page-locked; mi355_pipe_* overlaps the upload of frame
+ * n+1 and the download of frame n-1 with the kernels of frame n on side streams. The submit functions take the
+ * arguments of the synchronous entry point they mirror (mi355_hsvfilter_frame_ip, mi355_colorlut_frame,
+ * mi355_hsv_colorlut_frames_device on one frame), return at once with a ticket, and borrow the buffers until
+ * mi355_pipe_wait(ticket) (or a later submit that reclaims the slot) returns. Results are identical. */
+void *mi355_host_alloc(mi355_ctx *ctx, size_t bytes);
+int mi355_host_free(mi355_ctx *ctx, void *ptr);
+typedef struct mi355_pipe mi355_pipe;
+mi355_pipe *mi355_pipe_create(mi355_ctx *ctx, int depth, size_t max_frame_bytes);
+void mi355_pipe_destroy(mi355_pipe *pipe);
+int mi355_pipe_submit_hsvfilter(mi355_pipe *pipe, uint8_t *data, size_t data_len, int width, int stride,
+                                int format, const mi355_hsv_settings *settings, uint64_t *ticket);
+int mi355_pipe_submit_colorlut(mi355_pipe *pipe, const uint8_t *src, int src_stride, uint8_t *dst,
+                               int dst_stride, int width, int height, int format, uint64_t *ticket);
+int mi355_pipe_submit_hsv_colorlut(mi355_pipe *pipe, const uint8_t *src, int src_stride, uint8_t *dst,
+                                   int dst_stride, int width, int height,
+                                   const mi355_hsv_settings *settings, uint64_t *ticket);
+int mi355_pipe_wait(mi355_pipe *pipe, uint64_t ticket);
+int mi355_pipe_wait_all(mi355_pipe *pipe);
 
 /* ---------------------------------------------------------------- measurement helpers
  * Used by bench.py: run `iters` back-to-back launches of one kernel on the context's stream
