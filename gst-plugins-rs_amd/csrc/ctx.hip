@@ -140,6 +140,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   lut_release(ctx);
+  loudnorm_release(ctx);
   ebur128_release(ctx);
   hrtf_release(ctx);
   if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
@@ -532,6 +533,34 @@ int mi355_ebur128_relative_threshold(mi355_ctx *ctx, double *out) { REQUIRE_CTX(
 int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query(ctx, 4, out); }
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 0, channel, out); }
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out) { REQUIRE_CTX(ctx); return ebur128_peak(ctx, 1, channel, out); }
+
+/* ------------------------------------------------------------------ audioloudnorm */
+
+int mi355_loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak,
+                         double offset) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return loudnorm_setup(ctx, channels, loudness_target, loudness_range_target, max_true_peak, offset);
+}
+int mi355_loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out, size_t out_capacity_frames, size_t *out_frames) {
+  REQUIRE_CTX(ctx);
+  if ((frames && !data) || !out || !out_frames) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: null argument");
+  BIND_DEVICE(ctx);
+  return loudnorm_push(ctx, data, frames, out, out_capacity_frames, out_frames);
+}
+int mi355_loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_capacity_frames, size_t *out_frames, int *eos) {
+  REQUIRE_CTX(ctx);
+  if (!out || !out_frames || !eos) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: null argument");
+  BIND_DEVICE(ctx);
+  return loudnorm_drain(ctx, out, out_capacity_frames, out_frames, eos);
+}
+int mi355_loudnorm_teardown(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  loudnorm_release(ctx);
+  return MI355_OK;
+}
 
 /* ------------------------------------------------------------------ videocompare */
 

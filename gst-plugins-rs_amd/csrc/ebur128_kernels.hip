@@ -42,77 +42,121 @@ template <> __device__ __forceinline__ double eb_to_double<int32_t>(int32_t v) {
 template <> __device__ __forceinline__ double eb_to_double<float>(float v) { return (double)v; }
 template <> __device__ __forceinline__ double eb_to_double<double>(double v) { return v; }
 
-// K-weighting + sample peak, one lane per channel (one wave handles up to 64 channels). The 4th-order
-// recurrence is serial per channel by nature; a chunked parallel scan was
-// implemented and rejected: superposing zero-state and homogeneous responses through A^L loses ~7 digits
-// because the direct-form-II state of the high-pass stage is ~1e4 times larger than its output
-// (1e-9 LU deviations). Running the literal recurrence keeps the filtered samples bit-identical to a
-// serial CPU run; with interleaved input the wave's loads and ring stores are coalesced across
-// channels, and the loop is unrolled so the loads of the next frames are in flight while the dependent
-// chain of the current frame retires. src element (i,c) at src[i*stride_f + c*stride_c].
+// K-weighting + sample peak. The 4th-order recurrence is serial per channel by nature (SURVEY.md section 7
+// item 6); a chunked parallel scan was implemented and rejected: superposing zero-state and homogeneous
+// responses through A^L loses ~7 digits because the direct-form-II state of the high-pass stage is ~1e4 times
+// larger than its output (1e-9 LU deviations). The literal recurrence is kept, but only its loop-carried part
+// runs serially: per chunk of kEbChunk frames
+//   (1) all lanes convert the chunk to f64 into LDS (coalesced loads) and track the sample peak,
+//   (2) lane c walks   v0 = x - a1*v1 - a2*v2 - a3*v3 - a4*v4   for channel c (8 f64 ops per sample, the only
+//       dependent chain) and leaves the v sequence in LDS,
+//   (3) all lanes evaluate   y = b0*v0 + b1*v1 + b2*v2 + b3*v3 + b4*v4   (same expression, same order) and store the
+//       ring coalesced.
+// Results are bit-identical to the one-lane-does-everything form; the serial lane executes ~1/3 of the instructions.
+// src element (i,c) at src[i*stride_f + c*stride_c].
+constexpr int kEbChunk = 256;
 template <typename T>
-__global__ __launch_bounds__(64) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
-                                                       double *__restrict__ ring, size_t ring_frame0, unsigned channels,
-                                                       const int *__restrict__ channel_class, double *__restrict__ vstate,
-                                                       unsigned long long *__restrict__ peak, EbFilterK k) {
-  const unsigned c = threadIdx.x;
-  if (c >= channels) return;
-  const T *sp = src + (size_t)c * stride_c;
-  const bool used = channel_class[c] != 0;
-  double v1 = vstate[c * 4 + 0], v2 = vstate[c * 4 + 1], v3 = vstate[c * 4 + 2], v4 = vstate[c * 4 + 3];
-  double mx = 0.0;
-  double *dst = ring + ring_frame0 * channels + c;
-  constexpr int U = 8;
-  size_t i = 0;
-  for (; i + U <= n; i += U) {
-    double x[U];
+__global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
+                                                        double *__restrict__ ring, size_t ring_frame0, unsigned channels,
+                                                        const int *__restrict__ channel_class, double *__restrict__ vstate,
+                                                        unsigned long long *__restrict__ peak, EbFilterK k) {
+  extern __shared__ double eb_sm[];          // [channels][kEbChunk + 4] : 4 carried v values, then x -> v in place
+  __shared__ unsigned long long s_peak[64];
+  const unsigned tid = threadIdx.x;
+  const unsigned row = kEbChunk + 4;
+  if (tid < channels) {
+    s_peak[tid] = 0ull;
+    // carried state v4, v3, v2, v1 in front of the chunk (oldest first)
+    eb_sm[tid * row + 0] = vstate[tid * 4 + 3];
+    eb_sm[tid * row + 1] = vstate[tid * 4 + 2];
+    eb_sm[tid * row + 2] = vstate[tid * 4 + 1];
+    eb_sm[tid * row + 3] = vstate[tid * 4 + 0];
+  }
+  __syncthreads();
+  for (size_t i0 = 0; i0 < n; i0 += kEbChunk) {
+    const unsigned len = (unsigned)(n - i0 < (size_t)kEbChunk ? n - i0 : (size_t)kEbChunk);
+    // (1) stage + peak
+    for (unsigned e = tid; e < len * channels; e += 256) {
+      unsigned f, c;
+      if (stride_c == 1) { f = e / channels; c = e - f * channels; }   // interleaved: consecutive lanes = consecutive elements
+      else { c = e / len; f = e - c * len; }                            // planar
+      const double x = eb_to_double<T>(src[(i0 + f) * stride_f + (size_t)c * stride_c]);
+      eb_sm[c * row + 4 + f] = x;
+      if (peak) {
+        const double ax = x < 0.0 ? -x : x;
+        atomicMax(&s_peak[c], (unsigned long long)__double_as_longlong(ax));  // non-negative doubles order like their bits
+      }
+    }
+    __syncthreads();
+    // (2) the recurrence, one lane per used channel
+    if (tid < channels && channel_class[tid] != 0) {
+      double *r = eb_sm + tid * row;
+      double v4 = r[0], v3 = r[1], v2 = r[2], v1 = r[3];
+      const double a1 = k.a[1], a2 = k.a[2], a3 = k.a[3], a4 = k.a[4];
+      unsigned f = 0;
+      // 8 samples per trip: the x values are read ahead of the dependent chain and the v values written after it, so
+      // the LDS latency is off the loop-carried path (mul + 4 sub per sample)
+      for (; f + 8 <= len; f += 8) {
+        double x[8];
 #pragma unroll
-    for (int u = 0; u < U; u++) x[u] = eb_to_double<T>(sp[(i + u) * stride_f]);
+        for (int u = 0; u < 8; u++) x[u] = r[4 + f + u];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const double ax = x[u] < 0.0 ? -x[u] : x[u];
-      if (ax > mx) mx = ax;
-      if (used) {
-        const double v0 = x[u] - k.a[1] * v1 - k.a[2] * v2 - k.a[3] * v3 - k.a[4] * v4;
-        dst[(i + u) * channels] = k.b[0] * v0 + k.b[1] * v1 + k.b[2] * v2 + k.b[3] * v3 + k.b[4] * v4;
+        for (int u = 0; u < 8; u++) {
+          const double v0 = x[u] - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
+          x[u] = v0;
+          v4 = v3; v3 = v2; v2 = v1; v1 = v0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[4 + f + u] = x[u];
+      }
+      for (; f < len; f++) {
+        const double v0 = r[4 + f] - a1 * v1 - a2 * v2 - a3 * v3 - a4 * v4;
+        r[4 + f] = v0;
         v4 = v3; v3 = v2; v2 = v1; v1 = v0;
       }
     }
-  }
-  for (; i < n; i++) {
-    const double x = eb_to_double<T>(sp[i * stride_f]);
-    const double ax = x < 0.0 ? -x : x;
-    if (ax > mx) mx = ax;
-    if (used) {
-      const double v0 = x - k.a[1] * v1 - k.a[2] * v2 - k.a[3] * v3 - k.a[4] * v4;
-      dst[i * channels] = k.b[0] * v0 + k.b[1] * v1 + k.b[2] * v2 + k.b[3] * v3 + k.b[4] * v4;
-      v4 = v3; v3 = v2; v2 = v1; v1 = v0;
+    __syncthreads();
+    // (3) outputs
+    for (unsigned e = tid; e < len * channels; e += 256) {
+      const unsigned f = e / channels, c = e - f * channels;
+      if (channel_class[c] == 0) continue;
+      const double *r = eb_sm + c * row + 4 + f;  // r[0] = v0 of this frame, r[-1] = v1, ...
+      ring[(ring_frame0 + i0 + f) * channels + c] = k.b[0] * r[0] + k.b[1] * r[-1] + k.b[2] * r[-2] + k.b[3] * r[-3] + k.b[4] * r[-4];
     }
+    __syncthreads();
+    // carry the last four v values to the front for the next chunk
+    if (tid < channels && channel_class[tid] != 0) {
+      double *r = eb_sm + tid * row;
+      const double a0 = r[len + 0], a1 = r[len + 1], a2 = r[len + 2], a3 = r[len + 3];  // safe for len >= 1: indices len..len+3 hold v(len-4..len-1)
+      r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
+    }
+    __syncthreads();
   }
-  if (used) {  // libebur128 flushes denormal state at the end of every filtered segment
-    vstate[c * 4 + 0] = fabs(v1) < DBL_MIN ? 0.0 : v1;
-    vstate[c * 4 + 1] = fabs(v2) < DBL_MIN ? 0.0 : v2;
-    vstate[c * 4 + 2] = fabs(v3) < DBL_MIN ? 0.0 : v3;
-    vstate[c * 4 + 3] = fabs(v4) < DBL_MIN ? 0.0 : v4;
-  }
-  if (peak) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(mx);  // non-negative doubles order like their bits
-    if (bits > peak[c]) peak[c] = bits;
+  if (tid < channels) {
+    if (channel_class[tid] != 0) {  // libebur128 flushes denormal state at the end of every filtered segment
+      const double *r = eb_sm + tid * row;
+      const double v1 = r[3], v2 = r[2], v3 = r[1], v4 = r[0];
+      vstate[tid * 4 + 0] = fabs(v1) < DBL_MIN ? 0.0 : v1;
+      vstate[tid * 4 + 1] = fabs(v2) < DBL_MIN ? 0.0 : v2;
+      vstate[tid * 4 + 2] = fabs(v3) < DBL_MIN ? 0.0 : v3;
+      vstate[tid * 4 + 3] = fabs(v4) < DBL_MIN ? 0.0 : v4;
+    }
+    if (peak && s_peak[tid] > peak[tid]) peak[tid] = s_peak[tid];
   }
 }
 
 // Weighted mean square of the last `frames` frames before ring frame `end_frame` (wrapping), all channels.
-// One block; result -> out[slot].
-__global__ __launch_bounds__(kEbNT) void eb_energy_kernel(const double *__restrict__ ring, size_t ring_frames, size_t end_frame,
-                                                          size_t frames, unsigned channels, const int *__restrict__ channel_class,
-                                                          double *__restrict__ out, unsigned slot) {
+// eb_energy_partial_kernel: grid of kEbEnergyBlocks blocks, block b sums its slice per channel -> partial[slot][b][c];
+// eb_energy_final_kernel: fixed-order sum over the blocks, channel weights, division -> out[slot] (deterministic).
+constexpr unsigned kEbEnergyBlocks = 32;
+__global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *__restrict__ ring, size_t ring_frames, size_t end_frame,
+                                                                  size_t frames, unsigned channels, double *__restrict__ partial, unsigned slot) {
   __shared__ double wave_sum[kEbNT / 64];
-  double total = 0.0;
+  const size_t per = (frames + gridDim.x - 1) / gridDim.x;
+  const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < frames ? i0 + per : frames;
   for (unsigned c = 0; c < channels; c++) {
-    const int cls = channel_class[c];
-    if (cls == 0) continue;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < frames; i += kEbNT) {
+    for (size_t i = i0 + threadIdx.x; i < i1; i += kEbNT) {
       size_t f = end_frame + ring_frames - frames + i;  // end_frame - frames + i, modulo the ring
       if (f >= ring_frames) f -= ring_frames;
       const double x = ring[f * channels + c];
@@ -124,12 +168,25 @@ __global__ __launch_bounds__(kEbNT) void eb_energy_kernel(const double *__restri
     if (threadIdx.x == 0) {
       double cs = 0.0;
       for (int w = 0; w < kEbNT / 64; w++) cs += wave_sum[w];
-      if (cls == 2) cs *= 1.41; else if (cls == 3) cs *= 2.0;
-      total += cs;
+      partial[((size_t)slot * gridDim.x + blockIdx.x) * channels + c] = cs;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[slot] = total / (double)frames;
+}
+
+__global__ __launch_bounds__(64) void eb_energy_final_kernel(const double *__restrict__ partial, unsigned blocks, size_t frames, unsigned channels,
+                                                             const int *__restrict__ channel_class, double *__restrict__ out, unsigned slot) {
+  if (threadIdx.x != 0) return;
+  double total = 0.0;
+  for (unsigned c = 0; c < channels; c++) {
+    const int cls = channel_class[c];
+    if (cls == 0) continue;
+    double cs = 0.0;
+    for (unsigned b = 0; b < blocks; b++) cs += partial[((size_t)slot * blocks + b) * channels + c];
+    if (cls == 2) cs *= 1.41; else if (cls == 3) cs *= 2.0;
+    total += cs;
+  }
+  out[slot] = total / (double)frames;
 }
 
 // True-peak interpolator: polyphase FIR with per-phase tap lists (coeff/index tables, `delay` = taps per phase).
@@ -197,7 +254,7 @@ struct Ebur128State {
   unsigned long block_hist[kHistBins] = {0}, st_hist[kHistBins] = {0};
   std::vector<double> sample_peak, true_peak;
   // device
-  double *d_ring = nullptr, *d_vstate = nullptr, *d_energy = nullptr;
+  double *d_ring = nullptr, *d_vstate = nullptr, *d_energy = nullptr, *d_partial = nullptr;
   int *d_class = nullptr;
   unsigned long long *d_peak = nullptr;  // [channels] sample peak bits, [channels] true peak bits
   float *d_tail = nullptr;
@@ -276,6 +333,7 @@ void ebur128_release(mi355_ctx *ctx) {
   if (!st) return;
   if (st->d_ring) (void)hipFree(st->d_ring);
   if (st->d_vstate) (void)hipFree(st->d_vstate);
+  if (st->d_partial) (void)hipFree(st->d_partial);
   if (st->d_energy) (void)hipFree(st->d_energy);
   if (st->d_class) (void)hipFree(st->d_class);
   if (st->d_peak) (void)hipFree(st->d_peak);
@@ -358,6 +416,14 @@ int ebur128_reset(mi355_ctx *ctx) {
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
 
+// energy of the last `frames` ring frames -> d_energy[slot]
+static void eb_launch_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, unsigned slot) {
+  hipLaunchKernelGGL(eb_energy_partial_kernel, dim3(kEbEnergyBlocks), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring, st->ring_frames,
+                     st->index_frames, frames, st->channels, st->d_partial, slot);
+  hipLaunchKernelGGL(eb_energy_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)st->d_partial, kEbEnergyBlocks, frames, st->channels,
+                     (const int *)st->d_class, st->d_energy, slot);
+}
+
 template <typename T>
 static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, size_t frame0, size_t n, size_t stride_f, size_t stride_c) {
   const T *p = d_src + frame0 * stride_f;
@@ -365,7 +431,9 @@ static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, 
   if (st->have_interp)
     hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_tail,
                        st->d_peak + st->channels, st->ik);
-  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
+  const size_t filter_lds = (size_t)st->channels * (kEbChunk + 4) * sizeof(double);
+  (void)hipFuncSetAttribute((const void *)eb_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds);
+  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1), dim3(256), filter_lds, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
                      st->index_frames, st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk);
 }
 
@@ -403,6 +471,10 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
     int rc = check_hip(ctx, hipMalloc((void **)&st->d_energy, max_events * sizeof(double)), "hipMalloc(ebur128 energies)");
     if (rc) return rc;
     st->energy_cap = max_events;
+    if (st->d_partial) (void)hipFree(st->d_partial);
+    st->d_partial = nullptr;
+    rc = check_hip(ctx, hipMalloc((void **)&st->d_partial, max_events * kEbEnergyBlocks * C * sizeof(double)), "hipMalloc(ebur128 partial energies)");
+    if (rc) return rc;
   }
   std::vector<int> event_kind;  // 0 = gating block (I), 1 = short-term block (LRA), in stream order
   // ---- the add_frames loop of libebur128 (filter up to the next 100 ms boundary, then gate)
@@ -414,15 +486,13 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
       left -= st->needed_frames;
       st->index_frames += st->needed_frames;
       if (st->mode & EB_I) {
-        hipLaunchKernelGGL(eb_energy_kernel, dim3(1), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring, st->ring_frames, st->index_frames,
-                           st->samples_in_100ms * 4, C, (const int *)st->d_class, st->d_energy, (unsigned)event_kind.size());
+        eb_launch_energy(ctx, st, st->samples_in_100ms * 4, (unsigned)event_kind.size());
         event_kind.push_back(0);
       }
       if (st->mode & EB_LRA) {
         st->st_counter += st->needed_frames;
         if (st->st_counter == st->samples_in_100ms * 30) {
-          hipLaunchKernelGGL(eb_energy_kernel, dim3(1), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring, st->ring_frames, st->index_frames,
-                             st->samples_in_100ms * 30, C, (const int *)st->d_class, st->d_energy, (unsigned)event_kind.size());
+          eb_launch_energy(ctx, st, st->samples_in_100ms * 30, (unsigned)event_kind.size());
           event_kind.push_back(1);
           st->st_counter = st->samples_in_100ms * 20;
         }
@@ -486,10 +556,11 @@ static int eb_window_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, dou
   if (st->energy_cap < 1) {
     int rc = check_hip(ctx, hipMalloc((void **)&st->d_energy, 16 * sizeof(double)), "hipMalloc(ebur128 energies)");
     if (rc) return rc;
+    rc = check_hip(ctx, hipMalloc((void **)&st->d_partial, 16 * kEbEnergyBlocks * st->channels * sizeof(double)), "hipMalloc(ebur128 partial energies)");
+    if (rc) return rc;
     st->energy_cap = 16;
   }
-  hipLaunchKernelGGL(eb_energy_kernel, dim3(1), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring, st->ring_frames, st->index_frames, frames,
-                     st->channels, (const int *)st->d_class, st->d_energy, 0u);
+  eb_launch_energy(ctx, st, frames, 0u);
   int rc = check_hip(ctx, hipMemcpyAsync(out, st->d_energy, sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(ebur128 energy)");
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");

@@ -46,6 +46,7 @@ struct mi355_ctx {
   mi355::EchoDevice echo;
   void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
   void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
+  void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
@@ -90,6 +91,10 @@ int ebur128_reset(mi355_ctx *ctx);
 void ebur128_release(mi355_ctx *ctx);
 int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
                      int channels, unsigned long long *hashes);
+int loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak, double offset_db);
+int loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out, size_t out_cap_frames, size_t *out_frames);
+int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *out_frames, int *eos);
+void loudnorm_release(mi355_ctx *ctx);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
 int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);
 int hrtf_reset(mi355_ctx *ctx);

@@ -99,6 +99,10 @@ def load_library():
         "mi355_ebur128_loudness_range": (i, [vp, C.POINTER(C.c_double)]),
         "mi355_ebur128_sample_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_ebur128_true_peak": (i, [vp, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_loudnorm_setup": (i, [vp, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double]),
+        "mi355_loudnorm_push": (i, [vp, vp, sz, vp, sz, C.POINTER(sz)]),
+        "mi355_loudnorm_drain": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(i)]),
+        "mi355_loudnorm_teardown": (i, [vp]),
         "mi355_host_alloc": (vp, [vp, sz]),
         "mi355_host_free": (i, [vp, vp]),
         "mi355_pipe_create": (vp, [vp, i, sz]),
@@ -263,6 +267,30 @@ class Context:
         ms = C.c_float(0)
         self._ck(self.L.mi355_time_hsv_colorlut_device(self.h, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, C.byref(s), iters, C.byref(ms)))
         return ms.value
+
+    # ---- audioloudnorm (interleaved f64 @ 192 kHz)
+    def loudnorm_setup(self, channels, loudness_target=-24.0, loudness_range_target=7.0, max_true_peak=-2.0, offset=0.0):
+        self._ck(self.L.mi355_loudnorm_setup(self.h, channels, loudness_target, loudness_range_target, max_true_peak, offset))
+        self._ln_channels = channels
+
+    def loudnorm_push(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(-1)
+        frames = a.size // self._ln_channels
+        cap = (frames // 19200 + 32) * 19200
+        out = np.zeros(cap * self._ln_channels, np.float64)
+        n = C.c_size_t(0)
+        self._ck(self.L.mi355_loudnorm_push(self.h, a.ctypes.data, frames, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value * self._ln_channels]
+
+    def loudnorm_drain(self):
+        cap = 31 * 19200 + 3 * 192000
+        out = np.zeros(cap * self._ln_channels, np.float64)
+        n, eos = C.c_size_t(0), C.c_int(0)
+        self._ck(self.L.mi355_loudnorm_drain(self.h, out.ctypes.data, cap, C.byref(n), C.byref(eos)))
+        return None if eos.value else out[: n.value * self._ln_channels]
+
+    def loudnorm_teardown(self):
+        self._ck(self.L.mi355_loudnorm_teardown(self.h))
 
     # ---- pinned host memory + asynchronous host-buffer pipeline
     def host_array(self, nbytes):

@@ -211,6 +211,26 @@ int mi355_ebur128_loudness_range(mi355_ctx *ctx, double *out);
 int mi355_ebur128_sample_peak(mi355_ctx *ctx, unsigned channel, double *out);
 int mi355_ebur128_true_peak(mi355_ctx *ctx, unsigned channel, double *out);
 
+/* ---------------------------------------------------------------- audioloudnorm
+ * Replaces audioloudnorm's State (audio/audiofx/src/audioloudnorm/imp.rs:83-127) and its methods: State::new (:130-205),
+ * drain_full_frames / drain (:226-310), process and the frame handlers (:312-828), the true-peak limiter (:845-1430),
+ * detect_peak (:1438-1524), gaussian_filter (:1526-1541). Audio is interleaved f64 at 192 kHz, the only caps the
+ * element accepts (:1848-1851); the element keeps its pads, timestamps and events.
+ *   setup : State::new(settings, info) with the four properties (loudness-target [LUFS], loudness-range-target [LU],
+ *           max-true-peak [dbTP], offset [LU]; imp.rs:37-40).
+ *   push  : sink_chain -> adapter.push + drain_full_frames: every complete frame (3 s first, then 100 ms) is processed;
+ *           `out` receives *out_frames frames (0 while the first 3 s are still being collected).
+ *   drain : drain() at EOS / flush: the final frame (up to 3 s of latency comes out) or, with less than 3 s in total,
+ *           the linear-gain path; *eos = 1 when there was nothing at all to drain (FlowError::Eos, :289-293).
+ *           out_capacity_frames >= 30*19200 + pending frames covers every case. */
+int mi355_loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target,
+                         double loudness_range_target, double max_true_peak, double offset);
+int mi355_loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out,
+                        size_t out_capacity_frames, size_t *out_frames);
+int mi355_loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_capacity_frames, size_t *out_frames,
+                         int *eos);
+int mi355_loudnorm_teardown(mi355_ctx *ctx);
+
 /* ---------------------------------------------------------------- videocompare
  * Replaces HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79) for
  * HashAlgorithm::Blockhash, the element default (videocompare/imp.rs:31): image_hasher 3.1.1 blockhash, 8x8 bits, on

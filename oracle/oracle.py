@@ -94,6 +94,19 @@ def lib():
     L.oracle_blockhash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.oracle_hash_distance.restype = C.c_double
     L.oracle_hash_distance.argtypes = [C.c_uint64, C.c_uint64]
+    L.oracle_loudnorm_new.restype = C.c_void_p
+    L.oracle_loudnorm_new.argtypes = [C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.oracle_loudnorm_free.argtypes = [C.c_void_p]
+    for name in ("process", "push"):
+        fn = getattr(L, "oracle_loudnorm_" + name)
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_void_p, f64p, C.c_size_t, f64p]
+    L.oracle_loudnorm_drain.restype = C.c_size_t
+    L.oracle_loudnorm_drain.argtypes = [C.c_void_p, f64p]
+    L.oracle_loudnorm_frame_type.argtypes = [C.c_void_p]
+    L.oracle_loudnorm_limiter_state.argtypes = [C.c_void_p]
+    L.oracle_loudnorm_offset.restype = C.c_double
+    L.oracle_loudnorm_offset.argtypes = [C.c_void_p]
     _LIB = L
     return L
 
@@ -405,3 +418,37 @@ def blockhash(frame, width, height, stride, channels):
 
 def hash_distance(a, b):
     return lib().oracle_hash_distance(a, b)
+
+
+class LoudNorm:
+    """audioloudnorm State machine (audio/audiofx/src/audioloudnorm/imp.rs), interleaved f64 @ 192 kHz."""
+    FRAME = 19200
+
+    def __init__(self, channels, loudness_target=-24.0, loudness_range_target=7.0, max_true_peak=-2.0, offset=0.0):
+        self.channels = channels
+        self.h = lib().oracle_loudnorm_new(channels, loudness_target, loudness_range_target, max_true_peak, offset)
+
+    def push(self, data):
+        """sink_chain: returns the output of every full frame this buffer completes (possibly empty)."""
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(-1)
+        frames = a.size // self.channels
+        out = np.zeros((frames // self.FRAME + 32) * self.FRAME * self.channels, np.float64)
+        dp = C.POINTER(C.c_double)
+        n = lib().oracle_loudnorm_push(self.h, a.ctypes.data_as(dp), frames, out.ctypes.data_as(dp))
+        return out[: n * self.channels]
+
+    def drain(self):
+        out = np.zeros(31 * self.FRAME * self.channels + 3 * 192000 * self.channels, np.float64)
+        n = lib().oracle_loudnorm_drain(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        if n == C.c_size_t(-1).value:
+            return None
+        return out[: n * self.channels]
+
+    frame_type = property(lambda self: lib().oracle_loudnorm_frame_type(self.h))
+    limiter_state = property(lambda self: lib().oracle_loudnorm_limiter_state(self.h))
+    offset = property(lambda self: lib().oracle_loudnorm_offset(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.oracle_loudnorm_free(self.h)
+            self.h = None
