@@ -822,6 +822,98 @@ bool HrtfRender::stop() {
   return true;
 }
 
+// ------------------------------------------------------------------ AudioLoudNorm
+
+AudioLoudNorm::AudioLoudNorm(int device) : Element(device) {}
+
+const ElementMetadata &AudioLoudNorm::metadata() const {
+  static const ElementMetadata m{"Audio loudness normalizer", "Filter/Effect/Audio", "Normalizes perceived loudness of an audio stream",
+                                 "Sebastian Dröge <sebastian@centricular.com>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &AudioLoudNorm::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    auto dbl = [](const char *n, const char *nick, const char *blurb, double def, double lo, double hi) {
+      ParamSpec s;
+      s.name = n; s.nick = nick; s.blurb = blurb; s.type = PropType::Double;
+      s.def_num = def; s.min_num = lo; s.max_num = hi; s.mutability = Mutability::Ready;
+      return s;
+    };
+    return std::vector<ParamSpec>{
+        dbl("loudness-target", "Loudness Target", "Loudness target in LUFS", -24.0, -70.0, -5.0),
+        dbl("loudness-range-target", "Loudness Range Target", "Loudness range target in LU", 7.0, 1.0, 20.0),
+        dbl("max-true-peak", "Maximum True Peak", "Maximum True Peak in dbTP", -2.0, -9.0, 0.0),
+        dbl("offset", "Offset Gain", "Offset Gain in LU", 0.0, -99.0, 99.0),
+    };
+  }();
+  return p;
+}
+
+bool AudioLoudNorm::store_number(const std::string &n, double v) {
+  if (n == "loudness-target") loudness_target_ = v;
+  else if (n == "loudness-range-target") loudness_range_target_ = v;
+  else if (n == "max-true-peak") max_true_peak_ = v;
+  else if (n == "offset") offset_ = v;
+  else return false;
+  return true;
+}
+bool AudioLoudNorm::load_number(const std::string &n, double *v) const {
+  if (n == "loudness-target") *v = loudness_target_;
+  else if (n == "loudness-range-target") *v = loudness_range_target_;
+  else if (n == "max-true-peak") *v = max_true_peak_;
+  else if (n == "offset") *v = offset_;
+  else return false;
+  return true;
+}
+
+bool AudioLoudNorm::set_caps(int rate, int channels) {
+  if (!ctx_) return false;
+  have_state_ = false;
+  if (rate != 192000) { last_error_ = "audioloudnorm: caps must be F64 interleaved at 192000 Hz"; return false; }  // pad template (imp.rs:1848-1851)
+  double t, r, p, o;
+  {
+    std::lock_guard<std::mutex> g(settings_mutex_);
+    t = loudness_target_; r = loudness_range_target_; p = max_true_peak_; o = offset_;
+  }
+  if (mi355_loudnorm_setup(ctx_, (unsigned)channels, t, r, p, o) != MI355_OK) { last_error_ = mi355_ctx_last_error(ctx_); return false; }
+  channels_ = channels;
+  have_state_ = true;
+  return true;
+}
+
+FlowReturn AudioLoudNorm::chain(const double *data, size_t frames, std::vector<double> *out) {
+  if (!ctx_) return FlowReturn::Error;
+  if (!have_state_) { last_error_ = "audioloudnorm: not negotiated"; return FlowReturn::NotNegotiated; }  // imp.rs:1556-1563
+  const size_t cap = (frames / 19200 + 32) * 19200;
+  out->assign(cap * (size_t)channels_, 0.0);
+  size_t n = 0;
+  const int rc = mi355_loudnorm_push(ctx_, data, frames, out->data(), cap, &n);
+  out->resize(n * (size_t)channels_);
+  return flow_from_status(rc);
+}
+
+FlowReturn AudioLoudNorm::drain(std::vector<double> *out) {
+  if (!ctx_) return FlowReturn::Error;
+  out->clear();
+  if (!have_state_) return FlowReturn::Ok;  // no state: nothing to drain (imp.rs:1661-1664)
+  const size_t cap = 31 * 19200 + 3 * 192000;
+  out->assign(cap * (size_t)channels_, 0.0);
+  size_t n = 0;
+  int eos = 0;
+  const int rc = mi355_loudnorm_drain(ctx_, out->data(), cap, &n, &eos);
+  out->resize(n * (size_t)channels_);
+  if (rc != MI355_OK) return flow_from_status(rc);
+  return eos ? FlowReturn::Eos : FlowReturn::Ok;
+}
+
+bool AudioLoudNorm::stop() {
+  if (ctx_) mi355_loudnorm_teardown(ctx_);
+  have_state_ = false;
+  started_ = false;
+  return true;
+}
+
 // ------------------------------------------------------------------ VideoCompare
 
 VideoCompare::VideoCompare(int device) : Element(device) {}
@@ -913,7 +1005,7 @@ FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames,
 
 // ------------------------------------------------------------------ registry
 
-std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender", "videocompare"}; }
+std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender", "videocompare", "audioloudnorm"}; }
 
 std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error) {
   std::unique_ptr<Element> e;
@@ -924,6 +1016,7 @@ std::unique_ptr<Element> element_factory_make(const std::string &factory, int de
   else if (factory == "ebur128level") e.reset(new EbuR128Level(device));
   else if (factory == "hrtfrender") e.reset(new HrtfRender(device));
   else if (factory == "videocompare") e.reset(new VideoCompare(device));
+  else if (factory == "audioloudnorm") e.reset(new AudioLoudNorm(device));
   else {
     if (error) *error = "no such element factory: " + factory;
     return nullptr;
@@ -1126,6 +1219,37 @@ int mi355el_videocompare_aggregate(mi355el *h, int n_frames, const uint8_t *cons
   const FlowReturn r = e->aggregate_frames(fs, true, running_time, &msg, &p);
   if (posted) *posted = p ? 1 : 0;
   for (int k = 0; p && k < (int)msg.pad_distances.size() && k < max_distances; k++) distances[k] = msg.pad_distances[(size_t)k].distance;
+  return (int)r;
+}
+
+
+// ---- audioloudnorm
+int mi355el_loudnorm_set_caps(mi355el *h, int rate, int channels) {
+  auto *e = h ? dynamic_cast<AudioLoudNorm *>(h->e.get()) : nullptr;
+  if (!e) return -1;
+  return e->set_caps(rate, channels) ? 0 : -1;
+}
+// returns the GstFlowReturn value; *out_frames frames written (never more than out_capacity_frames)
+int mi355el_loudnorm_chain(mi355el *h, const double *data, size_t frames, int channels, double *out, size_t out_capacity_frames, size_t *out_frames) {
+  auto *e = h ? dynamic_cast<AudioLoudNorm *>(h->e.get()) : nullptr;
+  if (!e) return (int)FlowReturn::Error;
+  std::vector<double> o;
+  const FlowReturn r = e->chain(data, frames, &o);
+  const size_t n = channels > 0 ? o.size() / (size_t)channels : 0;
+  const size_t m = n < out_capacity_frames ? n : out_capacity_frames;
+  if (m) std::memcpy(out, o.data(), m * (size_t)channels * sizeof(double));
+  if (out_frames) *out_frames = n;
+  return (int)r;
+}
+int mi355el_loudnorm_drain(mi355el *h, int channels, double *out, size_t out_capacity_frames, size_t *out_frames) {
+  auto *e = h ? dynamic_cast<AudioLoudNorm *>(h->e.get()) : nullptr;
+  if (!e) return (int)FlowReturn::Error;
+  std::vector<double> o;
+  const FlowReturn r = e->drain(&o);
+  const size_t n = channels > 0 ? o.size() / (size_t)channels : 0;
+  const size_t m = n < out_capacity_frames ? n : out_capacity_frames;
+  if (m) std::memcpy(out, o.data(), m * (size_t)channels * sizeof(double));
+  if (out_frames) *out_frames = n;
   return (int)r;
 }
 

@@ -10,6 +10,7 @@
 //   AudioEcho    audio/audiofx/src/audioecho/imp.rs  (AudioFilter, AlwaysInPlace: setup/transform_ip/stop)
 //   HrtfRender   audio/hrtf/src/hrtf/imp.rs          (BaseTransform, NeverInPlace: set_caps/transform/drain/stop)
 //   VideoCompare video/videofx/src/videocompare/imp.rs (VideoAggregator: aggregate_frames)
+//   AudioLoudNorm audio/audiofx/src/audioloudnorm/imp.rs (Element: sink chain / drain)
 // Each object owns one mi355_ctx (include/mi355fx.h) and forwards its per-buffer vfunc to the C ABI,
 // exactly where the Rust element would call its inner loop. The GStreamer shim (gst/) wraps these.
 #pragma once
@@ -282,6 +283,33 @@ class HrtfRender final : public Element {
   int rate_ = 0, channels_ = 0;
   size_t block_samples_ = 0;
   std::vector<float> adapter_;
+};
+
+// audioloudnorm (audio/audiofx/src/audioloudnorm/imp.rs): plain Element with its own chain function; F64 interleaved
+// at 192 kHz only; 3 s of latency.
+class AudioLoudNorm final : public Element {
+ public:
+  explicit AudioLoudNorm(int device);
+  const char *factory_name() const override { return "audioloudnorm"; }
+  const char *type_name() const override { return "GstAudioLoudNorm"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {1}; }  // F64 interleaved, rate 192000
+  std::vector<int> src_formats() const override { return {1}; }
+  // sink_event(Caps) (imp.rs:1613-1650): a new State from the current settings; rate must be 192000
+  bool set_caps(int rate, int channels);
+  // sink_chain (imp.rs:1543-1611): `out` receives the frames completed by this buffer (possibly none)
+  FlowReturn chain(const double *data, size_t frames, std::vector<double> *out);
+  // sink_event(Eos / FlushStop...) -> drain (imp.rs:270-310); Eos when there was nothing to drain
+  FlowReturn drain(std::vector<double> *out);
+  bool stop() override;
+
+ private:
+  bool store_number(const std::string &name, double v) override;
+  bool load_number(const std::string &name, double *v) const override;
+  double loudness_target_ = -24.0, loudness_range_target_ = 7.0, max_true_peak_ = -2.0, offset_ = 0.0;  // imp.rs:37-40
+  bool have_state_ = false;
+  int channels_ = 0;
 };
 
 // videocompare (video/videofx/src/videocompare/imp.rs): VideoAggregator; the first sink pad is the reference, every

@@ -49,6 +49,9 @@ def _lib():
             "mi355el_ebur128_reset_signal": (None, [vp]),
             "mi355el_ebur128_pop_message": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double), i, C.POINTER(i)]),
+            "mi355el_loudnorm_set_caps": (i, [vp, i, i]),
+            "mi355el_loudnorm_chain": (i, [vp, vp, sz, i, vp, sz, C.POINTER(sz)]),
+            "mi355el_loudnorm_drain": (i, [vp, i, vp, sz, C.POINTER(sz)]),
             "mi355el_videocompare_aggregate": (i, [vp, i, C.POINTER(vp), i, i, i, i, C.c_uint64, C.POINTER(i), C.POINTER(C.c_double), i]),
             "mi355el_hrtf_set_hrir_raw": (i, [vp, vp, sz]),
             "mi355el_hrtf_set_objects": (i, [vp, i, C.POINTER(C.c_float), C.POINTER(i)]),
@@ -264,3 +267,26 @@ class Element:
         flow = self.L.mi355el_videocompare_aggregate(self.h, len(arrs), ptrs, FMT[fmt], width, height, stride, running_time,
                                                      C.byref(posted), dist, 64)
         return flow, bool(posted.value), [dist[k] for k in range(max(len(arrs) - 1, 0))] if posted.value else []
+
+    # ---- audioloudnorm
+    def loudnorm_set_caps(self, rate, channels):
+        self._ln_ch = channels
+        return self.L.mi355el_loudnorm_set_caps(self.h, rate, channels) == 0
+
+    def loudnorm_chain(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(-1)
+        ch = getattr(self, "_ln_ch", 1)
+        frames = a.size // ch
+        cap = (frames // 19200 + 32) * 19200
+        out = np.zeros(cap * ch, np.float64)
+        n = C.c_size_t(0)
+        flow = self.L.mi355el_loudnorm_chain(self.h, a.ctypes.data, frames, ch, out.ctypes.data, cap, C.byref(n))
+        return flow, out[: n.value * ch]
+
+    def loudnorm_drain(self):
+        ch = getattr(self, "_ln_ch", 1)
+        cap = 31 * 19200 + 3 * 192000
+        out = np.zeros(cap * ch, np.float64)
+        n = C.c_size_t(0)
+        flow = self.L.mi355el_loudnorm_drain(self.h, ch, out.ctypes.data, cap, C.byref(n))
+        return flow, out[: n.value * ch]

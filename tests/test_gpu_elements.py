@@ -370,3 +370,41 @@ def test_videocompare_several_pads_and_unsupported_algo(oracle):
     flow, posted, _ = e.videocompare_aggregate([ref, ref], "RGBA", 96, 64, 384)
     assert flow == -5 and not posted and "blockhash" in e.last_error   # ... but not implemented on the device: loud error, no fallback
     assert not e.set_property("hash-algo", "nonsense")
+
+
+# ------------------------------------------------------------------ audioloudnorm
+
+def test_audioloudnorm_element(oracle):
+    """Properties with the reference's ranges, caps restricted to 192 kHz, chain/drain through the adapter == oracle."""
+    from mi355fx.elements import Element
+    e = Element("audioloudnorm")
+    assert e.type_name == "GstAudioLoudNorm" and e.klass == "Filter/Effect/Audio"
+    p = e.properties()
+    assert (p["loudness-target"]["default"], p["loudness-target"]["min"], p["loudness-target"]["max"]) == (-24.0, -70.0, -5.0)
+    assert (p["max-true-peak"]["default"], p["max-true-peak"]["min"], p["max-true-peak"]["max"]) == (-2.0, -9.0, 0.0)
+    assert not e.set_property("loudness-target", -3.0)               # out of range: rejected, unchanged
+    assert e.set_property("loudness-target", -18.0) and e.set_property("max-true-peak", -1.5)
+    flow, out = e.loudnorm_chain(np.zeros(100))
+    assert flow == -4 and out.size == 0                               # NotNegotiated before caps
+    assert not e.loudnorm_set_caps(48000, 2)                          # only 192 kHz is accepted
+    assert e.loudnorm_set_caps(192000, 2), e.last_error
+    rate = 192000
+    t = np.arange(int(3.7 * rate)) / rate
+    x = np.stack([0.03 * np.sin(2 * np.pi * 330 * t), 0.03 * np.sin(2 * np.pi * 331 * t)], 1)
+    x[int(3.2 * rate): int(3.2 * rate) + 500] *= 50
+    ln = oracle.LoudNorm(2, loudness_target=-18.0, max_true_peak=-1.5)
+    got, exp = [], []
+    for k in range(0, len(x), 100000):
+        flow, o = e.loudnorm_chain(x[k:k + 100000])
+        assert flow == 0
+        got.append(o); exp.append(ln.push(x[k:k + 100000]))
+    flow, o = e.loudnorm_drain()
+    assert flow == 0
+    got.append(o); exp.append(ln.drain())
+    got, exp = np.concatenate(got), np.concatenate(exp)
+    assert got.size == x.size == exp.size
+    assert np.abs(got - exp).max() <= 1e-9 * np.abs(exp).max()
+    assert np.abs(got).max() <= 10 ** (-1.5 / 20)
+    assert e.stop()
+    flow, o = e.loudnorm_drain()
+    assert flow == 0 and o.size == 0
