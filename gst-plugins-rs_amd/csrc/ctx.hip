@@ -613,6 +613,56 @@ double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t f
   return (double)__builtin_popcountll(reference_hash ^ frame_hash);
 }
 
+/* ------------------------------------------------------------------ videocompare: Dssim engine */
+
+static int dssim_channels(mi355_ctx *ctx, int format, int *channels) {
+  if (format == MI355_FMT_RGBA) *channels = 4;
+  else if (format == MI355_FMT_RGB) *channels = 3;
+  else return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: format must be RGB or RGBA");
+  return MI355_OK;
+}
+
+int mi355_dssim_create_image_device(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width, int height, int format,
+                                    mi355_dssim_image **out) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = dssim_channels(ctx, format, &channels);
+  if (rc) return rc;
+  if (!d_frame || !out || width <= 0 || height <= 0 || (size_t)stride < (size_t)width * channels)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: bad frame");
+  BIND_DEVICE(ctx);
+  return dssim_create_image(ctx, d_frame, stride, width, height, channels, out);
+}
+
+int mi355_dssim_create_image(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height, int format, mi355_dssim_image **out) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = dssim_channels(ctx, format, &channels);
+  if (rc) return rc;
+  if (!data || !out || width <= 0 || height <= 0 || (size_t)stride < (size_t)width * channels)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: bad frame");
+  BIND_DEVICE(ctx);
+  const size_t row = (size_t)width * channels;
+  rc = ensure_stage(ctx, 0, row * (size_t)height);
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMemcpy2DAsync(ctx->d_stage[0], row, data, (size_t)stride, row, (size_t)height, hipMemcpyHostToDevice, ctx->stream), "dssim H2D");
+  if (rc) return rc;
+  return dssim_create_image(ctx, (const uint8_t *)ctx->d_stage[0], (int)row, width, height, channels, out);
+}
+
+void mi355_dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *image) {
+  if (!ctx || !image) return;
+  (void)hipSetDevice(ctx->device);
+  dssim_free_image(ctx, image);
+}
+
+int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original, const mi355_dssim_image *modified, double *dssim) {
+  REQUIRE_CTX(ctx);
+  if (!original || !modified || !dssim) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null argument");
+  BIND_DEVICE(ctx);
+  return dssim_compare(ctx, original, modified, dssim);
+}
+
 /* ------------------------------------------------------------------ hrtfrender */
 
 int mi355_hrtf_load_sphere(mi355_ctx *ctx, const void *bytes, size_t len, uint32_t device_rate) {

@@ -34,6 +34,8 @@ struct EchoDevice {
 
 }  // namespace mi355
 
+struct mi355_dssim_image;
+
 struct mi355_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -95,6 +97,9 @@ int loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target, do
 int loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out, size_t out_cap_frames, size_t *out_frames);
 int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *out_frames, int *eos);
 void loudnorm_release(mi355_ctx *ctx);
+int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width, int height, int channels, mi355_dssim_image **out);
+void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
+int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
 int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);
 int hrtf_reset(mi355_ctx *ctx);

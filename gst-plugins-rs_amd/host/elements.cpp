@@ -979,6 +979,33 @@ FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames,
   VideoCompareMessage m;
   m.have_running_time = have_running_time;
   m.running_time = running_time;
+  if (algo == MI355_HASH_DSSIM) {  // HasherEngine::DssimHasher (hashed_image.rs:41-53,66-70)
+    mi355_dssim_image *ref_img = nullptr;
+    int rc = mi355_dssim_create_image(ctx_, ref.data, ref.stride, ref.width, ref.height, ref.format, &ref_img);
+    if (rc != MI355_OK) return flow_from_status(rc);
+    for (size_t k = 1; k < frames.size(); k++) {
+      const VideoFrame &f = frames[k];
+      if (!f.data) { mi355_dssim_free_image(ctx_, ref_img); return FlowReturn::Ok; }
+      if (f.width != ref.width || f.height != ref.height) {
+        mi355_dssim_free_image(ctx_, ref_img);
+        last_error_ = "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)";
+        return FlowReturn::NotNegotiated;
+      }
+      mi355_dssim_image *img = nullptr;
+      rc = mi355_dssim_create_image(ctx_, f.data, f.stride, f.width, f.height, f.format, &img);
+      VideoCompareMessage::PadDistance pd;
+      pd.pad = "sink_" + std::to_string(k);
+      if (rc == MI355_OK) rc = mi355_dssim_compare(ctx_, ref_img, img, &pd.distance);
+      mi355_dssim_free_image(ctx_, img);
+      if (rc != MI355_OK) { mi355_dssim_free_image(ctx_, ref_img); return flow_from_status(rc); }
+      m.pad_distances.push_back(pd);
+    }
+    mi355_dssim_free_image(ctx_, ref_img);
+    bool any_d = false;
+    for (const auto &pd : m.pad_distances) any_d = any_d || pd.distance <= threshold;
+    if (any_d) { *msg = m; *posted = true; }
+    return FlowReturn::Ok;
+  }
   uint64_t ref_hash = 0;
   int rc = mi355_videocompare_hash_frame(ctx_, ref.data, ref.stride, ref.width, ref.height, ref.format, algo, &ref_hash);
   if (rc != MI355_OK) return flow_from_status(rc);

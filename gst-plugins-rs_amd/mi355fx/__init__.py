@@ -115,6 +115,10 @@ def load_library():
         "mi355_videocompare_hash_frame": (i, [vp, u8p, i, i, i, i, i, C.POINTER(C.c_uint64)]),
         "mi355_videocompare_hash_frames_device": (i, [vp, u8p, sz, i, i, i, i, i, i, C.POINTER(C.c_uint64)]),
         "mi355_videocompare_distance": (C.c_double, [i, C.c_uint64, C.c_uint64]),
+        "mi355_dssim_create_image": (i, [vp, u8p, i, i, i, i, C.POINTER(vp)]),
+        "mi355_dssim_create_image_device": (i, [vp, u8p, i, i, i, i, C.POINTER(vp)]),
+        "mi355_dssim_free_image": (None, [vp, vp]),
+        "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
         "mi355_hrtf_load_sphere": (i, [vp, vp, sz, C.c_uint32]),
         "mi355_hrtf_setup": (i, [vp, i, i, i]),
         "mi355_hrtf_reset": (i, [vp]),
@@ -355,6 +359,25 @@ class Context:
 
     def videocompare_distance(self, a, b, algo="blockhash"):
         return self.L.mi355_videocompare_distance(self.HASH_ALGO[algo], a, b)
+
+    # ---- videocompare: Dssim engine
+    def dssim_create_image(self, frame, stride, width, height, fmt="RGBA"):
+        h = C.c_void_p()
+        self._ck(self.L.mi355_dssim_create_image(self.h, _ptr(frame), stride, width, height, FMT[fmt], C.byref(h)))
+        return h
+
+    def dssim_create_image_device(self, d_frame, stride, width, height, fmt="RGBA"):
+        h = C.c_void_p()
+        self._ck(self.L.mi355_dssim_create_image_device(self.h, d_frame, stride, width, height, FMT[fmt], C.byref(h)))
+        return h
+
+    def dssim_free_image(self, img):
+        self.L.mi355_dssim_free_image(self.h, img)
+
+    def dssim_compare(self, a, b):
+        v = C.c_double(0)
+        self._ck(self.L.mi355_dssim_compare(self.h, a, b, C.byref(v)))
+        return v.value
 
     # ---- hrtfrender
     def hrtf_load_sphere(self, data, rate):

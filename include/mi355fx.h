@@ -249,6 +249,20 @@ int mi355_videocompare_hash_frames_device(mi355_ctx *ctx, const uint8_t *d_frame
                                           int algo, uint64_t *hashes);
 /* ImageHash::dist as f64 (hashed_image.rs:64): Hamming distance. Negative for an unsupported `algo`. */
 double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t frame_hash);
+/* HashAlgorithm::Dssim (cargo feature `dssim`; hashed_image.rs:41-53,66-70): crate dssim-core 3.4.0.
+ *   mi355_dssim_create_image  = Dssim::create_image_rgb / create_image_rgba on the packed frame (host pointer; the
+ *                               _device variant takes a device-resident frame). The DssimImage<f32> stays on the device.
+ *   mi355_dssim_compare       = Dssim::compare(original, modified).0 as f64 (0.0 for identical images).
+ * format: MI355_FMT_RGB or MI355_FMT_RGBA. Translucent RGBA pixels are treated as premultiplied over black (the
+ * crate blends them over a position-dependent pattern). */
+typedef struct mi355_dssim_image mi355_dssim_image;
+int mi355_dssim_create_image(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height,
+                             int format, mi355_dssim_image **out);
+int mi355_dssim_create_image_device(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width,
+                                    int height, int format, mi355_dssim_image **out);
+void mi355_dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *image);
+int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original,
+                        const mi355_dssim_image *modified, double *dssim);
 
 /* ---------------------------------------------------------------- hrtfrender
  * Replaces the per-block body of HrtfRender::process (audio/hrtf/src/hrtf/imp.rs:164-278) including the calls

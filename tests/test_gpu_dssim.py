@@ -1,0 +1,76 @@
+"""GPU tests for videocompare's Dssim engine through the C ABI vs the numpy restatement (parity unpinned w.r.t. the
+crate). The per-pixel f32 pipeline is written in the same operation order on both sides; the scores involve f64
+reductions whose order differs: tolerance 1e-9 relative (values are O(1e-4 .. 1))."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(rng, w, h, block=8):
+    base = np.kron(rng.integers(0, 256, (h // block, w // block, 4), dtype=np.uint8), np.ones((block, block, 1), np.uint8)).reshape(h, w * 4)
+    base[:, 3::4] = 255
+    return base
+
+
+def _noisy(rng, base, amp):
+    n = np.clip(base.astype(int) + rng.integers(-amp, amp + 1, base.shape), 0, 255).astype(np.uint8)
+    n[:, 3::4] = 255
+    return n
+
+
+@pytest.mark.parametrize("w,h", [(128, 96), (322, 246), (1920, 1080)])
+def test_dssim_matches_restatement(ctx, w, h):
+    from oracle import dssim_restate as D
+    rng = np.random.default_rng(w + h)
+    base = _frame(rng, w - w % 8, h - h % 8)
+    base = np.pad(base, ((0, h % 8), (0, (w % 8) * 4)), mode="edge") if (w % 8 or h % 8) else base
+    base[:, 3::4] = 255
+    ga = ctx.dssim_create_image(base, w * 4, w, h)
+    oa = D.DssimImage(base, w, h, w * 4, 4)
+    try:
+        assert ctx.dssim_compare(ga, ga) == 0.0
+        for amp in (3, 20, 90):
+            mod = _noisy(rng, base, amp)
+            gb = ctx.dssim_create_image(mod, w * 4, w, h)
+            got = ctx.dssim_compare(ga, gb)
+            ctx.dssim_free_image(gb)
+            exp = D.compare(oa, D.DssimImage(mod, w, h, w * 4, 4))
+            assert got == pytest.approx(exp, rel=1e-9, abs=1e-13), (amp, got, exp)
+    finally:
+        ctx.dssim_free_image(ga)
+
+
+def test_dssim_identical_4k_frames_exactly_zero_and_rgb(ctx):
+    """Reference test test_use_dssim_to_find_similar_frames: red vs red at threshold 0 -> distance <= 0.0."""
+    from oracle import dssim_restate as D
+    w, h = 3840, 2160
+    red = np.zeros((h, w * 4), np.uint8); red[:, 0::4] = 255; red[:, 3::4] = 255
+    a, b = ctx.dssim_create_image(red, w * 4, w, h), ctx.dssim_create_image(red.copy(), w * 4, w, h)
+    try:
+        assert ctx.dssim_compare(a, b) == 0.0
+    finally:
+        ctx.dssim_free_image(a); ctx.dssim_free_image(b)
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (72, 64 * 3), dtype=np.uint8)
+    pad = np.zeros((72, 64 * 3 + 5), np.uint8); pad[:, : 192] = rgb
+    other = rng.integers(0, 256, (72, 64 * 3), dtype=np.uint8)
+    ga, gb = ctx.dssim_create_image(pad, 197, 64, 72, "RGB"), ctx.dssim_create_image(other, 192, 64, 72, "RGB")
+    try:
+        exp = D.compare(D.DssimImage(rgb, 64, 72, 192, 3), D.DssimImage(other, 64, 72, 192, 3))
+        assert ctx.dssim_compare(ga, gb) == pytest.approx(exp, rel=1e-9)
+    finally:
+        ctx.dssim_free_image(ga); ctx.dssim_free_image(gb)
+
+
+def test_dssim_errors(ctx):
+    import mi355fx
+    f = np.zeros((16, 64), np.uint8)
+    with pytest.raises(mi355fx.Mi355Error):
+        ctx.dssim_create_image(f, 64, 16, 16, "BGRx")
+    a, b = ctx.dssim_create_image(f, 64, 16, 16), ctx.dssim_create_image(np.zeros((32, 128), np.uint8), 128, 32, 32)
+    try:
+        with pytest.raises(mi355fx.Mi355Error):
+            ctx.dssim_compare(a, b)
+    finally:
+        ctx.dssim_free_image(a); ctx.dssim_free_image(b)
