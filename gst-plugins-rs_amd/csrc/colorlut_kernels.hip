@@ -345,6 +345,108 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
   }
 }
 
+// ---------------------------------------------------------------- LDS three-pass kernel, minimal per-pixel state
+// Variant of colorlut3d_lds_kernel that keeps only TWO registers per pixel (input pixel, output pixel) instead of five
+// (pixel, LDS base, tx, ty, tz): every pass re-reads the three {offset, t} axis entries (one ds_read_b64 each) and
+// rebuilds base = ox+oy+oz. That costs 3 extra LDS reads per pixel and pass, but a lane can hold 2-2.7x more pixels,
+// so each plane staging (and each barrier / load / store phase) is amortised over that many more pixels.
+template <int P, int C, int S_CONST>
+__device__ __forceinline__ void lut_pass_lean(const unsigned char *lds, int Sy_rt, int Sz_rt, uint32_t plane_off, const uint32_t (&pin)[P],
+                                              uint32_t (&pout)[P]) {
+  const int Sy = S_CONST == 33 ? 35 : Sy_rt;
+  const int Sz = S_CONST == 33 ? 1161 : Sz_rt;
+  constexpr uint32_t sel = C == 0 ? 0x07060500u : (C == 1 ? 0x07060004u : 0x07000504u);
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    uint32_t pv = pin[i];
+    asm volatile("" : "+v"(pv));  // opaque copy: keeps the byte-offset arithmetic from being computed once and kept live across the three passes
+    const uint2 ex = *(const uint2 *)(lds + ((pv & 0xffu) << 3));
+    const uint2 ey = *(const uint2 *)(lds + 2048 + (((pv >> 8) & 0xffu) << 3));
+    const uint2 ez = *(const uint2 *)(lds + 4096 + (((pv >> 16) & 0xffu) << 3));
+    const float tx = __uint_as_float(ex.y), ty = __uint_as_float(ey.y), tz = __uint_as_float(ez.y);
+    const float *L1 = (const float *)(lds + (ex.x + ey.x + ez.x) + plane_off);
+    const float *L0 = L1 + Sz;
+    const float a0 = L0[0], a1 = L0[1], b0 = L0[Sy], b1 = L0[Sy + 1];
+    const float c0 = L1[0], c1 = L1[1], d0 = L1[Sy], d1 = L1[Sy + 1];
+    const float c00 = lerp1(a0, a1, tx), c10 = lerp1(b0, b1, tx);
+    const float c01 = lerp1(c0, c1, tx), c11 = lerp1(d0, d1, tx);
+    const float o = lerp1(lerp1(c00, c10, ty), lerp1(c01, c11, ty), tz);
+    const uint32_t v8 = round_half_away_nonneg(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
+    pout[i] = __builtin_amdgcn_perm(pout[i], v8, sel);
+    // keep the scheduler from hoisting every pixel's axis reads to the front (that is what the five-register
+    // variant stores): pixels are processed in groups of four
+    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT, int P4, int S_CONST>
+__global__ __launch_bounds__(NT) void colorlut3d_lean_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_groups,
+                                                             const float *__restrict__ planar, const uint32_t *__restrict__ axis_tab, int Sy_rt,
+                                                             int Sz_rt, uint32_t plane_floats, int all_resident) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int P = P4 * 4;
+  const size_t tile_groups = (size_t)NT * P4;
+  const size_t full_rounds = (n_groups / tile_groups) / gridDim.x;
+  const size_t full_tiles = full_rounds * gridDim.x;
+  const size_t rem_start = full_tiles * tile_groups;
+  const size_t rem_chunk = (n_groups - rem_start + gridDim.x - 1) / gridDim.x;
+  const size_t my_rounds = full_rounds + (rem_chunk > 0 ? 1 : 0);
+  for (int i = threadIdx.x; i < kAxisTableBytes / 4; i += NT) ((uint32_t *)lds)[i] = axis_tab[i];
+  const uint32_t plane_bytes = all_resident ? plane_floats * 4u : 0u;
+  if (all_resident) {
+    for (int c = 0; c < 3; c++) stage_plane<NT>(lds + (size_t)c * plane_bytes, planar + (size_t)c * plane_floats, plane_floats);
+  }
+  __syncthreads();
+  bool flip = false;
+  int resident = all_resident ? 3 : -1;
+  for (size_t round = 0; round < my_rounds; round++) {
+    size_t t_begin, t_end;
+    if (round < full_rounds) {
+      t_begin = (round * gridDim.x + blockIdx.x) * tile_groups;
+      t_end = t_begin + tile_groups;
+    } else {
+      t_begin = rem_start + (size_t)blockIdx.x * rem_chunk;
+      t_end = t_begin + rem_chunk;
+      if (t_end > n_groups) t_end = n_groups;
+      if (t_begin >= t_end) break;
+    }
+    uint32_t pin[P], pout[P];
+    const size_t g0 = t_begin + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < P4; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g < t_end) v = src[g];
+      pin[4 * j + 0] = v.x; pin[4 * j + 1] = v.y; pin[4 * j + 2] = v.z; pin[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) pout[i] = pin[i];
+#define MI355_STAGE(CH)                                                              \
+  if (resident != CH && resident != 3) {                                             \
+    __syncthreads();                                                                 \
+    stage_plane<NT>(lds, planar + (size_t)CH * plane_floats, plane_floats);          \
+    __syncthreads();                                                                 \
+    resident = CH;                                                                   \
+  }
+    if (!flip) {
+      MI355_STAGE(0) lut_pass_lean<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, pin, pout);
+      MI355_STAGE(1) lut_pass_lean<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, pin, pout);
+      MI355_STAGE(2) lut_pass_lean<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, pin, pout);
+    } else {
+      MI355_STAGE(2) lut_pass_lean<P, 2, S_CONST>(lds, Sy_rt, Sz_rt, 2u * plane_bytes, pin, pout);
+      MI355_STAGE(1) lut_pass_lean<P, 1, S_CONST>(lds, Sy_rt, Sz_rt, 1u * plane_bytes, pin, pout);
+      MI355_STAGE(0) lut_pass_lean<P, 0, S_CONST>(lds, Sy_rt, Sz_rt, 0u * plane_bytes, pin, pout);
+    }
+#undef MI355_STAGE
+    flip = !flip;
+#pragma unroll
+    for (int j = 0; j < P4; j++) {
+      const size_t g = g0 + (size_t)j * NT;
+      if (g < t_end) dst[g] = make_uint4(pout[4 * j + 0], pout[4 * j + 1], pout[4 * j + 2], pout[4 * j + 3]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fused hsvfilter -> colorlut, software pipelined
 // Same three-pass structure, but the hsvfilter arithmetic of tile n+1 (pure VALU, ~100 instructions per pixel)
 // runs inside the two plane-staging windows of tile n, where the CU otherwise only waits for the L2->LDS DMA:
@@ -802,6 +904,26 @@ static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");
 }
 
+template <int NT, int P4>
+static int launch_lean_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size_t n_groups) {
+  const LutDevice &L = ctx->lut;
+  const size_t lds = L.lds_bytes;
+  const void *k33 = (const void *)colorlut3d_lean_kernel<NT, P4, 33>, *k0 = (const void *)colorlut3d_lean_kernel<NT, P4, 0>;
+  int rc = check_hip(ctx, hipFuncSetAttribute(L.size == 33 ? k33 : k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(max dynamic LDS)");
+  if (rc) return rc;
+  size_t grid = (size_t)ctx->n_cu;
+  const size_t min_blocks = (n_groups + 255) / 256;
+  if (grid > min_blocks) grid = min_blocks;
+  if (grid < 1) grid = 1;
+  if (L.size == 33)
+    hipLaunchKernelGGL((colorlut3d_lean_kernel<NT, P4, 33>), dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
+                       (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0);
+  else
+    hipLaunchKernelGGL((colorlut3d_lean_kernel<NT, P4, 0>), dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
+                       (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0);
+  return check_hip(ctx, hipGetLastError(), "colorlut3d_lean kernel launch");
+}
+
 // Is the RGBA8 3D LDS kernel applicable to this geometry? (contiguous rows and frames, 16 B aligned)
 static bool lds3d_rgba_applicable(const mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst,
                                   size_t dst_pitch, int dst_stride, int n_frames, int width, int height, size_t *n_groups) {
@@ -923,6 +1045,10 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
       const uint4 *s = (const uint4 *)d_src;
       uint4 *d = (uint4 *)d_dst;
       constexpr int NT = 1024, P4 = 3;
+      // lean-state kernel (2 registers per pixel, 32 pixels per lane). Measured on 8x4K: 0.243-0.258 ms smooth /
+      // 0.440 ms noise vs 0.249-0.253 / 0.402 ms for the default: the larger tile amortises staging and barriers, the
+      // three extra axis reads per pixel and pass give it back. Not the default.
+      if (ctx->lut_variant == 2) return launch_lean_variant<1024, 8>(ctx, s, d, n_groups);
       if (ctx->lut_variant == 1)  // MI355_FLAG_LUT_VARIANT: next tile's pixels prefetched before the last pass
         return L.size == 33 ? launch_pipe_variant<NT, P4, 33, kNoHsv, true>(ctx, s, d, n_groups, HsvK{})
                             : launch_pipe_variant<NT, P4, 0, kNoHsv, true>(ctx, s, d, n_groups, HsvK{});

@@ -618,3 +618,18 @@ def test_fused_chain_errors(ctx, synth):
         assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
     finally:
         ctx.free(d)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("size", [17, 33])
+def test_colorlut_kernel_variants_allcolors(ctx, oracle, synth, variant, size):
+    """MI355_FLAG_LUT_VARIANT: the late-prefetch and lean-state forms of the 3D LDS kernel are bit-exact too."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size))
+    ac = synth.allcolors()
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+    got = np.zeros_like(ac)
+    ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)

@@ -9,7 +9,7 @@ from mi355fx import synth
 from mi355fx.cube import parse_cube
 
 W, H, N = 3840, 2160, 8
-NAMES = {0: "default", 1: "late prefetch of the next tile"}
+NAMES = {0: "default (5 regs/px, 1024x3)", 1: "late prefetch of the next tile", 2: "lean state (2 regs/px, 1024x8)"}
 
 
 def main():
