@@ -246,10 +246,10 @@ __device__ __forceinline__ void lut_pass(const unsigned char *lds, int Sy_rt, in
 // right after the load, so the chain costs one read and one write per pixel instead of two of each.
 constexpr int kNoHsv = -2;
 template <int NT, int P4, int S_CONST, int HSV>
-__global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
-                                                            size_t n_groups, const float *__restrict__ planar,
-                                                            const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
-                                                            uint32_t plane_floats, int all_resident, HsvK hk) {
+__device__ __forceinline__ void colorlut3d_lds_body(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                    size_t n_groups, const float *__restrict__ planar,
+                                                    const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
+                                                    uint32_t plane_floats, int all_resident, HsvK hk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t hsv_sel[HSV == kNoHsv ? 1 : 8];
   if constexpr (HSV != kNoHsv) {
@@ -343,6 +343,14 @@ __global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restr
       if (g < t_end) dst[g] = make_uint4(px[4 * j + 0], px[4 * j + 1], px[4 * j + 2], px[4 * j + 3]);
     }
   }
+}
+
+template <int NT, int P4, int S_CONST, int HSV>
+__global__ __launch_bounds__(NT) void colorlut3d_lds_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
+                                                            size_t n_groups, const float *__restrict__ planar,
+                                                            const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
+                                                            uint32_t plane_floats, int all_resident, HsvK hk) {
+  colorlut3d_lds_body<NT, P4, S_CONST, HSV>(src, dst, n_groups, planar, axis_tab, Sy_rt, Sz_rt, plane_floats, all_resident, hk);
 }
 
 // ---------------------------------------------------------------- LDS three-pass kernel, minimal per-pixel state
