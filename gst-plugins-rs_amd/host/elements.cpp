@@ -610,7 +610,17 @@ const std::vector<ParamSpec> &HrtfRender::properties() const {
     ParamSpec rayon;
     rayon.name = "use-rayon"; rayon.nick = "Use Rayon"; rayon.blurb = "Use Rayon to process input channels in parallel";
     rayon.type = PropType::Boolean; rayon.def_num = 0; rayon.min_num = 0; rayon.max_num = 1; rayon.mutability = Mutability::Ready;
+    // "hrir-raw" (GBytes) and "spatial-objects" (GstValueArray) are listed for introspection; they are set through
+    // set_hrir_raw / set_spatial_objects (no scalar spelling)
+    ParamSpec raw;
+    raw.name = "hrir-raw"; raw.nick = "Head Transform Impulse Response"; raw.blurb = "Head Transform Impulse Response raw bytes";
+    raw.type = PropType::String; raw.mutability = Mutability::Ready;
+    ParamSpec objs;
+    objs.name = "spatial-objects"; objs.nick = "Spatial Objects"; objs.blurb = "Spatial object Metadata to apply on input channels";
+    objs.type = PropType::String; objs.mutability = Mutability::Playing;
     return std::vector<ParamSpec>{
+        raw,
+        objs,
         file,
         u64("interpolation-steps", "Interpolation Steps", "Interpolation Steps is the amount of slices to cut source to", 8),
         u64("block-length", "Block Length", "Block Length is the length of each slice", 512),

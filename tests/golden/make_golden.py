@@ -18,13 +18,14 @@ sys.path.insert(0, os.path.join(ROOT, "gst-plugins-rs_amd"))
 def surface():
     d = json.load(open("/root/reference/docs/plugins/gst_plugins_cache.json"))
     out = {}
-    for plug, els in (("hsv", ["hsvfilter", "hsvdetector"]), ("colorlut", ["colorlut"]), ("rsaudiofx", ["rsaudioecho", "ebur128level"])):
+    for plug, els in (("hsv", ["hsvfilter", "hsvdetector"]), ("colorlut", ["colorlut"]), ("rsaudiofx", ["rsaudioecho", "ebur128level", "audioloudnorm"]),
+                      ("rsvideofx", ["videocompare"]), ("hrtf", ["hrtfrender"])):
         for e in els:
             el = d[plug]["elements"][e]
             props = {n: {k: p[k] for k in ("type", "default", "min", "max", "mutable") if k in p}
                      for n, p in el["properties"].items() if n not in ("name", "parent", "qos")}
             spec = {"type_name": el["hierarchy"][0], "klass": el["klass"], "properties": props}
-            if plug != "rsaudiofx":
+            if plug in ("hsv", "colorlut"):
                 def fmts(caps):
                     return [t.strip() for t in re.search(r"format:\s*\{([^}]*)\}", caps).group(1).split(",")]
                 spec["sink_formats"] = fmts(el["pad-templates"]["sink"]["caps"])
