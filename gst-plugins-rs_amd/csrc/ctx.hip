@@ -141,6 +141,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   lut_release(ctx);
   loudnorm_release(ctx);
+  dssim_release(ctx);
   ebur128_release(ctx);
   hrtf_release(ctx);
   if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
@@ -661,6 +662,13 @@ int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original, const
   if (!original || !modified || !dssim) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null argument");
   BIND_DEVICE(ctx);
   return dssim_compare(ctx, original, modified, dssim);
+}
+
+int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind, float *out, int *width, int *height) {
+  REQUIRE_CTX(ctx);
+  if (!image) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null image");
+  BIND_DEVICE(ctx);
+  return dssim_image_plane(ctx, image, scale, channel, kind, out, width, height);
 }
 
 /* ------------------------------------------------------------------ hrtfrender */

@@ -8,12 +8,11 @@
 //
 // A DssimImage lives on the device: 5 scales x 3 LAB planes x {img, mu, img_sq_blur} f32. All kernels are pointwise or
 // 3x3 stencils (HBM/L2-bound), the scores are block-reduced f64 sums finished on the host in a fixed order:
-//   dssim_linear_kernel     u8 sRGB(A) -> premultiplied linear float4 (256-entry table in LDS)
-//   dssim_downsample_kernel 2x2 box average
-//   dssim_lab_kernel        linear RGB -> L, a, b planes (polynomial + 2x Halley cube root)
-//   dssim_blur_kernel       one 3x3 pass with replicated edges; input optionally squared or a product of two planes
-//   dssim_ssim_kernel       SSIM map from the LAB-averaged moments + f64 partial sums
-//   dssim_absdev_kernel     sum |avg - ssim| partial sums
+//   dssim_linear_kernel / dssim_downsample_kernel   u8 sRGB(A) -> premultiplied linear float4; 2x2 box average chain
+//   dssim_scale_fused_kernel    per scale: LAB conversion (polynomial + 2x Halley cube root), chroma pre-blur and the
+//                               mu / img_sq_blur planes, all four blur passes through LDS tiles (halo 4)
+//   dssim_compare_fused_kernel  per scale: blur(img1*img2) through LDS (halo 2) + SSIM map + f64 block partials
+//   dssim_avg / absdev2 / sum   deterministic reductions; one D2H of 15 doubles per comparison
 // Every f32 expression is written in the operation order of the restatement (-ffp-contract=off), so the per-pixel maps
 // are bit-identical to it; only the f64 reductions differ in summation order.
 #include "internal.hpp"
@@ -37,6 +36,7 @@ struct mi355_dssim_image {
   int n_scales = 0;
   mi355::DssimScale s[mi355::kDssimScales];
   float *pool = nullptr;
+  size_t pool_bytes = 0;
 };
 
 namespace mi355 {
@@ -88,48 +88,130 @@ __device__ __forceinline__ float dssim_f(float t) {
   return t > eps ? dssim_cbrt_poly(t) - 16.0f / 116.0f : kk * t;
 }
 
-__global__ __launch_bounds__(256) void dssim_lab_kernel(const float4 *__restrict__ src, size_t n, float *__restrict__ L, float *__restrict__ A,
-                                                        float *__restrict__ B) {
+// ---- fused per-scale kernel: LAB conversion, chroma pre-blur and the mu / sq blurs of all three planes in one pass
+// over the scale. A block owns a 32x16 output tile; the linear-RGB source is read for the tile plus a halo of 4 (two
+// blur passes for the chroma pre-blur + two for mu/sq), everything in between lives in LDS. Replicated edges are
+// applied PER PASS as in the unfused form: an out-of-image neighbour of pass k reads pass k-1's value at the clamped
+// coordinate (always inside the tile's region because the region contains the border pixel), never a value computed
+// at a virtual position. Arithmetic and tap order are those of dssim_blur_kernel, so the planes are bit-identical.
+constexpr int kTw = 32, kTh = 16, kHalo = 4;
+constexpr int kRw = kTw + 2 * kHalo, kRh = kTh + 2 * kHalo;  // 40 x 24 region
+
+struct DssimSrc {          // source of the scale's linear RGB
+  const uint8_t *u8; int stride, channels; const float *lut;   // scale 0: packed sRGB(A) bytes + gamma table
+  const float4 *lin;                                           // other scales: premultiplied linear float4
+};
+
+__device__ __forceinline__ void dssim_lab_px(float r, float g, float b, float &L, float &A, float &B) {
   const float dx = 0.9505f, dy = 1.0f, dz = 1.089f;
-  const size_t gs = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
-    const float4 p = src[i];
-    const float fx = (p.x * (0.4124f / dx) + p.y * (0.3576f / dx)) + p.z * (0.1805f / dx);
-    const float fy = (p.x * (0.2126f / dy) + p.y * (0.7152f / dy)) + p.z * (0.0722f / dy);
-    const float fz = (p.x * (0.0193f / dz) + p.y * (0.1192f / dz)) + p.z * (0.9505f / dz);
-    const float X = dssim_f(fx), Y = dssim_f(fy), Z = dssim_f(fz);
-    L[i] = Y * 1.05f;
-    A[i] = (500.0f / 220.0f) * (X - Y) + 86.2f / 220.0f;
-    B[i] = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
-  }
+  const float fx = (r * (0.4124f / dx) + g * (0.3576f / dx)) + b * (0.1805f / dx);
+  const float fy = (r * (0.2126f / dy) + g * (0.7152f / dy)) + b * (0.0722f / dy);
+  const float fz = (r * (0.0193f / dz) + g * (0.1192f / dz)) + b * (0.9505f / dz);
+  const float X = dssim_f(fx), Y = dssim_f(fy), Z = dssim_f(fz);
+  L = Y * 1.05f;
+  A = (500.0f / 220.0f) * (X - Y) + 86.2f / 220.0f;
+  B = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
 }
 
-// OP 0: in = a; 1: in = a*a; 2: in = a*b
-template <int OP>
-__global__ __launch_bounds__(256) void dssim_blur_kernel(const float *__restrict__ a, const float *__restrict__ b, int w, int h, float *__restrict__ dst) {
+// one 3x3 pass inside the LDS region: dst(lx,ly) for region coords in [m, kRw-m) x [m, kRh-m), reading src with
+// per-pass edge replication in IMAGE coordinates. SQ: square the input on the fly.
+template <bool SQ>
+__device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, int m, int x0, int y0, int w, int h) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
-  const size_t n = (size_t)w * h, gs = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
-    const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+  const int rw = kRw - 2 * m, rh = kRh - 2 * m;
+  for (int e = threadIdx.x; e < rw * rh; e += 256) {
+    const int ly = m + e / rw, lx = m + e - (e / rw) * rw;
+    const int gx = x0 + lx, gy = y0 + ly;            // image coordinates of this region cell (may be outside the image)
     float acc = 0.0f;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {    // cells outside the image are never read (clamping maps inside)
 #pragma unroll
-    for (int dyy = 0; dyy < 3; dyy++) {
-      int yy = y + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+      for (int dyy = 0; dyy < 3; dyy++) {
+        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
-      for (int dxx = 0; dxx < 3; dxx++) {
-        int xx = x + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-        const size_t j = (size_t)yy * w + xx;
-        float v = a[j];
-        if (OP == 1) v = v * v;
-        if (OP == 2) v = v * b[j];
-        acc = acc + v * K[dyy * 3 + dxx];
+        for (int dxx = 0; dxx < 3; dxx++) {
+          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          float v = src[(yy - y0) * kRw + (xx - x0)];
+          if (SQ) v = v * v;
+          acc = acc + v * K[dyy * 3 + dxx];
+        }
       }
     }
-    dst[i] = acc;
+    dst[ly * kRw + lx] = acc;
   }
 }
 
-struct DssimPlanes { const float *mu1[3], *mu2[3], *sq1[3], *sq2[3], *i12[3]; };
+__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimSrc S, int w, int h, float *__restrict__ img0, float *__restrict__ img1,
+                                                                float *__restrict__ img2, float *__restrict__ mu0, float *__restrict__ mu1,
+                                                                float *__restrict__ mu2, float *__restrict__ sq0, float *__restrict__ sq1,
+                                                                float *__restrict__ sq2) {
+  __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
+  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
+  __shared__ float s_lut[256];
+  if (S.u8) s_lut[threadIdx.x] = S.lut[threadIdx.x];
+  const int tiles_x = (w + kTw - 1) / kTw;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;  // image coords of region cell (0,0)
+  __syncthreads();
+  // 1. LAB of every in-image region cell
+  for (int e = threadIdx.x; e < kRw * kRh; e += 256) {
+    const int ly = e / kRw, lx = e - ly * kRw;
+    const int gx = x0 + lx, gy = y0 + ly;
+    float L = 0, A = 0, B = 0;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      float r, g, b;
+      if (S.u8) {
+        const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
+        if (S.channels == 4) { const float a = (float)p[3] / 255.0f; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a; }
+        else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
+      } else {
+        const float4 v = S.lin[(size_t)gy * w + gx];
+        r = v.x; g = v.y; b = v.z;
+      }
+      dssim_lab_px(r, g, b, L, A, B);
+    }
+    s_lab[0][e] = L; s_lab[1][e] = A; s_lab[2][e] = B;
+  }
+  __syncthreads();
+  // 2. chroma pre-blur (two passes): valid on the region minus a margin of 2
+  for (int c = 1; c < 3; c++) {
+    dssim_region_pass<false>(s_lab[c], s_a, 1, x0, y0, w, h);
+    __syncthreads();
+    dssim_region_pass<false>(s_a, s_lab[c], 2, x0, y0, w, h);
+    __syncthreads();
+  }
+  // 3. per plane: img = plane (tile), mu = blur(plane), sq = blur(plane^2); margins 3 and 4
+  float *imgs[3] = {img0, img1, img2}, *mus[3] = {mu0, mu1, mu2}, *sqs[3] = {sq0, sq1, sq2};
+  for (int c = 0; c < 3; c++) {
+    dssim_region_pass<false>(s_lab[c], s_a, 3, x0, y0, w, h);
+    dssim_region_pass<true>(s_lab[c], s_b, 3, x0, y0, w, h);
+    __syncthreads();
+    // second passes straight to global for the tile cells
+    const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
+    for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
+      const int ly = kHalo + e / kTw, lx = kHalo + e - (e / kTw) * kTw;
+      const int gx = x0 + lx, gy = y0 + ly;
+      if (gx < w && gy < h) {
+        float am = 0.0f, as = 0.0f;
+#pragma unroll
+        for (int dyy = 0; dyy < 3; dyy++) {
+          int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+          for (int dxx = 0; dxx < 3; dxx++) {
+            int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+            const int j = (yy - y0) * kRw + (xx - x0);
+            am = am + s_a[j] * K[dyy * 3 + dxx];
+            as = as + s_b[j] * K[dyy * 3 + dxx];
+          }
+        }
+        const size_t o = (size_t)gy * w + gx;
+        imgs[c][o] = s_lab[c][ly * kRw + lx];
+        mus[c][o] = am;
+        sqs[c][o] = as;
+      }
+    }
+    __syncthreads();
+  }
+}
 
 __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -141,31 +223,103 @@ __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void dssim_ssim_kernel(DssimPlanes P, size_t n, float *__restrict__ ssim_map, double *__restrict__ partial) {
+// ---- fused comparison kernel: i12 = blur(img1*img2) (two passes through LDS, halo 2) and the SSIM map + its f64 block
+// partial in one pass. Tile 32x16, region 36x20. Same per-pass edge replication and arithmetic as the unfused form.
+constexpr int kCh = 2, kCw = kTw + 2 * kCh, kChh = kTh + 2 * kCh;  // 36 x 20
+struct DssimCmp { const float *img1[3], *img2[3], *mu1[3], *mu2[3], *sq1[3], *sq2[3]; };
+
+__global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
+  __shared__ float s_p[3][kCw * kChh];   // products img1*img2 of the region
+  __shared__ float s_q[3][kCw * kChh];   // first blur pass
   __shared__ double s_w[4];
-  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
-  const size_t gs = (size_t)gridDim.x * 256;
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
-    float m1[3], m2[3], q1[3], q2[3], x12[3];
+  const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
+  const int tiles_x = (w + kTw - 1) / kTw;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * kTw - kCh, y0 = ty * kTh - kCh;
+  for (int e = threadIdx.x; e < kCw * kChh; e += 256) {
+    const int ly = e / kCw, lx = e - ly * kCw;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    const size_t o = in ? (size_t)gy * w + gx : 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) { m1[c] = P.mu1[c][i]; m2[c] = P.mu2[c][i]; q1[c] = P.sq1[c][i]; q2[c] = P.sq2[c][i]; x12[c] = P.i12[c][i]; }
-    const float mu1mu1 = ((m1[0] * m1[0] + m1[1] * m1[1]) + m1[2] * m1[2]) * third;
-    const float mu2mu2 = ((m2[0] * m2[0] + m2[1] * m2[1]) + m2[2] * m2[2]) * third;
-    const float mu1mu2 = ((m1[0] * m2[0] + m1[1] * m2[1]) + m1[2] * m2[2]) * third;
-    const float sig1 = (((q1[0] - m1[0] * m1[0]) + (q1[1] - m1[1] * m1[1])) + (q1[2] - m1[2] * m1[2])) * third;
-    const float sig2 = (((q2[0] - m2[0] * m2[0]) + (q2[1] - m2[1] * m2[1])) + (q2[2] - m2[2] * m2[2])) * third;
-    const float sig12 = (((x12[0] - m1[0] * m2[0]) + (x12[1] - m1[1] * m2[1])) + (x12[2] - m1[2] * m2[2])) * third;
-    const float ssim = ((2.0f * mu1mu2 + c1) * (2.0f * sig12 + c2)) / (((mu1mu1 + mu2mu2) + c1) * ((sig1 + sig2) + c2));
-    ssim_map[i] = ssim;
-    acc += (double)ssim;
+    for (int c = 0; c < 3; c++) s_p[c][e] = in ? P.img1[c][o] * P.img2[c][o] : 0.0f;
   }
-  const double t = dssim_block_sum(acc, s_w);
+  __syncthreads();
+  // pass 1 on the region minus a margin of 1
+  for (int e = threadIdx.x; e < (kCw - 2) * (kChh - 2); e += 256) {
+    const int ly = 1 + e / (kCw - 2), lx = 1 + e - (e / (kCw - 2)) * (kCw - 2);
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+      float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int dyy = 0; dyy < 3; dyy++) {
+        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+        for (int dxx = 0; dxx < 3; dxx++) {
+          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          const int j = (yy - y0) * kCw + (xx - x0);
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[c] = acc[c] + s_p[c][j] * K[dyy * 3 + dxx];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) s_q[c][ly * kCw + lx] = acc[c];
+    }
+  }
+  __syncthreads();
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
+  double dsum = 0.0;
+  for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
+    const int ly = kCh + e / kTw, lx = kCh + e - (e / kTw) * kTw;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx < w && gy < h) {
+      float x12[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int dyy = 0; dyy < 3; dyy++) {
+        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+        for (int dxx = 0; dxx < 3; dxx++) {
+          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          const int j = (yy - y0) * kCw + (xx - x0);
+#pragma unroll
+          for (int c = 0; c < 3; c++) x12[c] = x12[c] + s_q[c][j] * K[dyy * 3 + dxx];
+        }
+      }
+      const size_t i = (size_t)gy * w + gx;
+      float m1[3], m2[3], q1[3], q2[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { m1[c] = P.mu1[c][i]; m2[c] = P.mu2[c][i]; q1[c] = P.sq1[c][i]; q2[c] = P.sq2[c][i]; }
+      const float mu1mu1 = ((m1[0] * m1[0] + m1[1] * m1[1]) + m1[2] * m1[2]) * third;
+      const float mu2mu2 = ((m2[0] * m2[0] + m2[1] * m2[1]) + m2[2] * m2[2]) * third;
+      const float mu1mu2 = ((m1[0] * m2[0] + m1[1] * m2[1]) + m1[2] * m2[2]) * third;
+      const float sig1 = (((q1[0] - m1[0] * m1[0]) + (q1[1] - m1[1] * m1[1])) + (q1[2] - m1[2] * m1[2])) * third;
+      const float sig2 = (((q2[0] - m2[0] * m2[0]) + (q2[1] - m2[1] * m2[1])) + (q2[2] - m2[2] * m2[2])) * third;
+      const float sig12 = (((x12[0] - m1[0] * m2[0]) + (x12[1] - m1[1] * m2[1])) + (x12[2] - m1[2] * m2[2])) * third;
+      const float ssim = ((2.0f * mu1mu2 + c1) * (2.0f * sig12 + c2)) / (((mu1mu1 + mu2mu2) + c1) * ((sig1 + sig2) + c2));
+      ssim_map[i] = ssim;
+      dsum += (double)ssim;
+    }
+  }
+  const double t = dssim_block_sum(dsum, s_w);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(256) void dssim_absdev_kernel(const float *__restrict__ ssim_map, size_t n, double avg, double *__restrict__ partial) {
+// sum the block partials (256 lanes, strided, then the fixed-order block reduction: deterministic);
+// slot[0] = sum, slot[1] = avg = max(sum/len, 0)^(0.5^scale)
+__global__ __launch_bounds__(256) void dssim_avg_kernel(const double *__restrict__ partial, unsigned n_partial, double len, double exponent, double *__restrict__ slot) {
   __shared__ double s_w[4];
+  double acc = 0.0;
+  for (unsigned i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  const double sum = dssim_block_sum(acc, s_w);
+  if (threadIdx.x == 0) {
+    slot[0] = sum;
+    slot[1] = pow(fmax(sum / len, 0.0), exponent);
+  }
+}
+
+__global__ __launch_bounds__(256) void dssim_absdev2_kernel(const float *__restrict__ ssim_map, size_t n, const double *__restrict__ slot, double *__restrict__ partial) {
+  __shared__ double s_w[4];
+  const double avg = slot[1];
   const size_t gs = (size_t)gridDim.x * 256;
   double acc = 0.0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) acc += fabs(avg - (double)ssim_map[i]);
@@ -173,7 +327,35 @@ __global__ __launch_bounds__(256) void dssim_absdev_kernel(const float *__restri
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+__global__ __launch_bounds__(256) void dssim_sum_kernel(const double *__restrict__ partial, unsigned n_partial, double *__restrict__ out) {
+  __shared__ double s_w[4];
+  double acc = 0.0;
+  for (unsigned i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  const double sum = dssim_block_sum(acc, s_w);
+  if (threadIdx.x == 0) *out = sum;
+}
+
 // ------------------------------------------------------------------ host side
+
+// per-context cache: the gamma table (uploaded once) and released image pools kept for reuse (a stream of frames of one
+// size allocates once instead of once per frame; hipMalloc/hipFree of ~400 MB cost more than the kernels)
+struct DssimCache {
+  float *d_lut = nullptr;
+  struct Pool { float *p; size_t bytes; };
+  std::vector<Pool> free_pools;
+};
+static DssimCache *dssim_cache(mi355_ctx *ctx) {
+  if (!ctx->dssim_cache) ctx->dssim_cache = new DssimCache();
+  return (DssimCache *)ctx->dssim_cache;
+}
+void dssim_release(mi355_ctx *ctx) {
+  DssimCache *c = (DssimCache *)ctx->dssim_cache;
+  if (!c) return;
+  if (c->d_lut) (void)hipFree(c->d_lut);
+  for (auto &p : c->free_pools) (void)hipFree(p.p);
+  delete c;
+  ctx->dssim_cache = nullptr;
+}
 
 static unsigned dssim_grid(mi355_ctx *ctx, size_t n) {
   size_t b = (n + 255) / 256;
@@ -194,18 +376,14 @@ static int dssim_scratch(mi355_ctx *ctx, int slot, size_t bytes, void **out) {
   return MI355_OK;
 }
 
-static void dssim_blur(mi355_ctx *ctx, int op, const float *a, const float *b, int w, int h, float *tmp, float *dst) {
-  const unsigned g = dssim_grid(ctx, (size_t)w * h);
-  if (op == 0) hipLaunchKernelGGL((dssim_blur_kernel<0>), dim3(g), dim3(256), 0, ctx->stream, a, b, w, h, tmp);
-  else if (op == 1) hipLaunchKernelGGL((dssim_blur_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, a, b, w, h, tmp);
-  else hipLaunchKernelGGL((dssim_blur_kernel<2>), dim3(g), dim3(256), 0, ctx->stream, a, b, w, h, tmp);
-  hipLaunchKernelGGL((dssim_blur_kernel<0>), dim3(g), dim3(256), 0, ctx->stream, (const float *)tmp, (const float *)nullptr, w, h, dst);
-}
-
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img) {
   if (!img) return;
   (void)hipStreamSynchronize(ctx->stream);
-  if (img->pool) (void)hipFree(img->pool);
+  if (img->pool) {
+    DssimCache *c = dssim_cache(ctx);
+    if (c->free_pools.size() < 8) c->free_pools.push_back({img->pool, img->pool_bytes});
+    else (void)hipFree(img->pool);
+  }
   delete img;
 }
 
@@ -222,7 +400,14 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   size_t planes_px = 0;
   for (int k = 0; k < ns; k++) planes_px += (size_t)ws[k] * hs[k];
   mi355_dssim_image *img = new mi355_dssim_image();
-  int rc = check_hip(ctx, hipMalloc((void **)&img->pool, planes_px * 9 * sizeof(float)), "hipMalloc(dssim image)");
+  int rc = MI355_OK;
+  img->pool_bytes = planes_px * 9 * sizeof(float);
+  {
+    DssimCache *c = dssim_cache(ctx);
+    for (size_t i = 0; i < c->free_pools.size(); i++)
+      if (c->free_pools[i].bytes == img->pool_bytes) { img->pool = c->free_pools[i].p; c->free_pools.erase(c->free_pools.begin() + (std::ptrdiff_t)i); break; }
+  }
+  if (!img->pool) rc = check_hip(ctx, hipMalloc((void **)&img->pool, img->pool_bytes), "hipMalloc(dssim image)");
   if (rc) { delete img; return rc; }
   float *p = img->pool;
   img->n_scales = ns;
@@ -237,34 +422,36 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   void *scr = nullptr;
   if ((rc = dssim_scratch(ctx, 1, n0 * 16 + (n0 / 4 + 16) * 16 + n0 * 4 + 1024, &scr))) { dssim_free_image(ctx, img); return rc; }
   float4 *lin_a = (float4 *)scr, *lin_b = lin_a + n0;
-  float *tmp = (float *)(lin_b + (n0 / 4 + 16));
-  float *d_lut = tmp + n0;
-  float lut[256];
-  for (int i = 0; i < 256; i++) {
-    const double s = (double)i / 255.0;
-    lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
+  DssimCache *cache = dssim_cache(ctx);
+  if (!cache->d_lut) {
+    float lut[256];
+    for (int i = 0; i < 256; i++) {
+      const double s = (double)i / 255.0;
+      lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
+    }
+    if ((rc = check_hip(ctx, hipMalloc((void **)&cache->d_lut, sizeof lut), "hipMalloc(dssim gamma table)"))) { dssim_free_image(ctx, img); return rc; }
+    if ((rc = check_hip(ctx, hipMemcpy(cache->d_lut, lut, sizeof lut, hipMemcpyHostToDevice), "dssim: gamma table"))) { dssim_free_image(ctx, img); return rc; }
   }
-  if ((rc = check_hip(ctx, hipMemcpyAsync(d_lut, lut, sizeof lut, hipMemcpyHostToDevice, ctx->stream), "dssim: gamma table"))) { dssim_free_image(ctx, img); return rc; }
-  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) { dssim_free_image(ctx, img); return rc; }  // lut[] is a stack buffer
-  hipLaunchKernelGGL(dssim_linear_kernel, dim3(dssim_grid(ctx, n0)), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin_a);
+  float *d_lut = cache->d_lut;
+  // scale 0 straight from the packed bytes; the linear float4 image is only materialised for the downsampling chain
+  if (ns > 1) hipLaunchKernelGGL(dssim_linear_kernel, dim3(dssim_grid(ctx, n0)), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin_a);
   float4 *cur = lin_a, *nxt = lin_b;
   for (int k = 0; k < ns; k++) {
     DssimScale &s = img->s[k];
-    const size_t n = (size_t)s.w * s.h;
-    hipLaunchKernelGGL(dssim_lab_kernel, dim3(dssim_grid(ctx, n)), dim3(256), 0, ctx->stream, (const float4 *)cur, n, s.img[0], s.img[1], s.img[2]);
-    for (int c = 0; c < 3; c++) {
-      if (c > 0) {  // chroma pre-blur, in place through mu[] as the second buffer
-        dssim_blur(ctx, 0, s.img[c], nullptr, s.w, s.h, tmp, s.mu[c]);
-        rc = check_hip(ctx, hipMemcpyAsync(s.img[c], s.mu[c], n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream), "dssim: chroma copy");
-        if (rc) { dssim_free_image(ctx, img); return rc; }
-      }
-      dssim_blur(ctx, 0, s.img[c], nullptr, s.w, s.h, tmp, s.mu[c]);
-      dssim_blur(ctx, 1, s.img[c], nullptr, s.w, s.h, tmp, s.sq[c]);
-    }
+    DssimSrc S;
+    if (k == 0) { S.u8 = d_frame; S.stride = stride; S.channels = channels; S.lut = d_lut; S.lin = nullptr; }
+    else { S.u8 = nullptr; S.stride = 0; S.channels = 0; S.lut = nullptr; S.lin = cur; }
+    const unsigned tiles = (unsigned)(((s.w + kTw - 1) / kTw) * ((s.h + kTh - 1) / kTh));
+    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, S, s.w, s.h, s.img[0], s.img[1], s.img[2], s.mu[0], s.mu[1], s.mu[2],
+                       s.sq[0], s.sq[1], s.sq[2]);
     if (k + 1 < ns) {
-      hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[k + 1] * hs[k + 1])), dim3(256), 0, ctx->stream, (const float4 *)cur, s.w, s.h, nxt);
-      float4 *t = cur; cur = nxt; nxt = t;
-      if (k == 0) nxt = lin_a;  // lin_a (full size) is free from now on; lin_b is quarter size: keep ping-ponging inside both
+      if (k == 0) {
+        hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[1] * hs[1])), dim3(256), 0, ctx->stream, (const float4 *)lin_a, s.w, s.h, lin_b);
+        cur = lin_b; nxt = lin_a;
+      } else {
+        hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[k + 1] * hs[k + 1])), dim3(256), 0, ctx->stream, (const float4 *)cur, s.w, s.h, nxt);
+        float4 *t = cur; cur = nxt; nxt = t;
+      }
     }
   }
   rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch");
@@ -274,47 +461,62 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   return MI355_OK;
 }
 
-// Dssim::compare -> the f64 value
+// diagnostics: copy one plane (kind 0 img, 1 mu, 2 img_sq_blur) of one scale/channel to the host; dims via w/h
+int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, int channel, int kind, float *out, int *w, int *h) {
+  if (scale < 0 || scale >= img->n_scales || channel < 0 || channel > 2 || kind < 0 || kind > 2)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: bad plane selector");
+  const DssimScale &s = img->s[scale];
+  if (w) *w = s.w;
+  if (h) *h = s.h;
+  if (!out) return MI355_OK;
+  const float *p = kind == 0 ? s.img[channel] : (kind == 1 ? s.mu[channel] : s.sq[channel]);
+  int rc = check_hip(ctx, hipMemcpyAsync(out, p, (size_t)s.w * s.h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream), "dssim: plane D2H");
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync");
+}
+
+// Dssim::compare -> the f64 value. One fused kernel per scale + two tiny reductions; a single D2H/sync at the end.
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out) {
   if (a->n_scales != b->n_scales || a->s[0].w != b->s[0].w || a->s[0].h != b->s[0].h)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: images differ in size");
   const size_t n0 = (size_t)a->s[0].w * a->s[0].h;
+  const unsigned tiles0 = (unsigned)(((a->s[0].w + kTw - 1) / kTw) * ((a->s[0].h + kTh - 1) / kTh));
   const unsigned gmax = dssim_grid(ctx, n0);
+  const size_t n_part = (size_t)(tiles0 > gmax ? tiles0 : gmax);
   void *scr = nullptr;
-  int rc = dssim_scratch(ctx, 1, n0 * 4 * 5 + (size_t)gmax * 8 + 64, &scr);
+  int rc = dssim_scratch(ctx, 1, n0 * 4 + n_part * 8 + 64 * 8 + 64, &scr);
   if (rc) return rc;
-  float *tmp = (float *)scr, *i12[3] = {tmp + n0, tmp + 2 * n0, tmp + 3 * n0}, *map = tmp + 4 * n0;
-  double *d_partial = (double *)(map + n0);
-  std::vector<double> partial(gmax);
-  double ssim_sum = 0.0, weight_sum = 0.0;
+  float *map = (float *)scr;
+  double *d_partial = (double *)(map + n0 + (n0 & 1));
+  double *d_slots = d_partial + n_part;  // per scale: [sum, avg, dev]
   for (int k = 0; k < a->n_scales; k++) {
     const DssimScale &s1 = a->s[k], &s2 = b->s[k];
     const size_t n = (size_t)s1.w * s1.h;
-    const unsigned g = dssim_grid(ctx, n);
-    DssimPlanes P;
+    const unsigned tiles = (unsigned)(((s1.w + kTw - 1) / kTw) * ((s1.h + kTh - 1) / kTh));
+    DssimCmp P;
     for (int c = 0; c < 3; c++) {
-      dssim_blur(ctx, 2, s1.img[c], s2.img[c], s1.w, s1.h, tmp, i12[c]);
-      P.mu1[c] = s1.mu[c]; P.mu2[c] = s2.mu[c]; P.sq1[c] = s1.sq[c]; P.sq2[c] = s2.sq[c]; P.i12[c] = i12[c];
+      P.img1[c] = s1.img[c]; P.img2[c] = s2.img[c]; P.mu1[c] = s1.mu[c]; P.mu2[c] = s2.mu[c]; P.sq1[c] = s1.sq[c]; P.sq2[c] = s2.sq[c];
     }
-    hipLaunchKernelGGL(dssim_ssim_kernel, dim3(g), dim3(256), 0, ctx->stream, P, n, map, d_partial);
-    if ((rc = check_hip(ctx, hipMemcpyAsync(partial.data(), d_partial, g * 8, hipMemcpyDeviceToHost, ctx->stream), "dssim: partial D2H"))) return rc;
-    if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
-    double sum = 0.0;
-    for (unsigned i = 0; i < g; i++) sum += partial[i];
-    const double len = (double)n;
-    const double avg = std::pow(std::fmax(sum / len, 0.0), std::pow(0.5, (double)k));
-    hipLaunchKernelGGL(dssim_absdev_kernel, dim3(g), dim3(256), 0, ctx->stream, (const float *)map, n, avg, d_partial);
-    if ((rc = check_hip(ctx, hipMemcpyAsync(partial.data(), d_partial, g * 8, hipMemcpyDeviceToHost, ctx->stream), "dssim: partial D2H"))) return rc;
-    if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
-    double dev = 0.0;
-    for (unsigned i = 0; i < g; i++) dev += partial[i];
-    const double score = 1.0 - dev / len;
+    hipLaunchKernelGGL(dssim_compare_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, P, s1.w, s1.h, map, d_partial);
+    hipLaunchKernelGGL(dssim_avg_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)d_partial, tiles, (double)n, std::pow(0.5, (double)k), d_slots + 3 * k);
+    const unsigned g = dssim_grid(ctx, n);
+    hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(g), dim3(256), 0, ctx->stream, (const float *)map, n, (const double *)(d_slots + 3 * k), d_partial);
+    hipLaunchKernelGGL(dssim_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)d_partial, g, d_slots + 3 * k + 2);
+  }
+  if ((rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch"))) return rc;
+  double slots[3 * kDssimScales];
+  if ((rc = check_hip(ctx, hipMemcpyAsync(slots, d_slots, sizeof(double) * 3 * a->n_scales, hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
+  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
+  double ssim_sum = 0.0, weight_sum = 0.0;
+  for (int k = 0; k < a->n_scales; k++) {
+    const double len = (double)a->s[k].w * (double)a->s[k].h;
+    const double score = 1.0 - slots[3 * k + 2] / len;
     ssim_sum += score * kDssimWeights[k];
     weight_sum += kDssimWeights[k];
   }
   const double total = ssim_sum / weight_sum;
   *out = 1.0 / std::fmax(total, 2.220446049250313e-16) - 1.0;
-  return check_hip(ctx, hipGetLastError(), "dssim kernel launch");
+  return MI355_OK;
 }
 
 }  // namespace mi355

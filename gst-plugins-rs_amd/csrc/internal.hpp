@@ -49,6 +49,7 @@ struct mi355_ctx {
   void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
   void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
+  void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
@@ -100,6 +101,8 @@ void loudnorm_release(mi355_ctx *ctx);
 int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width, int height, int channels, mi355_dssim_image **out);
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);
+void dssim_release(mi355_ctx *ctx);
+int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, int channel, int kind, float *out, int *w, int *h);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
 int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);
 int hrtf_reset(mi355_ctx *ctx);

@@ -119,6 +119,7 @@ def load_library():
         "mi355_dssim_create_image_device": (i, [vp, u8p, i, i, i, i, C.POINTER(vp)]),
         "mi355_dssim_free_image": (None, [vp, vp]),
         "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
+        "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_hrtf_load_sphere": (i, [vp, vp, sz, C.c_uint32]),
         "mi355_hrtf_setup": (i, [vp, i, i, i]),
         "mi355_hrtf_reset": (i, [vp]),
@@ -373,6 +374,15 @@ class Context:
 
     def dssim_free_image(self, img):
         self.L.mi355_dssim_free_image(self.h, img)
+
+    def dssim_image_plane(self, img, scale, channel, kind):
+        """kind: 'img' | 'mu' | 'sq' -> (h, w) float32 array copied from the device image."""
+        w, h = C.c_int(0), C.c_int(0)
+        k = {"img": 0, "mu": 1, "sq": 2}[kind]
+        self._ck(self.L.mi355_dssim_image_plane(self.h, img, scale, channel, k, None, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.float32)
+        self._ck(self.L.mi355_dssim_image_plane(self.h, img, scale, channel, k, out.ctypes.data_as(C.POINTER(C.c_float)), None, None))
+        return out
 
     def dssim_compare(self, a, b):
         v = C.c_double(0)

@@ -263,6 +263,10 @@ int mi355_dssim_create_image_device(mi355_ctx *ctx, const uint8_t *d_frame, int 
 void mi355_dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *image);
 int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original,
                         const mi355_dssim_image *modified, double *dssim);
+/* Diagnostics: one f32 plane of the image (kind 0 = LAB plane, 1 = mu, 2 = img_sq_blur) copied to `out` (may be NULL
+ * to query the scale's size only). */
+int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind,
+                            float *out, int *width, int *height);
 
 /* ---------------------------------------------------------------- hrtfrender
  * Replaces the per-block body of HrtfRender::process (audio/hrtf/src/hrtf/imp.rs:164-278) including the calls

@@ -74,3 +74,27 @@ def test_dssim_errors(ctx):
             ctx.dssim_compare(a, b)
     finally:
         ctx.dssim_free_image(a); ctx.dssim_free_image(b)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(128, 96, "RGBA"), (322, 246, "RGBA"), (100, 50, "RGB"), (37, 19, "RGBA")])
+def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
+    """Every plane of every scale (LAB image, mu, img_sq_blur) equals the numpy restatement bit for bit: pins the fused
+    per-scale kernel (tiles, halos, per-pass edge replication) incl. sizes that are not multiples of the tile."""
+    from oracle import dssim_restate as D
+    rng = np.random.default_rng(w * h)
+    ch = 4 if fmt == "RGBA" else 3
+    f = rng.integers(0, 256, (h, w * ch), dtype=np.uint8)
+    if ch == 4:
+        f[:, 3::4] = np.where(rng.random((h, w)) < 0.2, rng.integers(0, 256, (h, w)), 255)   # some translucent pixels (premultiplied)
+    g = ctx.dssim_create_image(f, w * ch, w, h, fmt)
+    o = D.DssimImage(f, w, h, w * ch, ch)
+    try:
+        for s, chans in enumerate(o.scales):
+            for c in range(3):
+                for kind in ("img", "mu", "sq"):
+                    got = ctx.dssim_image_plane(g, s, c, kind)
+                    exp = chans[c][kind]
+                    assert got.shape == exp.shape
+                    assert (got.view(np.uint32) == exp.view(np.uint32)).all(), (s, c, kind, int((got != exp).sum()))
+    finally:
+        ctx.dssim_free_image(g)
