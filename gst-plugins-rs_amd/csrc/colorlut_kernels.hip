@@ -249,7 +249,9 @@ template <int NT, int P4, int S_CONST, int HSV>
 __device__ __forceinline__ void colorlut3d_lds_body(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                     size_t n_groups, const float *__restrict__ planar,
                                                     const uint32_t *__restrict__ axis_tab, int Sy_rt, int Sz_rt,
-                                                    uint32_t plane_floats, int all_resident, HsvK hk) {
+                                                    uint32_t plane_floats, int all_resident_and_stagger, HsvK hk) {
+  const int all_resident = all_resident_and_stagger & 1;
+  const unsigned stagger = (unsigned)all_resident_and_stagger >> 8;  // x256 clock ticks: spread of the per-block start delay (0 = off)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t hsv_sel[HSV == kNoHsv ? 1 : 8];
   if constexpr (HSV != kNoHsv) {
@@ -277,6 +279,14 @@ __device__ __forceinline__ void colorlut3d_lds_body(const uint4 *__restrict__ sr
 
   // Channel order alternates R,G,B / B,G,R from tile to tile so the plane left in LDS by one tile's
   // last pass serves the next tile's first pass: two stagings per tile instead of three.
+  if (stagger) {
+    // De-synchronise the CUs: every block runs the same load / stage / pass / store cycle, so without this all 256 CUs
+    // hit HBM in the same microsecond and then leave it idle together. A per-block start offset (hashed, up to
+    // `stagger` ticks, of the order of one tile period) persists because all tiles take the same time.
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long d = ((unsigned long long)(((blockIdx.x * 2654435769u) >> 16) & 0xffffu) * ((unsigned long long)stagger << 8)) >> 16;
+    while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
   bool flip = false;
   int resident = all_resident ? 3 : -1;  // 3 = "every plane"
   for (size_t round = 0; round < my_rounds; round++) {
@@ -908,7 +918,8 @@ static int launch_lds_variant(mi355_ctx *ctx, const uint4 *src, uint4 *dst, size
   if (grid > min_blocks) grid = min_blocks;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, src, dst, n_groups, (const float *)L.d_planar,
-                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats, L.lds_all_resident ? 1 : 0, hk);
+                     (const uint32_t *)L.d_axis, L.lds_Sy, L.lds_Sz, (uint32_t)L.planar_plane_floats,
+                     (L.lds_all_resident ? 1 : 0) | (ctx->lut_stagger << 8), hk);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_lds kernel launch");
 }
 

@@ -176,6 +176,7 @@ int mi355_ctx_synchronize(mi355_ctx *ctx) {
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   REQUIRE_CTX(ctx);
   if (flag == MI355_FLAG_FORCE_GENERIC) { ctx->force_generic = value != 0; return MI355_OK; }
+  if (flag == MI355_FLAG_LUT_STAGGER && value >= 0 && value <= 4096) { ctx->lut_stagger = value; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 2) { ctx->lut_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }

@@ -53,6 +53,7 @@ struct mi355_ctx {
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
+  int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

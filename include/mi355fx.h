@@ -83,6 +83,7 @@ typedef enum mi355_flag {
   MI355_FLAG_FORCE_GENERIC = 1,
   MI355_FLAG_HSV_BLOCKS_PER_CU = 2, /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
   MI355_FLAG_LUT_VARIANT = 4,  /* colorlut 3D LDS kernel: 0 = default; 1 = next tile prefetched before the last pass; 2 = lean per-pixel state (32 px/lane) */
+  MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
