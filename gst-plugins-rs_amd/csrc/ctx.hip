@@ -568,8 +568,8 @@ int mi355_loudnorm_teardown(mi355_ctx *ctx) {
 
 static int videocompare_channels(mi355_ctx *ctx, int format, int algo, int *channels) {
   if (algo < MI355_HASH_MEAN || algo > MI355_HASH_DSSIM) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: unknown hash-algo");
-  if (algo != MI355_HASH_BLOCKHASH)
-    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: only hash-algo=blockhash is implemented on the device");
+  if (algo == MI355_HASH_DSSIM)
+    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: hash-algo=dssim has no 64-bit hash: use mi355_dssim_create_image / mi355_dssim_compare");
   if (format == MI355_FMT_RGBA) *channels = 4;
   else if (format == MI355_FMT_RGB) *channels = 3;
   else return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: format must be RGB or RGBA");  // pad template caps (imp.rs:167-172)
@@ -587,6 +587,8 @@ int mi355_videocompare_hash_frames_device(mi355_ctx *ctx, const uint8_t *d_frame
   if (!d_frames || !hashes) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: null data");
   if ((size_t)stride < (size_t)width * channels) return set_error(ctx, MI355_ERR_INVALID_ARG, "videocompare: stride smaller than row bytes");
   BIND_DEVICE(ctx);
+  if (algo != MI355_HASH_BLOCKHASH)
+    return launch_imghash(ctx, d_frames, frame_pitch, stride, n_frames, width, height, channels, algo, (unsigned long long *)hashes);
   return launch_blockhash(ctx, d_frames, frame_pitch, stride, n_frames, width, height, channels, (unsigned long long *)hashes);
 }
 
@@ -606,12 +608,15 @@ int mi355_videocompare_hash_frame(mi355_ctx *ctx, const uint8_t *data, int strid
   rc = check_hip(ctx, hipMemcpy2DAsync(ctx->d_stage[0], pitch, data, (size_t)stride, row, (size_t)height, hipMemcpyHostToDevice, ctx->stream),
                  "videocompare H2D");
   if (rc) return rc;
+  if (algo != MI355_HASH_BLOCKHASH)
+    return launch_imghash(ctx, (const uint8_t *)ctx->d_stage[0], pitch * (size_t)height, (int)pitch, 1, width, height, channels, algo,
+                          (unsigned long long *)hash);
   return launch_blockhash(ctx, (const uint8_t *)ctx->d_stage[0], pitch * (size_t)height, (int)pitch, 1, width, height, channels,
                           (unsigned long long *)hash);
 }
 
 double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t frame_hash) {
-  if (algo != MI355_HASH_BLOCKHASH) return -1.0;
+  if (algo < MI355_HASH_MEAN || algo > MI355_HASH_BLOCKHASH) return -1.0;
   return (double)__builtin_popcountll(reference_hash ^ frame_hash);
 }
 

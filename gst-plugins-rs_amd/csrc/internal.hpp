@@ -95,6 +95,8 @@ int ebur128_reset(mi355_ctx *ctx);
 void ebur128_release(mi355_ctx *ctx);
 int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
                      int channels, unsigned long long *hashes);
+int launch_imghash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height, int channels,
+                   int algo, unsigned long long *hashes);
 int loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak, double offset_db);
 int loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out, size_t out_cap_frames, size_t *out_frames);
 int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *out_frames, int *eos);

@@ -13,6 +13,9 @@
 // a workgroup are flushed with one global atomic each. Integer adds: the result is order-independent, bit-exact.
 #include "internal.hpp"
 
+#include <cmath>
+#include <vector>
+
 namespace mi355 {
 
 __device__ __forceinline__ uint32_t sum_px_rgba(uint32_t p) {
@@ -213,6 +216,123 @@ int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch
   rc = check_hip(ctx, hipMemcpyAsync(hashes, d_hashes, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream), "blockhash D2H");
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "blockhash sync");
+}
+
+
+// ------------------------------------------------------------------ resize-based hashes (Mean / Gradient / VertGradient / DoubleGradient)
+// image_hasher 3.1.1 with HasherConfig::new(): grayscale (integer luma), image::imageops::resize with Lanczos3 to
+// 8x8 / 9x8 / 8x9 / 5x5 (vertical_sample to f32, then horizontal_sample with clamp + round), then the bit rule
+// (restated in oracle/imghash_oracle.c; parity unpinned). The filter weights are computed on the host exactly as
+// the crate does (f32, sinf) and the two sampling passes accumulate in the crate's order, one lane per output sample:
+//   imghash_vertical_kernel   one lane per (frame, output row, column): sum over ~3*height/rows input rows of luma*w
+//   imghash_finish_kernel     one lane per output pixel: horizontal sum, clamp, round; lane 0 packs the bits
+struct ImgHashW {            // per output sample: first input index, tap count, offset into the weight array
+  int left[9], count[9], offset[9];
+};
+
+__global__ __launch_bounds__(256) void imghash_vertical_kernel(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride, int channels, int width,
+                                                               ImgHashW vw, const float *__restrict__ weights, int rh, float *__restrict__ tmp) {
+  const int x = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, f = blockIdx.z;
+  if (x >= width) return;
+  const float *w = weights + vw.offset[oy];
+  const int n = vw.count[oy];
+  const uint8_t *p = frames + (size_t)f * frame_pitch + (size_t)vw.left[oy] * stride + (size_t)x * channels;
+  float t = 0.0f;
+  for (int i = 0; i < n; i++, p += stride) {
+    const uint32_t l = (2126u * p[0] + 7152u * p[1] + 722u * p[2]) / 10000u;
+    t += (float)l * w[i];
+  }
+  tmp[((size_t)f * rh + oy) * width + x] = t;
+}
+
+__global__ __launch_bounds__(128) void imghash_finish_kernel(const float *__restrict__ tmp, int width, ImgHashW hw, const float *__restrict__ weights, int rw,
+                                                             int rh, int algo, unsigned long long *__restrict__ hashes) {
+  __shared__ uint8_t img[81];
+  const int f = blockIdx.x, e = threadIdx.x;
+  if (e < rw * rh) {
+    const int y = e / rw, ox = e - y * rw;
+    const float *w = weights + hw.offset[ox];
+    const float *row = tmp + ((size_t)f * rh + y) * width + hw.left[ox];
+    float t = 0.0f;
+    for (int i = 0; i < hw.count[ox]; i++) t += row[i] * w[i];
+    t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+    img[e] = (uint8_t)roundf(t);
+  }
+  __syncthreads();
+  if (e == 0) {
+    unsigned long long h = 0;
+    int nb = 0;
+    if (algo == 0) {
+      uint32_t sum = 0;
+      for (int i = 0; i < 64; i++) sum += img[i];
+      const uint8_t mean = (uint8_t)(sum / 64u);
+      for (int i = 0; i < 64; i++, nb++) if (img[i] >= mean) h |= 1ull << nb;
+    } else if (algo == 1 || algo == 3) {
+      for (int y = 0; y < rh; y++) for (int x = 0; x + 1 < rw; x++, nb++) if (img[y * rw + x] < img[y * rw + x + 1]) h |= 1ull << nb;
+      if (algo == 3) for (int y = 0; y + 1 < rh; y++) for (int x = 0; x < rw; x++, nb++) if (img[y * rw + x] < img[(y + 1) * rw + x]) h |= 1ull << nb;
+    } else {
+      for (int y = 0; y + 1 < rh; y++) for (int x = 0; x < rw; x++, nb++) if (img[y * rw + x] < img[(y + 1) * rw + x]) h |= 1ull << nb;
+    }
+    hashes[f] = h;
+  }
+}
+
+static float ih_sinc(float t) { const float a = t * 3.14159265358979323846f; return t == 0.0f ? 1.0f : sinf(a) / a; }
+static float ih_lanczos3(float x) { return fabsf(x) < 3.0f ? ih_sinc(x) * ih_sinc(x / 3.0f) : 0.0f; }
+
+// image::imageops::sample weights for `out` samples over `in` inputs (same f32 expressions as the crate)
+static void ih_weights(int in, int out, ImgHashW *W, std::vector<float> *all) {
+  const float ratio = (float)in / (float)out;
+  const float sratio = ratio < 1.0f ? 1.0f : ratio;
+  const float support = 3.0f * sratio;
+  for (int o = 0; o < out; o++) {
+    float centre = ((float)o + 0.5f) * ratio;
+    long left = (long)floorf(centre - support);
+    if (left < 0) left = 0;
+    if (left > in - 1) left = in - 1;
+    long right = (long)ceilf(centre + support);
+    if (right < left + 1) right = left + 1;
+    if (right > in) right = in;
+    centre = centre - 0.5f;
+    const size_t off = all->size();
+    float sum = 0.0f;
+    for (long i = left; i < right; i++) { const float w = ih_lanczos3(((float)i - centre) / sratio); all->push_back(w); sum += w; }
+    for (size_t i = off; i < all->size(); i++) (*all)[i] /= sum;
+    W->left[o] = (int)left; W->count[o] = (int)(right - left); W->offset[o] = (int)off;
+  }
+}
+
+// algo 0..3 as GstVideoCompareHashAlgorithm; `hashes` is a HOST array of n_frames u64
+int launch_imghash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height, int channels,
+                   int algo, unsigned long long *hashes) {
+  int rw, rh;
+  switch (algo) { case 0: rw = 8; rh = 8; break; case 1: rw = 9; rh = 8; break; case 2: rw = 8; rh = 9; break; default: rw = 5; rh = 5; break; }
+  ImgHashW vw, hw;
+  std::vector<float> wts;
+  ih_weights(height, rh, &vw, &wts);
+  ih_weights(width, rw, &hw, &wts);
+  // scratch (slot 1): weights | tmp [n_frames][rh][width] f32 | hashes
+  const size_t wbytes = (wts.size() * 4 + 15) & ~(size_t)15, tbytes = (size_t)n_frames * rh * width * 4;
+  const size_t need = wbytes + tbytes + (size_t)n_frames * 8;
+  if (ctx->d_stage_bytes[1] < need) {
+    if (ctx->d_stage[1]) (void)hipFree(ctx->d_stage[1]);
+    ctx->d_stage[1] = nullptr; ctx->d_stage_bytes[1] = 0;
+    int rc = check_hip(ctx, hipMalloc(&ctx->d_stage[1], need), "hipMalloc(imghash scratch)");
+    if (rc) return rc;
+    ctx->d_stage_bytes[1] = need;
+  }
+  float *d_w = (float *)ctx->d_stage[1];
+  float *d_tmp = (float *)((char *)ctx->d_stage[1] + wbytes);
+  unsigned long long *d_h = (unsigned long long *)((char *)d_tmp + tbytes);
+  int rc = check_hip(ctx, hipMemcpyAsync(d_w, wts.data(), wts.size() * 4, hipMemcpyHostToDevice, ctx->stream), "imghash: weights H2D");
+  if (rc) return rc;
+  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "imghash: sync"))) return rc;  // wts is a local vector
+  hipLaunchKernelGGL(imghash_vertical_kernel, dim3((width + 255) / 256, rh, n_frames), dim3(256), 0, ctx->stream, d_frames, frame_pitch, stride, channels, width,
+                     vw, (const float *)d_w, rh, d_tmp);
+  hipLaunchKernelGGL(imghash_finish_kernel, dim3(n_frames), dim3(128), 0, ctx->stream, (const float *)d_tmp, width, hw, (const float *)d_w, rw, rh, algo, d_h);
+  if ((rc = check_hip(ctx, hipGetLastError(), "imghash kernel launch"))) return rc;
+  if ((rc = check_hip(ctx, hipMemcpyAsync(hashes, d_h, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream), "imghash D2H"))) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "imghash sync");
 }
 
 }  // namespace mi355

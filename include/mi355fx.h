@@ -236,8 +236,10 @@ int mi355_loudnorm_teardown(mi355_ctx *ctx);
  * Replaces HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79) for
  * HashAlgorithm::Blockhash, the element default (videocompare/imp.rs:31): image_hasher 3.1.1 blockhash, 8x8 bits, on
  * the packed RGB / RGBA frame (rows addressed by `stride`, which covers tightly_packed_framebuffer :110-130).
- * `algo` takes GstVideoCompareHashAlgorithm values (videocompare/mod.rs:60-100); every other algorithm and frame
- * sizes not divisible by 8 return MI355_ERR_UNSUPPORTED. A hash is the 64 block bits, bit i = block i row-major. */
+ * `algo` takes GstVideoCompareHashAlgorithm values (videocompare/mod.rs:60-100). Blockhash needs frame sizes divisible
+ * by 8 (else MI355_ERR_UNSUPPORTED); its hash is the 64 block bits, bit i = block i row-major. Mean / Gradient /
+ * VertGradient / DoubleGradient (grayscale + Lanczos3 resize of the `image` crate + bit rule) give 64/64/64/40 bits in the
+ * crate's iteration order. Dssim has no hash: see mi355_dssim_* below. */
 typedef enum mi355_hash_algo {
   MI355_HASH_MEAN = 0, MI355_HASH_GRADIENT = 1, MI355_HASH_VERTGRADIENT = 2, MI355_HASH_DOUBLEGRADIENT = 3,
   MI355_HASH_BLOCKHASH = 4, MI355_HASH_DSSIM = 5

@@ -94,6 +94,7 @@ def lib():
     L.oracle_blockhash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.oracle_hash_distance.restype = C.c_double
     L.oracle_hash_distance.argtypes = [C.c_uint64, C.c_uint64]
+    L.oracle_imghash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
     L.oracle_loudnorm_new.restype = C.c_void_p
     L.oracle_loudnorm_new.argtypes = [C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double]
     L.oracle_loudnorm_free.argtypes = [C.c_void_p]
@@ -452,3 +453,16 @@ class LoudNorm:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.oracle_loudnorm_free(self.h)
             self.h = None
+
+
+IMGHASH_ALGO = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3}
+
+
+def imghash(frame, width, height, stride, channels, algo):
+    """image_hasher Mean / Gradient / VertGradient / DoubleGradient (8x8 config, Lanczos3): (hash bits as int, n_bits, resized u8 image)."""
+    a = np.ascontiguousarray(frame, dtype=np.uint8)
+    h = C.c_uint64(0)
+    small = np.zeros(81, np.uint8)
+    nb = lib().oracle_imghash(a.ctypes.data, width, height, stride, channels, IMGHASH_ALGO[algo], C.byref(h), small.ctypes.data)
+    dims = {"mean": (8, 8), "gradient": (8, 9), "vertgradient": (9, 8), "doublegradient": (5, 5)}[algo]   # (rows, cols)
+    return h.value, nb, small[: dims[0] * dims[1]].reshape(dims)

@@ -69,10 +69,9 @@ def test_config5_batch_of_4k_streams_on_device(ctx, oracle):
 def test_unsupported_and_errors(ctx):
     import mi355fx
     f = np.zeros((16, 64), np.uint8)
-    for algo in ("mean", "gradient", "vertgradient", "doublegradient", "dssim"):
-        with pytest.raises(mi355fx.Mi355Error) as e:
-            ctx.videocompare_hash_frame(f, 64, 16, 16, "RGBA", algo)
-        assert e.value.status == mi355fx.ERR_UNSUPPORTED
+    with pytest.raises(mi355fx.Mi355Error) as e:      # Dssim has no 64-bit hash (mi355_dssim_* is its API)
+        ctx.videocompare_hash_frame(f, 64, 16, 16, "RGBA", "dssim")
+    assert e.value.status == mi355fx.ERR_UNSUPPORTED
     with pytest.raises(mi355fx.Mi355Error) as e:      # fast path only
         ctx.videocompare_hash_frame(np.zeros((16, 60), np.uint8), 60, 15, 16, "RGBA")
     assert e.value.status == mi355fx.ERR_UNSUPPORTED
@@ -80,3 +79,28 @@ def test_unsupported_and_errors(ctx):
         ctx.videocompare_hash_frame(f, 64, 16, 16, "BGRx")
     assert e.value.status == mi355fx.ERR_INVALID_ARG
     assert ctx.videocompare_distance(1, 2, "dssim") < 0
+    assert ctx.videocompare_distance(0b1011, 0b0001, "gradient") == 2.0
+
+
+@pytest.mark.parametrize("algo,bits", [("mean", 64), ("gradient", 64), ("vertgradient", 64), ("doublegradient", 40)])
+@pytest.mark.parametrize("w,h,c", [(640, 360, 4), (3840, 2160, 4), (101, 57, 3), (8, 9, 4), (5, 4, 3)])
+def test_resize_based_hashes_match_oracle(ctx, oracle, algo, bits, w, h, c):
+    """image_hasher Mean / Gradient / VertGradient / DoubleGradient: integer luma, Lanczos3 resize in the image crate's
+    f32 accumulation order, bit rule — bit-exact against the C restatement (same libm sinf for the weights), including
+    up-sampling cases (frames smaller than the hash grid)."""
+    rng = np.random.default_rng(w * 3 + h + c)
+    yy, xx = np.mgrid[0:h, 0:w]
+    f = np.zeros((h, w, c), np.uint8)
+    f[..., 0] = (xx * 255 // max(w - 1, 1)) ^ rng.integers(0, 32, (h, w))
+    f[..., 1] = (yy * 255 // max(h - 1, 1))
+    f[..., 2] = rng.integers(0, 256, (h, w))
+    if c == 4:
+        f[..., 3] = 255
+    frame = f.reshape(h, w * c)
+    exp, nb, small = oracle.imghash(frame, w, h, w * c, c, algo)
+    assert nb == bits
+    got = ctx.videocompare_hash_frame(frame, w * c, w, h, "RGBA" if c == 4 else "RGB", algo)
+    assert got == exp, (hex(got), hex(exp))
+    other = frame[::-1].copy()
+    assert ctx.videocompare_distance(got, ctx.videocompare_hash_frame(other, w * c, w, h, "RGBA" if c == 4 else "RGB", algo), algo) == \
+        oracle.hash_distance(exp, oracle.imghash(other, w, h, w * c, c, algo)[0])

@@ -54,3 +54,26 @@ def test_rgb_and_stride(oracle):
     assert oracle.blockhash(rgb, 40, 48, 120, 3) == oracle.blockhash(padded, 40, 48, 133, 3)
     with pytest.raises(ValueError):
         oracle.blockhash(rgb, 39, 48, 120, 3)
+
+
+def test_resize_based_hashes_basic_properties(oracle):
+    """Mean/Gradient/VertGradient/DoubleGradient restatement (oracle/imghash_oracle.c): bit counts, a horizontal ramp has
+    all Gradient bits set and no VertGradient bits, identical frames have distance 0."""
+    w, h = 320, 200
+    ramp = np.zeros((h, w, 4), np.uint8)
+    ramp[..., 0] = ramp[..., 1] = ramp[..., 2] = (np.arange(w) * 255 // (w - 1))[None, :]
+    ramp[..., 3] = 255
+    f = ramp.reshape(h, w * 4)
+    hg, nb, small = oracle.imghash(f, w, h, w * 4, 4, "gradient")
+    assert nb == 64 and hg == 0xFFFFFFFFFFFFFFFF and small.shape == (8, 9)
+    assert (np.diff(small.astype(int), axis=1) > 0).all()
+    hv, nb, _ = oracle.imghash(f, w, h, w * 4, 4, "vertgradient")
+    assert nb == 64 and hv == 0
+    hd, nb, _ = oracle.imghash(f, w, h, w * 4, 4, "doublegradient")
+    assert nb == 40 and hd == (1 << 20) - 1          # 5 rows x 4 gradient bits set, 4 x 5 vertical bits clear
+    hm, nb, sm = oracle.imghash(f, w, h, w * 4, 4, "mean")
+    assert nb == 64 and bin(hm).count("1") in (32, 40)  # right half (>= mean) of every row
+    assert oracle.hash_distance(hg, oracle.imghash(f.copy(), w, h, w * 4, 4, "gradient")[0]) == 0.0
+    # resizing a constant image returns the constant (weights are normalised)
+    const = np.full((64, 64 * 3), 77, np.uint8)
+    assert (oracle.imghash(const, 64, 64, 192, 3, "mean")[2] == 77).all()
