@@ -1,0 +1,16 @@
+#!/bin/bash
+# tools/bench_all.sh <tag> — run ON THE GPU BOX (via gpurun): every per-config bench tool, outputs collected into
+# gpurun_out/configs_<tag>.jsonl (one JSON object per line, tagged with the tool name). Copy into profiles/ afterwards:
+#   cp gpurun_out/configs_<tag>.jsonl gpurun_out/configs_<tag>_elements.txt profiles/
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/configs_$TAG.jsonl
+mkdir -p "$R/gpurun_out"; : > "$OUT"
+python3 "$R/tools/bench_elements.py" 2>/dev/null > "$R/gpurun_out/configs_${TAG}_elements.txt"
+for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_pipeline bench_streams; do
+  echo "== $t" >&2
+  python3 "$R/tools/$t.py" 2>/dev/null | grep '^{' | tail -1 | sed "s/^{/{\"tool\": \"$t\", /" >> "$OUT"
+done
+python3 "$R/tools/bench_hrtf.py" --taps 512 --no-cpu 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench_hrtf_512taps", /' >> "$OUT"
+wc -l "$OUT" >&2
