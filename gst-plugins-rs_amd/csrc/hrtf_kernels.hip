@@ -187,7 +187,15 @@ __global__ __launch_bounds__(256) void hrtf_mix_kernel(const float *__restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;  // index into [frames][2]
   if (i >= 2 * frames) return;
   float acc = 0.0f;
-  for (int c = 0; c < C; c++) acc += partial[(size_t)c * frames * 2 + i];
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {  // eight independent loads in flight, added in channel order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(c + u) * frames * 2 + i];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += v[u];
+  }
+  for (; c < C; c++) acc += partial[(size_t)c * frames * 2 + i];
   out[i] = acc;
 }
 
