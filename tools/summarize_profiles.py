@@ -48,6 +48,11 @@ def main():
             wb = w.get(k, (0.0, 0))[0] * 1024
             out["kernels"][short] = {"fetch_size_kib_raw": f[k][0], "write_size_kib_raw": w.get(k, (0.0, 0))[0],
                                      "hbm_read_bytes": fb, "hbm_write_bytes": wb, "hbm_bytes": fb + wb, "launches_sampled": f[k][1]}
+    b0 = os.path.join(src, "bench.json")
+    try:
+        out["frames_per_step"] = json.load(open(b0))["config"]["frames_per_step"]   # the PMC passes ran the same default workload
+    except (OSError, ValueError, KeyError):
+        out["frames_per_step"] = None
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     shutil.copy(os.path.join(dst, tag + "_pmc.json"), os.path.join(dst, "pmc_latest.json"))
     b = os.path.join(src, "bench.json")
