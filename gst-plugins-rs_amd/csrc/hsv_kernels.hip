@@ -277,6 +277,36 @@ __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__rest
   }
 }
 
+// Same for the 3-byte input formats (RGB / BGR): one lane reads 12 B = 4 pixels as three dwords, splits them into four
+// pixel words (byte 3 = scratch) and writes 16 B.
+template <bool IN_BGR>
+__global__ __launch_bounds__(256) void hsvdetect_rgb24_kernel(const Rgb24x4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_grp, HsvDetK k,
+                                                              uint32_t out_sel) {
+  constexpr int RPOS = IN_BGR ? 2 : 0, GPOS = 1, BPOS = IN_BGR ? 0 : 2;
+  const float off = 180.0f - k.hue_ref;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grp; i += stride) {
+    const Rgb24x4 v = src[i];
+    const uint32_t in[4] = {v.d0, (v.d0 >> 24) | (v.d1 << 8), (v.d1 >> 16) | (v.d2 << 16), v.d2 >> 8};
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      f2 h, s, vv;
+      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS>(in[j], in[j + 1], h, s, vv);
+      f2 sh = h + splat2(off);
+      const f2 u = sh - splat2(360.0f);
+      sh.x = (u.x >= 0.0f) ? u.x : sh.x;
+      sh.y = (u.y >= 0.0f) ? u.y : sh.y;
+      const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = vv - splat2(k.val_ref);
+      const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
+      const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;
+      out[j] = __builtin_amdgcn_perm(in[j], hit0 ? 255u : 0u, out_sel);
+      out[j + 1] = __builtin_amdgcn_perm(in[j + 1], hit1 ? 255u : 0u, out_sel);
+    }
+    dst[i] = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                      const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                      int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,
@@ -307,6 +337,23 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
     else if (sfmt.first == 1 && !sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<1, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
     else hipLaunchKernelGGL((hsvdetect_flat_kernel<1, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
     return check_hip(ctx, hipGetLastError(), "hsvdetect flat kernel launch");
+  }
+  const size_t row3 = (size_t)width * 3;
+  const bool contiguous3 = sfmt.pixel_stride == 3 && sfmt.first == 0 && (size_t)src_stride == row3 && (size_t)dst_stride == row_bytes &&
+                           (n_frames == 1 || (src_pitch == row3 * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+  if (fast && contiguous3 && ((uintptr_t)d_src % 4 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total % 4 == 0)) {
+    const int in_pos[3] = {sfmt.bgr ? 2 : 0, 1, sfmt.bgr ? 0 : 2};
+    const int cbase = dst_alpha_first ? 1 : 0;
+    uint32_t sel = 0;
+    for (int c = 0; c < 3; c++) {
+      const int out_byte = cbase + (dst_bgr ? 2 - c : c);
+      sel |= (uint32_t)(4 + in_pos[c]) << (8 * out_byte);
+    }
+    const size_t n_grp = total / 4;
+    const int fgrid = grid_for(ctx, n_grp, 256, 64);
+    if (sfmt.bgr) hipLaunchKernelGGL((hsvdetect_rgb24_kernel<true>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    else hipLaunchKernelGGL((hsvdetect_rgb24_kernel<false>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    return check_hip(ctx, hipGetLastError(), "hsvdetect rgb24 kernel launch");
   }
   const int grid = grid_for(ctx, total, 256, 32);
   hipLaunchKernelGGL(hsvdetect_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_src, src_pitch, src_stride,

@@ -633,3 +633,19 @@ def test_colorlut_kernel_variants_allcolors(ctx, oracle, synth, variant, size):
     got = np.zeros_like(ac)
     ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("st", [(0.0, 10.0, 0.0, 0.15, 0.0, 0.3), (120.0, 40.0, 0.8, 0.5, 0.7, 0.6), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5)])
+@pytest.mark.parametrize("in_fmt,out_fmt", [("RGB", "RGBA"), ("BGR", "ARGB"), ("RGB", "ABGR"), ("BGR", "BGRA")])
+def test_hsvdetect_rgb24_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
+    """3-byte input formats on every colour: the 12-byte vector kernel (and the literal kernel for hue-ref outside
+    [-180,180]) against the oracle."""
+    bgr = in_fmt == "BGR"
+    af, obgr = {"RGBA": (0, 0), "ARGB": (1, 0), "BGRA": (0, 1), "ABGR": (1, 1)}[out_fmt]
+    rgb = synth.allcolors().reshape(-1, 4)[:, :3]
+    src = np.ascontiguousarray(rgb[:, ::-1] if bgr else rgb).reshape(4096, 4096 * 3)
+    exp = np.zeros((4096, 4096 * 4), np.uint8)
+    oracle.hsvdetect(src, 4096 * 3, 3, 0, bgr, exp, 4096 * 4, bool(af), bool(obgr), 4096, st)
+    got = np.zeros_like(exp)
+    ctx.hsvdetect_frame(src, 4096 * 3, in_fmt, got, 4096 * 4, out_fmt, 4096, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
