@@ -43,7 +43,6 @@ struct HrtfState {
   int *d_face = nullptr;         // [C][S] face index or -1 (diagnostics/tests)
   float *d_uvw = nullptr;        // [C][S][3]
   float *d_partial = nullptr;    // [C][frames][2]
-  float *d_vecgain = nullptr;    // [4][C][... ] prev_vec[C][3], new_vec[C][3], prev_gain[C], new_gain[C]
   float *d_in = nullptr, *d_out = nullptr;  // staging for the host entry point
   std::vector<float> prev_vec, prev_gain;
   std::vector<unsigned char> have_prev;
@@ -83,17 +82,21 @@ __device__ __forceinline__ bool ray_face(V3 dir, V3 a, V3 b, V3 c, float &u, flo
   return true;
 }
 
+// previous / new direction and gain of every channel, passed by value in the kernel arguments (<= 64 channels: 2 KiB)
+struct HrtfVecGain { float v[8 * 64]; };  // prev_vec[C][3], new_vec[C][3], prev_gain[C], new_gain[C] with C = channels
+
 // One block per channel.
 __global__ __launch_bounds__(256) void hrtf_prepare_kernel(const float *__restrict__ in, int C, int S, int B, int L,
                                                            const float *__restrict__ pos, const uint32_t *__restrict__ idx, int F,
-                                                           const float *__restrict__ hrir, const float *__restrict__ vecgain,
+                                                           const float *__restrict__ hrir, HrtfVecGain VG,
                                                            const float *__restrict__ x_old, float *__restrict__ x_new,
                                                            float *__restrict__ taps, float *__restrict__ last_taps,
                                                            float *__restrict__ gain, int *__restrict__ face_out, float *__restrict__ uvw_out) {
   const int c = blockIdx.x;
   const int frames = S * B, pad = L - 1;
-  const float *pv = vecgain + 3 * c, *nv = vecgain + 3 * C + 3 * c;
-  const float pg = vecgain[6 * C + c], ng = vecgain[7 * C + c];
+  const float pv[3] = {VG.v[3 * c], VG.v[3 * c + 1], VG.v[3 * c + 2]};
+  const float nv[3] = {VG.v[3 * C + 3 * c], VG.v[3 * C + 3 * c + 1], VG.v[3 * C + 3 * c + 2]};
+  const float pg = VG.v[6 * C + c], ng = VG.v[7 * C + c];
   __shared__ int s_face[64];
   __shared__ float s_uvw[64][3];
   // ---- mesh lookup: one wave-sized group of lanes per step scans the faces in file order; the FIRST hit wins
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void hrtf_mix_kernel(const float *__restrict__
 
 static void hrtf_free_processors(HrtfState *H) {
   for (int i = 0; i < 2; i++) { if (H->d_x[i]) (void)hipFree(H->d_x[i]); H->d_x[i] = nullptr; }
-  float **fp[] = {&H->d_taps, &H->d_last_taps, &H->d_gain, &H->d_uvw, &H->d_partial, &H->d_vecgain, &H->d_in, &H->d_out};
+  float **fp[] = {&H->d_taps, &H->d_last_taps, &H->d_gain, &H->d_uvw, &H->d_partial, &H->d_in, &H->d_out};
   for (auto p : fp) { if (*p) (void)hipFree(*p); *p = nullptr; }
   if (H->d_face) (void)hipFree(H->d_face);
   H->d_face = nullptr;
@@ -279,7 +282,7 @@ int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps) {
     if ((rc = check_hip(ctx, hipMemset(H->d_x[i], 0, C * (pad + frames) * 4), "hipMemset(hrtf input rows)"))) return rc;
   }
   struct { float **p; size_t n; } bufs[] = {{&H->d_taps, C * S * 2 * L}, {&H->d_last_taps, C * 2 * L}, {&H->d_gain, C * S}, {&H->d_uvw, C * S * 3},
-                                            {&H->d_partial, C * frames * 2}, {&H->d_vecgain, 8 * C}, {&H->d_in, frames * C}, {&H->d_out, frames * 2}};
+                                            {&H->d_partial, C * frames * 2}, {&H->d_in, frames * C}, {&H->d_out, frames * 2}};
   for (auto &b : bufs) {
     if ((rc = check_hip(ctx, hipMalloc(b.p, b.n * 4 + 4), "hipMalloc(hrtf state)"))) return rc;
     if ((rc = check_hip(ctx, hipMemset(*b.p, 0, b.n * 4), "hipMemset(hrtf state)"))) return rc;
@@ -309,25 +312,21 @@ int hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, c
   HrtfState *H = hrtf_of(ctx);
   if (!H || !H->configured) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "hrtfrender: not negotiated (setup not called)");
   const int C = H->channels, S = H->steps, B = H->block_len, L = (int)H->len, frames = S * B;
-  std::vector<float> vg((size_t)8 * C);
+  HrtfVecGain vg;
   for (int c = 0; c < C; c++) {
     const float *nv = positions + 3 * c;
     const float *pv = H->have_prev[c] ? &H->prev_vec[3 * c] : nv;  // prev_sample_vector.unwrap_or(new) (imp.rs:236)
-    for (int j = 0; j < 3; j++) { vg[3 * c + j] = pv[j]; vg[3 * C + 3 * c + j] = nv[j]; }
-    vg[6 * C + c] = H->have_prev[c] ? H->prev_gain[c] : gains[c];
-    vg[7 * C + c] = gains[c];
+    for (int j = 0; j < 3; j++) { vg.v[3 * c + j] = pv[j]; vg.v[3 * C + 3 * c + j] = nv[j]; }
+    vg.v[6 * C + c] = H->have_prev[c] ? H->prev_gain[c] : gains[c];
+    vg.v[7 * C + c] = gains[c];
   }
-  int rc = check_hip(ctx, hipMemcpyAsync(H->d_vecgain, vg.data(), vg.size() * 4, hipMemcpyHostToDevice, ctx->stream), "upload hrtf vectors");
-  if (rc) return rc;
-  rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "hrtf vector upload sync");  // vg is a stack-lifetime host buffer
-  if (rc) return rc;
   float *x_old = H->d_x[H->cur], *x_new = H->d_x[H->cur ^ 1];
   hipLaunchKernelGGL(hrtf_prepare_kernel, dim3(C), dim3(256), 0, ctx->stream, d_in, C, S, B, L, (const float *)H->d_pos, (const uint32_t *)H->d_idx,
-                     (int)H->n_faces, (const float *)H->d_hrir, (const float *)H->d_vecgain, (const float *)x_old, x_new, H->d_taps, H->d_last_taps,
+                     (int)H->n_faces, (const float *)H->d_hrir, vg, (const float *)x_old, x_new, H->d_taps, H->d_last_taps,
                      H->d_gain, H->d_face, H->d_uvw);
   const int T = B < 1024 ? B : 1024, tiles = (B + T - 1) / T;
   const size_t lds = (size_t)(T + (L - 1) + 2 * L) * 4;
-  rc = check_hip(ctx, hipFuncSetAttribute((const void *)hrtf_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(hrtf fir LDS)");
+  int rc = check_hip(ctx, hipFuncSetAttribute((const void *)hrtf_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(hrtf fir LDS)");
   if (rc) return rc;
   hipLaunchKernelGGL(hrtf_fir_kernel, dim3(S * tiles, C), dim3(256), lds, ctx->stream, (const float *)x_new, (const float *)H->d_taps,
                      (const float *)H->d_gain, H->d_partial, S, B, L, T, tiles);
