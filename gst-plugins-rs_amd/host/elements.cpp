@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 
 #include "mi355fx_host.h"
 
@@ -924,6 +925,136 @@ bool AudioLoudNorm::stop() {
   return true;
 }
 
+// ------------------------------------------------------------------ RoundedCorners
+
+RoundedCorners::RoundedCorners(int device) : Element(device) {}
+RoundedCorners::~RoundedCorners() {
+  if (cairo_) dlclose(cairo_);
+}
+
+const ElementMetadata &RoundedCorners::metadata() const {
+  static const ElementMetadata m{"Rounded Corners", "Filter/Effect/Converter/Video", "Adds rounded corners to video",
+                                 "Sanchayan Maity <sanchayan@asymptotic.io>"};
+  return m;
+}
+
+const std::vector<ParamSpec> &RoundedCorners::properties() const {
+  static const std::vector<ParamSpec> p = [] {
+    ParamSpec s;
+    s.name = "border-radius-px"; s.nick = "Border radius in pixels"; s.blurb = "Draw rounded corners with given border radius";
+    s.type = PropType::UInt64;  // guint in the reference
+    s.def_num = 0; s.min_num = 0; s.max_num = 4294967295.0; s.mutability = Mutability::Playing;
+    return std::vector<ParamSpec>{s};
+  }();
+  return p;
+}
+
+bool RoundedCorners::store_u64(const std::string &n, uint64_t v) {
+  if (n != "border-radius-px") return false;
+  if (border_radius_px_ != (uint32_t)v) {  // imp.rs:296-308: remember the change, renegotiate
+    changed_ = true;
+    border_radius_px_ = (uint32_t)v;
+  }
+  return true;
+}
+bool RoundedCorners::load_u64(const std::string &n, uint64_t *v) const {
+  if (n != "border-radius-px") return false;
+  *v = border_radius_px_;
+  return true;
+}
+
+std::vector<int> RoundedCorners::transform_caps_to_src() const {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  if (border_radius_px_ == 0) return {100, 101};
+  return {101};
+}
+
+bool RoundedCorners::set_caps(int width, int height, int out_format) {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  have_state_ = false;
+  if (width <= 0 || height <= 0 || (out_format != 100 && out_format != 101)) { last_error_ = "Failed to parse output caps"; return false; }
+  if (out_format == 100) { passthrough_ = true; return true; }
+  passthrough_ = false;
+  width_ = width; height_ = height;
+  alpha_stride_ = (width + 3) & ~3;                         // GstVideoInfo: A420 plane 3 stride = GST_ROUND_UP_4(width)
+  const size_t ru2_height = ((size_t)height + 1) & ~(size_t)1;
+  alpha_mem_.assign((size_t)alpha_stride_ * ru2_height, 0);  // alpha_mem_size (imp.rs:469-470)
+  have_state_ = true;
+  changed_ = true;
+  return true;
+}
+
+// generate_alpha_mask + draw_rounded_corners (imp.rs:57-180) with the C API of the same library the cairo crate binds
+bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
+  if (radius == 0) { std::fill(alpha_mem_.begin(), alpha_mem_.end(), 0xff); return true; }
+  std::fill(alpha_mem_.begin(), alpha_mem_.end(), 0);
+  if (!cairo_) cairo_ = dlopen("libcairo.so.2", RTLD_NOW | RTLD_LOCAL);
+  if (!cairo_) { last_error_ = "Failed to create cairo image surface: libcairo.so.2 not found"; return false; }
+  typedef void *(*surf_create_t)(unsigned char *, int, int, int, int);
+  typedef void *(*create_t)(void *);
+  typedef void (*v_t)(void *);
+  typedef void (*arc_t)(void *, double, double, double, double, double);
+  typedef void (*rgb_t)(void *, double, double, double);
+  typedef void (*rgba_t)(void *, double, double, double, double);
+  typedef void (*lw_t)(void *, double);
+  typedef int (*status_t)(void *);
+  auto sym = [&](const char *n) { return dlsym(cairo_, n); };
+  auto surf_create = (surf_create_t)sym("cairo_image_surface_create_for_data");
+  auto create = (create_t)sym("cairo_create");
+  auto new_sub_path = (v_t)sym("cairo_new_sub_path"), close_path = (v_t)sym("cairo_close_path"), fill_preserve = (v_t)sym("cairo_fill_preserve");
+  auto stroke = (v_t)sym("cairo_stroke"), destroy = (v_t)sym("cairo_destroy"), surf_flush = (v_t)sym("cairo_surface_flush"), surf_destroy = (v_t)sym("cairo_surface_destroy");
+  auto arc = (arc_t)sym("cairo_arc");
+  auto set_rgb = (rgb_t)sym("cairo_set_source_rgb");
+  auto set_rgba = (rgba_t)sym("cairo_set_source_rgba");
+  auto set_lw = (lw_t)sym("cairo_set_line_width");
+  auto surf_status = (status_t)sym("cairo_surface_status"), cr_status = (status_t)sym("cairo_status");
+  if (!surf_create || !create || !new_sub_path || !close_path || !fill_preserve || !stroke || !destroy || !surf_flush || !surf_destroy || !arc || !set_rgb ||
+      !set_rgba || !set_lw || !surf_status || !cr_status) { last_error_ = "Failed to create cairo image surface: symbols missing"; return false; }
+  void *surface = surf_create(alpha_mem_.data(), 2 /* CAIRO_FORMAT_A8 */, width_, height_, alpha_stride_);
+  if (!surface || surf_status(surface) != 0) { last_error_ = "Failed to create cairo image surface"; if (surface) surf_destroy(surface); return false; }
+  void *cr = create(surface);
+  const double r = (double)radius, w = (double)width_, h = (double)height_, deg = 3.14159265358979323846 / 180.0;
+  new_sub_path(cr);
+  arc(cr, w - r, r, r, -90.0 * deg, 0.0 * deg);
+  arc(cr, w - r, h - r, r, 0.0 * deg, 90.0 * deg);
+  arc(cr, r, h - r, r, 90.0 * deg, 180.0 * deg);
+  arc(cr, r, r, r, 180.0 * deg, 270.0 * deg);
+  close_path(cr);
+  set_rgb(cr, 0.0, 0.0, 0.0);
+  fill_preserve(cr);
+  set_rgba(cr, 0.0, 0.0, 0.0, 1.0);
+  set_lw(cr, 1.0);
+  stroke(cr);
+  const bool ok = cr_status(cr) == 0;
+  destroy(cr);
+  surf_flush(surface);
+  surf_destroy(surface);
+  if (!ok) last_error_ = "Failed to draw rounded corners";
+  return ok;
+}
+
+FlowReturn RoundedCorners::prepare_output_buffer(const uint8_t **alpha, size_t *size, int *stride) {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  if (passthrough_) { if (alpha) *alpha = nullptr; if (size) *size = 0; if (stride) *stride = 0; return FlowReturn::Ok; }
+  if (!have_state_) { last_error_ = "roundedcorners: not negotiated"; return FlowReturn::NotNegotiated; }
+  if (changed_) {  // imp.rs:490-497
+    if (!generate_alpha_mask(border_radius_px_)) return FlowReturn::NotNegotiated;
+    changed_ = false;
+  }
+  if (alpha) *alpha = alpha_mem_.data();
+  if (size) *size = alpha_mem_.size();
+  if (stride) *stride = alpha_stride_;
+  return FlowReturn::Ok;
+}
+
+bool RoundedCorners::stop() {
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  have_state_ = false;
+  alpha_mem_.clear();
+  started_ = false;
+  return true;
+}
+
 // ------------------------------------------------------------------ VideoCompare
 
 VideoCompare::VideoCompare(int device) : Element(device) {}
@@ -1042,7 +1173,7 @@ FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames,
 
 // ------------------------------------------------------------------ registry
 
-std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender", "videocompare", "audioloudnorm"}; }
+std::vector<std::string> registered_factories() { return {"hsvfilter", "hsvdetector", "colorlut", "rsaudioecho", "ebur128level", "hrtfrender", "videocompare", "audioloudnorm", "roundedcorners"}; }
 
 std::unique_ptr<Element> element_factory_make(const std::string &factory, int device, std::string *error) {
   std::unique_ptr<Element> e;
@@ -1054,6 +1185,7 @@ std::unique_ptr<Element> element_factory_make(const std::string &factory, int de
   else if (factory == "hrtfrender") e.reset(new HrtfRender(device));
   else if (factory == "videocompare") e.reset(new VideoCompare(device));
   else if (factory == "audioloudnorm") e.reset(new AudioLoudNorm(device));
+  else if (factory == "roundedcorners") e.reset(new RoundedCorners(device));
   else {
     if (error) *error = "no such element factory: " + factory;
     return nullptr;
@@ -1288,6 +1420,35 @@ int mi355el_loudnorm_drain(mi355el *h, int channels, double *out, size_t out_cap
   if (m) std::memcpy(out, o.data(), m * (size_t)channels * sizeof(double));
   if (out_frames) *out_frames = n;
   return (int)r;
+}
+
+
+// ---- roundedcorners
+int mi355el_roundedcorners_set_caps(mi355el *h, int width, int height, int a420) {
+  auto *e = h ? dynamic_cast<RoundedCorners *>(h->e.get()) : nullptr;
+  if (!e) return -1;
+  return e->set_caps(width, height, a420 ? 101 : 100) ? 0 : -1;
+}
+// copies the alpha plane (if any) into `out` (capacity bytes); *size / *stride describe it; returns the flow value
+int mi355el_roundedcorners_prepare(mi355el *h, uint8_t *out, size_t capacity, size_t *size, int *stride, int *passthrough) {
+  auto *e = h ? dynamic_cast<RoundedCorners *>(h->e.get()) : nullptr;
+  if (!e) return (int)FlowReturn::Error;
+  const uint8_t *a = nullptr;
+  size_t n = 0;
+  int st = 0;
+  const FlowReturn r = e->prepare_output_buffer(&a, &n, &st);
+  if (passthrough) *passthrough = e->passthrough() ? 1 : 0;
+  if (size) *size = n;
+  if (stride) *stride = st;
+  if (a && out && n) std::memcpy(out, a, n < capacity ? n : capacity);
+  return (int)r;
+}
+int mi355el_roundedcorners_src_formats(mi355el *h) {  // bit 0: I420 offered, bit 1: A420 offered
+  auto *e = h ? dynamic_cast<RoundedCorners *>(h->e.get()) : nullptr;
+  if (!e) return 0;
+  int m = 0;
+  for (int f : e->transform_caps_to_src()) m |= (f == 100) ? 1 : 2;
+  return m;
 }
 
 }  // extern "C"

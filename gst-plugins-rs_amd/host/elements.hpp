@@ -11,6 +11,7 @@
 //   HrtfRender   audio/hrtf/src/hrtf/imp.rs          (BaseTransform, NeverInPlace: set_caps/transform/drain/stop)
 //   VideoCompare video/videofx/src/videocompare/imp.rs (VideoAggregator: aggregate_frames)
 //   AudioLoudNorm audio/audiofx/src/audioloudnorm/imp.rs (Element: sink chain / drain)
+//   RoundedCorners video/videofx/src/border/imp.rs    (BaseTransform: set_caps / prepare_output_buffer; host only)
 // Each object owns one mi355_ctx (include/mi355fx.h) and forwards its per-buffer vfunc to the C ABI,
 // exactly where the Rust element would call its inner loop. The GStreamer shim (gst/) wraps these.
 #pragma once
@@ -310,6 +311,45 @@ class AudioLoudNorm final : public Element {
   double loudness_target_ = -24.0, loudness_range_target_ = 7.0, max_true_peak_ = -2.0, offset_ = 0.0;  // imp.rs:37-40
   bool have_state_ = false;
   int channels_ = 0;
+};
+
+// roundedcorners (video/videofx/src/border/imp.rs): BaseTransform, AlwaysInPlace, I420 in -> I420 (passthrough) or A420.
+// There is NO per-pixel work per buffer in the reference: an A8 alpha plane is rendered once per caps / radius
+// change with cairo (four arcs, antialiased fill + 1 px stroke, imp.rs:57-180) and the same memory is appended to every
+// output buffer (imp.rs:444-480, :482-559). The mask bytes are defined by cairo's rasteriser, so this mirror renders
+// them the same way — through the system libcairo, loaded at run time — and nothing runs on the device.
+class RoundedCorners final : public Element {
+ public:
+  explicit RoundedCorners(int device);
+  ~RoundedCorners() override;
+  const char *factory_name() const override { return "roundedcorners"; }
+  const char *type_name() const override { return "GstRoundedCorners"; }
+  const ElementMetadata &metadata() const override;
+  const std::vector<ParamSpec> &properties() const override;
+  std::vector<int> sink_formats() const override { return {100}; }        // I420
+  std::vector<int> src_formats() const override { return {100, 101}; }    // I420, A420
+  // transform_caps sink->src (imp.rs:398-425): formats offered downstream for the current border radius
+  std::vector<int> transform_caps_to_src() const;
+  // set_caps (imp.rs:444-480): out_format 100 = I420 (passthrough) or 101 = A420 (alpha plane allocated,
+  // stride = round_up_4(width), rows = round_up_2(height))
+  bool set_caps(int width, int height, int out_format);
+  bool passthrough() const { return passthrough_; }
+  // prepare_output_buffer (imp.rs:482-559): regenerates the mask when the radius changed, then hands out the shared
+  // alpha plane that the element appends to the buffer (plane 3 of A420)
+  FlowReturn prepare_output_buffer(const uint8_t **alpha, size_t *size, int *stride);
+  bool stop() override;
+
+ private:
+  bool store_number(const std::string &, double) override { return false; }
+  bool load_number(const std::string &, double *) const override { return false; }
+  bool store_u64(const std::string &name, uint64_t v) override;
+  bool load_u64(const std::string &name, uint64_t *v) const override;
+  bool generate_alpha_mask(uint32_t radius);
+  uint32_t border_radius_px_ = 0;  // DEFAULT_BORDER_RADIUS (imp.rs:27)
+  bool changed_ = false, have_state_ = false, passthrough_ = true;
+  int width_ = 0, height_ = 0, alpha_stride_ = 0;
+  std::vector<uint8_t> alpha_mem_;
+  void *cairo_ = nullptr;  // dlopen handle
 };
 
 // videocompare (video/videofx/src/videocompare/imp.rs): VideoAggregator; the first sink pad is the reference, every

@@ -49,6 +49,9 @@ def _lib():
             "mi355el_ebur128_reset_signal": (None, [vp]),
             "mi355el_ebur128_pop_message": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                 C.POINTER(C.c_double), i, C.POINTER(i)]),
+            "mi355el_roundedcorners_set_caps": (i, [vp, i, i, i]),
+            "mi355el_roundedcorners_prepare": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(i), C.POINTER(i)]),
+            "mi355el_roundedcorners_src_formats": (i, [vp]),
             "mi355el_loudnorm_set_caps": (i, [vp, i, i]),
             "mi355el_loudnorm_chain": (i, [vp, vp, sz, i, vp, sz, C.POINTER(sz)]),
             "mi355el_loudnorm_drain": (i, [vp, i, vp, sz, C.POINTER(sz)]),
@@ -290,3 +293,23 @@ class Element:
         n = C.c_size_t(0)
         flow = self.L.mi355el_loudnorm_drain(self.h, ch, out.ctypes.data, cap, C.byref(n))
         return flow, out[: n.value * ch]
+
+    # ---- roundedcorners (host only: the mask is rendered with the system libcairo exactly as the reference does)
+    def roundedcorners_set_caps(self, width, height, a420=True):
+        self._rc_dims = (width, height)
+        return self.L.mi355el_roundedcorners_set_caps(self.h, width, height, int(a420)) == 0
+
+    def roundedcorners_src_formats(self):
+        m = self.L.mi355el_roundedcorners_src_formats(self.h)
+        return [f for f, bit in (("I420", 1), ("A420", 2)) if m & bit]
+
+    def roundedcorners_prepare(self):
+        """-> (flow, passthrough, alpha plane as (rows, stride) uint8 array or None)"""
+        w, h = self._rc_dims
+        cap = ((w + 3) & ~3) * ((h + 1) & ~1)
+        out = np.zeros(cap, np.uint8)
+        n, st, pt = C.c_size_t(0), C.c_int(0), C.c_int(0)
+        flow = self.L.mi355el_roundedcorners_prepare(self.h, out.ctypes.data, cap, C.byref(n), C.byref(st), C.byref(pt))
+        if flow != 0 or pt.value or n.value == 0:
+            return flow, bool(pt.value), None
+        return flow, False, out[: n.value].reshape(-1, st.value)

@@ -412,3 +412,37 @@ def test_audioloudnorm_element(oracle):
     assert e.stop()
     flow, o = e.loudnorm_drain()
     assert flow == 0 and o.size == 0
+
+
+# ------------------------------------------------------------------ roundedcorners (host only, cairo-rendered mask)
+
+def test_roundedcorners_element_masks_match_cairo_goldens():
+    """The alpha plane the element attaches equals the committed cairo renderings byte for byte (CRC of the whole plane +
+    the corner bytes), radius 0 gives an opaque plane, the mask is regenerated when border-radius-px changes."""
+    import zlib
+    from mi355fx.elements import Element
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cairo_masks.json")))
+    e = Element("roundedcorners")
+    assert e.type_name == "GstRoundedCorners" and e.klass == "Filter/Effect/Converter/Video"
+    assert e.roundedcorners_src_formats() == ["I420", "A420"]       # radius 0: both offered (imp.rs:408-416)
+    for key, g in gold["cases"].items():
+        dims, r = key.split("_r")
+        w, h = (int(v) for v in dims.split("x"))
+        assert e.set_property("border-radius-px", int(r))
+        assert e.roundedcorners_src_formats() == (["I420", "A420"] if int(r) == 0 else ["A420"])
+        assert e.roundedcorners_set_caps(w, h, True)
+        flow, passthrough, alpha = e.roundedcorners_prepare()
+        assert flow == 0 and not passthrough
+        assert list(alpha.shape) == g["shape"]
+        assert alpha[:12, :12].tolist() == g["corner"], key
+        assert zlib.crc32(alpha.tobytes()) == g["crc32"], key
+    # property change while negotiated: next buffer carries the new mask
+    assert e.roundedcorners_set_caps(40, 24, True) and e.set_property("border-radius-px", 8)
+    _, _, a8 = e.roundedcorners_prepare()
+    assert e.set_property("border-radius-px", 0)
+    _, _, a0 = e.roundedcorners_prepare()
+    assert (a0 == 255).all() and (a8 != a0).any() and a8[0, 0] == 0 and a8[12, 20] == 255
+    # I420 output caps: passthrough, no alpha plane
+    assert e.roundedcorners_set_caps(40, 24, False)
+    flow, passthrough, alpha = e.roundedcorners_prepare()
+    assert flow == 0 and passthrough and alpha is None
