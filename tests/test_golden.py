@@ -44,3 +44,27 @@ def test_gpu_reproduces_committed_crcs(ctx, synth):
     ctx.echo_process(x, 24000, 0.6, 0.4)
     got["echo_config1_f32"] = zlib.crc32(x.tobytes())
     assert got == GOLDEN
+
+
+def test_cubetool_roundtrip(tmp_path):
+    """tools/cubetool.py: identity writer -> product host reader -> identity table; HRIR info on the reference fixture."""
+    import subprocess, sys, os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "cubetool.py")
+    out = tmp_path / "id9.cube"
+    assert subprocess.call([sys.executable, tool, "cube-identity", "9", str(out)]) == 0
+    sys.path.insert(0, os.path.join(root, "gst-plugins-rs_amd"))
+    from mi355fx.cube import parse_cube_file
+    lut = parse_cube_file(str(out))
+    assert lut.is3d and lut.size == 9
+    t = lut.table.reshape(9, 9, 9, 4)
+    g = (np.arange(9) / 8.0).astype(np.float32)
+    assert np.allclose(t[..., 0], g[None, None, :], atol=1e-6) and np.allclose(t[..., 2], g[:, None, None], atol=1e-6)
+    r = subprocess.run([sys.executable, tool, "cube-validate", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "3D LUT, size 9" in r.stdout
+    r = subprocess.run([sys.executable, tool, "hrir-info", os.path.join(root, "tests", "golden", "test.hrir")], capture_output=True, text=True)
+    assert r.returncode == 0 and "187 vertices, 370 faces" in r.stdout
+    bad = tmp_path / "bad.cube"
+    bad.write_text("LUT_3D_SIZE 2\n0 0 0\n")
+    assert subprocess.call([sys.executable, tool, "cube-validate", str(bad)], stdout=subprocess.DEVNULL) == 1
