@@ -245,3 +245,43 @@ def test_rgba64_le_be_are_byte_swaps_of_each_other(oracle, synth):
     out = np.zeros_like(le)
     oracle.colorlut_rgba64(ident, le.view(np.uint8), w * 8, out.view(np.uint8), w * 8, w, h, le=True)
     assert np.abs(out.astype(np.int32) - le.astype(np.int32)).max() <= 1
+
+
+def test_parsers_agree_on_fuzzed_cube_texts(parsers):
+    """Property test (hypothesis, seeded/derandomised): the two independent restatements of CubeLut::parse — the oracle's C
+    parser and the product's C++ host reader — agree on accept/reject and, when both accept, on every parsed value, for
+    texts assembled from valid and invalid .cube ingredients (keywords in any order, comments, blank and odd-whitespace
+    lines, malformed numbers, wrong counts)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    num = st.one_of(st.sampled_from(["0", "1", "0.5", "1.0", "-0.25", "1e-3", "+0.75", ".5", "5.", "1e400", "nan", "inf", "abc", "0x10", "1,0", ""]),
+                    st.floats(-2, 2, allow_nan=False, width=32).map(lambda v: "%.6f" % v))
+    data_line = st.lists(num, min_size=1, max_size=5).map(" ".join)
+    keyword = st.sampled_from(["LUT_3D_SIZE 2", "LUT_3D_SIZE 3", "LUT_1D_SIZE 2", "LUT_1D_SIZE 4", "LUT_3D_SIZE", "LUT_3D_SIZE x", "LUT_1D_SIZE -1",
+                               "LUT_3D_SIZE 1", "LUT_3D_SIZE 300", "LUT_1D_SIZE 70000", 'TITLE "t"', "TITLE", "DOMAIN_MIN 0 0 0", "DOMAIN_MAX 1 1 1",
+                               "DOMAIN_MIN 0.1 0.2 0.3", "DOMAIN_MAX 2 2 2", "DOMAIN_MIN 1 1 1", "DOMAIN_MAX 0 0", "DOMAIN_MAX a b c",
+                               "LUT_1D_INPUT_RANGE 0 1", "LUT_3D_INPUT_RANGE 0 1", "UNKNOWN_KEY 1", "# comment", "#", "", "   ", "\t",
+                               " LUT_3D_SIZE 2", "LUT_3D_SIZE 2"])
+    sep = st.sampled_from(["\n", "\r\n", "\n\n", " \n"])
+
+    @settings(max_examples=400, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.lists(st.one_of(keyword, data_line), min_size=0, max_size=14), sep, st.integers(0, 27))
+    def run(lines, joiner, pad_rows):
+        body = joiner.join(lines)
+        if pad_rows:   # often complete the table so that acceptance paths are exercised too
+            body += joiner + joiner.join("%.3f %.3f %.3f" % (k / 27.0, (k * 7 % 27) / 27.0, (k * 11 % 27) / 27.0) for k in range(pad_rows))
+        res = {}
+        for name, (fn, exc) in parsers.items():
+            try:
+                res[name] = fn(body)
+            except exc:
+                res[name] = None
+        a, b = res["oracle"], res["host"]
+        assert (a is None) == (b is None), (body, a is None, b is None)
+        if a is not None:
+            assert a["is3d"] == b["is3d"] and a["size"] == b["size"]
+            assert np.array_equal(np.asarray(a["table"]).view(np.uint32), np.asarray(b["table"]).view(np.uint32))
+            assert np.array_equal(np.asarray(a["scale"]).view(np.uint32), np.asarray(b["scale"]).view(np.uint32))
+            assert np.array_equal(np.asarray(a["offset"]).view(np.uint32), np.asarray(b["offset"]).view(np.uint32))
+
+    run()
