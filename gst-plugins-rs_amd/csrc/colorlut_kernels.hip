@@ -1076,7 +1076,7 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
     }
   }
 
-  if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && L.is3d && L.lds_ok && !L.lds_all_resident && !ctx->force_generic) {
+  if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && L.is3d && L.lds_ok && !ctx->force_generic) {
     const size_t row_bytes = (size_t)width * 8;
     const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
                             (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));

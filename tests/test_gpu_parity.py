@@ -477,12 +477,13 @@ def test_independent_contexts_are_concurrent_safe(oracle, synth, mi355lib):
         assert (results[i] == exp).all(), "stream %d" % i
 
 
+@pytest.mark.parametrize("size", [33, 17, 5, 2])
 @pytest.mark.parametrize("le", [True, False])
 @pytest.mark.parametrize("domain", [None, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))])
-def test_colorlut_rgba64_lds_kernel(ctx, oracle, synth, le, domain):
-    """RGBA64 + 33^3 LUT on contiguous frames takes the LDS three-pass kernel (VALU coordinates, exact
-    /65535): random 16-bit pixels plus every channel value 0..65535 on the diagonal."""
-    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33, amp=0.06, domain=domain))
+def test_colorlut_rgba64_lds_kernel(ctx, oracle, synth, le, domain, size):
+    """RGBA64 + a 3D LUT whose plane fits LDS, on contiguous frames, takes the LDS three-pass kernel (VALU coordinates,
+    exact /65535): random 16-bit pixels plus every channel value 0..65535 on the diagonal."""
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size, amp=0.06, domain=domain))
     rng = np.random.default_rng(23)
     w, h = 1024, 320
     px = rng.integers(0, 65536, size=(h * w, 4), dtype=np.uint16)
