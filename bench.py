@@ -197,21 +197,27 @@ def main():
             return dtf, ms
 
         dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
+        lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
         fused = None
         if not args.no_extra:
             dtf, fused_ms = measure_fused(args.content, args.steps, args.warmup)
             fused_fps = sharding.aggregate_throughput(args.steps * args.batch, world, dtf)
             fb = BYTES_PER_FRAME_PER_KERNEL * args.batch
-            fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms, "kernel": "colorlut3d_lds_kernel<HSV>",
+            f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
+            fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
+                     "kernel": "colorlut_table_kernel (composed hsv+lut table)" if f_tab else "colorlut3d_lds_kernel<HSV>",
+                     "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
                      "algorithmic_bytes_per_launch": fb, "GBps": fb / (fused_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": fb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "one launch per batch, 8 B/px algorithmic (SURVEY 8d fused accounting); bit-identical to the two-kernel chain"}
         extra = None
         if not args.no_extra and rank == 0 and world == 1:
             other = "noise" if args.content == "smooth" else "smooth"
-            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 2, True)
+            # warm-up long enough for the colorlut kernel choice to follow the change of content (sampled every 4th launch)
+            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 10, True)
             extra = {"content": other, "frames_per_s": max(10, args.steps // 2) * args.batch / dt2,
-                     "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2}
+                     "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2,
+                     "colorlut_kernel": "colorlut_table_kernel" if ctx.colorlut_kernel_choice()[0] else "colorlut3d_lds_kernel"}
 
     fps = sharding.aggregate_throughput(args.steps * args.batch, world, dt)
     ms_per_step = dt / args.steps * 1e3
@@ -220,7 +226,7 @@ def main():
         # dominant kernel = the longer of the two launches
         per_launch_bytes = BYTES_PER_FRAME_PER_KERNEL * args.batch
         if lut_ms >= hsv_ms:
-            dom, dom_ms = "colorlut3d_lds_kernel", lut_ms
+            dom, dom_ms = ("colorlut_table_kernel" if lut_tab else "colorlut3d_lds_kernel"), lut_ms
         else:
             dom, dom_ms = "hsvfilter_flat_kernel", hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
@@ -250,7 +256,9 @@ def main():
             "kernels": {"hsvfilter_ms_per_launch": hsv_ms, "colorlut_ms_per_launch": lut_ms,
                         "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
-                        "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS},
+                        "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
+                        "colorlut_kernel": "colorlut_table_kernel" if lut_tab else "colorlut3d_lds_kernel",
+                        "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt}},
         }
         if fused:
             out["fused_chain"] = fused

@@ -778,7 +778,106 @@ __global__ __launch_bounds__(NT) void colorlut1d_lds_kernel(const uint4 *__restr
 
 static constexpr size_t kLdsBytes = 160 * 1024;
 
+// ---------------------------------------------------------------- full-domain table ("memoised") kernel, RGBA8
+// An 8-bit RGB -> 8-bit RGB per-pixel function has only 2^24 inputs. The exact LUT kernel is run ONCE over all of them
+// when the table is requested (16.7 M pixels = two 4K frames' worth of work) and its outputs are kept as a 64 MiB table
+// in HBM / Infinity Cache; a frame is then one 4-byte gather per pixel plus the alpha merge. Bit-identical to the
+// kernel that built the table by construction, for every LUT kind and size. The table index is either the colour itself
+// (linear: consecutive R share a cache line) or its 3-way bit interleave (Morton: a 128 B line holds a 4x4x2 colour
+// cube, so pixels that differ a little in every channel still share lines).
+constexpr uint32_t kTableEntries = 1u << 24;
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // bit k of an 8-bit value -> bit 3k
+  v &= 0x000000ffu;
+  v = (v | (v << 8)) & 0x0000f00fu;
+  v = (v | (v << 4)) & 0x000c30c3u;
+  v = (v | (v << 2)) & 0x00249249u;
+  return v;
+}
+__device__ __forceinline__ uint32_t compact3(uint32_t v) {  // inverse of spread3: bit 3k -> bit k
+  v &= 0x00249249u;
+  v = (v | (v >> 2)) & 0x000c30c3u;
+  v = (v | (v >> 4)) & 0x0000f00fu;
+  v = (v | (v >> 8)) & 0x000000ffu;
+  return v;
+}
+
+// in[i] = the colour whose table slot is i (alpha 0xff)
+__global__ __launch_bounds__(256) void table_domain_kernel(uint32_t *__restrict__ in, int morton) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t c = i;
+  if (morton) c = compact3(i) | (compact3(i >> 1) << 8) | (compact3(i >> 2) << 16);
+  in[i] = c | 0xff000000u;
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// A wave handles 512 consecutive pixels per iteration: two 16-byte loads per lane (1 KiB contiguous per instruction,
+// non-temporal so that the pixel stream does not evict table lines from L2), a transpose through a wave-private 2 KiB LDS
+// strip so that gather j of lane l serves pixel 64 j + l - neighbouring lanes then look up neighbouring pixels, whose
+// colours tend to share table lines (0.187 -> 0.160 ms per 8x4K against each lane gathering its own four pixels) - eight
+// gathers in flight per lane, and the way back through the strip to two 16-byte stores.
+template <bool MORTON>
+__global__ __launch_bounds__(256) void colorlut_table_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec,
+                                                             const uint32_t *__restrict__ table) {
+  __shared__ uint32_t s_spread[256];
+  __shared__ uint32_t s_strip[4][512];
+  if (MORTON) {
+    s_spread[threadIdx.x] = spread3(threadIdx.x);
+    __syncthreads();
+  }
+  auto index = [&](uint32_t p) -> uint32_t {
+    if (MORTON) return s_spread[p & 0xffu] | (s_spread[(p >> 8) & 0xffu] << 1) | (s_spread[(p >> 16) & 0xffu] << 2);
+    return p & 0x00ffffffu;
+  };
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t *x = s_strip[wave];
+  const u32x4_t *s4 = (const u32x4_t *)src;
+  u32x4_t *d4 = (u32x4_t *)dst;
+  const size_t n_chunks = n_vec / 128;
+  const size_t wstride = (size_t)gridDim.x * 4;
+  auto wave_sync = [] {  // LDS writes of this wave visible to its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (size_t c = (size_t)blockIdx.x * 4 + wave; c < n_chunks; c += wstride) {
+    const u32x4_t p = __builtin_nontemporal_load(s4 + c * 128 + lane), q = __builtin_nontemporal_load(s4 + c * 128 + 64 + lane);
+    *(u32x4_t *)(x + lane * 4) = p;
+    *(u32x4_t *)(x + 256 + lane * 4) = q;
+    wave_sync();
+    uint32_t px[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) px[j] = x[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = table[index(px[j])];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
+    wave_sync();
+    const u32x4_t r0 = *(u32x4_t *)(x + lane * 4), r1 = *(u32x4_t *)(x + 256 + lane * 4);
+    wave_sync();
+    __builtin_nontemporal_store(r0, d4 + c * 128 + lane);
+    __builtin_nontemporal_store(r1, d4 + c * 128 + 64 + lane);
+  }
+  // fewer than 128 pixel groups left over: the first block's lanes take one group each, twice
+  if (blockIdx.x == 0 && threadIdx.x < 128) {
+    const size_t i = n_chunks * 128 + threadIdx.x;
+    if (i < n_vec) {
+      const u32x4_t p = s4[i];
+      const uint32_t pp[4] = {p.x, p.y, p.z, p.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[j] = (table[index(pp[j])] & 0x00ffffffu) | (pp[j] & 0xff000000u);
+      const u32x4_t r = {o[0], o[1], o[2], o[3]};
+      d4[i] = r;
+    }
+  }
+}
+
 void lut_release(mi355_ctx *ctx) {
+  for (int i = 0; i < 2; i++) {
+    if (ctx->lut.d_table[i]) (void)hipFree(ctx->lut.d_table[i]);
+    if (ctx->lut.pick[i].ev0) (void)hipEventDestroy(ctx->lut.pick[i].ev0);
+    if (ctx->lut.pick[i].ev1) (void)hipEventDestroy(ctx->lut.pick[i].ev1);
+  }
   if (ctx->lut.d_cells) (void)hipFree(ctx->lut.d_cells);
   if (ctx->lut.d_planar) (void)hipFree(ctx->lut.d_planar);
   if (ctx->lut.d_axis) (void)hipFree(ctx->lut.d_axis);
@@ -988,9 +1087,13 @@ static int launch_fused_variant(mi355_ctx *ctx, const uint4 *s, uint4 *d, size_t
 // hsvfilter followed by colorlut on RGBA frames. One fused launch when the 3D LDS kernel applies; otherwise the
 // two element kernels back to back (copy src -> dst, hsvfilter in place on dst, colorlut dst -> dst; every colorlut
 // kernel reads a pixel before it writes the same pixel, so in-place is safe).
-int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
-                        size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
-                        const mi355_hsv_settings &hs) {
+static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst, size_t dst_pitch,
+                                  int dst_stride, int n_frames, int width, int height, int format);
+
+// `plain`: the colorlut half of the unfused fallback uses the compute kernel directly (table builds)
+static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                                       size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
+                                       const mi355_hsv_settings &hs, bool plain) {
   const LutDevice &L = ctx->lut;
   if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
@@ -1021,10 +1124,11 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   }
   int rc = launch_hsvfilter(ctx, d_dst, n_frames, dst_pitch, width, height, dst_stride, fmt, hs);
   if (rc) return rc;
+  if (plain) return launch_colorlut_compute(ctx, d_dst, dst_pitch, dst_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, MI355_FMT_RGBA);
   return launch_colorlut(ctx, d_dst, dst_pitch, dst_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, MI355_FMT_RGBA);
 }
 
-int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
                     size_t dst_pitch, int dst_stride, int n_frames, int width, int height, int format) {
   const LutDevice &L = ctx->lut;
   if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
@@ -1126,6 +1230,181 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   }
 #undef MI355_ROWS
   return check_hip(ctx, hipGetLastError(), "colorlut rows kernel launch");
+}
+
+
+// geometry test shared by the table path and the auto-selector: contiguous RGBA8 frames, 16 B aligned
+static bool rgba8_flat(const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
+                       int width, int height, size_t *n_vec) {
+  const size_t row_bytes = (size_t)width * 4;
+  const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                          (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+  const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+  if (!(contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0))) return false;
+  *n_vec = total_bytes / 16;
+  return true;
+}
+
+static bool same_hs(const mi355_hsv_settings &a, const mi355_hsv_settings &b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+
+// Builds table `which` (0: colorlut, 1: hsvfilter -> colorlut under *hs) in the requested layout unless it is current:
+// the table buffer is filled with the colour of every slot and the exact compute path is run over it in place, all on
+// the context's stream with no host wait.
+static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_settings *hs) {
+  LutDevice &L = ctx->lut;
+  if (L.d_table[which] && L.table_morton[which] == morton && (which == 0 || same_hs(L.table_hs, *hs))) return MI355_OK;
+  int rc;
+  if (!L.d_table[which] && (rc = check_hip(ctx, hipMalloc((void **)&L.d_table[which], (size_t)kTableEntries * 4), "hipMalloc(colorlut table)")))
+    return rc;
+  uint8_t *t = (uint8_t *)L.d_table[which];
+  L.table_morton[which] = -1;
+  hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, L.d_table[which], morton);
+  rc = which == 0 ? launch_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, MI355_FMT_RGBA)
+                  : launch_hsv_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, *hs, true);
+  if (rc) return rc;
+  L.table_morton[which] = morton;
+  if (which == 1) L.table_hs = *hs;
+  return MI355_OK;
+}
+
+static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int morton, const mi355_hsv_settings *hs) {
+  int rc = table_ensure(ctx, which, morton, hs);
+  if (rc) return rc;
+  size_t grid = (size_t)ctx->n_cu * 16;
+  const size_t max_blocks = n_vec / 512 + 1;  // a block's four waves take one 128-group chunk each per iteration
+  if (grid > max_blocks) grid = max_blocks;
+  const uint32_t *t = ctx->lut.d_table[which];
+  if (morton) hipLaunchKernelGGL((colorlut_table_kernel<true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_vec, t);
+  else hipLaunchKernelGGL((colorlut_table_kernel<false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_vec, t);
+  return check_hip(ctx, hipGetLastError(), "colorlut table kernel launch");
+}
+
+// MI355_FLAG_LUT_VARIANT: 0 = auto (default). The interpolating ("compute") kernel and the table kernel are both exact;
+// which one is faster depends on the content (the table kernel's gathers need colour locality: 0.18 vs 0.25 ms per
+// 8x4K on natural-like frames, 1.2 vs 0.40 ms on uniform noise), on the LUT size (the table kernel does not care) and on
+// the launch size. Auto keeps a per-pixel-group time for each kind, measured with event pairs that are recorded around
+// every n-th launch (n = 4..32, about one sample per 64 Mpixel) and read back at the start of a later launch - without
+// blocking if the events have completed, and blocking once the sample is n-1 launches old, which bounds how far a host
+// that enqueues in bursts can run ahead of the decision while the device still has n-2 launches queued:
+//   * the first eligible launch after a LUT load runs the compute kernel, the second one builds the table and runs the
+//     table kernel, both measured and waited for; from then on the kind with the smaller time serves the launches;
+//   * the kind in use keeps being sampled, so content that turns hostile to the table (its time rises above the compute
+//     kernel's last time) flips the choice at the next sample;
+//   * the kind NOT in use is tried again after `probe_period` launches (64, doubling up to 1024 while the answer stays
+//     the same, back to 64 when it changes);
+//   * measurements are dropped when the launch size changes by more than 2x.
+// 1, 2, 6 = compute kernels only (6 = the default compute kernel), 4 / 5 = table kernel only (linear / Morton index).
+// The same policy, with its own state and table, serves the fused hsvfilter -> colorlut entry point.
+constexpr unsigned kProbeMin = 64, kProbeMax = 1024;
+
+static void auto_harvest(AutoPick &A, unsigned max_lag) {
+  if (A.pending_kind < 0) return;
+  if (A.calls - A.pending_call >= max_lag) {
+    if (hipEventSynchronize(A.ev1) != hipSuccess) { (void)hipGetLastError(); A.pending_kind = -1; return; }
+  } else if (hipEventQuery(A.ev1) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess && ms > 0.0f) {
+    const double per_vec = (double)ms / (double)A.pending_vec;
+    if (A.pending_kind == 0) A.t_compute = per_vec; else A.t_table = per_vec;
+    if (A.t_compute > 0.0 && A.t_table > 0.0) {
+      const bool table = A.t_table < A.t_compute;
+      if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
+      else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
+      A.table = table;
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  A.pending_kind = -1;
+}
+
+template <class Compute, class Ensure, class Table>
+static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&compute, Ensure &&ensure, Table &&table) {
+  int rc;
+  if (!A.ev0) {
+    if ((rc = check_hip(ctx, hipEventCreate(&A.ev0), "hipEventCreate"))) return rc;
+    if ((rc = check_hip(ctx, hipEventCreate(&A.ev1), "hipEventCreate"))) return rc;
+  }
+  unsigned sample_every = (unsigned)(((size_t)1 << 24) / n_vec);
+  sample_every = sample_every < 4 ? 4 : (sample_every > 32 ? 32 : sample_every);
+  const bool learning = A.t_compute == 0.0 || A.t_table == 0.0;
+  auto_harvest(A, learning ? 0 : sample_every - 1);
+  if (A.vec && (n_vec > 2 * A.vec || 2 * n_vec < A.vec) && A.pending_kind < 0) {
+    A.t_compute = A.t_table = 0.0;
+    A.probe_period = kProbeMin;
+    A.since_probe = 0;
+  }
+  if (A.pending_kind < 0) A.vec = n_vec;
+  int kind;
+  bool probe = false;
+  if (A.t_compute == 0.0) { kind = 0; probe = true; }
+  else if (A.t_table == 0.0) { kind = 1; probe = true; }
+  else {
+    kind = A.table ? 1 : 0;
+    if (++A.since_probe >= A.probe_period && A.pending_kind < 0) { kind ^= 1; probe = true; A.since_probe = 0; }
+  }
+  const bool measure = A.pending_kind < 0 && (probe || (A.calls % sample_every) == 0);
+  A.calls++;
+  if (kind == 1 && (rc = ensure())) return rc;  // a table build stays outside the measurement
+  if (measure && (rc = check_hip(ctx, hipEventRecord(A.ev0, ctx->stream), "hipEventRecord"))) return rc;
+  if ((rc = kind ? table() : compute())) return rc;
+  if (measure) {
+    if ((rc = check_hip(ctx, hipEventRecord(A.ev1, ctx->stream), "hipEventRecord"))) return rc;
+    A.pending_kind = kind;
+    A.pending_call = A.calls;
+    A.pending_vec = n_vec;
+    A.pending_probe = probe && A.t_compute > 0.0 && A.t_table > 0.0;
+  }
+  return MI355_OK;
+}
+
+// below 64 K pixels a launch is all fixed cost and a 64 MiB table is not worth building
+constexpr size_t kAutoMinVec = 16384;
+
+int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                    size_t dst_pitch, int dst_stride, int n_frames, int width, int height, int format) {
+  LutDevice &L = ctx->lut;
+  if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
+  size_t n_vec = 0;
+  const bool table_ok = format == MI355_FMT_RGBA && !ctx->force_generic &&
+                        rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
+  const int v = ctx->lut_variant;
+  auto compute = [&]() { return launch_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format); };
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, n_vec, v == 5 ? 1 : 0, nullptr);
+  if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
+  return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, n_vec, 1, nullptr); });
+}
+
+// The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
+// with a table built by the fused compute path under the call's hsv settings. A table is only built for settings that
+// have been the same for kStableCalls consecutive calls (an animated property would otherwise rebuild it every buffer).
+constexpr unsigned kStableCalls = 8;
+int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
+                        size_t dst_pitch, int dst_stride, int n_frames, int width, int height,
+                        const mi355_hsv_settings &hs) {
+  LutDevice &L = ctx->lut;
+  if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
+  size_t n_vec = 0;
+  const bool table_ok = !ctx->force_generic && rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
+  const int v = ctx->lut_variant;
+  auto compute = [&]() { return launch_hsv_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, hs, false); };
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, n_vec, v == 5 ? 1 : 0, &hs);
+  if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
+  if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
+  else { L.seen_hs = hs; L.seen_stable = 0; }
+  const bool have = L.d_table[1] && L.table_morton[1] == 1 && same_hs(L.table_hs, hs);
+  if (!have && L.seen_stable < kStableCalls) return compute();
+  if (!have) {  // measurements of the table kernel belong to the old table's colours only loosely; start over
+    L.pick[1].t_table = 0.0;
+  }
+  return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, 1, &hs); });
 }
 
 }  // namespace mi355

@@ -9,6 +9,20 @@
 namespace mi355 {
 
 // Device-side copy of a loaded CubeLut (video/colorlut/src/parser.rs:69-75).
+// Choice between an interpolating ("compute") kernel and the memoised-table kernel for one entry point
+// (colorlut_kernels.hip: auto_launch).
+struct AutoPick {
+  unsigned calls = 0, since_probe = 0, probe_period = 64;
+  bool table = false;
+  double t_compute = 0.0, t_table = 0.0;  // ms per 16-byte pixel group, last measurement (0 = none yet)
+  size_t vec = 0;                         // launch size the measurements belong to
+  int pending_kind = -1;                  // measurement in flight: -1 none, 0 compute, 1 table
+  size_t pending_vec = 0;
+  unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
+  bool pending_probe = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
 struct LutDevice {
   int is3d = 0;
   int size = 0;
@@ -22,6 +36,14 @@ struct LutDevice {
   size_t lds_bytes = 0;            // dynamic LDS per block
   bool lds_all_resident = false;   // all three planes staged once (small LUTs)
   bool lds_ok = false;        // LDS fast path legal for this LUT (fits, finite, bounded)
+  // 2^24-entry memoised tables (RGBA8): see colorlut_table_kernel. [0] = colorlut alone, [1] = hsvfilter -> colorlut
+  // under the hsv settings in table_hs.
+  uint32_t *d_table[2] = {nullptr, nullptr};
+  int table_morton[2] = {-1, -1};  // layout of the table: 0 linear, 1 Morton, -1 not built
+  mi355_hsv_settings table_hs{};   // settings d_table[1] was built for
+  mi355_hsv_settings seen_hs{};    // settings of the previous fused call and for how many calls they have not changed
+  unsigned seen_stable = 0;
+  AutoPick pick[2];                // compute-kernel / table-kernel choice for the two entry points
   bool loaded = false;
 };
 

@@ -79,6 +79,7 @@ def load_library():
         "mi355_hsvdetect_frames_device": (i, [vp, u8p, sz, i, i, u8p, sz, i, i, i, i, i, C.POINTER(HsvDetectSettings)]),
         "mi355_colorlut_load": (i, [vp, i, sz, f32p, f32p, f32p]),
         "mi355_colorlut_unload": (i, [vp]),
+        "mi355_colorlut_kernel_choice": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
         "mi355_hsv_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings)]),
@@ -250,6 +251,12 @@ class Context:
 
     def colorlut_unload(self):
         self._ck(self.L.mi355_colorlut_unload(self.h))
+
+    def colorlut_kernel_choice(self, fused=False):
+        """(table_in_use, ms per megapixel of the interpolating kernel, of the table kernel) for LUT variant 0 (auto)."""
+        k, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._ck(self.L.mi355_colorlut_kernel_choice(self.h, int(fused), C.byref(k), C.byref(a), C.byref(b)))
+        return bool(k.value), a.value, b.value
 
     def colorlut_frame(self, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
         self._ck(self.L.mi355_colorlut_frame(self.h, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt]))

@@ -82,7 +82,12 @@ int mi355_ctx_synchronize(mi355_ctx *ctx);
 typedef enum mi355_flag {
   MI355_FLAG_FORCE_GENERIC = 1,
   MI355_FLAG_HSV_BLOCKS_PER_CU = 2, /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
-  MI355_FLAG_LUT_VARIANT = 4,  /* colorlut 3D LDS kernel: 0 = default; 1 = next tile prefetched before the last pass; 2 = lean per-pixel state (32 px/lane) */
+  /* colorlut kernel choice for packed RGBA8 frames. 0 = auto (default): the interpolating kernel and the 2^24-entry
+   * memoised-table kernel (built on the device from the interpolating kernel, so bit-identical) are both timed on the
+   * first two launches after a LUT load and every 1024 launches after that, and the faster one serves the launches in
+   * between; mi355_hsv_colorlut_* does the same with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms (tuning experiments);
+   * 4 / 5 = table kernel only, linear / Morton table index. */
+  MI355_FLAG_LUT_VARIANT = 4,
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
 } mi355_flag;
@@ -143,6 +148,11 @@ int mi355_colorlut_load(mi355_ctx *ctx, int is3d, size_t size, const float *tabl
                         const float domain_scale[3], const float domain_offset[3]);
 /* ColorLut::stop (colorlut/imp.rs:196-199). */
 int mi355_colorlut_unload(mi355_ctx *ctx);
+/* Diagnostics for MI355_FLAG_LUT_VARIANT 0 (auto): which kernel kind serves packed RGBA8 launches right now
+ * (*table_in_use: 0 interpolating kernel, 1 memoised table) and the last measured time of each kind in ms per
+ * megapixel (0 = not measured yet); fused = 0 for mi355_colorlut_*, 1 for mi355_hsv_colorlut_*. No reference
+ * counterpart. */
+int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
 /* Replaces transform_frame's body: transform_rgba / transform_rgba64::<LE>
  * (colorlut/imp.rs:203-223 -> :226-397). format in {RGBA, RGBA64_LE, RGBA64_BE}; src and dst are
  * plane 0 of two different frames with independent strides; rows = chunks(stride).take(height). */

@@ -609,6 +609,45 @@ def test_fused_chain_4k_batch_equals_two_element_launches(ctx, oracle, synth):
     assert (fused[: exp0.size] == exp0).all()
 
 
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("setting,kind,size", [("hue90", "3d", 33), ("mixed", "3d", 65), ("nonfinite", "3d", 17), ("mixed", "1d", 128)])
+def test_fused_chain_table_kernel_allcolors(ctx, oracle, synth, variant, setting, kind, size):
+    """The memoised table of the COMPOSED function (hsvfilter then colorlut) on every colour, for LUTs the fused
+    compute kernel handles (17, 33) and ones that take the two-kernel route when the table is built (65, 1D)."""
+    import mi355fx
+    st = {"nonfinite": (float("inf"), 1.3, -0.1, 0.9, 0.05)}.get(setting) or synth.HSV_SETTINGS[setting]
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size) if kind == "3d" else synth.cube_text_1d(size))
+    ac = synth.allcolors()
+    exp = _oracle_chain(oracle, cube, ac, 4096, 4096, st)
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+    got, src_after = _fused_device(ctx, ac.reshape(1, 4096, 4096 * 4), 4096, 4096, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+    assert (src_after == ac.reshape(-1)).all()
+
+
+def test_fused_chain_auto_builds_table_for_stable_settings_only(ctx, oracle, synth):
+    """Auto mode on the fused entry point: no table while the hsv settings keep changing; once they have been the same
+    for 8 calls the table is built and (on natural-like content) used; a settings change is honoured immediately."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    w, h = W4K, H4K
+    frame = synth.smooth_frame(w, h, seed=77).reshape(1, h, w * 4)
+    sts = [synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"]]
+    exps = [_oracle_chain(oracle, cube, frame[0], w, h, st) for st in sts]
+    for k in range(6):  # alternating settings: compute kernel every time
+        got, _ = _fused_device(ctx, frame, w, h, sts[k % 2])
+        assert (got == exps[k % 2]).all()
+    assert ctx.colorlut_kernel_choice(fused=True) == (False, 0.0, 0.0)
+    for k in range(24):
+        got, _ = _fused_device(ctx, frame, w, h, sts[0])
+        assert (got == exps[0]).all(), "call %d" % k
+    on_table, t_c, t_t = ctx.colorlut_kernel_choice(fused=True)
+    assert t_c > 0.0 and t_t > 0.0 and on_table == (t_t < t_c)
+    assert on_table, (t_c, t_t)
+    got, _ = _fused_device(ctx, frame, w, h, sts[1])  # new settings: must not be served from the old table
+    assert (got == exps[1]).all()
+
+
 def test_fused_chain_errors(ctx, synth):
     import mi355fx
     ctx.colorlut_unload()
@@ -634,6 +673,111 @@ def test_colorlut_kernel_variants_allcolors(ctx, oracle, synth, variant, size):
     got = np.zeros_like(ac)
     ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("variant", [4, 5, 0])
+@pytest.mark.parametrize("kind,size", [("3d", 2), ("3d", 33), ("3d", 65), ("1d", 256)])
+def test_colorlut_table_kernel_allcolors(ctx, oracle, synth, variant, kind, size):
+    """The 2^24-entry memoised-table kernel (MI355_FLAG_LUT_VARIANT 4 linear / 5 Morton index, and whatever 0 = auto
+    picks on the second and later launches) on every colour, with a varying alpha that must pass through."""
+    import mi355fx
+    text = synth.cube_text_3d(size) if kind == "3d" else synth.cube_text_1d(size)
+    cube = _load_cube(ctx, oracle, text)
+    ac = synth.allcolors().copy()
+    ac.reshape(-1, 4)[:, 3] = (np.arange(4096 * 4096, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+    exp = np.zeros_like(ac)
+    oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+    for _ in range(3 if variant == 0 else 1):  # auto: interpolating kernel, then the table build + table kernel, then its pick
+        got = np.zeros_like(ac)
+        ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
+        assert (got == exp).all(), _mismatch_report(got, exp)
+    if variant == 0:
+        _, t_c, t_t = ctx.colorlut_kernel_choice()
+        assert t_c > 0.0 and t_t > 0.0  # both kinds ran and were measured
+
+
+def test_colorlut_table_follows_lut_reload(ctx, oracle, synth):
+    """A new LUT invalidates the memoised table."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 5)
+    px = synth.noise_frame(256, 64, seed=3)
+    for size in (17, 33):
+        cube = _load_cube(ctx, oracle, synth.cube_text_3d(size, amp=0.01 * size / 8))
+        exp = np.zeros_like(px)
+        oracle.colorlut_rgba8(cube, px, 256 * 4, exp, 256 * 4, 256, 64)
+        got = np.zeros_like(px)
+        ctx.colorlut_frame(px, 256 * 4, got, 256 * 4, 256, 64, "RGBA")
+        assert (got == exp).all()
+
+
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("w,h", [(4, 1), (100, 37), (128, 4), (516, 3), (1920, 1081)])
+def test_colorlut_table_kernel_chunk_tails(ctx, oracle, synth, variant, w, h):
+    """Frame sizes around the table kernel's 512-pixel wave chunks (none, exactly one, one plus a remainder ...)."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(17))
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+    src = synth.noise_frame(w, h, seed=w + h).reshape(-1)
+    exp = np.zeros_like(src)
+    oracle.colorlut_rgba8(cube, src, w * 4, exp, w * 4, w, h)
+    got = np.full_like(src, 0x5A)
+    ctx.colorlut_frame(src, w * 4, got, w * 4, w, h, "RGBA")
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_table_geometry_fallback(ctx, oracle, synth):
+    """Padded rows and odd sizes are not eligible for the table kernel; the flag must not change the result."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 5)
+    w, h, stride = 37, 11, 37 * 4 + 12
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, size=h * stride, dtype=np.uint8)
+    exp = np.zeros_like(src)
+    oracle.colorlut_rgba8(cube, src, stride, exp, stride, w, h)
+    got = np.zeros_like(src)
+    ctx.colorlut_frame(src, stride, got, stride, w, h, "RGBA")
+    rows = lambda a: np.stack([a[y * stride: y * stride + w * 4] for y in range(h)])
+    assert (rows(got) == rows(exp)).all()
+
+
+def test_colorlut_auto_switches_with_content(ctx, oracle, synth):
+    """Auto mode: natural-like frames end up on the table kernel, uniform noise flips it back to the interpolating
+    kernel within the sampling interval; output stays exact throughout."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
+    n = 2
+    nb = n * W4K * H4K * 4
+    d_s, d_n, d_o = ctx.alloc(nb), ctx.alloc(nb), ctx.alloc(nb)
+    try:
+        smooth = np.stack([synth.smooth_frame(W4K, H4K, seed=40 + i) for i in range(n)]).reshape(-1)
+        noise = np.stack([synth.noise_frame(W4K, H4K, seed=50 + i) for i in range(n)]).reshape(-1)
+        ctx.h2d(d_s, smooth)
+        ctx.h2d(d_n, noise)
+        run = lambda d: ctx.colorlut_frames_device(d, H4K * W4K * 4, W4K * 4, d_o, H4K * W4K * 4, W4K * 4, n, W4K, H4K, "RGBA")
+        for _ in range(40):
+            run(d_s)
+            ctx.synchronize()
+        on_table, t_c, t_t = ctx.colorlut_kernel_choice()
+        assert on_table and 0.0 < t_t < t_c, (on_table, t_c, t_t)
+        out = np.zeros_like(smooth)
+        ctx.d2h(out, d_o)
+        exp = np.zeros(W4K * H4K * 4, np.uint8)
+        oracle.colorlut_rgba8(cube, smooth[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
+        assert (out[: exp.size] == exp).all()
+        for _ in range(40):
+            run(d_n)
+            ctx.synchronize()
+        on_table, t_c, t_t = ctx.colorlut_kernel_choice()
+        assert not on_table and t_t > t_c, (on_table, t_c, t_t)
+        ctx.d2h(out, d_o)
+        oracle.colorlut_rgba8(cube, noise[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
+        assert (out[: exp.size] == exp).all()
+    finally:
+        for d in (d_s, d_n, d_o):
+            ctx.free(d)
 
 
 @pytest.mark.parametrize("st", [(0.0, 10.0, 0.0, 0.15, 0.0, 0.3), (120.0, 40.0, 0.8, 0.5, 0.7, 0.6), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5)])
