@@ -40,6 +40,8 @@ def parse_args():
                          "(first plane stagings, tail imbalance) make 8 frames/launch ~10 %% slower per frame")
     ap.add_argument("--ring", type=int, default=2, help="distinct batches cycled through (working set > Infinity Cache)")
     ap.add_argument("--content", default="smooth", choices=["smooth", "noise"], help="headline frame content")
+    ap.add_argument("--lut-variant", type=int, default=0,
+                    help="MI355_FLAG_LUT_VARIANT: 0 auto (default), 6 interpolating kernel only, 5 table kernel only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
     return ap.parse_args()
@@ -154,6 +156,8 @@ def main():
     with torch.cuda.stream(stream):
         ctx.set_stream(stream.cuda_stream)
         ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+        if args.lut_variant:
+            ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
 
         def measure(content, steps, warmup, record):
             srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
@@ -249,7 +253,8 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
                        "frames_per_step": args.batch, "ring_batches": args.ring, "content": args.content,
-                       "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1},
+                       "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
+                       "lut_variant": args.lut_variant},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms},

@@ -5,14 +5,17 @@
 # Outputs land in gpurun_out/profiles_<tag>/ ; tools/summarize_profiles.py condenses them into profiles/.
 set -u
 TAG=${1:-r01}
+EXTRA=${2:-}   # extra bench.py arguments, e.g. "--lut-variant 6"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > "$OUT/pmc_fetch.log" 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > "$OUT/pmc_write.log" 2>&1; echo "write rc=$?"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_tcc" -o c -- $BENCH > "$OUT/pmc_tcc.log" 2>&1; echo "tcc rc=$?"
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d "$OUT/pmc_tcp" -o p -- $BENCH > "$OUT/pmc_tcp.log" 2>&1; echo "tcp rc=$?"
 grep -h '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
-python3 $R/bench.py --steps 50 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+python3 $R/bench.py --steps 50 --warmup 5 $EXTRA > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"

@@ -48,6 +48,19 @@ def main():
             wb = w.get(k, (0.0, 0))[0] * 1024
             out["kernels"][short] = {"fetch_size_kib_raw": f[k][0], "write_size_kib_raw": w.get(k, (0.0, 0))[0],
                                      "hbm_read_bytes": fb, "hbm_write_bytes": wb, "hbm_bytes": fb + wb, "launches_sampled": f[k][1]}
+    # L2 (TCC) hit rate and L1 (TCP) miss traffic per kernel, where the extra passes exist
+    for sub, names in (("pmc_tcc", ("TCC_HIT_sum", "TCC_MISS_sum")), ("pmc_tcp", ("TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"))):
+        files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        for name in names:
+            for k, (v, _) in avg_counter(files[0], name).items():
+                if "mi355::" in k:
+                    short = k.split("mi355::")[1].split("(")[0]
+                    out["kernels"].setdefault(short, {})[name] = v
+    for rec in out["kernels"].values():
+        if "TCC_HIT_sum" in rec and rec["TCC_HIT_sum"] + rec.get("TCC_MISS_sum", 0) > 0:
+            rec["l2_hit_rate"] = rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"])
     b0 = os.path.join(src, "bench.json")
     try:
         out["frames_per_step"] = json.load(open(b0))["config"]["frames_per_step"]   # the PMC passes ran the same default workload
