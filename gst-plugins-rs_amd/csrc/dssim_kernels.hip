@@ -113,26 +113,41 @@ __device__ __forceinline__ void dssim_lab_px(float r, float g, float b, float &L
   B = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
 }
 
-// one 3x3 pass inside the LDS region: dst(lx,ly) for region coords in [m, kRw-m) x [m, kRh-m), reading src with
-// per-pass edge replication in IMAGE coordinates. SQ: square the input on the fly.
-template <bool SQ>
-__device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, int m, int x0, int y0, int w, int h) {
+// one 3x3 pass inside the LDS region: dst(lx,ly) for region coords in [M, kRw-M) x [M, kRh-M), reading src with
+// per-pass edge replication in IMAGE coordinates. SQ: square the input on the fly. INTERIOR (block-uniform: the whole
+// region lies inside the image) drops the clamps and the in-image test - the per-tap coordinate arithmetic was ~80 % of
+// the kernel's instructions - and leaves nine LDS reads at constant offsets; the taps and their order are the same.
+template <bool SQ, int M, bool INTERIOR>
+__device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, int x0, int y0, int w, int h) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
-  const int rw = kRw - 2 * m, rh = kRh - 2 * m;
+  constexpr int rw = kRw - 2 * M, rh = kRh - 2 * M;
   for (int e = threadIdx.x; e < rw * rh; e += 256) {
-    const int ly = m + e / rw, lx = m + e - (e / rw) * rw;
-    const int gx = x0 + lx, gy = y0 + ly;            // image coordinates of this region cell (may be outside the image)
+    const int ly = M + e / rw, lx = M + e - (e / rw) * rw;
     float acc = 0.0f;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {    // cells outside the image are never read (clamping maps inside)
+    if (INTERIOR) {
+      const float *p = src + ly * kRw + lx;
 #pragma unroll
       for (int dyy = 0; dyy < 3; dyy++) {
-        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
         for (int dxx = 0; dxx < 3; dxx++) {
-          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-          float v = src[(yy - y0) * kRw + (xx - x0)];
+          float v = p[(dyy - 1) * kRw + (dxx - 1)];
           if (SQ) v = v * v;
           acc = acc + v * K[dyy * 3 + dxx];
+        }
+      }
+    } else {
+      const int gx = x0 + lx, gy = y0 + ly;            // image coordinates of this region cell (may be outside the image)
+      if (gx >= 0 && gx < w && gy >= 0 && gy < h) {    // cells outside the image are never read (clamping maps inside)
+#pragma unroll
+        for (int dyy = 0; dyy < 3; dyy++) {
+          int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+          for (int dxx = 0; dxx < 3; dxx++) {
+            int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+            float v = src[(yy - y0) * kRw + (xx - x0)];
+            if (SQ) v = v * v;
+            acc = acc + v * K[dyy * 3 + dxx];
+          }
         }
       }
     }
@@ -140,24 +155,17 @@ __device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, 
   }
 }
 
-__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimSrc S, int w, int h, float *__restrict__ img0, float *__restrict__ img1,
-                                                                float *__restrict__ img2, float *__restrict__ mu0, float *__restrict__ mu1,
-                                                                float *__restrict__ mu2, float *__restrict__ sq0, float *__restrict__ sq1,
-                                                                float *__restrict__ sq2) {
-  __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
-  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
-  __shared__ float s_lut[256];
-  if (S.u8) s_lut[threadIdx.x] = S.lut[threadIdx.x];
-  const int tiles_x = (w + kTw - 1) / kTw;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;  // image coords of region cell (0,0)
-  __syncthreads();
+struct DssimPlanes { float *img[3], *mu[3], *sq[3]; };
+
+template <bool INTERIOR>
+__device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h, const DssimPlanes &O, float (*s_lab)[kRw * kRh], float *s_a,
+                                                 float *s_b, const float *s_lut, int x0, int y0) {
   // 1. LAB of every in-image region cell
   for (int e = threadIdx.x; e < kRw * kRh; e += 256) {
     const int ly = e / kRw, lx = e - ly * kRw;
     const int gx = x0 + lx, gy = y0 + ly;
     float L = 0, A = 0, B = 0;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+    if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
       float r, g, b;
       if (S.u8) {
         const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
@@ -174,43 +182,57 @@ __global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimSrc S, int 
   __syncthreads();
   // 2. chroma pre-blur (two passes): valid on the region minus a margin of 2
   for (int c = 1; c < 3; c++) {
-    dssim_region_pass<false>(s_lab[c], s_a, 1, x0, y0, w, h);
+    dssim_region_pass<false, 1, INTERIOR>(s_lab[c], s_a, x0, y0, w, h);
     __syncthreads();
-    dssim_region_pass<false>(s_a, s_lab[c], 2, x0, y0, w, h);
+    dssim_region_pass<false, 2, INTERIOR>(s_a, s_lab[c], x0, y0, w, h);
     __syncthreads();
   }
   // 3. per plane: img = plane (tile), mu = blur(plane), sq = blur(plane^2); margins 3 and 4
-  float *imgs[3] = {img0, img1, img2}, *mus[3] = {mu0, mu1, mu2}, *sqs[3] = {sq0, sq1, sq2};
   for (int c = 0; c < 3; c++) {
-    dssim_region_pass<false>(s_lab[c], s_a, 3, x0, y0, w, h);
-    dssim_region_pass<true>(s_lab[c], s_b, 3, x0, y0, w, h);
+    dssim_region_pass<false, 3, INTERIOR>(s_lab[c], s_a, x0, y0, w, h);
+    dssim_region_pass<true, 3, INTERIOR>(s_lab[c], s_b, x0, y0, w, h);
     __syncthreads();
     // second passes straight to global for the tile cells
     const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
     for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
       const int ly = kHalo + e / kTw, lx = kHalo + e - (e / kTw) * kTw;
       const int gx = x0 + lx, gy = y0 + ly;
-      if (gx < w && gy < h) {
+      if (INTERIOR || (gx < w && gy < h)) {
         float am = 0.0f, as = 0.0f;
 #pragma unroll
         for (int dyy = 0; dyy < 3; dyy++) {
-          int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+          int yy = gy + dyy - 1;
+          if (!INTERIOR) yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
           for (int dxx = 0; dxx < 3; dxx++) {
-            int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-            const int j = (yy - y0) * kRw + (xx - x0);
+            int xx = gx + dxx - 1;
+            if (!INTERIOR) xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+            const int j = INTERIOR ? (ly + dyy - 1) * kRw + (lx + dxx - 1) : (yy - y0) * kRw + (xx - x0);
             am = am + s_a[j] * K[dyy * 3 + dxx];
             as = as + s_b[j] * K[dyy * 3 + dxx];
           }
         }
         const size_t o = (size_t)gy * w + gx;
-        imgs[c][o] = s_lab[c][ly * kRw + lx];
-        mus[c][o] = am;
-        sqs[c][o] = as;
+        O.img[c][o] = s_lab[c][ly * kRw + lx];
+        O.mu[c][o] = am;
+        O.sq[c][o] = as;
       }
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimSrc S, int w, int h, DssimPlanes O) {
+  __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
+  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
+  __shared__ float s_lut[256];
+  if (S.u8) s_lut[threadIdx.x] = S.lut[threadIdx.x];
+  const int tiles_x = (w + kTw - 1) / kTw;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;  // image coords of region cell (0,0)
+  __syncthreads();
+  if (x0 >= 0 && y0 >= 0 && x0 + kRw <= w && y0 + kRh <= h) dssim_scale_body<true>(S, w, h, O, s_lab, s_a, s_b, s_lut, x0, y0);
+  else dssim_scale_body<false>(S, w, h, O, s_lab, s_a, s_b, s_lut, x0, y0);
 }
 
 __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
@@ -228,18 +250,14 @@ __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
 constexpr int kCh = 2, kCw = kTw + 2 * kCh, kChh = kTh + 2 * kCh;  // 36 x 20
 struct DssimCmp { const float *img1[3], *img2[3], *mu1[3], *mu2[3], *sq1[3], *sq2[3]; };
 
-__global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
-  __shared__ float s_p[3][kCw * kChh];   // products img1*img2 of the region
-  __shared__ float s_q[3][kCw * kChh];   // first blur pass
-  __shared__ double s_w[4];
+template <bool INTERIOR>
+__device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, int h, float *__restrict__ ssim_map, float (*s_p)[kCw * kChh],
+                                                     float (*s_q)[kCw * kChh], int x0, int y0) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
-  const int tiles_x = (w + kTw - 1) / kTw;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x0 = tx * kTw - kCh, y0 = ty * kTh - kCh;
   for (int e = threadIdx.x; e < kCw * kChh; e += 256) {
     const int ly = e / kCw, lx = e - ly * kCw;
     const int gx = x0 + lx, gy = y0 + ly;
-    const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    const bool in = INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h);
     const size_t o = in ? (size_t)gy * w + gx : 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) s_p[c][e] = in ? P.img1[c][o] * P.img2[c][o] : 0.0f;
@@ -249,15 +267,17 @@ __global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, in
   for (int e = threadIdx.x; e < (kCw - 2) * (kChh - 2); e += 256) {
     const int ly = 1 + e / (kCw - 2), lx = 1 + e - (e / (kCw - 2)) * (kCw - 2);
     const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+    if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
       float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int dyy = 0; dyy < 3; dyy++) {
-        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        int yy = gy + dyy - 1;
+        if (!INTERIOR) yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
         for (int dxx = 0; dxx < 3; dxx++) {
-          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-          const int j = (yy - y0) * kCw + (xx - x0);
+          int xx = gx + dxx - 1;
+          if (!INTERIOR) xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          const int j = INTERIOR ? (ly + dyy - 1) * kCw + (lx + dxx - 1) : (yy - y0) * kCw + (xx - x0);
 #pragma unroll
           for (int c = 0; c < 3; c++) acc[c] = acc[c] + s_p[c][j] * K[dyy * 3 + dxx];
         }
@@ -272,15 +292,17 @@ __global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, in
   for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
     const int ly = kCh + e / kTw, lx = kCh + e - (e / kTw) * kTw;
     const int gx = x0 + lx, gy = y0 + ly;
-    if (gx < w && gy < h) {
+    if (INTERIOR || (gx < w && gy < h)) {
       float x12[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int dyy = 0; dyy < 3; dyy++) {
-        int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        int yy = gy + dyy - 1;
+        if (!INTERIOR) yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
 #pragma unroll
         for (int dxx = 0; dxx < 3; dxx++) {
-          int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-          const int j = (yy - y0) * kCw + (xx - x0);
+          int xx = gx + dxx - 1;
+          if (!INTERIOR) xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+          const int j = INTERIOR ? (ly + dyy - 1) * kCw + (lx + dxx - 1) : (yy - y0) * kCw + (xx - x0);
 #pragma unroll
           for (int c = 0; c < 3; c++) x12[c] = x12[c] + s_q[c][j] * K[dyy * 3 + dxx];
         }
@@ -300,6 +322,18 @@ __global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, in
       dsum += (double)ssim;
     }
   }
+  return dsum;
+}
+
+__global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
+  __shared__ float s_p[3][kCw * kChh];   // products img1*img2 of the region
+  __shared__ float s_q[3][kCw * kChh];   // first blur pass
+  __shared__ double s_w[4];
+  const int tiles_x = (w + kTw - 1) / kTw;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * kTw - kCh, y0 = ty * kTh - kCh;
+  const double dsum = (x0 >= 0 && y0 >= 0 && x0 + kCw <= w && y0 + kChh <= h) ? dssim_compare_body<true>(P, w, h, ssim_map, s_p, s_q, x0, y0)
+                                                                             : dssim_compare_body<false>(P, w, h, ssim_map, s_p, s_q, x0, y0);
   const double t = dssim_block_sum(dsum, s_w);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -442,8 +476,9 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     if (k == 0) { S.u8 = d_frame; S.stride = stride; S.channels = channels; S.lut = d_lut; S.lin = nullptr; }
     else { S.u8 = nullptr; S.stride = 0; S.channels = 0; S.lut = nullptr; S.lin = cur; }
     const unsigned tiles = (unsigned)(((s.w + kTw - 1) / kTw) * ((s.h + kTh - 1) / kTh));
-    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, S, s.w, s.h, s.img[0], s.img[1], s.img[2], s.mu[0], s.mu[1], s.mu[2],
-                       s.sq[0], s.sq[1], s.sq[2]);
+    DssimPlanes O;
+    for (int c = 0; c < 3; c++) { O.img[c] = s.img[c]; O.mu[c] = s.mu[c]; O.sq[c] = s.sq[c]; }
+    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, S, s.w, s.h, O);
     if (k + 1 < ns) {
       if (k == 0) {
         hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[1] * hs[1])), dim3(256), 0, ctx->stream, (const float4 *)lin_a, s.w, s.h, lin_b);
