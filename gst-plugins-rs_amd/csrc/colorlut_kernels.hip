@@ -885,6 +885,67 @@ __global__ __launch_bounds__(256) void colorlut_table_kernel(const uint4 *__rest
   }
 }
 
+// Tiled form for frames whose rows are whole pixel groups (width % 4 == 0): a wave's 512 pixels are a 256 x 2 (or 128 x 4)
+// patch of the picture instead of 512 consecutive pixels of one row, and the four waves of a block take four patches
+// stacked vertically (256 x 8). Vertically adjacent pixels have (almost) the same colours, so the table lines a block
+// touches are reused more often before they fall out of the 32 KB L1: 0.163 -> 0.132-0.137 ms per 8x4K (128 x 4: 0.140,
+// 64 x 8: 0.143, 32 x 16: 0.157 - narrow patches cut the loads into short segments; blocks of 512 / 1024 lanes: 0.143 / 0.149). What costs time in this kernel is not the divergent gather
+// itself (64 random colours, all L1 hits: 0.119 ms per 8x4K, next to 0.093 ms for a single colour) but L1 misses: each
+// moves a 128 B line from L2 for 4 useful bytes (1024..4096 random colours, every gather an L2 hit: 0.28-0.31 ms =
+// 30 TB/s of line traffic = the L2's bandwidth). tools/table_gather_probe.py.
+// The frames are contiguous, so the batch is one picture of `rows` = n_frames * height rows of w4 pixel groups.
+template <bool MORTON, int TW4>  // TW4 = patch width in pixel groups (64 = 256 px); a wave's patch is TW4*4 px x 128/TW4 rows
+__global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned w4, unsigned rows,
+                                                                   unsigned n_cols, unsigned n_tiles, const uint32_t *__restrict__ table) {
+  __shared__ uint32_t s_spread[256];
+  __shared__ uint32_t s_strip[4][512];
+  if (MORTON) {
+    s_spread[threadIdx.x] = spread3(threadIdx.x);
+    __syncthreads();
+  }
+  auto index = [&](uint32_t p) -> uint32_t {
+    if (MORTON) return s_spread[p & 0xffu] | (s_spread[(p >> 8) & 0xffu] << 1) | (s_spread[(p >> 16) & 0xffu] << 2);
+    return p & 0x00ffffffu;
+  };
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t *x = s_strip[wave];
+  const u32x4_t *s4 = (const u32x4_t *)src;
+  u32x4_t *d4 = (u32x4_t *)dst;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  constexpr unsigned RPL = 64 / TW4;            // rows covered by one 64-lane load
+  const unsigned sub = lane / TW4, g = lane % TW4;
+  // tiles in row-major order, grid-stride: the resident blocks sweep the picture together (a block walking down its
+  // own column instead is 10 % slower: the HBM streams scatter)
+  for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const unsigned tx = t % n_cols, ty = t / n_cols;
+    const unsigned col = tx * TW4 + g;
+    const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
+    const bool ok0 = col < w4 && r0 < rows, ok1 = col < w4 && r1 < rows;
+    const size_t i0 = (size_t)r0 * w4 + col, i1 = (size_t)r1 * w4 + col;
+    u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (ok0) p = __builtin_nontemporal_load(s4 + i0);
+    if (ok1) q = __builtin_nontemporal_load(s4 + i1);
+    *(u32x4_t *)(x + lane * 4) = p;
+    *(u32x4_t *)(x + 256 + lane * 4) = q;
+    wave_sync();
+    uint32_t px[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) px[j] = x[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = table[index(px[j])];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
+    wave_sync();
+    const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
+    wave_sync();
+    if (ok0) __builtin_nontemporal_store(r0v, d4 + i0);
+    if (ok1) __builtin_nontemporal_store(r1v, d4 + i1);
+  }
+}
+
 void lut_release(mi355_ctx *ctx) {
   for (int i = 0; i < 2; i++) {
     if (ctx->lut.d_table[i]) (void)hipFree(ctx->lut.d_table[i]);
@@ -1280,13 +1341,34 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   return MI355_OK;
 }
 
-static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int morton, const mi355_hsv_settings *hs) {
+static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton,
+                        const mi355_hsv_settings *hs) {
   int rc = table_ensure(ctx, which, morton, hs);
   if (rc) return rc;
+  const uint32_t *t = ctx->lut.d_table[which];
+  if (width % 4 == 0 && width >= 128 && rows < (1u << 30)) {
+    const unsigned w4 = (unsigned)width / 4;
+    // 256-pixel patches unless 128-pixel ones waste fewer masked lanes in the last column
+    const unsigned pad64 = (w4 + 63) / 64 * 64 - w4, pad32 = (w4 + 31) / 32 * 32 - w4;
+    const unsigned tw4 = pad64 <= pad32 ? 64 : 32;
+    const unsigned n_cols = (w4 + tw4 - 1) / tw4, rpb = 8 * (64 / tw4);
+    const size_t n_tiles = (size_t)n_cols * ((rows + rpb - 1) / rpb);
+    if (n_tiles < (1u << 31)) {
+      size_t grid = (size_t)ctx->n_cu * 16;
+      if (grid > n_tiles) grid = n_tiles;
+#define MI355_LT(M, T) hipLaunchKernelGGL((colorlut_table_tiled_kernel<M, T>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, \
+                                          (uint4 *)d_dst, w4, (unsigned)rows, n_cols, (unsigned)n_tiles, t)
+      if (morton && tw4 == 64) MI355_LT(true, 64);
+      else if (morton) MI355_LT(true, 32);
+      else if (tw4 == 64) MI355_LT(false, 64);
+      else MI355_LT(false, 32);
+#undef MI355_LT
+      return check_hip(ctx, hipGetLastError(), "colorlut table kernel launch");
+    }
+  }
   size_t grid = (size_t)ctx->n_cu * 16;
   const size_t max_blocks = n_vec / 512 + 1;  // a block's four waves take one 128-group chunk each per iteration
   if (grid > max_blocks) grid = max_blocks;
-  const uint32_t *t = ctx->lut.d_table[which];
   if (morton) hipLaunchKernelGGL((colorlut_table_kernel<true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_vec, t);
   else hipLaunchKernelGGL((colorlut_table_kernel<false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_vec, t);
   return check_hip(ctx, hipGetLastError(), "colorlut table kernel launch");
@@ -1387,10 +1469,10 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
                         rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, n_vec, v == 5 ? 1 : 0, nullptr);
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, n_vec, width, (size_t)n_frames * height, v == 5 ? 1 : 0, nullptr);
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
-                     [&]() { return launch_table(ctx, 0, d_src, d_dst, n_vec, 1, nullptr); });
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, nullptr); });
 }
 
 // The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
@@ -1407,7 +1489,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   const bool table_ok = !ctx->force_generic && rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_hsv_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, hs, false); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, n_vec, v == 5 ? 1 : 0, &hs);
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, v == 5 ? 1 : 0, &hs);
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
   else { L.seen_hs = hs; L.seen_stable = 0; }
@@ -1417,7 +1499,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
     L.pick[1].t_table = 0.0;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
-                     [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, 1, &hs); });
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, &hs); });
 }
 
 }  // namespace mi355

@@ -712,9 +712,10 @@ def test_colorlut_table_follows_lut_reload(ctx, oracle, synth):
 
 
 @pytest.mark.parametrize("variant", [4, 5])
-@pytest.mark.parametrize("w,h", [(4, 1), (100, 37), (128, 4), (516, 3), (1920, 1081)])
+@pytest.mark.parametrize("w,h", [(4, 1), (100, 37), (128, 4), (516, 3), (1920, 1081), (3840, 7), (1000, 9), (256, 8), (260, 17)])
 def test_colorlut_table_kernel_chunk_tails(ctx, oracle, synth, variant, w, h):
-    """Frame sizes around the table kernel's 512-pixel wave chunks (none, exactly one, one plus a remainder ...)."""
+    """Frame sizes around the table kernels' 512-pixel wave patches: flat kernel (width < 128 or not a multiple of 4) and the
+    tiled kernel with 128- and 256-pixel-wide patches, masked last columns and rows."""
     import mi355fx
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(17))
     ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
