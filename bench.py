@@ -223,7 +223,7 @@ def main():
             fb = BYTES_PER_FRAME_PER_KERNEL * args.batch
             f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
             fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
-                     "kernel": "colorlut_table_kernel (composed hsv+lut table)" if f_tab else "colorlut3d_lds_kernel<HSV>",
+                     "kernel": "colorlut_table_tiled_kernel (composed hsv+lut table)" if f_tab else "colorlut3d_lds_kernel<HSV>",
                      "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
                      "algorithmic_bytes_per_launch": fb, "GBps": fb / (fused_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": fb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -235,7 +235,7 @@ def main():
             dt2, h2, l2 = measure(other, max(10, args.steps // 2), 10, True)
             extra = {"content": other, "frames_per_s": max(10, args.steps // 2) * args.batch / dt2,
                      "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2,
-                     "colorlut_kernel": "colorlut_table_kernel" if ctx.colorlut_kernel_choice()[0] else "colorlut3d_lds_kernel"}
+                     "colorlut_kernel": "colorlut_table_tiled_kernel" if ctx.colorlut_kernel_choice()[0] else "colorlut3d_lds_kernel"}
 
     fps = sharding.aggregate_throughput(args.steps * args.batch, world, dt)
     ms_per_step = dt / args.steps * 1e3
@@ -244,7 +244,7 @@ def main():
         # dominant kernel = the longer of the two launches
         per_launch_bytes = BYTES_PER_FRAME_PER_KERNEL * args.batch
         if lut_ms >= hsv_ms:
-            dom, dom_ms = ("colorlut_table_kernel" if lut_tab else "colorlut3d_lds_kernel"), lut_ms
+            dom, dom_ms = ("colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel"), lut_ms
         else:
             dom, dom_ms = "hsvfilter_flat_kernel", hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
@@ -276,7 +276,7 @@ def main():
                         "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
-                        "colorlut_kernel": "colorlut_table_kernel" if lut_tab else "colorlut3d_lds_kernel",
+                        "colorlut_kernel": "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel",
                         "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt}},
         }
         if interp:
