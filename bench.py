@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--content", default="smooth", choices=["smooth", "noise"], help="headline frame content")
     ap.add_argument("--lut-variant", type=int, default=0,
                     help="MI355_FLAG_LUT_VARIANT: 0 auto (default), 6 interpolating kernel only, 5 table kernel only")
+    ap.add_argument("--hsv-blocks-per-cu", type=int, default=0, help="MI355_FLAG_HSV_BLOCKS_PER_CU (tuning; 0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
     return ap.parse_args()
@@ -159,6 +160,8 @@ def main():
         ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
         if args.lut_variant:
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
+        if args.hsv_blocks_per_cu:
+            ctx.set_flag(mi355fx.FLAG_HSV_BLOCKS_PER_CU, args.hsv_blocks_per_cu)
 
         def measure(content, steps, warmup, record):
             srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
@@ -194,9 +197,9 @@ def main():
                         evs.append((e0, e1))
                 return evs
 
-            # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures one
-            # launch of each kind: keep that learning phase out of the timed region
-            region(max(warmup, 12), False)
+            # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
+            # launches of each kind: keep that learning phase out of the timed region
+            region(max(warmup, 14), False)
             evs = []
             dtf = sharding.timed_region(lambda: evs.extend(region(steps, True)), dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
             ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
@@ -231,8 +234,8 @@ def main():
         extra = None
         if not args.no_extra and rank == 0 and world == 1:
             other = "noise" if args.content == "smooth" else "smooth"
-            # warm-up long enough for the colorlut kernel choice to follow the change of content (sampled every 4th launch)
-            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 10, True)
+            # warm-up long enough for the colorlut kernel choice to follow the change of content (sampled every 8th launch)
+            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 18, True)
             extra = {"content": other, "frames_per_s": max(10, args.steps // 2) * args.batch / dt2,
                      "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2,
                      "colorlut_kernel": "colorlut_table_tiled_kernel" if ctx.colorlut_kernel_choice()[0] else "colorlut3d_lds_kernel"}

@@ -1378,11 +1378,12 @@ static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t
 // which one is faster depends on the content (the table kernel's gathers need colour locality: 0.18 vs 0.25 ms per
 // 8x4K on natural-like frames, 1.2 vs 0.40 ms on uniform noise), on the LUT size (the table kernel does not care) and on
 // the launch size. Auto keeps a per-pixel-group time for each kind, measured with event pairs that are recorded around
-// every n-th launch (n = 4..32, about one sample per 64 Mpixel) and read back at the start of a later launch - without
+// every n-th launch (n = 8..32, about one sample per 128 Mpixel) and read back at the start of a later launch - without
 // blocking if the events have completed, and blocking once the sample is n-1 launches old, which bounds how far a host
 // that enqueues in bursts can run ahead of the decision while the device still has n-2 launches queued:
-//   * the first eligible launch after a LUT load runs the compute kernel, the second one builds the table and runs the
-//     table kernel, both measured and waited for; from then on the kind with the smaller time serves the launches;
+//   * the first four eligible launches after a LUT load run compute, compute, table build + table, table, each waited
+//     for; the first launch of each kind is not used (its interval holds one-off costs: code upload, cold caches);
+//     from then on the kind with the smaller time serves the launches;
 //   * the kind in use keeps being sampled, so content that turns hostile to the table (its time rises above the compute
 //     kernel's last time) flips the choice at the next sample;
 //   * the kind NOT in use is tried again after `probe_period` launches (64, doubling up to 1024 while the answer stays
@@ -1401,7 +1402,9 @@ static void auto_harvest(AutoPick &A, unsigned max_lag) {
     return;
   }
   float ms = 0.0f;
-  if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess && ms > 0.0f) {
+  if (A.pending_discard) {
+    // first launch of a kind after a (re)start: its interval contains one-off costs (code upload, cold caches)
+  } else if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess && ms > 0.0f) {
     const double per_vec = (double)ms / (double)A.pending_vec;
     if (A.pending_kind == 0) A.t_compute = per_vec; else A.t_table = per_vec;
     if (A.t_compute > 0.0 && A.t_table > 0.0) {
@@ -1423,21 +1426,26 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev0), "hipEventCreate"))) return rc;
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev1), "hipEventCreate"))) return rc;
   }
-  unsigned sample_every = (unsigned)(((size_t)1 << 24) / n_vec);
-  sample_every = sample_every < 4 ? 4 : (sample_every > 32 ? 32 : sample_every);
-  const bool learning = A.t_compute == 0.0 || A.t_table == 0.0;
-  auto_harvest(A, learning ? 0 : sample_every - 1);
+  // a sampled launch costs ~10 us more (two timestamped events): every 8th launch at most
+  unsigned sample_every = (unsigned)(((size_t)1 << 25) / n_vec);
+  sample_every = sample_every < 8 ? 8 : (sample_every > 32 ? 32 : sample_every);
+  // learning: compute, compute, table, table - each launch waited for, the first of each kind discarded
+  auto_harvest(A, (A.learn < 4 || A.t_compute == 0.0 || A.t_table == 0.0) ? 0 : sample_every - 1);
   if (A.vec && (n_vec > 2 * A.vec || 2 * n_vec < A.vec) && A.pending_kind < 0) {
     A.t_compute = A.t_table = 0.0;
+    A.learn = 0;
     A.probe_period = kProbeMin;
     A.since_probe = 0;
   }
   if (A.pending_kind < 0) A.vec = n_vec;
   int kind;
-  bool probe = false;
-  if (A.t_compute == 0.0) { kind = 0; probe = true; }
-  else if (A.t_table == 0.0) { kind = 1; probe = true; }
-  else {
+  bool probe = false, discard = false;
+  if (A.learn < 4) {
+    kind = A.learn < 2 ? 0 : 1;
+    discard = (A.learn & 1) == 0;
+    probe = true;
+    if (A.pending_kind < 0) A.learn++;
+  } else {
     kind = A.table ? 1 : 0;
     if (++A.since_probe >= A.probe_period && A.pending_kind < 0) { kind ^= 1; probe = true; A.since_probe = 0; }
   }
@@ -1452,6 +1460,7 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
     A.pending_call = A.calls;
     A.pending_vec = n_vec;
     A.pending_probe = probe && A.t_compute > 0.0 && A.t_table > 0.0;
+    A.pending_discard = discard;
   }
   return MI355_OK;
 }
@@ -1495,8 +1504,9 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   else { L.seen_hs = hs; L.seen_stable = 0; }
   const bool have = L.d_table[1] && L.table_morton[1] == 1 && same_hs(L.table_hs, hs);
   if (!have && L.seen_stable < kStableCalls) return compute();
-  if (!have) {  // measurements of the table kernel belong to the old table's colours only loosely; start over
+  if (!have && L.pick[1].learn > 2) {  // the table kernel's time belongs to the old table only loosely: measure it again
     L.pick[1].t_table = 0.0;
+    L.pick[1].learn = 2;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
                      [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, &hs); });

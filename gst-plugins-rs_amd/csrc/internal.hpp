@@ -19,7 +19,8 @@ struct AutoPick {
   int pending_kind = -1;                  // measurement in flight: -1 none, 0 compute, 1 table
   size_t pending_vec = 0;
   unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
-  bool pending_probe = false;
+  bool pending_probe = false, pending_discard = false;
+  unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 

@@ -84,9 +84,10 @@ typedef enum mi355_flag {
   MI355_FLAG_HSV_BLOCKS_PER_CU = 2, /* grid cap (blocks per CU) of the streaming hsvfilter kernel; tuning knob */
   /* colorlut kernel choice for packed RGBA8 frames. 0 = auto (default): the interpolating kernel and the 2^24-entry
    * memoised-table kernel (built on the device from the interpolating kernel, so bit-identical) are both timed on the
-   * first two launches after a LUT load and every 1024 launches after that, and the faster one serves the launches in
-   * between; mi355_hsv_colorlut_* does the same with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms (tuning experiments);
-   * 4 / 5 = table kernel only, linear / Morton table index. */
+   * first four launches after a LUT load; afterwards the kind in use is re-timed every 8th-32nd launch and the other
+   * one every 64-1024 launches, and the faster one serves the launches in between. mi355_hsv_colorlut_* does the same
+   * with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms
+   * (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. */
   MI355_FLAG_LUT_VARIANT = 4,
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */

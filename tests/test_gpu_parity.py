@@ -688,7 +688,7 @@ def test_colorlut_table_kernel_allcolors(ctx, oracle, synth, variant, kind, size
     exp = np.zeros_like(ac)
     oracle.colorlut_rgba8(cube, ac, 4096 * 4, exp, 4096 * 4, 4096, 4096, nthreads=8)
     ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
-    for _ in range(3 if variant == 0 else 1):  # auto: interpolating kernel, then the table build + table kernel, then its pick
+    for _ in range(6 if variant == 0 else 1):  # auto: interpolating kernel twice, table build + table kernel twice, then its pick
         got = np.zeros_like(ac)
         ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
         assert (got == exp).all(), _mismatch_report(got, exp)
