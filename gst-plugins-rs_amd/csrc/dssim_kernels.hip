@@ -8,7 +8,8 @@
 //
 // A DssimImage lives on the device: 5 scales x 3 LAB planes x {img, mu, img_sq_blur} f32. All kernels are pointwise or
 // 3x3 stencils (HBM/L2-bound), the scores are block-reduced f64 sums finished on the host in a fixed order:
-//   dssim_linear_kernel / dssim_downsample_kernel   u8 sRGB(A) -> premultiplied linear float4; 2x2 box average chain
+//   dssim_downsample_u8_kernel / dssim_downsample_kernel   u8 sRGB(A) -> premultiplied linear float4 at half size; 2x2
+//                               box average chain (scale 0's linear values are converted on the fly by the scale kernel)
 //   dssim_scale_fused_kernel    per scale: LAB conversion (polynomial + 2x Halley cube root), chroma pre-blur and the
 //                               mu / img_sq_blur planes, all four blur passes through LDS tiles (halo 4)
 //   dssim_compare_fused_kernel  per scale: blur(img1*img2) through LDS (halo 2) + SSIM map + f64 block partials
@@ -41,26 +42,6 @@ struct mi355_dssim_image {
 
 namespace mi355 {
 
-__global__ __launch_bounds__(256) void dssim_linear_kernel(const uint8_t *__restrict__ src, int stride, int w, int h, int channels,
-                                                           const float *__restrict__ lut, float4 *__restrict__ dst) {
-  __shared__ float s_lut[256];
-  s_lut[threadIdx.x] = lut[threadIdx.x];
-  __syncthreads();
-  const size_t n = (size_t)w * h, gs = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
-    const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
-    const uint8_t *p = src + (size_t)y * stride + (size_t)x * channels;
-    float4 o;
-    if (channels == 4) {
-      const float a = (float)p[3] / 255.0f;
-      o = make_float4(s_lut[p[0]] * a, s_lut[p[1]] * a, s_lut[p[2]] * a, a);
-    } else {
-      o = make_float4(s_lut[p[0]], s_lut[p[1]], s_lut[p[2]], 1.0f);
-    }
-    dst[i] = o;
-  }
-}
-
 __global__ __launch_bounds__(256) void dssim_downsample_kernel(const float4 *__restrict__ src, int w, int h, float4 *__restrict__ dst) {
   const int w2 = w / 2, h2 = h / 2;
   const size_t n = (size_t)w2 * h2, gs = (size_t)gridDim.x * 256;
@@ -70,6 +51,49 @@ __global__ __launch_bounds__(256) void dssim_downsample_kernel(const float4 *__r
     const float4 c = src[(size_t)(2 * y + 1) * w + 2 * x], d = src[(size_t)(2 * y + 1) * w + 2 * x + 1];
     dst[i] = make_float4((((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f, (((a.z + b.z) + c.z) + d.z) * 0.25f,
                          (((a.w + b.w) + c.w) + d.w) * 0.25f);
+  }
+}
+
+// scale 1's linear image straight from the packed bytes: each of the four source pixels is converted (gamma table,
+// premultiplied by alpha/255) and averaged in dssim_downsample_kernel's order, so the full-size float4 image (133 MB for 4K)
+// is never written or read.
+__global__ __launch_bounds__(256) void dssim_downsample_u8_kernel(const uint8_t *__restrict__ src, int stride, int w, int h, int channels,
+                                                                  const float *__restrict__ lut, float4 *__restrict__ dst) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int w2 = w / 2, h2 = h / 2;
+  const size_t n = (size_t)w2 * h2, gs = (size_t)gridDim.x * 256;
+  const bool wide = channels == 4 && ((uintptr_t)src % 8 == 0) && (stride % 8 == 0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) {
+    const int y = (int)(i / w2), x = (int)(i - (size_t)y * w2);
+    float4 v[4];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint8_t *p = src + (size_t)(2 * y + r) * stride + (size_t)(2 * x) * channels;
+      uint8_t b[8];
+      if (wide) {
+        const uint2 q = *(const uint2 *)p;
+        b[0] = q.x & 255; b[1] = (q.x >> 8) & 255; b[2] = (q.x >> 16) & 255; b[3] = q.x >> 24;
+        b[4] = q.y & 255; b[5] = (q.y >> 8) & 255; b[6] = (q.y >> 16) & 255; b[7] = q.y >> 24;
+      } else if (channels == 4) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) b[j] = p[j];
+      } else {
+        b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = 255; b[4] = p[3]; b[5] = p[4]; b[6] = p[5]; b[7] = 255;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (channels == 4) {
+          const float a = (float)b[4 * j + 3] / 255.0f;
+          v[2 * r + j] = make_float4(s_lut[b[4 * j]] * a, s_lut[b[4 * j + 1]] * a, s_lut[b[4 * j + 2]] * a, a);
+        } else {
+          v[2 * r + j] = make_float4(s_lut[b[4 * j]], s_lut[b[4 * j + 1]], s_lut[b[4 * j + 2]], 1.0f);
+        }
+      }
+    }
+    dst[i] = make_float4((((v[0].x + v[1].x) + v[2].x) + v[3].x) * 0.25f, (((v[0].y + v[1].y) + v[2].y) + v[3].y) * 0.25f,
+                         (((v[0].z + v[1].z) + v[2].z) + v[3].z) * 0.25f, (((v[0].w + v[1].w) + v[2].w) + v[3].w) * 0.25f);
   }
 }
 
@@ -222,13 +246,23 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
   }
 }
 
-__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimSrc S, int w, int h, DssimPlanes O) {
+// up to three scales per launch (the small ones are launch-bound on their own): blocks [first[j], first[j+1]) belong
+// to entry j
+struct DssimScaleJob { DssimSrc S; int w, h; DssimPlanes O; };
+struct DssimScaleJobs { DssimScaleJob job[3]; unsigned first[4]; };
+
+__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimScaleJobs J) {
   __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
   __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
   __shared__ float s_lut[256];
+  const int j = blockIdx.x >= J.first[2] ? 2 : (blockIdx.x >= J.first[1] ? 1 : 0);
+  const DssimSrc &S = J.job[j].S;
+  const DssimPlanes &O = J.job[j].O;
+  const int w = J.job[j].w, h = J.job[j].h;
+  const unsigned tile = blockIdx.x - J.first[j];
   if (S.u8) s_lut[threadIdx.x] = S.lut[threadIdx.x];
   const int tiles_x = (w + kTw - 1) / kTw;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;  // image coords of region cell (0,0)
   __syncthreads();
   if (x0 >= 0 && y0 >= 0 && x0 + kRw <= w && y0 + kRh <= h) dssim_scale_body<true>(S, w, h, O, s_lab, s_a, s_b, s_lut, x0, y0);
@@ -338,35 +372,57 @@ __global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, in
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// sum the block partials (256 lanes, strided, then the fixed-order block reduction: deterministic);
+// The reductions of all scales of a comparison run in three launches (one block per scale, or a block range per scale):
+// per scale the work, the grid share and the summation order are what one launch per scale did, so the values are the
+// same; only ~12 launch overheads per comparison are gone.
+struct DssimRed {
+  const float *map[kDssimScales];        // SSIM map of the scale
+  const double *part_a[kDssimScales];    // block partials of the SSIM sum (n_a of them)
+  double *part_b[kDssimScales];          // block partials of the absolute deviations (first_b[k+1] - first_b[k] of them)
+  unsigned n_a[kDssimScales];
+  unsigned first_b[kDssimScales + 1];
+  double len[kDssimScales], exponent[kDssimScales];
+  size_t n[kDssimScales];
+  double *slots;                         // per scale: [sum, avg, dev]
+  int n_scales;
+};
+
+// block k: sum the block partials of scale k (256 lanes, strided, then the fixed-order block reduction: deterministic);
 // slot[0] = sum, slot[1] = avg = max(sum/len, 0)^(0.5^scale)
-__global__ __launch_bounds__(256) void dssim_avg_kernel(const double *__restrict__ partial, unsigned n_partial, double len, double exponent, double *__restrict__ slot) {
+__global__ __launch_bounds__(256) void dssim_avg_kernel(DssimRed R) {
   __shared__ double s_w[4];
+  const int k = blockIdx.x;
   double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  for (unsigned i = threadIdx.x; i < R.n_a[k]; i += 256) acc += R.part_a[k][i];
   const double sum = dssim_block_sum(acc, s_w);
   if (threadIdx.x == 0) {
-    slot[0] = sum;
-    slot[1] = pow(fmax(sum / len, 0.0), exponent);
+    R.slots[3 * k] = sum;
+    R.slots[3 * k + 1] = pow(fmax(sum / R.len[k], 0.0), R.exponent[k]);
   }
 }
 
-__global__ __launch_bounds__(256) void dssim_absdev2_kernel(const float *__restrict__ ssim_map, size_t n, const double *__restrict__ slot, double *__restrict__ partial) {
+__global__ __launch_bounds__(256) void dssim_absdev2_kernel(DssimRed R) {
   __shared__ double s_w[4];
-  const double avg = slot[1];
-  const size_t gs = (size_t)gridDim.x * 256;
+  int k = 0;
+  while (k + 1 < R.n_scales && blockIdx.x >= R.first_b[k + 1]) k++;
+  const unsigned j = blockIdx.x - R.first_b[k], g = R.first_b[k + 1] - R.first_b[k];
+  const double avg = R.slots[3 * k + 1];
+  const size_t gs = (size_t)g * 256, n = R.n[k];
+  const float *map = R.map[k];
   double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) acc += fabs(avg - (double)ssim_map[i]);
+  for (size_t i = (size_t)j * 256 + threadIdx.x; i < n; i += gs) acc += fabs(avg - (double)map[i]);
   const double t = dssim_block_sum(acc, s_w);
-  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+  if (threadIdx.x == 0) R.part_b[k][j] = t;
 }
 
-__global__ __launch_bounds__(256) void dssim_sum_kernel(const double *__restrict__ partial, unsigned n_partial, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void dssim_sum_kernel(DssimRed R) {
   __shared__ double s_w[4];
+  const int k = blockIdx.x;
+  const unsigned g = R.first_b[k + 1] - R.first_b[k];
   double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  for (unsigned i = threadIdx.x; i < g; i += 256) acc += R.part_b[k][i];
   const double sum = dssim_block_sum(acc, s_w);
-  if (threadIdx.x == 0) *out = sum;
+  if (threadIdx.x == 0) R.slots[3 * k + 2] = sum;
 }
 
 // ------------------------------------------------------------------ host side
@@ -451,11 +507,16 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     const size_t n = (size_t)s.w * s.h;
     for (int c = 0; c < 3; c++) { s.img[c] = p; p += n; s.mu[c] = p; p += n; s.sq[c] = p; p += n; }
   }
-  // scratch: two float4 linear images (ping-pong) + one f32 plane + the gamma table
-  const size_t n0 = (size_t)width * height;
+  // scratch: the linear float4 images of scales 1.. (scale 0 is converted from the bytes on the fly)
+  size_t lin_px = 0;
+  for (int k = 1; k < ns; k++) lin_px += (size_t)ws[k] * hs[k];
   void *scr = nullptr;
-  if ((rc = dssim_scratch(ctx, 1, n0 * 16 + (n0 / 4 + 16) * 16 + n0 * 4 + 1024, &scr))) { dssim_free_image(ctx, img); return rc; }
-  float4 *lin_a = (float4 *)scr, *lin_b = lin_a + n0;
+  if ((rc = dssim_scratch(ctx, 1, (lin_px + 16) * 16 + 1024, &scr))) { dssim_free_image(ctx, img); return rc; }
+  float4 *lin[kDssimScales] = {nullptr};
+  {
+    float4 *q = (float4 *)scr;
+    for (int k = 1; k < ns; k++) { lin[k] = q; q += (size_t)ws[k] * hs[k]; }
+  }
   DssimCache *cache = dssim_cache(ctx);
   if (!cache->d_lut) {
     float lut[256];
@@ -467,27 +528,36 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     if ((rc = check_hip(ctx, hipMemcpy(cache->d_lut, lut, sizeof lut, hipMemcpyHostToDevice), "dssim: gamma table"))) { dssim_free_image(ctx, img); return rc; }
   }
   float *d_lut = cache->d_lut;
-  // scale 0 straight from the packed bytes; the linear float4 image is only materialised for the downsampling chain
-  if (ns > 1) hipLaunchKernelGGL(dssim_linear_kernel, dim3(dssim_grid(ctx, n0)), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin_a);
-  float4 *cur = lin_a, *nxt = lin_b;
-  for (int k = 0; k < ns; k++) {
-    DssimScale &s = img->s[k];
-    DssimSrc S;
-    if (k == 0) { S.u8 = d_frame; S.stride = stride; S.channels = channels; S.lut = d_lut; S.lin = nullptr; }
-    else { S.u8 = nullptr; S.stride = 0; S.channels = 0; S.lut = nullptr; S.lin = cur; }
-    const unsigned tiles = (unsigned)(((s.w + kTw - 1) / kTw) * ((s.h + kTh - 1) / kTh));
-    DssimPlanes O;
-    for (int c = 0; c < 3; c++) { O.img[c] = s.img[c]; O.mu[c] = s.mu[c]; O.sq[c] = s.sq[c]; }
-    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, S, s.w, s.h, O);
-    if (k + 1 < ns) {
-      if (k == 0) {
-        hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[1] * hs[1])), dim3(256), 0, ctx->stream, (const float4 *)lin_a, s.w, s.h, lin_b);
-        cur = lin_b; nxt = lin_a;
-      } else {
-        hipLaunchKernelGGL(dssim_downsample_kernel, dim3(dssim_grid(ctx, (size_t)ws[k + 1] * hs[k + 1])), dim3(256), 0, ctx->stream, (const float4 *)cur, s.w, s.h, nxt);
-        float4 *t = cur; cur = nxt; nxt = t;
-      }
+  // the downsampling chain first (scale 1 straight from the bytes), then the per-scale kernels: scales 0 and 1 on their
+  // own, the small ones in one launch
+  for (int k = 1; k < ns; k++) {
+    const unsigned g = dssim_grid(ctx, (size_t)ws[k] * hs[k]);
+    if (k == 1) hipLaunchKernelGGL(dssim_downsample_u8_kernel, dim3(g), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin[1]);
+    else hipLaunchKernelGGL(dssim_downsample_kernel, dim3(g), dim3(256), 0, ctx->stream, (const float4 *)lin[k - 1], ws[k - 1], hs[k - 1], lin[k]);
+  }
+  auto job_of = [&](int k) {
+    DssimScaleJob j;
+    const DssimScale &s = img->s[k];
+    if (k == 0) { j.S.u8 = d_frame; j.S.stride = stride; j.S.channels = channels; j.S.lut = d_lut; j.S.lin = nullptr; }
+    else { j.S.u8 = nullptr; j.S.stride = 0; j.S.channels = 0; j.S.lut = nullptr; j.S.lin = lin[k]; }
+    j.w = s.w; j.h = s.h;
+    for (int c = 0; c < 3; c++) { j.O.img[c] = s.img[c]; j.O.mu[c] = s.mu[c]; j.O.sq[c] = s.sq[c]; }
+    return j;
+  };
+  auto tiles_of = [&](int k) { return (unsigned)(((img->s[k].w + kTw - 1) / kTw) * ((img->s[k].h + kTh - 1) / kTh)); };
+  for (int k = 0; k < ns; ) {
+    DssimScaleJobs J;
+    const int count = k < 2 ? 1 : (ns - k < 3 ? ns - k : 3);
+    unsigned total = 0;
+    for (int j = 0; j < 3; j++) {
+      J.first[j] = total;
+      if (j < count) { J.job[j] = job_of(k + j); total += tiles_of(k + j); }
+      else J.job[j] = J.job[0];
     }
+    J.first[3] = total;
+    for (int j = count; j < 3; j++) J.first[j] = total;  // empty ranges
+    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(total), dim3(256), 0, ctx->stream, J);
+    k += count;
   }
   rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch");
   if (rc) { dssim_free_image(ctx, img); return rc; }
@@ -514,30 +584,53 @@ int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, i
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out) {
   if (a->n_scales != b->n_scales || a->s[0].w != b->s[0].w || a->s[0].h != b->s[0].h)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: images differ in size");
-  const size_t n0 = (size_t)a->s[0].w * a->s[0].h;
-  const unsigned tiles0 = (unsigned)(((a->s[0].w + kTw - 1) / kTw) * ((a->s[0].h + kTh - 1) / kTh));
-  const unsigned gmax = dssim_grid(ctx, n0);
-  const size_t n_part = (size_t)(tiles0 > gmax ? tiles0 : gmax);
+  // scratch: the SSIM maps of all scales, the two families of block partials, the result slots
+  DssimRed R;
+  R.n_scales = a->n_scales;
+  size_t map_px = 0, n_pa = 0;
+  unsigned n_pb = 0;
+  unsigned tiles[kDssimScales];
+  for (int k = 0; k < a->n_scales; k++) {
+    const size_t n = (size_t)a->s[k].w * a->s[k].h;
+    tiles[k] = (unsigned)(((a->s[k].w + kTw - 1) / kTw) * ((a->s[k].h + kTh - 1) / kTh));
+    R.n[k] = n;
+    R.n_a[k] = tiles[k];
+    R.first_b[k] = n_pb;
+    R.len[k] = (double)n;
+    R.exponent[k] = std::pow(0.5, (double)k);
+    map_px += n + (n & 1);
+    n_pa += tiles[k];
+    n_pb += dssim_grid(ctx, n);
+  }
+  R.first_b[a->n_scales] = n_pb;
+  for (int k = a->n_scales; k < kDssimScales; k++) { R.n[k] = 0; R.n_a[k] = 0; R.first_b[k + 1] = n_pb; R.len[k] = 1.0; R.exponent[k] = 1.0; R.map[k] = nullptr; R.part_a[k] = nullptr; R.part_b[k] = nullptr; }
   void *scr = nullptr;
-  int rc = dssim_scratch(ctx, 1, n0 * 4 + n_part * 8 + 64 * 8 + 64, &scr);
+  int rc = dssim_scratch(ctx, 1, map_px * 4 + (n_pa + n_pb) * 8 + 64 * 8 + 64, &scr);
   if (rc) return rc;
   float *map = (float *)scr;
-  double *d_partial = (double *)(map + n0 + (n0 & 1));
-  double *d_slots = d_partial + n_part;  // per scale: [sum, avg, dev]
+  double *d_pa = (double *)(map + map_px), *d_pb = d_pa + n_pa;
+  double *d_slots = d_pb + n_pb;  // per scale: [sum, avg, dev]
+  R.slots = d_slots;
+  {
+    float *m = map;
+    double *pa = d_pa;
+    for (int k = 0; k < a->n_scales; k++) {
+      R.map[k] = m; m += R.n[k] + (R.n[k] & 1);
+      R.part_a[k] = pa; pa += tiles[k];
+      R.part_b[k] = d_pb + R.first_b[k];
+    }
+  }
   for (int k = 0; k < a->n_scales; k++) {
     const DssimScale &s1 = a->s[k], &s2 = b->s[k];
-    const size_t n = (size_t)s1.w * s1.h;
-    const unsigned tiles = (unsigned)(((s1.w + kTw - 1) / kTw) * ((s1.h + kTh - 1) / kTh));
     DssimCmp P;
     for (int c = 0; c < 3; c++) {
       P.img1[c] = s1.img[c]; P.img2[c] = s2.img[c]; P.mu1[c] = s1.mu[c]; P.mu2[c] = s2.mu[c]; P.sq1[c] = s1.sq[c]; P.sq2[c] = s2.sq[c];
     }
-    hipLaunchKernelGGL(dssim_compare_fused_kernel, dim3(tiles), dim3(256), 0, ctx->stream, P, s1.w, s1.h, map, d_partial);
-    hipLaunchKernelGGL(dssim_avg_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)d_partial, tiles, (double)n, std::pow(0.5, (double)k), d_slots + 3 * k);
-    const unsigned g = dssim_grid(ctx, n);
-    hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(g), dim3(256), 0, ctx->stream, (const float *)map, n, (const double *)(d_slots + 3 * k), d_partial);
-    hipLaunchKernelGGL(dssim_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)d_partial, g, d_slots + 3 * k + 2);
+    hipLaunchKernelGGL(dssim_compare_fused_kernel, dim3(tiles[k]), dim3(256), 0, ctx->stream, P, s1.w, s1.h, (float *)R.map[k], (double *)R.part_a[k]);
   }
+  hipLaunchKernelGGL(dssim_avg_kernel, dim3(a->n_scales), dim3(256), 0, ctx->stream, R);
+  hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb), dim3(256), 0, ctx->stream, R);
+  hipLaunchKernelGGL(dssim_sum_kernel, dim3(a->n_scales), dim3(256), 0, ctx->stream, R);
   if ((rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch"))) return rc;
   double slots[3 * kDssimScales];
   if ((rc = check_hip(ctx, hipMemcpyAsync(slots, d_slots, sizeof(double) * 3 * a->n_scales, hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
