@@ -208,6 +208,7 @@ def main():
 
         dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
         lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
+        hsv_tab, hsv_tc, hsv_tt = ctx.colorlut_kernel_choice(fused=2)
         interp = None
         if not args.no_extra and args.lut_variant == 0 and lut_tab and world == 1:  # single-process only: the branch depends on a per-rank choice
             # the same two-launch chain with the interpolating colorlut kernel pinned (no memoised table), for comparison
@@ -249,7 +250,7 @@ def main():
         if lut_ms >= hsv_ms:
             dom, dom_ms = ("colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel"), lut_ms
         else:
-            dom, dom_ms = "hsvfilter_flat_kernel", hsv_ms
+            dom, dom_ms = ("colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel"), hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes/launch of the dominant kernel from the last committed rocprofv3 --pmc passes
         # (tools/collect_profiles.sh + tools/summarize_profiles.py); counters cannot be read from inside
@@ -280,7 +281,9 @@ def main():
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
                         "colorlut_kernel": "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel",
-                        "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt}},
+                        "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt},
+                        "hsvfilter_kernel": "colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel",
+                        "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt}},
         }
         if interp:
             out["interpolating_kernel_only"] = interp

@@ -1196,7 +1196,7 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
       if (rc) return rc;
     }
   }
-  int rc = launch_hsvfilter(ctx, d_dst, n_frames, dst_pitch, width, height, dst_stride, fmt, hs);
+  int rc = launch_hsvfilter_compute(ctx, d_dst, n_frames, dst_pitch, width, height, dst_stride, fmt, hs);
   if (rc) return rc;
   if (plain) return launch_colorlut_compute(ctx, d_dst, dst_pitch, dst_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, MI355_FMT_RGBA);
   return launch_colorlut(ctx, d_dst, dst_pitch, dst_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, MI355_FMT_RGBA);
@@ -1341,11 +1341,15 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   return MI355_OK;
 }
 
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton);
 static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton,
                         const mi355_hsv_settings *hs) {
   int rc = table_ensure(ctx, which, morton, hs);
   if (rc) return rc;
-  const uint32_t *t = ctx->lut.d_table[which];
+  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, n_vec, width, rows, morton);
+}
+
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton) {
   if (width % 4 == 0 && width >= 128 && rows < (1u << 30)) {
     const unsigned w4 = (unsigned)width / 4;
     // 256-pixel patches unless 128-pixel ones waste fewer masked lanes in the last column
@@ -1510,6 +1514,64 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
                      [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, &hs); });
+}
+
+// hsvfilter alone is a function of the colour too, and MI355_FLAG_HSV_TABLE = 1 / 2 runs it through the same machinery
+// (auto choice / table only; the table is built by the arithmetic kernel, in place over the colours of all slots, once the
+// settings and the byte order have been the same for kStableCalls calls; colour-first packed 4-byte formats only: RGBx,
+// RGBA, BGRx, BGRA). It is OFF by default: the arithmetic kernel is close to the streaming floor for large launches from
+// HBM (0.107-0.12 ms per 8x4K against 0.132-0.137 ms for the table kernel), and for per-buffer launches, where the table
+// kernel measures faster on its own (0.0025 against 0.0029 ms per Mpixel at one 4K frame per launch), a second 64 MiB
+// table competes with colorlut's for L2 and the Infinity Cache: hsvfilter -> colorlut at one frame per launch drops from
+// 26.3-27.4 k to 24.6 k frames/s with both tables live. It pays for the GENERIC arithmetic (huge / non-finite hue-shift)
+// and for an hsvfilter that runs without a table-driven colorlut behind it.
+void hsv_table_release(mi355_ctx *ctx) {
+  HsvTable &T = ctx->hsv_table;
+  if (T.d_table) (void)hipFree(T.d_table);
+  if (T.pick.ev0) (void)hipEventDestroy(T.pick.ev0);
+  if (T.pick.ev1) (void)hipEventDestroy(T.pick.ev1);
+  T = HsvTable{};
+}
+
+static int hsv_table_ensure(mi355_ctx *ctx, const PixFmt &fmt, const mi355_hsv_settings &hs) {
+  HsvTable &T = ctx->hsv_table;
+  if (T.valid && T.bgr == fmt.bgr && same_hs(T.hs, hs)) return MI355_OK;
+  int rc;
+  if (!T.d_table && (rc = check_hip(ctx, hipMalloc((void **)&T.d_table, (size_t)kTableEntries * 4), "hipMalloc(hsvfilter table)"))) return rc;
+  T.valid = false;
+  hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, T.d_table, 1);
+  if ((rc = launch_hsvfilter_compute(ctx, (uint8_t *)T.d_table, 1, 0, 4096, 4096, 4096 * 4, fmt, hs))) return rc;
+  T.valid = true;
+  T.bgr = fmt.bgr;
+  T.hs = hs;
+  return MI355_OK;
+}
+
+int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width, int height, int stride, const PixFmt &fmt,
+                     const mi355_hsv_settings &hs) {
+  if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
+  HsvTable &T = ctx->hsv_table;
+  auto compute = [&]() { return launch_hsvfilter_compute(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, hs); };
+  size_t n_vec = 0;
+  const bool table_ok = ctx->hsv_table_mode != 0 && !ctx->force_generic && fmt.pixel_stride == 4 && fmt.first == 0 &&
+                        rgba8_flat(d_data, frame_pitch, stride, d_data, frame_pitch, stride, n_frames, width, height, &n_vec);
+  if (!table_ok) return compute();
+  const size_t rows = (size_t)n_frames * height;
+  if (ctx->hsv_table_mode == 2) {
+    int rc = hsv_table_ensure(ctx, fmt, hs);
+    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1);
+  }
+  if (n_vec < kAutoMinVec) return compute();
+  if (same_hs(hs, T.seen_hs) && fmt.bgr == T.seen_bgr) { if (T.seen_stable < kStableCalls) T.seen_stable++; }
+  else { T.seen_hs = hs; T.seen_bgr = fmt.bgr; T.seen_stable = 0; }
+  const bool have = T.valid && T.bgr == fmt.bgr && same_hs(T.hs, hs);
+  if (!have && T.seen_stable < kStableCalls) return compute();
+  if (!have && T.pick.learn > 2) {
+    T.pick.t_table = 0.0;
+    T.pick.learn = 2;
+  }
+  return auto_launch(ctx, T.pick, n_vec, compute, [&]() { return hsv_table_ensure(ctx, fmt, hs); },
+                     [&]() { return launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1); });
 }
 
 }  // namespace mi355

@@ -153,7 +153,7 @@ static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, i
   else hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
 }
 
-int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
+int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
                      int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s) {
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;  // nothing to do
   const HsvK k{s.hue_shift, s.saturation_mul, s.saturation_off, s.value_mul, s.value_off};

@@ -48,6 +48,19 @@ struct LutDevice {
   bool loaded = false;
 };
 
+// hsvfilter through a memoised table (colorlut_kernels.hip: launch_hsvfilter): the table of the element's per-pixel
+// function under `hs` for colour-first 4-byte formats (bgr selects the byte order the table was built for).
+struct HsvTable {
+  uint32_t *d_table = nullptr;
+  bool valid = false;
+  int bgr = 0;
+  mi355_hsv_settings hs{};       // settings the table was built for
+  mi355_hsv_settings seen_hs{};  // settings of the previous call and for how many calls they (and the byte order) have not changed
+  int seen_bgr = 0;
+  unsigned seen_stable = 0;
+  AutoPick pick;
+};
+
 struct EchoDevice {
   double *d_ring = nullptr;
   size_t ring_len = 0;
@@ -76,6 +89,8 @@ struct mi355_ctx {
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
+  int hsv_table_mode = 0; // MI355_FLAG_HSV_TABLE: 0 arithmetic kernel only (default), 1 auto, 2 table kernel only
+  mi355::HsvTable hsv_table;
   int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
@@ -98,6 +113,9 @@ int check_hip(mi355_ctx *ctx, hipError_t e, const char *what);
 // kernel launchers (asynchronous on ctx->stream)
 int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
                      int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s);
+int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
+                     int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s);
+void hsv_table_release(mi355_ctx *ctx);
 int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                      const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                      int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,

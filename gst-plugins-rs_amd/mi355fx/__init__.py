@@ -27,6 +27,7 @@ FLAG_HSV_BLOCKS_PER_CU = 2
 FLAG_FUSED_VARIANT = 3
 FLAG_LUT_VARIANT = 4
 FLAG_LUT_STAGGER = 5
+FLAG_HSV_TABLE = 6
 
 
 class HsvSettings(C.Structure):

@@ -157,6 +157,80 @@ def test_hsvfilter_4k_batch_device_is_pure_per_pixel_function(ctx, oracle, synth
     assert (got.reshape(-1).view(np.uint32) == exp).all()
 
 
+@pytest.mark.parametrize("fmt", ["RGBA", "BGRx"])
+@pytest.mark.parametrize("st", [(90.0, 1.0, 0.0, 1.0, 0.0), (-33.3, 1.2, -0.05, 0.9, 0.02), (725.5, 1.0, 0.0, 1.0, 0.0),
+                                (float("inf"), 1.3, -0.1, 0.9, 0.05)])
+def test_hsvfilter_table_kernel_allcolors(ctx, oracle, synth, fmt, st):
+    """MI355_FLAG_HSV_TABLE = 2: hsvfilter through the memoised table (built by the arithmetic kernel for the format's byte
+    order) on every colour with a varying 4th byte, FAST and GENERIC settings."""
+    import mi355fx
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    ac = synth.allcolors().copy().reshape(-1)
+    ac[3::4] = (np.arange(4096 * 4096, dtype=np.uint32) * 2654435761 >> 11).astype(np.uint8)
+    exp = ac.copy()
+    oracle.hsvfilter(exp, 4096, 4096 * 4, ps, first, bool(bgr), st, nthreads=8)
+    ctx.set_flag(mi355fx.FLAG_HSV_TABLE, 2)
+    got = ac.copy()
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 4, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+    assert ctx.colorlut_kernel_choice(fused=2)[0]
+
+
+@pytest.mark.parametrize("fmt,w,h,pad", [("xRGB", 256, 64, 0), ("RGB", 256, 64, 0), ("RGBA", 250, 7, 24), ("ABGR", 128, 8, 0)])
+def test_hsvfilter_table_mode_ineligible_geometry_falls_back(ctx, oracle, synth, fmt, w, h, pad):
+    """Alpha-first / 3-byte formats and padded rows never use the table; the flag must not change the result."""
+    import mi355fx
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    stride = w * ps + pad
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, size=stride * h, dtype=np.uint8)
+    st = synth.HSV_SETTINGS["mixed"]
+    exp = frame.copy()
+    oracle.hsvfilter(exp, w, stride, ps, first, bool(bgr), st)
+    ctx.set_flag(mi355fx.FLAG_HSV_TABLE, 2)
+    got = frame.copy()
+    ctx.hsvfilter_frame_ip(got, w, stride, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_hsvfilter_auto_table_per_buffer_launches(ctx, oracle, synth):
+    """MI355_FLAG_HSV_TABLE = 1 (auto), one 4K frame per launch: compute kernel while the settings are young, then both kinds are measured and
+    one is chosen; the output is exact at every call and a settings / byte-order change is honoured at once."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_HSV_TABLE, 1)
+    w, h = W4K, H4K
+    frame = synth.smooth_frame(w, h, seed=91).reshape(-1)
+    sts = [synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"]]
+    exps = []
+    for st in sts:
+        e = frame.copy()
+        oracle.hsvfilter(e, w, w * 4, 4, 0, False, st, nthreads=8)
+        exps.append(e)
+    d = ctx.alloc(frame.nbytes)
+    got = np.zeros_like(frame)
+    try:
+        def run(st, fmt="RGBA"):
+            ctx.h2d(d, frame)
+            ctx.hsvfilter_frames_device(d, 1, w * h * 4, w, h, w * 4, fmt, st)
+            ctx.synchronize()
+            ctx.d2h(got, d)
+        for k in range(20):
+            run(sts[0])
+            assert (got == exps[0]).all(), "call %d" % k
+        on_table, t_c, t_t = ctx.colorlut_kernel_choice(fused=2)
+        assert t_c > 0.0 and t_t > 0.0 and on_table == (t_t < t_c)
+        run(sts[1])
+        assert (got == exps[1]).all()
+        e = frame.copy()
+        oracle.hsvfilter(e, w, w * 4, 4, 0, True, sts[1], nthreads=8)
+        run(sts[1], "BGRA")
+        assert (got == e).all()
+    finally:
+        ctx.free(d)
+
+
 # ------------------------------------------------------------------ colorlut
 
 def _load_cube(ctx, oracle, text):
