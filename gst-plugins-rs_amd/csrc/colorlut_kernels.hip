@@ -919,17 +919,31 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   const unsigned sub = lane / TW4, g = lane % TW4;
   // tiles in row-major order, grid-stride: the resident blocks sweep the picture together (a block walking down its
   // own column instead is 10 % slower: the HBM streams scatter)
-  for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  struct Patch { size_t i0, i1; bool ok0, ok1; };
+  auto patch_of = [&](unsigned t) {
     const unsigned tx = t % n_cols, ty = t / n_cols;
     const unsigned col = tx * TW4 + g;
     const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
-    const bool ok0 = col < w4 && r0 < rows, ok1 = col < w4 && r1 < rows;
-    const size_t i0 = (size_t)r0 * w4 + col, i1 = (size_t)r1 * w4 + col;
-    u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-    if (ok0) p = __builtin_nontemporal_load(s4 + i0);
-    if (ok1) q = __builtin_nontemporal_load(s4 + i1);
+    Patch P;
+    P.ok0 = t < n_tiles && col < w4 && r0 < rows;
+    P.ok1 = t < n_tiles && col < w4 && r1 < rows;
+    P.i0 = (size_t)r0 * w4 + col;
+    P.i1 = (size_t)r1 * w4 + col;
+    return P;
+  };
+  Patch cur = patch_of(blockIdx.x);
+  u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  if (cur.ok0) p = __builtin_nontemporal_load(s4 + cur.i0);
+  if (cur.ok1) q = __builtin_nontemporal_load(s4 + cur.i1);
+  for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     *(u32x4_t *)(x + lane * 4) = p;
     *(u32x4_t *)(x + 256 + lane * 4) = q;
+    // the next tile's pixels travel while this tile's gathers do
+    const Patch nxt = patch_of(t + gridDim.x);
+    p = u32x4_t{0, 0, 0, 0};
+    q = u32x4_t{0, 0, 0, 0};
+    if (nxt.ok0) p = __builtin_nontemporal_load(s4 + nxt.i0);
+    if (nxt.ok1) q = __builtin_nontemporal_load(s4 + nxt.i1);
     wave_sync();
     uint32_t px[8], o[8];
 #pragma unroll
@@ -941,8 +955,9 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
     wave_sync();
     const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
     wave_sync();
-    if (ok0) __builtin_nontemporal_store(r0v, d4 + i0);
-    if (ok1) __builtin_nontemporal_store(r1v, d4 + i1);
+    if (cur.ok0) __builtin_nontemporal_store(r0v, d4 + cur.i0);
+    if (cur.ok1) __builtin_nontemporal_store(r1v, d4 + cur.i1);
+    cur = nxt;
   }
 }
 
