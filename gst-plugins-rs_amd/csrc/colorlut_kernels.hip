@@ -888,15 +888,16 @@ __global__ __launch_bounds__(256) void colorlut_table_kernel(const uint4 *__rest
 // Tiled form for frames whose rows are whole pixel groups (width % 4 == 0): a wave's 512 pixels are a 256 x 2 (or 128 x 4)
 // patch of the picture instead of 512 consecutive pixels of one row, and the four waves of a block take four patches
 // stacked vertically (256 x 8). Vertically adjacent pixels have (almost) the same colours, so the table lines a block
-// touches are reused more often before they fall out of the 32 KB L1: 0.163 -> 0.132-0.137 ms per 8x4K (128 x 4: 0.140,
-// 64 x 8: 0.143, 32 x 16: 0.157 - narrow patches cut the loads into short segments; blocks of 512 / 1024 lanes: 0.143 / 0.149). What costs time in this kernel is not the divergent gather
+// touches are reused more often before they fall out of the 32 KB L1: 0.163 -> 0.132-0.137 ms per 8x4K with a persistent
+// grid (128 x 4: 0.140, 64 x 8: 0.143, 32 x 16: 0.157 - narrow patches cut the loads into short segments; blocks of
+// 512 / 1024 lanes: 0.143 / 0.149), 0.117 ms with one tile per block. What costs time in this kernel is not the divergent gather
 // itself (64 random colours, all L1 hits: 0.119 ms per 8x4K, next to 0.093 ms for a single colour) but L1 misses: each
 // moves a 128 B line from L2 for 4 useful bytes (1024..4096 random colours, every gather an L2 hit: 0.28-0.31 ms =
 // 30 TB/s of line traffic = the L2's bandwidth). tools/table_gather_probe.py.
 // The frames are contiguous, so the batch is one picture of `rows` = n_frames * height rows of w4 pixel groups.
 template <bool MORTON, int TW4>  // TW4 = patch width in pixel groups (64 = 256 px); a wave's patch is TW4*4 px x 128/TW4 rows
 __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned w4, unsigned rows,
-                                                                   unsigned n_cols, unsigned n_tiles, const uint32_t *__restrict__ table) {
+                                                                   unsigned n_cols, const uint32_t *__restrict__ table) {
   __shared__ uint32_t s_spread[256];
   __shared__ uint32_t s_strip[4][512];
   if (MORTON) {
@@ -917,48 +918,33 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   };
   constexpr unsigned RPL = 64 / TW4;            // rows covered by one 64-lane load
   const unsigned sub = lane / TW4, g = lane % TW4;
-  // tiles in row-major order, grid-stride: the resident blocks sweep the picture together (a block walking down its
-  // own column instead is 10 % slower: the HBM streams scatter)
-  struct Patch { size_t i0, i1; bool ok0, ok1; };
-  auto patch_of = [&](unsigned t) {
-    const unsigned tx = t % n_cols, ty = t / n_cols;
-    const unsigned col = tx * TW4 + g;
-    const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
-    Patch P;
-    P.ok0 = t < n_tiles && col < w4 && r0 < rows;
-    P.ok1 = t < n_tiles && col < w4 && r1 < rows;
-    P.i0 = (size_t)r0 * w4 + col;
-    P.i1 = (size_t)r1 * w4 + col;
-    return P;
-  };
-  Patch cur = patch_of(blockIdx.x);
+  // ONE tile per block, tiles in row-major order: the blocks resident at any time then work on neighbouring tiles, so
+  // the table lines in flight across the chip belong to one band of the picture (a persistent grid whose blocks stride
+  // over the tile list spreads them over the whole batch: 0.133 ms per 8x4K with 16 blocks per CU, 0.128 / 0.123 with
+  // 32 / 64, 0.117 with one tile per block; column-major or banded tile orders: 0.120-0.124)
+  const unsigned t = blockIdx.x;
+  const unsigned tx = t % n_cols, ty = t / n_cols;
+  const unsigned col = tx * TW4 + g;
+  const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
+  const bool ok0 = col < w4 && r0 < rows, ok1 = col < w4 && r1 < rows;
+  const size_t i0 = (size_t)r0 * w4 + col, i1 = (size_t)r1 * w4 + col;
   u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-  if (cur.ok0) p = __builtin_nontemporal_load(s4 + cur.i0);
-  if (cur.ok1) q = __builtin_nontemporal_load(s4 + cur.i1);
-  for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    *(u32x4_t *)(x + lane * 4) = p;
-    *(u32x4_t *)(x + 256 + lane * 4) = q;
-    // the next tile's pixels travel while this tile's gathers do
-    const Patch nxt = patch_of(t + gridDim.x);
-    p = u32x4_t{0, 0, 0, 0};
-    q = u32x4_t{0, 0, 0, 0};
-    if (nxt.ok0) p = __builtin_nontemporal_load(s4 + nxt.i0);
-    if (nxt.ok1) q = __builtin_nontemporal_load(s4 + nxt.i1);
-    wave_sync();
-    uint32_t px[8], o[8];
+  if (ok0) p = __builtin_nontemporal_load(s4 + i0);
+  if (ok1) q = __builtin_nontemporal_load(s4 + i1);
+  *(u32x4_t *)(x + lane * 4) = p;
+  *(u32x4_t *)(x + 256 + lane * 4) = q;
+  wave_sync();
+  uint32_t px[8], o[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) px[j] = x[j * 64 + lane];
+  for (int j = 0; j < 8; j++) px[j] = x[j * 64 + lane];
 #pragma unroll
-    for (int j = 0; j < 8; j++) o[j] = table[index(px[j])];
+  for (int j = 0; j < 8; j++) o[j] = table[index(px[j])];
 #pragma unroll
-    for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
-    wave_sync();
-    const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
-    wave_sync();
-    if (cur.ok0) __builtin_nontemporal_store(r0v, d4 + cur.i0);
-    if (cur.ok1) __builtin_nontemporal_store(r1v, d4 + cur.i1);
-    cur = nxt;
-  }
+  for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
+  wave_sync();
+  const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
+  if (ok0) __builtin_nontemporal_store(r0v, d4 + i0);
+  if (ok1) __builtin_nontemporal_store(r1v, d4 + i1);
 }
 
 void lut_release(mi355_ctx *ctx) {
@@ -1373,10 +1359,9 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
     const unsigned n_cols = (w4 + tw4 - 1) / tw4, rpb = 8 * (64 / tw4);
     const size_t n_tiles = (size_t)n_cols * ((rows + rpb - 1) / rpb);
     if (n_tiles < (1u << 31)) {
-      size_t grid = (size_t)ctx->n_cu * 16;
-      if (grid > n_tiles) grid = n_tiles;
+      const size_t grid = n_tiles;
 #define MI355_LT(M, T) hipLaunchKernelGGL((colorlut_table_tiled_kernel<M, T>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, \
-                                          (uint4 *)d_dst, w4, (unsigned)rows, n_cols, (unsigned)n_tiles, t)
+                                          (uint4 *)d_dst, w4, (unsigned)rows, n_cols, t)
       if (morton && tw4 == 64) MI355_LT(true, 64);
       else if (morton) MI355_LT(true, 32);
       else if (tw4 == 64) MI355_LT(false, 64);
