@@ -380,7 +380,35 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
     for (int c = 0; c < 3; c++) s_p[c][e] = in ? P.img1[c][o] * P.img2[c][o] : 0.0f;
   }
   __syncthreads();
-  // pass 1 on the region minus a margin of 1
+  // pass 1 on the region minus a margin of 1; interior regions: 2 x 2 outputs per lane from one 4 x 4 window per plane
+  if (INTERIOR) {
+    constexpr int cw = (kCw - 2) / 2, ch = (kChh - 2) / 2;
+    static_assert((kCw - 2) % 2 == 0 && (kChh - 2) % 2 == 0, "even pass extents");
+    for (int e = threadIdx.x; e < cw * ch; e += 256) {
+      const int cy = e / cw, cx = e - cy * cw;
+      const int ly = 1 + 2 * cy, lx = 1 + 2 * cx;
+      const int j0 = (ly - 1) * kCw + (lx - 1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float v[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) v[r][q] = s_p[c][j0 + r * kCw + q];
+#pragma unroll
+        for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+          for (int ox = 0; ox < 2; ox++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int dyy = 0; dyy < 3; dyy++)
+#pragma unroll
+              for (int dxx = 0; dxx < 3; dxx++) acc = acc + v[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
+            s_q[c][(ly + oy) * kCw + lx + ox] = acc;
+          }
+      }
+    }
+  } else
   for (int e = threadIdx.x; e < (kCw - 2) * (kChh - 2); e += 256) {
     const int ly = 1 + e / (kCw - 2), lx = 1 + e - (e / (kCw - 2)) * (kCw - 2);
     const int gx = x0 + lx, gy = y0 + ly;
