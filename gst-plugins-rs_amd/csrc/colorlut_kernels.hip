@@ -1412,7 +1412,8 @@ static void auto_harvest(AutoPick &A, unsigned max_lag) {
     const double per_vec = (double)ms / (double)A.pending_vec;
     if (A.pending_kind == 0) A.t_compute = per_vec; else A.t_table = per_vec;
     if (A.t_compute > 0.0 && A.t_table > 0.0) {
-      const bool table = A.t_table < A.t_compute;
+      // 3 % hysteresis: measurements of near-equal kernels must not flip the choice back and forth
+      const bool table = A.t_table < A.t_compute * (A.table ? 1.03 : 0.97);
       if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
       else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
       A.table = table;
