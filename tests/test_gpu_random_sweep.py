@@ -35,7 +35,13 @@ def _random_settings(rng):
     return (hue, sm, so, vm, vo)
 
 
-def test_hsvfilter_random_settings_sweep(ctx, oracle):
+@pytest.mark.parametrize("table", [False, True])
+def test_hsvfilter_random_settings_sweep(ctx, oracle, table):
+    """table=True: the same sweep through the memoised-table kernel (MI355_FLAG_HSV_TABLE = 2; the table is rebuilt by
+    the arithmetic kernel for every settings / byte-order change, alpha-first formats fall back)."""
+    import mi355fx
+    if table:
+        ctx.set_flag(mi355fx.FLAG_HSV_TABLE, 2)
     rng = np.random.default_rng(20260101)
     w, h = 512, 128
     base = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
@@ -58,7 +64,11 @@ def test_hsvfilter_random_settings_sweep(ctx, oracle):
     assert not bad, bad[:5]
 
 
-def test_colorlut_random_luts_sweep(ctx, oracle):
+@pytest.mark.parametrize("variant", [6, 5, 4])
+def test_colorlut_random_luts_sweep(ctx, oracle, variant):
+    """variant 6: interpolating kernels; 5 / 4: the memoised-table kernel (Morton / linear index), rebuilt per LUT."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
     rng = np.random.default_rng(77)
     w, h = 256, 96
     frame = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
@@ -84,7 +94,11 @@ def test_colorlut_random_luts_sweep(ctx, oracle):
     assert not bad, bad[:5]
 
 
-def test_fused_chain_random_sweep(ctx, oracle):
+@pytest.mark.parametrize("variant", [6, 5])
+def test_fused_chain_random_sweep(ctx, oracle, variant):
+    """variant 6: fused interpolating kernel; 5: the table of the composed function, rebuilt per LUT / settings."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
     rng = np.random.default_rng(5150)
     w, h = 256, 64
     frame = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
