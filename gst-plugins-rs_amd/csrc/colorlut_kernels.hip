@@ -1427,6 +1427,7 @@ static void auto_harvest(AutoPick &A, unsigned max_lag) {
 template <class Compute, class Ensure, class Table>
 static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&compute, Ensure &&ensure, Table &&table) {
   int rc;
+  if (A.table_unavailable) return compute();
   if (!A.ev0) {
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev0), "hipEventCreate"))) return rc;
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev1), "hipEventCreate"))) return rc;
@@ -1456,7 +1457,14 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
   }
   const bool measure = A.pending_kind < 0 && (probe || (A.calls % sample_every) == 0);
   A.calls++;
-  if (kind == 1 && (rc = ensure())) return rc;  // a table build stays outside the measurement
+  if (kind == 1 && (rc = ensure())) {  // a table build stays outside the measurement
+    // no memory for the 64 MiB table (or the build failed): this entry point stays on the compute kernel for good
+    A.table_unavailable = true;
+    A.learn = 4;
+    A.table = false;
+    (void)hipGetLastError();
+    return compute();
+  }
   if (measure && (rc = check_hip(ctx, hipEventRecord(A.ev0, ctx->stream), "hipEventRecord"))) return rc;
   if ((rc = kind ? table() : compute())) return rc;
   if (measure) {
@@ -1518,14 +1526,15 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
 }
 
 // hsvfilter alone is a function of the colour too, and MI355_FLAG_HSV_TABLE = 1 / 2 runs it through the same machinery
-// (auto choice / table only; the table is built by the arithmetic kernel, in place over the colours of all slots, once the
+// (auto choice for all settings / table only; the table is built by the arithmetic kernel, in place over the colours of all slots, once the
 // settings and the byte order have been the same for kStableCalls calls; colour-first packed 4-byte formats only: RGBx,
-// RGBA, BGRx, BGRA). It is OFF by default: the arithmetic kernel is close to the streaming floor for large launches from
+// RGBA, BGRx, BGRA). By default (0) only settings outside the FAST envelope (huge / non-finite hue-shift: GENERIC
+// arithmetic, 0.336 ms per 32 x 1080p against 0.117 ms) get the auto choice; for FAST settings it is off (3 = off for
+// all settings): the arithmetic kernel is close to the streaming floor for large launches from
 // HBM (0.107-0.12 ms per 8x4K against 0.132-0.137 ms for the table kernel), and for per-buffer launches, where the table
 // kernel measures faster on its own (0.0025 against 0.0029 ms per Mpixel at one 4K frame per launch), a second 64 MiB
 // table competes with colorlut's for L2 and the Infinity Cache: hsvfilter -> colorlut at one frame per launch drops from
-// 26.3-27.4 k to 24.6 k frames/s with both tables live. It pays for the GENERIC arithmetic (huge / non-finite hue-shift)
-// and for an hsvfilter that runs without a table-driven colorlut behind it.
+// 26.3-27.4 k to 24.6 k frames/s with both tables live.
 void hsv_table_release(mi355_ctx *ctx) {
   HsvTable &T = ctx->hsv_table;
   if (T.d_table) (void)hipFree(T.d_table);
@@ -1554,12 +1563,16 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   HsvTable &T = ctx->hsv_table;
   auto compute = [&]() { return launch_hsvfilter_compute(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, hs); };
   size_t n_vec = 0;
-  const bool table_ok = ctx->hsv_table_mode != 0 && !ctx->force_generic && fmt.pixel_stride == 4 && fmt.first == 0 &&
+  // mode 0 (default): only settings that need the GENERIC arithmetic (3x slower than the FAST kernels) are candidates
+  const bool candidate = ctx->hsv_table_mode == 1 || ctx->hsv_table_mode == 2 || (ctx->hsv_table_mode == 0 && hsv_variant_for(hs, false) < 0);
+  const bool table_ok = candidate && !ctx->force_generic && fmt.pixel_stride == 4 && fmt.first == 0 &&
                         rgba8_flat(d_data, frame_pitch, stride, d_data, frame_pitch, stride, n_frames, width, height, &n_vec);
+  T.last_table = false;
   if (!table_ok) return compute();
   const size_t rows = (size_t)n_frames * height;
   if (ctx->hsv_table_mode == 2) {
     int rc = hsv_table_ensure(ctx, fmt, hs);
+    T.last_table = true;
     return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1);
   }
   if (n_vec < kAutoMinVec) return compute();
@@ -1572,7 +1585,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
     T.pick.learn = 2;
   }
   return auto_launch(ctx, T.pick, n_vec, compute, [&]() { return hsv_table_ensure(ctx, fmt, hs); },
-                     [&]() { return launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1); });
+                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1); });
 }
 
 }  // namespace mi355

@@ -179,7 +179,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_FORCE_GENERIC) { ctx->force_generic = value != 0; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_STAGGER && value >= 0 && value <= 4096) { ctx->lut_stagger = value; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 6 && value != 3) { ctx->lut_variant = value; return MI355_OK; }
-  if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 2) { ctx->hsv_table_mode = value; return MI355_OK; }
+  if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 3) { ctx->hsv_table_mode = value; return MI355_OK; }
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
   return set_error(ctx, MI355_ERR_INVALID_ARG, "unknown flag");
@@ -359,7 +359,7 @@ int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, d
   const AutoPick &A = fused == 2 ? ctx->hsv_table.pick : ctx->lut.pick[fused ? 1 : 0];
   // times are kept per 16-byte group = 4 pixels
   if (table_in_use)
-    *table_in_use = fused == 2 ? (ctx->hsv_table_mode == 2 || (ctx->hsv_table_mode == 1 && A.t_table > 0.0 && A.table))
+    *table_in_use = fused == 2 ? (ctx->hsv_table.last_table ? 1 : 0)
                                : (ctx->lut_variant == 4 || ctx->lut_variant == 5 || (ctx->lut_variant == 0 && A.t_table > 0.0 && A.table));
   if (ms_per_mpx_compute) *ms_per_mpx_compute = A.t_compute * 250000.0;
   if (ms_per_mpx_table) *ms_per_mpx_table = A.t_table * 250000.0;

@@ -21,6 +21,7 @@ struct AutoPick {
   unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
   bool pending_probe = false, pending_discard = false;
   unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
+  bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -58,6 +59,7 @@ struct HsvTable {
   mi355_hsv_settings seen_hs{};  // settings of the previous call and for how many calls they (and the byte order) have not changed
   int seen_bgr = 0;
   unsigned seen_stable = 0;
+  bool last_table = false;       // the last launch_hsvfilter call ran the table kernel
   AutoPick pick;
 };
 
@@ -89,7 +91,7 @@ struct mi355_ctx {
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
-  int hsv_table_mode = 0; // MI355_FLAG_HSV_TABLE: 0 arithmetic kernel only (default), 1 auto, 2 table kernel only
+  int hsv_table_mode = 0; // MI355_FLAG_HSV_TABLE: 0 auto for GENERIC settings only (default), 1 auto for all, 2 table only, 3 off
   mi355::HsvTable hsv_table;
   int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)

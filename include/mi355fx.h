@@ -89,7 +89,10 @@ typedef enum mi355_flag {
    * with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms
    * (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. */
   MI355_FLAG_LUT_VARIANT = 4,
-  MI355_FLAG_HSV_TABLE = 6,    /* hsvfilter on packed colour-first 4-byte frames through a memoised table: 0 = off (default: arithmetic kernel), 1 = auto choice as for colorlut, 2 = table only */
+  /* hsvfilter on packed colour-first 4-byte frames through a memoised table: 0 (default) = auto choice as for colorlut,
+   * but only for settings that need the literal GENERIC arithmetic (|hue-shift| > 360 or non-finite); 1 = auto choice
+   * for all settings; 2 = table only; 3 = arithmetic kernels only */
+  MI355_FLAG_HSV_TABLE = 6,
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
 } mi355_flag;
@@ -153,7 +156,7 @@ int mi355_colorlut_unload(mi355_ctx *ctx);
 /* Diagnostics for MI355_FLAG_LUT_VARIANT 0 (auto): which kernel kind serves packed RGBA8 launches right now
  * (*table_in_use: 0 interpolating kernel, 1 memoised table) and the last measured time of each kind in ms per
  * megapixel (0 = not measured yet); fused = 0 for mi355_colorlut_*, 1 for mi355_hsv_colorlut_*, 2 for
- * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE). No reference
+ * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran). No reference
  * counterpart. */
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
 /* Replaces transform_frame's body: transform_rgba / transform_rgba64::<LE>

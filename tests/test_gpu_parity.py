@@ -232,6 +232,33 @@ def test_hsvfilter_auto_table_per_buffer_launches(ctx, oracle, synth):
         ctx.free(d)
 
 
+def test_hsvfilter_generic_settings_get_the_table_by_default(ctx, oracle, synth):
+    """Default flags: settings outside the FAST envelope (literal GENERIC arithmetic, 3x slower) are served from the
+    memoised table once they have been stable and the table kernel has measured faster; FAST settings never are."""
+    w, h, n = 1920, 1080, 8
+    frames = np.stack([synth.smooth_frame(w, h, seed=60 + i) for i in range(n)]).reshape(-1)
+    d = ctx.alloc(frames.nbytes)
+    got = np.zeros_like(frames)
+    try:
+        for st, expect_table in (((725.5, 1.1, 0.0, 0.9, 0.0), True), (synth.HSV_SETTINGS["hue90"], False)):
+            exp = frames.copy()
+            for f in range(n):
+                oracle.hsvfilter(exp[f * w * h * 4:(f + 1) * w * h * 4], w, w * 4, 4, 0, True, st, nthreads=8)
+            for k in range(16):
+                ctx.h2d(d, frames)
+                ctx.hsvfilter_frames_device(d, n, w * h * 4, w, h, w * 4, "BGRx", st)
+                ctx.synchronize()
+                ctx.d2h(got, d)
+                assert (got == exp).all(), "call %d" % k
+            on_table, t_c, t_t = ctx.colorlut_kernel_choice(fused=2)
+            if expect_table:
+                assert t_c > 0.0 and t_t > 0.0 and on_table and t_t < t_c, (on_table, t_c, t_t)
+            else:
+                assert not on_table
+    finally:
+        ctx.free(d)
+
+
 # ------------------------------------------------------------------ colorlut
 
 def _load_cube(ctx, oracle, text):
