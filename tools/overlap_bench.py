@@ -1,7 +1,10 @@
 """Does hsvfilter of batch n+1 overlap colorlut of batch n when the two elements run on their own streams?
 Compares one stream (serial) with two streams + events. 8 x 4K RGBA per batch, ring of 3 batches.
-Measured: 23.5 k frames/s either way — the colorlut kernel (1024 threads x 121 VGPRs) owns every SIMD's register file, so
-no hsvfilter wave can be co-resident; a build limited to 96 VGPRs (amdgpu_waves_per_eu(5,5)) spills and drops to 14.8 k."""
+Measured with the interpolating colorlut kernel: 23.5 k frames/s either way - that kernel (1024 threads x 121 VGPRs) owns
+every SIMD's register file, so no hsvfilter wave can be co-resident; a build limited to 96 VGPRs (amdgpu_waves_per_eu(5,5))
+spills and drops to 14.8 k. With the table kernel (small blocks, co-residency possible): 36.1-42.8 k serial against 33.1-36.0 k
+on two streams - hsvfilter of batch n+1 streams 0.5 GB through the Infinity Cache while colorlut of batch n is reading the
+batch hsvfilter left there, and the lost cache hits cost more than the overlap gains."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
