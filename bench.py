@@ -32,8 +32,11 @@ BYTES_PER_FRAME_PER_KERNEL = 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--ramp-seconds", type=float, default=0.25,
+                    help="untimed preamble before the W warm-up steps of each measured leg: the same launches for this long,\n"
+                         "so that the GPU has left its idle clocks (a cold 50-step run measures 35 k frames/s, a warm one 43 k)")
     ap.add_argument("--batch", type=int, default=8,
                     help="4K frames per launch (one step = one batch). 8 frames = 265 MB: the batch hsvfilter has just written\n"
                          "in place is still in the 256 MiB Infinity Cache when the colorlut launch reads it (32.0 k frames/s; 32 frames\n"
@@ -163,9 +166,17 @@ def main():
         if args.hsv_blocks_per_cu:
             ctx.set_flag(mi355fx.FLAG_HSV_BLOCKS_PER_CU, args.hsv_blocks_per_cu)
 
+        def ramp(run_n):
+            """Untimed: keep the device busy with the leg's own launches for --ramp-seconds (clock ramp-up)."""
+            t_end = time.perf_counter() + args.ramp_seconds
+            while time.perf_counter() < t_end:
+                run_n(20)
+                torch.cuda.synchronize()
+
         def measure(content, steps, warmup, record):
             srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
             dsts = [torch.empty_like(s) for s in srcs]
+            ramp(lambda n: run_region(torch, ctx, srcs, dsts, settings, n, args.batch, False))
             run_region(torch, ctx, srcs, dsts, settings, warmup, args.batch, False)
             evs = []
             dt = sharding.timed_region(lambda: evs.extend(run_region(torch, ctx, srcs, dsts, settings, steps, args.batch, record)),
@@ -199,6 +210,7 @@ def main():
 
             # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
             # launches of each kind: keep that learning phase out of the timed region
+            ramp(lambda n: region(n, False))
             region(max(warmup, 14), False)
             evs = []
             dtf = sharding.timed_region(lambda: evs.extend(region(steps, True)), dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)

@@ -17,5 +17,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENC
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_tcc" -o c -- $BENCH > "$OUT/pmc_tcc.log" 2>&1; echo "tcc rc=$?"
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d "$OUT/pmc_tcp" -o p -- $BENCH > "$OUT/pmc_tcp.log" 2>&1; echo "tcp rc=$?"
 grep -h '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
-python3 $R/bench.py --steps 50 --warmup 5 $EXTRA > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
+python3 $R/bench.py $EXTRA > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"
