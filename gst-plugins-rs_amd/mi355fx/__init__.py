@@ -516,3 +516,14 @@ class Context:
         v = C.c_double(0)
         self._ck(self.L.mi355_ebur128_true_peak(self.h, c, C.byref(v)))
         return v.value
+
+
+def warm_clocks(fn, sync, seconds=0.25):
+    """Untimed preamble for microbenchmarks: run fn() for `seconds` so that the GPU has left its idle clocks (the first
+    ~20 ms of work after idling run 15-20 % slower on MI355X)."""
+    import time as _t
+    t_end = _t.perf_counter() + seconds
+    while _t.perf_counter() < t_end:
+        for _ in range(8):
+            fn()
+        sync()

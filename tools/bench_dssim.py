@@ -16,9 +16,10 @@ def main():
     ctx = mi355fx.Context(0)
     da, db = ctx.alloc(a.nbytes), ctx.alloc(b.nbytes)
     ctx.h2d(da, a.reshape(-1)); ctx.h2d(db, b.reshape(-1))
-    for _ in range(2):
+    def one():
         x = ctx.dssim_create_image_device(da, w * 4, w, h); ctx.dssim_free_image(x)
-    n = 20
+    mi355fx.warm_clocks(one, ctx.synchronize)
+    n = 100
     t0 = time.perf_counter()
     for _ in range(n):
         x = ctx.dssim_create_image_device(da, w * 4, w, h); ctx.dssim_free_image(x)

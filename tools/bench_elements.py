@@ -18,7 +18,8 @@ from mi355fx.cube import parse_cube
 ctx = mi355fx.Context(0)
 
 
-def timeit(fn, n=30, warm=3):
+def timeit(fn, n=200, warm=3):
+    mi355fx.warm_clocks(fn, ctx.synchronize)
     for _ in range(warm):
         fn()
     ctx.synchronize()
@@ -58,8 +59,8 @@ L = ctx.L
 report("hsvdetector 4K RGBx->RGBA, batch 8", timeit(lambda: L.mi355_hsvdetect_frames_device(ctx.h, ds, W * H * 4, W * 4, FMT["RGBx"], dd, W * H * 4, W * 4, FMT["RGBA"], B, W, H, C.byref(s))), 2 * fr.nbytes, B)
 
 # colorlut variants on 4K RGBA batch 8
-for name, text in (("colorlut 33^3 LDS (config 3)", synth.cube_text_3d(33)), ("colorlut 17^3 LDS", synth.cube_text_3d(17)),
-                   ("colorlut 65^3 gather kernel", synth.cube_text_3d(65)), ("colorlut 1D 1024 LDS", synth.cube_text_1d(1024))):
+for name, text in (("colorlut 33^3 (config 3), auto kernel choice", synth.cube_text_3d(33)), ("colorlut 17^3, auto kernel choice", synth.cube_text_3d(17)),
+                   ("colorlut 65^3, auto kernel choice", synth.cube_text_3d(65)), ("colorlut 1D 1024, auto kernel choice", synth.cube_text_1d(1024))):
     lut = parse_cube(text)
     ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
     report(name + ", 4K RGBA batch 8", timeit(lambda: ctx.colorlut_frames_device(ds, W * H * 4, W * 4, dd, W * H * 4, W * 4, B, W, H, "RGBA"), n=10), 2 * fr.nbytes, B)

@@ -31,9 +31,7 @@ def main():
     gains = np.full(a.sources, 0.5, np.float32)
     d_in, d_out = ctx.alloc(x.nbytes), ctx.alloc(frames * 8)
     ctx.h2d(d_in, x.reshape(-1))
-    for _ in range(5):
-        ctx.hrtf_process_block_device(d_in, d_out, pos, gains)
-    ctx.synchronize()
+    mi355fx.warm_clocks(lambda: ctx.hrtf_process_block_device(d_in, d_out, pos, gains), ctx.synchronize)
     t0 = time.perf_counter()
     for i in range(a.blocks):
         pos[i % a.sources, 0] += 0.01

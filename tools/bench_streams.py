@@ -31,10 +31,13 @@ def run(n_streams, frames_per_stream, fused):
             else:
                 c.hsvfilter_frames_device(a, 1, frame.nbytes, W, H, W * 4, "RGBA", st)
                 c.colorlut_frames_device(a, frame.nbytes, W * 4, b, frame.nbytes, W * 4, 1, W, H, "RGBA")
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
+    mi355fx.warm_clocks(step, sync_all)
     for _ in range(3):
         step()
-    for c in ctxs:
-        c.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(frames_per_stream):
         step()
@@ -49,8 +52,8 @@ def run(n_streams, frames_per_stream, fused):
 def main():
     out = {}
     for n in (1, 8, 32):
-        out["two_kernels_%d_streams_fps" % n] = run(n, 64, False)
-        out["fused_%d_streams_fps" % n] = run(n, 64, True)
+        out["two_kernels_%d_streams_fps" % n] = run(n, 256, False)
+        out["fused_%d_streams_fps" % n] = run(n, 256, True)
     print(json.dumps(out))
 
 
