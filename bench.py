@@ -173,6 +173,22 @@ def main():
                 run_n(20)
                 torch.cuda.synchronize()
 
+        marker = {}
+
+        def marker_ms():
+            """Average interval between two back-to-back timestamped events on the launch stream while it is busy."""
+            if "ms" not in marker:
+                pairs = []
+                for _ in range(32):
+                    ctx.hsvfilter_frames_device(cal.data_ptr(), 1, FRAME_BYTES, W, H, W * 4, "RGBA", settings)  # keep the queue busy
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); b.record()
+                    pairs.append((a, b))
+                torch.cuda.synchronize()
+                vals = sorted(a.elapsed_time(b) for a, b in pairs)
+                marker["ms"] = vals[len(vals) // 2]
+            return marker["ms"]
+
         def measure(content, steps, warmup, record):
             srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
             dsts = [torch.empty_like(s) for s in srcs]
@@ -183,8 +199,10 @@ def main():
                                        dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
             hsv_ms = lut_ms = None
             if record and evs:
-                hsv_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)
-                lut_ms = sum(b.elapsed_time(c) for _, b, c in evs) / len(evs)
+                # an event bracket is longer than the kernel inside it by the cost of one timestamped marker; that cost is
+                # calibrated live (empty brackets on the same stream, GPU busy) and subtracted
+                hsv_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs) - marker_ms()
+                lut_ms = sum(b.elapsed_time(c) for _, b, c in evs) / len(evs) - marker_ms()
             del srcs, dsts
             return dt, hsv_ms, lut_ms
 
@@ -214,10 +232,11 @@ def main():
             region(max(warmup, 14), False)
             evs = []
             dtf = sharding.timed_region(lambda: evs.extend(region(steps, True)), dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
-            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs) - marker_ms()
             del srcs, dsts
             return dtf, ms
 
+        cal = torch.zeros(FRAME_BYTES, dtype=torch.uint8, device=dev)
         dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
         lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
         hsv_tab, hsv_tc, hsv_tt = ctx.colorlut_kernel_choice(fused=2)
@@ -295,7 +314,8 @@ def main():
                         "colorlut_kernel": "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel",
                         "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt},
                         "hsvfilter_kernel": "colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel",
-                        "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt}},
+                        "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt},
+                        "event_marker_ms_subtracted": marker_ms()},
         }
         if interp:
             out["interpolating_kernel_only"] = interp

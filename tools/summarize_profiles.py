@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/summarize_profiles.py <tag> — condense gpurun_out/profiles_<tag>/ into tracked files under profiles/:
-  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim) of `bench.py --no-cpu-baseline --no-extra`
+  profiles/<tag>_kernel_stats_full.csv   the same for the plain `bench.py` command (all legs)
   profiles/<tag>_pmc.json           per-kernel FETCH_SIZE / WRITE_SIZE averages and corrected HBM bytes/launch
   profiles/<tag>_bench.json         the bench.py line of the same run
   profiles/pmc_latest.json          copy of <tag>_pmc.json that bench.py reads for roofline.traffic
@@ -35,6 +36,9 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    full = glob.glob(os.path.join(src, "trace_full", "**", "*kernel_stats.csv"), recursive=True)
+    if full:
+        shutil.copy(full[0], os.path.join(dst, tag + "_kernel_stats_full.csv"))
     fetch = glob.glob(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)
     write = glob.glob(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"), recursive=True)
     out = {"tag": tag, "units": "bytes per launch", "fetch_correction": "FETCH_SIZE(KiB) * 1024 * 2", "kernels": {}}
