@@ -87,7 +87,9 @@ typedef enum mi355_flag {
    * first four launches after a LUT load; afterwards the kind in use is re-timed every 8th-32nd launch and the other
    * one every 64-1024 launches, and the faster one serves the launches in between. mi355_hsv_colorlut_* does the same
    * with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms
-   * (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. */
+   * (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. Auto records, queries and
+   * occasionally waits for events on the context's stream: pin a variant (6 or 5) before capturing that stream
+   * into a hipGraph. */
   MI355_FLAG_LUT_VARIANT = 4,
   /* hsvfilter on packed colour-first 4-byte frames through a memoised table: 0 (default) = auto choice as for colorlut,
    * but only for settings that need the literal GENERIC arithmetic (|hue-shift| > 360 or non-finite); 1 = auto choice
