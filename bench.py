@@ -140,13 +140,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (torch.cuda unavailable); there is no CPU fallback")
+    if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
+        # test scaffolding only: exercise the N>1 control flow (barriers, max-over-ranks, aggregation) on a 1-GPU box by
+        # putting every rank on device 0 and using gloo; the numbers of such a run mean nothing
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
     settings = synth.HSV_SETTINGS["hue90"]
