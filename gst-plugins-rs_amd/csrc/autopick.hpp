@@ -1,0 +1,110 @@
+// autopick.hpp - the policy of the run-time choice between an interpolating ("compute") kernel and the memoised-table
+// kernel (colorlut_kernels.hip: auto_launch), free of HIP so that it can be exercised on a CPU-only box through
+// mi355_selftest_autopick (tests/test_autopick.py). The mechanism around it (events on the stream, table builds) lives in
+// colorlut_kernels.hip.
+//
+//   * learning: compute, compute, table, table - each launch measured and waited for, the first of each kind discarded
+//     (its interval holds one-off costs: code upload, cold caches);
+//   * afterwards the kind with the smaller time per pixel group serves the launches (3 % hysteresis); every n-th launch
+//     of it is measured (n = 8..32, about one sample per 128 Mpixel), the result is read without blocking when complete
+//     and waited for once it is n-1 launches old;
+//   * the kind NOT in use is tried again after probe_period launches (64, doubling up to 1024 while the answer stays the
+//     same, back to 64 when it changes);
+//   * a change of launch size by more than 2x restarts the learning.
+#pragma once
+#include <cstddef>
+
+namespace mi355 {
+
+constexpr unsigned kProbeMin = 64, kProbeMax = 1024;
+
+struct AutoPolicy {
+  unsigned calls = 0, since_probe = 0, probe_period = kProbeMin;
+  bool table = false;                     // kind in use once both times are known
+  double t_compute = 0.0, t_table = 0.0;  // ms per 16-byte pixel group, last measurement (0 = none yet)
+  size_t vec = 0;                         // launch size the measurements belong to
+  int pending_kind = -1;                  // measurement in flight: -1 none, 0 compute, 1 table
+  size_t pending_vec = 0;
+  unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
+  bool pending_probe = false, pending_discard = false;
+  unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
+  bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
+};
+
+struct AutoDecision {
+  int kind;        // 0 compute, 1 table
+  bool measure;    // bracket this launch with events
+  bool probe, discard;
+};
+
+// a sampled launch costs ~10 us more (two timestamped events): every 8th launch at most
+inline unsigned auto_sample_every(size_t n_vec) {
+  unsigned n = (unsigned)(((size_t)1 << 25) / (n_vec ? n_vec : 1));
+  return n < 8 ? 8 : (n > 32 ? 32 : n);
+}
+
+// must the measurement in flight be waited for before this call proceeds?
+inline bool auto_must_wait(const AutoPolicy &A, size_t n_vec) {
+  if (A.pending_kind < 0) return false;
+  const unsigned max_lag = (A.learn < 4 || A.t_compute == 0.0 || A.t_table == 0.0) ? 0 : auto_sample_every(n_vec) - 1;
+  return A.calls - A.pending_call >= max_lag;
+}
+
+// the measurement in flight has completed: ms <= 0 means it could not be read
+inline void auto_complete(AutoPolicy &A, double ms) {
+  if (A.pending_kind < 0) return;
+  if (!A.pending_discard && ms > 0.0) {
+    const double per_vec = ms / (double)A.pending_vec;
+    if (A.pending_kind == 0) A.t_compute = per_vec; else A.t_table = per_vec;
+    if (A.t_compute > 0.0 && A.t_table > 0.0) {
+      // 3 % hysteresis: measurements of near-equal kernels must not flip the choice back and forth
+      const bool table = A.t_table < A.t_compute * (A.table ? 1.03 : 0.97);
+      if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
+      else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
+      A.table = table;
+    }
+  }
+  A.pending_kind = -1;
+}
+
+// what this call runs (after the harvest step); updates the counters
+inline AutoDecision auto_decide(AutoPolicy &A, size_t n_vec) {
+  if (A.vec && (n_vec > 2 * A.vec || 2 * n_vec < A.vec) && A.pending_kind < 0) {
+    A.t_compute = A.t_table = 0.0;
+    A.learn = 0;
+    A.probe_period = kProbeMin;
+    A.since_probe = 0;
+  }
+  if (A.pending_kind < 0) A.vec = n_vec;
+  AutoDecision D{0, false, false, false};
+  if (A.learn < 4) {
+    D.kind = A.learn < 2 ? 0 : 1;
+    D.discard = (A.learn & 1) == 0;
+    D.probe = true;
+    if (A.pending_kind < 0) A.learn++;
+  } else {
+    D.kind = A.table ? 1 : 0;
+    if (++A.since_probe >= A.probe_period && A.pending_kind < 0) { D.kind ^= 1; D.probe = true; A.since_probe = 0; }
+  }
+  D.measure = A.pending_kind < 0 && (D.probe || (A.calls % auto_sample_every(n_vec)) == 0);
+  A.calls++;
+  return D;
+}
+
+// the launch decided by D has been enqueued between two events
+inline void auto_sampled(AutoPolicy &A, const AutoDecision &D, size_t n_vec) {
+  A.pending_kind = D.kind;
+  A.pending_call = A.calls;
+  A.pending_vec = n_vec;
+  A.pending_probe = D.probe && A.t_compute > 0.0 && A.t_table > 0.0;
+  A.pending_discard = D.discard;
+}
+
+// the table cannot be had: compute kernel for good
+inline void auto_give_up_table(AutoPolicy &A) {
+  A.table_unavailable = true;
+  A.learn = 4;
+  A.table = false;
+}
+
+}  // namespace mi355

@@ -1395,33 +1395,18 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
 //   * measurements are dropped when the launch size changes by more than 2x.
 // 1, 2, 6 = compute kernels only (6 = the default compute kernel), 4 / 5 = table kernel only (linear / Morton index).
 // The same policy, with its own state and table, serves the fused hsvfilter -> colorlut entry point.
-constexpr unsigned kProbeMin = 64, kProbeMax = 1024;
-
-static void auto_harvest(AutoPick &A, unsigned max_lag) {
+// The policy itself is autopick.hpp (HIP-free, unit-tested on the CPU); this is the mechanism around it.
+static void auto_harvest(AutoPick &A, size_t n_vec) {
   if (A.pending_kind < 0) return;
-  if (A.calls - A.pending_call >= max_lag) {
-    if (hipEventSynchronize(A.ev1) != hipSuccess) { (void)hipGetLastError(); A.pending_kind = -1; return; }
+  if (auto_must_wait(A, n_vec)) {
+    if (hipEventSynchronize(A.ev1) != hipSuccess) { (void)hipGetLastError(); auto_complete(A, 0.0); return; }
   } else if (hipEventQuery(A.ev1) != hipSuccess) {
     (void)hipGetLastError();
-    return;
+    return;  // not finished yet: look again at a later call
   }
   float ms = 0.0f;
-  if (A.pending_discard) {
-    // first launch of a kind after a (re)start: its interval contains one-off costs (code upload, cold caches)
-  } else if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess && ms > 0.0f) {
-    const double per_vec = (double)ms / (double)A.pending_vec;
-    if (A.pending_kind == 0) A.t_compute = per_vec; else A.t_table = per_vec;
-    if (A.t_compute > 0.0 && A.t_table > 0.0) {
-      // 3 % hysteresis: measurements of near-equal kernels must not flip the choice back and forth
-      const bool table = A.t_table < A.t_compute * (A.table ? 1.03 : 0.97);
-      if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
-      else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
-      A.table = table;
-    }
-  } else {
-    (void)hipGetLastError();
-  }
-  A.pending_kind = -1;
+  if (hipEventElapsedTime(&ms, A.ev0, A.ev1) != hipSuccess) { (void)hipGetLastError(); ms = 0.0f; }
+  auto_complete(A, (double)ms);
 }
 
 template <class Compute, class Ensure, class Table>
@@ -1432,48 +1417,19 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev0), "hipEventCreate"))) return rc;
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev1), "hipEventCreate"))) return rc;
   }
-  // a sampled launch costs ~10 us more (two timestamped events): every 8th launch at most
-  unsigned sample_every = (unsigned)(((size_t)1 << 25) / n_vec);
-  sample_every = sample_every < 8 ? 8 : (sample_every > 32 ? 32 : sample_every);
-  // learning: compute, compute, table, table - each launch waited for, the first of each kind discarded
-  auto_harvest(A, (A.learn < 4 || A.t_compute == 0.0 || A.t_table == 0.0) ? 0 : sample_every - 1);
-  if (A.vec && (n_vec > 2 * A.vec || 2 * n_vec < A.vec) && A.pending_kind < 0) {
-    A.t_compute = A.t_table = 0.0;
-    A.learn = 0;
-    A.probe_period = kProbeMin;
-    A.since_probe = 0;
-  }
-  if (A.pending_kind < 0) A.vec = n_vec;
-  int kind;
-  bool probe = false, discard = false;
-  if (A.learn < 4) {
-    kind = A.learn < 2 ? 0 : 1;
-    discard = (A.learn & 1) == 0;
-    probe = true;
-    if (A.pending_kind < 0) A.learn++;
-  } else {
-    kind = A.table ? 1 : 0;
-    if (++A.since_probe >= A.probe_period && A.pending_kind < 0) { kind ^= 1; probe = true; A.since_probe = 0; }
-  }
-  const bool measure = A.pending_kind < 0 && (probe || (A.calls % sample_every) == 0);
-  A.calls++;
-  if (kind == 1 && (rc = ensure())) {  // a table build stays outside the measurement
+  auto_harvest(A, n_vec);
+  const AutoDecision D = auto_decide(A, n_vec);
+  if (D.kind == 1 && (rc = ensure())) {  // a table build stays outside the measurement
     // no memory for the 64 MiB table (or the build failed): this entry point stays on the compute kernel for good
-    A.table_unavailable = true;
-    A.learn = 4;
-    A.table = false;
+    auto_give_up_table(A);
     (void)hipGetLastError();
     return compute();
   }
-  if (measure && (rc = check_hip(ctx, hipEventRecord(A.ev0, ctx->stream), "hipEventRecord"))) return rc;
-  if ((rc = kind ? table() : compute())) return rc;
-  if (measure) {
+  if (D.measure && (rc = check_hip(ctx, hipEventRecord(A.ev0, ctx->stream), "hipEventRecord"))) return rc;
+  if ((rc = D.kind ? table() : compute())) return rc;
+  if (D.measure) {
     if ((rc = check_hip(ctx, hipEventRecord(A.ev1, ctx->stream), "hipEventRecord"))) return rc;
-    A.pending_kind = kind;
-    A.pending_call = A.calls;
-    A.pending_vec = n_vec;
-    A.pending_probe = probe && A.t_compute > 0.0 && A.t_table > 0.0;
-    A.pending_discard = discard;
+    auto_sampled(A, D, n_vec);
   }
   return MI355_OK;
 }
@@ -1589,3 +1545,26 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
 }
 
 }  // namespace mi355
+
+// Runs the kernel-choice policy (autopick.hpp) against a scripted device: call i has n_vec[i] pixel groups; if it is
+// measured, its interval is ms_compute[i] or ms_table[i] depending on the kind it ran, and the measurement becomes readable
+// `lag` calls later (or at once when the policy insists on waiting). kind_out[i] = 0 / 1, measured_out[i] = 0 / 1.
+// No device, no context: host logic only (tests/test_autopick.py).
+extern "C" int mi355_selftest_autopick(int n_calls, const uint64_t *n_vec, const double *ms_compute, const double *ms_table, int lag,
+                                       int *kind_out, int *measured_out) {
+  if (n_calls < 0 || !n_vec || !ms_compute || !ms_table || !kind_out || lag < 0) return MI355_ERR_INVALID_ARG;
+  mi355::AutoPolicy A;
+  double pending_ms = 0.0;
+  for (int i = 0; i < n_calls; i++) {
+    const size_t nv = (size_t)n_vec[i];
+    if (A.pending_kind >= 0 && (mi355::auto_must_wait(A, nv) || A.calls - A.pending_call >= (unsigned)lag)) mi355::auto_complete(A, pending_ms);
+    const mi355::AutoDecision D = mi355::auto_decide(A, nv);
+    kind_out[i] = D.kind;
+    if (measured_out) measured_out[i] = D.measure ? 1 : 0;
+    if (D.measure) {
+      mi355::auto_sampled(A, D, nv);
+      pending_ms = D.kind ? ms_table[i] : ms_compute[i];
+    }
+  }
+  return MI355_OK;
+}

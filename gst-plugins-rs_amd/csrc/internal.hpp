@@ -6,22 +6,14 @@
 #include <string>
 #include "../../include/mi355fx.h"
 
+#include "autopick.hpp"
+
 namespace mi355 {
 
 // Device-side copy of a loaded CubeLut (video/colorlut/src/parser.rs:69-75).
-// Choice between an interpolating ("compute") kernel and the memoised-table kernel for one entry point
-// (colorlut_kernels.hip: auto_launch).
-struct AutoPick {
-  unsigned calls = 0, since_probe = 0, probe_period = 64;
-  bool table = false;
-  double t_compute = 0.0, t_table = 0.0;  // ms per 16-byte pixel group, last measurement (0 = none yet)
-  size_t vec = 0;                         // launch size the measurements belong to
-  int pending_kind = -1;                  // measurement in flight: -1 none, 0 compute, 1 table
-  size_t pending_vec = 0;
-  unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
-  bool pending_probe = false, pending_discard = false;
-  unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
-  bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
+// Choice between an interpolating ("compute") kernel and the memoised-table kernel for one entry point: the policy
+// state (autopick.hpp) plus the two events that bracket a sampled launch (colorlut_kernels.hip: auto_launch).
+struct AutoPick : AutoPolicy {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 

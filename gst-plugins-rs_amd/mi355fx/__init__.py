@@ -80,6 +80,7 @@ def load_library():
         "mi355_hsvdetect_frames_device": (i, [vp, u8p, sz, i, i, u8p, sz, i, i, i, i, i, C.POINTER(HsvDetectSettings)]),
         "mi355_colorlut_load": (i, [vp, i, sz, f32p, f32p, f32p]),
         "mi355_colorlut_unload": (i, [vp]),
+        "mi355_selftest_autopick": (i, [i, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mi355_colorlut_kernel_choice": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),

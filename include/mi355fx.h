@@ -161,6 +161,11 @@ int mi355_colorlut_unload(mi355_ctx *ctx);
  * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran). No reference
  * counterpart. */
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
+/* Host-logic self test of the auto-choice policy against a scripted device (no GPU needed): call i has n_vec[i] 16-byte
+ * pixel groups and, if measured, takes ms_compute[i] or ms_table[i] depending on the kind it ran; a measurement becomes
+ * readable `lag` calls later. kind_out[i] = 0 interpolating / 1 table, measured_out[i] (optional) = launch was bracketed. */
+int mi355_selftest_autopick(int n_calls, const uint64_t *n_vec, const double *ms_compute, const double *ms_table, int lag,
+                            int *kind_out, int *measured_out);
 /* Replaces transform_frame's body: transform_rgba / transform_rgba64::<LE>
  * (colorlut/imp.rs:203-223 -> :226-397). format in {RGBA, RGBA64_LE, RGBA64_BE}; src and dst are
  * plane 0 of two different frames with independent strides; rows = chunks(stride).take(height). */

@@ -1,0 +1,106 @@
+"""Host logic of the run-time kernel choice (csrc/autopick.hpp) against a scripted device, through the C ABI test hook
+mi355_selftest_autopick - no GPU needed. The same policy drives colorlut, the fused chain and hsvfilter on the device
+(tests/test_gpu_parity.py::test_colorlut_auto_*, tools/stress_auto.py)."""
+import ctypes as C
+
+import numpy as np
+
+NV = 16_588_800  # pixel groups of an 8 x 4K launch
+
+
+def run(mi355lib, n_vec, ms_c, ms_t, lag=2):
+    n = len(n_vec)
+    nv = (C.c_uint64 * n)(*[int(v) for v in n_vec])
+    a = (C.c_double * n)(*[float(v) for v in ms_c])
+    b = (C.c_double * n)(*[float(v) for v in ms_t])
+    kind = (C.c_int * n)()
+    meas = (C.c_int * n)()
+    f = mi355lib.mi355_selftest_autopick
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    assert f(n, nv, a, b, lag, kind, meas) == 0
+    return np.array(kind[:]), np.array(meas[:])
+
+
+def test_learning_phase_then_faster_kind(mi355lib):
+    n = 60
+    kind, meas = run(mi355lib, [NV] * n, [0.25] * n, [0.12] * n)
+    assert list(kind[:4]) == [0, 0, 1, 1] and list(meas[:4]) == [1, 1, 1, 1]
+    assert (kind[4:] == 1).all()           # table is faster: it serves everything until the first probe (call 64+)
+    kind, _ = run(mi355lib, [NV] * n, [0.25] * n, [0.60] * n)
+    assert list(kind[:4]) == [0, 0, 1, 1] and (kind[4:] == 0).all()
+
+
+def test_first_launch_of_each_kind_is_discarded(mi355lib):
+    """One-off costs in the first compute / table launch must not decide: here they would point the wrong way."""
+    n = 40
+    ms_c = [5.0, 0.25] + [0.25] * (n - 2)      # first compute launch inflated
+    ms_t = [0.12] * 2 + [0.05, 0.6] + [0.6] * (n - 4)   # first table launch (call 2) flatteringly fast, real ones slow
+    kind, _ = run(mi355lib, [NV] * n, ms_c, ms_t)
+    assert (kind[4:] == 0).all()
+
+
+def test_probe_of_the_other_kind_backs_off(mi355lib):
+    n = 2600
+    kind, meas = run(mi355lib, [NV] * n, [0.25] * n, [0.12] * n)
+    probes = [i for i in range(4, n) if kind[i] == 0]
+    assert probes, "the kind not in use must be tried again"
+    gaps = np.diff([4] + probes)
+    assert 60 <= gaps[0] <= 70
+    assert all(g2 >= g1 for g1, g2 in zip(gaps, gaps[1:])) and gaps[-1] <= 1030   # 64, 128, 256, 512, 1024, 1024 ...
+    assert all(meas[i] for i in probes)
+
+
+def test_content_change_flips_within_a_sample_interval(mi355lib):
+    n, change = 400, 200
+    ms_t = [0.12] * change + [1.2] * (n - change)   # the table kernel becomes 10x slower (noise)
+    kind, meas = run(mi355lib, [NV] * n, [0.4] * n, ms_t, lag=3)
+    after = kind[change:]
+    first_compute = int(np.argmax(after == 0))
+    assert after[first_compute] == 0 and first_compute <= 8 + 7 + 1   # next sample (every 8th launch) + read-back lag
+    assert (after[first_compute:first_compute + 60] == 0).all()
+    # and back when the content becomes friendly again: only a probe can find that out
+    ms_t2 = ms_t + [0.12] * 400
+    kind2, _ = run(mi355lib, [NV] * (n + 400), [0.4] * (n + 400), ms_t2, lag=3)
+    assert kind2[-1] == 1
+
+
+def test_hysteresis_no_flip_flop_on_equal_kernels(mi355lib):
+    rng = np.random.default_rng(0)
+    n = 3000
+    ms_c = 0.200 * (1 + rng.uniform(-0.01, 0.01, n))
+    ms_t = 0.200 * (1 + rng.uniform(-0.01, 0.01, n))
+    kind, _ = run(mi355lib, [NV] * n, ms_c, ms_t)
+    steady = kind[4:]
+    # ignore single-launch probes: count changes of the kind that serves runs of >= 2 launches
+    runs = [k for k, g in zip(steady[:-1], steady[1:]) if k == g]
+    assert np.count_nonzero(np.diff(runs)) <= 2
+
+
+def test_size_jump_restarts_learning(mi355lib):
+    nv = [NV] * 50 + [NV // 8] * 50 + [NV // 7] * 10
+    n = len(nv)
+    kind, meas = run(mi355lib, nv, [0.25] * n, [0.12] * n, lag=0)
+    assert list(kind[:4]) == [0, 0, 1, 1]
+    assert list(kind[50:54]) == [0, 0, 1, 1] and list(meas[50:54]) == [1, 1, 1, 1]   # > 2x smaller: start over
+    assert (kind[54:100] == 1).all()
+    assert (kind[100:] == 1).all()          # a 14 % change does not
+
+
+def test_sampling_cadence(mi355lib):
+    n = 400
+    _, meas = run(mi355lib, [NV] * n, [0.25] * n, [0.12] * n, lag=1)
+    steady = np.nonzero(meas[8:64])[0]
+    assert len(steady) and (np.diff(steady) == 8).all()          # big launches: every 8th
+    small = NV // 64
+    _, meas = run(mi355lib, [small] * n, [0.25] * n, [0.12] * n, lag=1)
+    steady = np.nonzero(meas[8:64])[0]
+    assert len(steady) and (np.diff(steady) == 32).all()         # small launches: every 32nd
+
+
+def test_unread_measurement_is_waited_for(mi355lib):
+    """A host that never finds the events complete (huge lag) is made to wait after n-1 launches: the choice still adapts."""
+    n, change = 300, 100
+    ms_t = [0.12] * change + [1.2] * (n - change)
+    kind, _ = run(mi355lib, [NV] * n, [0.4] * n, ms_t, lag=10 ** 6)
+    assert (kind[change + 24:change + 60] == 0).all()
