@@ -504,7 +504,18 @@ __global__ __launch_bounds__(256) void dssim_avg_kernel(DssimRed R) {
   __shared__ double s_w[4];
   const int k = blockIdx.x;
   double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < R.n_a[k]; i += 256) acc += R.part_a[k][i];
+  // eight loads in flight; the additions stay in index order
+  const unsigned n_a = R.n_a[k];
+  const double *pa = R.part_a[k];
+  unsigned i = threadIdx.x;
+  for (; i + 7 * 256 < n_a; i += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = pa[i + j * 256];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc += v[j];
+  }
+  for (; i < n_a; i += 256) acc += pa[i];
   const double sum = dssim_block_sum(acc, s_w);
   if (threadIdx.x == 0) {
     R.slots[3 * k] = sum;
