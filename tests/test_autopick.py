@@ -104,3 +104,25 @@ def test_unread_measurement_is_waited_for(mi355lib):
     ms_t = [0.12] * change + [1.2] * (n - change)
     kind, _ = run(mi355lib, [NV] * n, [0.4] * n, ms_t, lag=10 ** 6)
     assert (kind[change + 24:change + 60] == 0).all()
+
+
+def test_property_steady_timings_pick_the_faster_kind(mi355lib):
+    """Hypothesis: for any constant pair of timings at least 10 % apart, any launch size and any read-back lag, every
+    launch after the learning phase runs the faster kind except single probe launches of the other one, which are
+    measured and at least 64 launches apart."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(tc=st.floats(0.01, 10.0), ratio=st.floats(1.1, 20.0), table_faster=st.booleans(), nv=st.integers(16384, 1 << 27),
+           lag=st.integers(0, 40), n=st.integers(80, 1500))
+    def prop(tc, ratio, table_faster, nv, lag, n):
+        tt = tc / ratio if table_faster else tc * ratio
+        kind, meas = run(mi355lib, [nv] * n, [tc] * n, [tt] * n, lag=lag)
+        want = 1 if table_faster else 0
+        assert list(kind[:4]) == [0, 0, 1, 1]
+        other = [i for i in range(4, n) if kind[i] != want]
+        # learning results may arrive up to `lag`-bounded calls late: the policy waits for them, so the choice is made at call 4
+        assert all(meas[i] for i in other), "a launch of the slower kind that is not a measured probe"
+        assert all(b - a >= 64 for a, b in zip([3] + other, other)), other[:5]
+
+    prop()
