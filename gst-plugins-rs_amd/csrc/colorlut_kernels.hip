@@ -17,7 +17,18 @@
 //                              staged in LDS (33^3*4 B = 143.7 KB of the CU's 160 KB). Bit-identical
 //                              to the generic kernel for LUTs with finite, bounded entries and a finite
 //                              domain (checked at load time; otherwise the generic kernel is used).
-// Algorithmic traffic of both: 4 B read + 4 B written per pixel (RGBA8); the LUT is a
+//   colorlut1d_lds_kernel / colorlut3d_rgba64_lds_kernel / hsv_colorlut3d_pipe_kernel / colorlut3d_lean_kernel
+//                              1D LUTs from LDS tables; the RGBA64 form of the three-pass kernel; the fused
+//                              hsvfilter -> colorlut forms (HSV template argument, software-pipelined variant);
+//                              the lean-state experiment.
+//   colorlut_table_tiled_kernel / colorlut_table_kernel + table_domain_kernel
+//                              packed RGBA8 through a 2^24-entry memoised table that the kernels above build on
+//                              the device (bit-identical by construction): one gather per pixel; 2D-tiled or flat
+//                              pixel-to-wave mapping. Serves colorlut, the fused chain (table of the composed
+//                              function) and, opt-in / for GENERIC settings, hsvfilter.
+// Host side at the end of the file: LUT upload and layout (lut_upload), the launchers, and the run-time choice between
+// the interpolating and the table kernels (auto_launch; policy in autopick.hpp).
+// Algorithmic traffic of all of them: 4 B read + 4 B written per pixel (RGBA8; 8 + 8 for RGBA64); the LUT / table is a
 // cache/LDS-resident constant.
 #include "internal.hpp"
 #include "hsv_device.hpp"
