@@ -17,7 +17,7 @@
 //                              staged in LDS (33^3*4 B = 143.7 KB of the CU's 160 KB). Bit-identical
 //                              to the generic kernel for LUTs with finite, bounded entries and a finite
 //                              domain (checked at load time; otherwise the generic kernel is used).
-//   colorlut1d_lds_kernel / colorlut3d_rgba64_lds_kernel / hsv_colorlut3d_pipe_kernel / colorlut3d_lean_kernel
+//   colorlut1d_lds_kernel / colorlut3d_lds64_kernel / hsv_colorlut3d_pipe_kernel / colorlut3d_lean_kernel
 //                              1D LUTs from LDS tables; the RGBA64 form of the three-pass kernel; the fused
 //                              hsvfilter -> colorlut forms (HSV template argument, software-pipelined variant);
 //                              the lean-state experiment.
