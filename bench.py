@@ -7,8 +7,11 @@ torch.distributed.run with one rank per GPU. One JSON line on rank 0.
 
 A "step" = one pass of the hot path over one batch of `--batch` device-resident 4K RGBA frames:
 one hsvfilter launch (in place, hue-shift=90) + one colorlut launch (33^3 LUT) — the two-kernel mode
-of SURVEY.md §8d (algorithmic 16 B/pixel/frame = 132,710,400 B per frame). Successive steps walk a
-ring of batches larger than the 256 MiB Infinity Cache so every step streams from HBM.
+of SURVEY.md §8d (algorithmic 16 B/pixel/frame = 132,710,400 B per frame). hsvfilter is AlwaysInPlace in the
+reference (video/hsv/src/hsvfilter/imp.rs:315-320): upstream hands it a fresh frame every time. The bench does the
+same: every warm-up and timed step filters its OWN never-touched pristine batch (steps + warmup distinct source
+batches, far larger than the 256 MiB Infinity Cache, so every step streams from HBM); only the untimed clock ramp
+re-filters scratch batches.
 Streams are independent: ranks share nothing (no collective on the data path), scaling = "weak".
 """
 import argparse
@@ -32,8 +35,8 @@ BYTES_PER_FRAME_PER_KERNEL = 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--ramp-seconds", type=float, default=0.25,
                     help="untimed preamble before the W warm-up steps of each measured leg: the same launches for this long,\n"
                          "so that the GPU has left its idle clocks (a cold 50-step run measures 35 k frames/s, a warm one 43 k)")
@@ -41,8 +44,11 @@ def parse_args():
                     help="4K frames per launch (one step = one batch). 8 frames = 265 MB: the batch hsvfilter has just written\n"
                          "in place is still in the 256 MiB Infinity Cache when the colorlut launch reads it (32.0 k frames/s; 32 frames\n"
                          "per launch: 28-29 k; 1 frame per launch: 24.6 k)")
-    ap.add_argument("--ring", type=int, default=4, help="distinct batches cycled through (sources + outputs = 2.1 GB >> Infinity Cache,\n"
-                                                         "so every step's source comes from HBM)")
+    ap.add_argument("--ring", type=int, default=4, help="destination batches cycled through, and scratch source batches of the untimed ramp\n"
+                                                         "(the timed and warm-up steps have one pristine source batch EACH)")
+    ap.add_argument("--max-source-gib", type=float, default=96.0,
+                    help="cap on the pristine source batches held at once; a run needing more is timed in chunks with the sources\n"
+                         "regenerated between chunks outside the timed region (reported as config.source_chunks)")
     ap.add_argument("--content", default="smooth", choices=["smooth", "noise"], help="headline frame content")
     ap.add_argument("--lut-variant", type=int, default=0,
                     help="MI355_FLAG_LUT_VARIANT: 0 auto (default), 6 interpolating kernel only, 5 table kernel only")
@@ -52,32 +58,47 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_batches(torch, synth, dev, batch, ring, content):
-    """`ring` batches of `batch` frames each, generated from two seeded base frames per batch and
-    cheap byte rotations (keeps host generation time small while making every frame distinct)."""
-    gen = synth.smooth_frame if content == "smooth" else synth.noise_frame
-    bufs = []
-    for r in range(ring):
-        base = torch.from_numpy(gen(W, H, seed=synth.SEED + 17 * r)).to(dev)  # (H, W*4) uint8
-        frames = [torch.roll(base, shifts=4 * 97 * i, dims=1) for i in range(batch)]  # whole-pixel shifts
-        bufs.append(torch.stack(frames).contiguous())
-    return bufs
+class SourcePool:
+    """Pristine source batches. Batch number `index` is a pure function of (content, index): a seeded base frame
+    (synth.smooth_frame / noise_frame, one of N_BASE seeds) and whole-pixel rotations along the row, different for every
+    frame of every batch, so that all frames are distinct while keeping the content statistics of the base frame."""
+    N_BASE = 4
+
+    def __init__(self, torch, synth, dev, batch, content):
+        gen = synth.smooth_frame if content == "smooth" else synth.noise_frame
+        self.torch, self.batch = torch, batch
+        self.bases = [torch.from_numpy(gen(W, H, seed=synth.SEED + 17 * r)).to(dev) for r in range(self.N_BASE)]  # (H, W*4) u8
+
+    def fill(self, buf, index):
+        base, k = self.bases[index % self.N_BASE], index // self.N_BASE
+        for i in range(self.batch):
+            buf[i].copy_(self.torch.roll(base, shifts=4 * ((97 * i + 389 * k) % W), dims=1))
+        return buf
+
+    def new(self, index):
+        return self.fill(self.torch.empty((self.batch, H, W * 4), dtype=self.torch.uint8, device=self.bases[0].device), index)
+
+
+def batch_stats(torch, b):
+    """Byte sum of a batch and the number of distinct colours of its first frame (content fingerprint)."""
+    rgb = b[0].reshape(-1).view(torch.int32) & 0x00FFFFFF
+    return {"byte_sum": int(b.sum(dtype=torch.int64).item()), "distinct_colours_frame0": int(torch.unique(rgb).numel())}
 
 
 EVENT_EVERY = 4  # steps between per-kernel event samples inside the timed region
 
 
-def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record):
-    """K steps on ctx's stream (== torch current stream). With `record`, every EVENT_EVERY-th step has its two
-    launches bracketed by in-stream events (the timestamps cost a few microseconds each and keep consecutive
-    kernels from overlapping their tails, so bracketing every launch would lower the throughput being measured);
-    returns the event triples of the sampled steps."""
+def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVENT_EVERY):
+    """`steps` steps on ctx's stream (== torch current stream); step k filters srcs[k % len(srcs)] in place and maps it into
+    dsts[k % len(dsts)]. With `record`, every `every`-th step has its two launches bracketed by in-stream events (the
+    timestamps cost a few microseconds each and keep consecutive kernels from overlapping their tails, so bracketing every
+    launch would lower the throughput being measured); returns the event triples of the sampled steps."""
     evs = []
     pitch = FRAME_BYTES
     for k in range(steps):
         s = srcs[k % len(srcs)]
         d = dsts[k % len(dsts)]
-        sample = record and (k % EVENT_EVERY == 0)
+        sample = record and (k % every == 0)
         if sample:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
@@ -142,27 +163,27 @@ def main():
         raise SystemExit("bench.py needs a MI355X (torch.cuda unavailable); there is no CPU fallback")
     if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
         # test scaffolding only: exercise the N>1 control flow (barriers, max-over-ranks, aggregation) on a 1-GPU box by
-        # putting every rank on device 0 and using gloo; the numbers of such a run mean nothing
+        # putting every rank on device 0; the numbers of such a run mean nothing
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        # Streams are independent (north_star: "no RCCL: there is no cross-stream collective"): the only cross-rank
+        # traffic of the whole run is the barrier and the MAX of one double around the timed region, over a CPU (gloo)
+        # group. Neither the data path nor the harness touches RCCL / xGMI.
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
-            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
 
     settings = synth.HSV_SETTINGS["hue90"]
     cube_text = synth.cube_text_3d(33)
-    # product-side LUT parse: the host mirror of CubeLut::parse lives in the C++ host layer; here the
-    # table is produced numerically the same way (decimal text -> f32) via numpy to avoid any oracle use
+    # product-side LUT parse (the host mirror of CubeLut::parse; no oracle on this path)
     from mi355fx.cube import parse_cube
     lut = parse_cube(cube_text)
 
+    per_batch = args.batch * FRAME_BYTES
     ctx = mi355fx.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -183,7 +204,7 @@ def main():
         marker = {}
 
         def marker_ms():
-            """Average interval between two back-to-back timestamped events on the launch stream while it is busy."""
+            """Median interval between two back-to-back timestamped events on the launch stream while it is busy."""
             if "ms" not in marker:
                 pairs = []
                 for _ in range(32):
@@ -196,109 +217,155 @@ def main():
                 marker["ms"] = vals[len(vals) // 2]
             return marker["ms"]
 
-        def measure(content, steps, warmup, record):
-            srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
-            dsts = [torch.empty_like(s) for s in srcs]
-            ramp(lambda n: run_region(torch, ctx, srcs, dsts, settings, n, args.batch, False))
-            run_region(torch, ctx, srcs, dsts, settings, warmup, args.batch, False)
-            evs = []
-            dt = sharding.timed_region(lambda: evs.extend(run_region(torch, ctx, srcs, dsts, settings, steps, args.batch, record)),
-                                       dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
-            hsv_ms = lut_ms = None
-            if record and evs:
-                # an event bracket is longer than the kernel inside it by the cost of one timestamped marker; that cost is
-                # calibrated live (empty brackets on the same stream, GPU busy) and subtracted
-                hsv_ms = sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs) - marker_ms()
-                lut_ms = sum(b.elapsed_time(c) for _, b, c in evs) / len(evs) - marker_ms()
-            del srcs, dsts
-            return dt, hsv_ms, lut_ms
+        def hold_count(need):
+            free, _total = torch.cuda.mem_get_info(dev)
+            cap = int(min(args.max_source_gib * 2 ** 30, 0.6 * free) // per_batch)
+            return max(1, min(need, cap))
 
-        def measure_fused(content, steps, warmup):
-            """Same chain as ONE launch per batch (mi355_hsv_colorlut_frames_device): SURVEY §8(d) 'fused' accounting."""
-            srcs = make_batches(torch, synth, dev, args.batch, args.ring, content)
-            dsts = [torch.empty_like(s) for s in srcs]
+        def consume(pool, srcs, n_total, first_index, body):
+            """Feeds body(src_slice, n) with pristine batches first_index .. first_index+n_total-1, refilling `srcs`
+            (outside anything body times) whenever it runs out. Returns the number of refills."""
+            done, fills = 0, 0
+            while done < n_total:
+                n = min(len(srcs), n_total - done)
+                for j in range(n):
+                    pool.fill(srcs[j], first_index + done + j)
+                torch.cuda.synchronize()
+                fills += 1
+                body(srcs[:n], n, first_index + done)
+                done += n
+            return fills
+
+        def measure(content, steps, warmup, record, fused=False):
+            """One leg: ramp on scratch batches, W warm-up steps and K timed steps, each on its own pristine batch."""
+            pool = SourcePool(torch, synth, dev, args.batch, content)
+            dsts = [torch.empty((args.batch, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
+            scratch = [pool.new(10_000 + r) for r in range(args.ring)]
             pitch = FRAME_BYTES
 
-            def region(n, record):
-                evs = []
+            def region(srcs_, n, rec, every=EVENT_EVERY):
+                if not fused:
+                    return run_region(torch, ctx, srcs_, dsts, settings, n, args.batch, rec, every)
+                evs_ = []
                 for k in range(n):
-                    s_, d_ = srcs[k % len(srcs)], dsts[k % len(dsts)]
-                    sample = record and (k % EVENT_EVERY == 0)
+                    s_, d_ = srcs_[k % len(srcs_)], dsts[k % len(dsts)]
+                    sample = rec and (k % every == 0)
                     if sample:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                     ctx.hsv_colorlut_frames_device(s_.data_ptr(), pitch, W * 4, d_.data_ptr(), pitch, W * 4, args.batch, W, H, settings)
                     if sample:
                         e1.record()
-                        evs.append((e0, e1))
-                return evs
+                        evs_.append((e0, e1))
+                return evs_
 
-            # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
-            # launches of each kind: keep that learning phase out of the timed region
-            ramp(lambda n: region(n, False))
-            region(max(warmup, 14), False)
-            evs = []
-            dtf = sharding.timed_region(lambda: evs.extend(region(steps, True)), dist=dist, device_sync=torch.cuda.synchronize, reduce_device=dev)
-            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs) - marker_ms()
-            del srcs, dsts
-            return dtf, ms
+            ramp(lambda n: region(scratch, n, False))
+            if fused:
+                # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
+                # launches of each kind: keep that learning phase out of the timed region (out-of-place: scratch stays pristine)
+                region(scratch, 14, False)
+            srcs = [torch.empty((args.batch, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(hold_count(steps + warmup))]
+            stats = {}
+            evs, dts = [], []
+
+            def warm(sl, n, first):
+                region(sl, n, False)
+
+            def timed(sl, n, first):
+                if "first" not in stats:
+                    stats["first"] = batch_stats(torch, sl[0])
+                if first + n == warmup + steps:
+                    stats["last"] = batch_stats(torch, sl[n - 1])
+                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record)), dist=dist, device_sync=torch.cuda.synchronize))
+
+            consume(pool, srcs, warmup, 0, warm)
+            chunks = consume(pool, srcs, steps, warmup, timed)
+            dt = sum(dts)
+            res = {"dt": dt, "chunks": chunks, "held": len(srcs), "source_stats": stats, "samples": len(evs)}
+            if record:
+                if len(evs) < 32:
+                    # few in-region samples (small K): a dedicated bracketed pass on fresh pristine batches, every launch timed
+                    extra = []
+                    consume(pool, srcs, 64, warmup + steps, lambda sl, n, first: extra.extend(region(sl, n, True, 1)))
+                    torch.cuda.synchronize()
+                    evs = evs + extra
+                    res["samples"] = len(evs)
+                    res["dedicated_pass_samples"] = len(extra)
+                torch.cuda.synchronize()
+                # an event bracket is longer than the kernel inside it by the cost of one timestamped marker; that cost is
+                # calibrated live (empty brackets on the same stream, GPU busy), reported, and subtracted
+                if fused:
+                    res["raw_ms"] = (sum(a.elapsed_time(b) for a, b in evs) / len(evs),)
+                else:
+                    res["raw_ms"] = (sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs), sum(b.elapsed_time(c) for _, b, c in evs) / len(evs))
+                res["ms"] = tuple(v - marker_ms() for v in res["raw_ms"])
+            del srcs, dsts, scratch, pool
+            torch.cuda.empty_cache()
+            return res
 
         cal = torch.zeros(FRAME_BYTES, dtype=torch.uint8, device=dev)
-        dt, hsv_ms, lut_ms = measure(args.content, args.steps, args.warmup, True)
+        main_leg = measure(args.content, args.steps, args.warmup, True)
+        dt = main_leg["dt"]
+        hsv_ms, lut_ms = main_leg["ms"]
         lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
         hsv_tab, hsv_tc, hsv_tt = ctx.colorlut_kernel_choice(fused=2)
+        lb = BYTES_PER_FRAME_PER_KERNEL * args.batch
         interp = None
-        if not args.no_extra and args.lut_variant == 0 and lut_tab and world == 1:  # single-process only: the branch depends on a per-rank choice
-            # the same two-launch chain with the interpolating colorlut kernel pinned (no memoised table), for comparison
+        if not args.no_extra and args.lut_variant == 0 and world == 1:
+            # the same two-launch chain with the interpolating (arithmetic) colorlut kernel pinned: no memoised table
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 6)
             n_i = max(10, args.steps // 2)
-            dti, h_i, l_i = measure(args.content, n_i, 2, True)
+            leg = measure(args.content, n_i, 4, True)
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
-            lb = BYTES_PER_FRAME_PER_KERNEL * args.batch
-            interp = {"frames_per_s": sharding.aggregate_throughput(n_i * args.batch, world, dti), "colorlut_kernel": "colorlut3d_lds_kernel",
+            h_i, l_i = leg["ms"]
+            interp = {"frames_per_s": sharding.aggregate_throughput(n_i * args.batch, world, leg["dt"]), "colorlut_kernel": ctx.colorlut_kernel_name(),
                       "colorlut_ms_per_launch": l_i, "colorlut_GBps": lb / (l_i * 1e-3) / 1e9,
                       "colorlut_frac_of_hbm_peak": lb / (l_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "hsvfilter_ms_per_launch": h_i}
         fused = None
-        if not args.no_extra:
-            dtf, fused_ms = measure_fused(args.content, args.steps, args.warmup)
-            fused_fps = sharding.aggregate_throughput(args.steps * args.batch, world, dtf)
-            fb = BYTES_PER_FRAME_PER_KERNEL * args.batch
+        if not args.no_extra and world == 1:
+            leg = measure(args.content, args.steps, args.warmup, True, fused=True)
+            fused_fps = sharding.aggregate_throughput(args.steps * args.batch, world, leg["dt"])
+            fused_ms = leg["ms"][0]
             f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
             fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
-                     "kernel": "colorlut_table_tiled_kernel (composed hsv+lut table)" if f_tab else "colorlut3d_lds_kernel<HSV>",
+                     "kernel": "colorlut_table_tiled_kernel (composed hsv+lut table)" if f_tab else "fused compute kernel",
                      "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
-                     "algorithmic_bytes_per_launch": fb, "GBps": fb / (fused_ms * 1e-3) / 1e9,
-                     "frac_of_hbm_peak": fb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": lb, "GBps": lb / (fused_ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": lb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "one launch per batch, 8 B/px algorithmic (SURVEY 8d fused accounting); bit-identical to the two-kernel chain"}
         extra = None
-        if not args.no_extra and rank == 0 and world == 1:
+        if not args.no_extra and world == 1:
             other = "noise" if args.content == "smooth" else "smooth"
+            n_o = max(10, args.steps // 2)
             # warm-up long enough for the colorlut kernel choice to follow the change of content (sampled every 8th launch)
-            dt2, h2, l2 = measure(other, max(10, args.steps // 2), 18, True)
-            extra = {"content": other, "frames_per_s": max(10, args.steps // 2) * args.batch / dt2,
-                     "hsvfilter_ms_per_launch": h2, "colorlut_ms_per_launch": l2,
-                     "colorlut_kernel": "colorlut_table_tiled_kernel" if ctx.colorlut_kernel_choice()[0] else "colorlut3d_lds_kernel"}
+            leg = measure(other, n_o, 18, True)
+            extra = {"content": other, "frames_per_s": n_o * args.batch / leg["dt"],
+                     "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
+                     "colorlut_kernel": ctx.colorlut_kernel_name(), "source_stats": leg["source_stats"]}
 
     fps = sharding.aggregate_throughput(args.steps * args.batch, world, dt)
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
         # dominant kernel = the longer of the two launches
-        per_launch_bytes = BYTES_PER_FRAME_PER_KERNEL * args.batch
+        per_launch_bytes = lb
+        lut_name = "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d (interpolating)"
         if lut_ms >= hsv_ms:
-            dom, dom_ms = ("colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel"), lut_ms
+            dom, dom_ms = lut_name, lut_ms
         else:
             dom, dom_ms = ("colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel"), hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM bytes/launch of the dominant kernel from the last committed rocprofv3 --pmc passes
-        # (tools/collect_profiles.sh + tools/summarize_profiles.py); counters cannot be read from inside
-        # the process, so this is the profile's per-launch figure for the same batch size, or null.
-        traffic = None
+        # HBM bytes per launch cannot be read from inside the process. `traffic` is the per-launch figure of the committed
+        # rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/pmc_latest.json) when that profile was
+        # taken with the same batch size, content and kernel; otherwise null. Its provenance is spelled out next to it.
+        traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            for kname, rec in pmc.get("kernels", {}).items():
-                if kname.startswith(dom.split("<")[0]) and pmc.get("frames_per_step") == args.batch:
-                    traffic = rec["hbm_bytes"]
+            if pmc.get("frames_per_step") == args.batch and pmc.get("content", "smooth") == args.content and pmc.get("pristine_sources"):
+                for kname, rec in pmc.get("kernels", {}).items():
+                    if kname.startswith(dom.split(" ")[0].split("<")[0]):
+                        traffic = rec["hbm_bytes"]
+                        traffic_src = "profiles/pmc_latest.json: separate rocprofv3 --pmc passes of this command (%s)" % pmc.get("collected", "?")
         except (OSError, ValueError, KeyError):
             traffic = None
         chain_gbs = 2 * per_launch_bytes / ((hsv_ms + lut_ms) * 1e-3) / 1e9
@@ -308,21 +375,29 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
-                       "frames_per_step": args.batch, "ring_batches": args.ring, "content": args.content,
+                       "frames_per_step": args.batch, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
-                       "lut_variant": args.lut_variant},
+                       "lut_variant": args.lut_variant, "ramp_seconds": args.ramp_seconds, "event_marker_ms": marker_ms(),
+                       "sources": "pristine: every warm-up/timed step filters its own never-touched batch (in place)",
+                       "source_batches_held": main_leg["held"], "source_chunks": main_leg["chunks"],
+                       "source_stats": main_leg["source_stats"], "dst_ring_batches": args.ring,
+                       "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms,
+                         "avg_launch_ms_raw_bracket": main_leg["raw_ms"][1] if lut_ms >= hsv_ms else main_leg["raw_ms"][0],
+                         "launch_samples": main_leg["samples"]},
             "kernels": {"hsvfilter_ms_per_launch": hsv_ms, "colorlut_ms_per_launch": lut_ms,
+                        "hsvfilter_ms_raw_bracket": main_leg["raw_ms"][0], "colorlut_ms_raw_bracket": main_leg["raw_ms"][1],
                         "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
-                        "colorlut_kernel": "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d_lds_kernel",
+                        "colorlut_kernel": lut_name,
                         "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt},
                         "hsvfilter_kernel": "colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel",
                         "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt},
-                        "event_marker_ms_subtracted": marker_ms()},
+                        "event_marker_ms_subtracted": marker_ms(), "samples": main_leg["samples"],
+                        "dedicated_pass_samples": main_leg.get("dedicated_pass_samples", 0)},
         }
         if interp:
             out["interpolating_kernel_only"] = interp
@@ -330,7 +405,7 @@ def main():
             out["fused_chain"] = fused
         if extra:
             out["other_content"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             one, mt = cpu_baseline(synth, settings, cube_text)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = mt
@@ -338,6 +413,7 @@ def main():
 
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

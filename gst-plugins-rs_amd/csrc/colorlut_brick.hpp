@@ -1,0 +1,50 @@
+// colorlut_brick.hpp — host-side handle of the brick-cache colorlut kernel (colorlut_brick.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+struct mi355_ctx;
+struct mi355_hsv_settings;
+
+namespace mi355 {
+
+constexpr int kBrickMaxSize = 65;  // size^3 lines of 128 B: 35 MB at 65 (the tag field itself would allow 128)
+
+// Device-side brick form of a loaded 3D LUT (built by brick_upload at mi355_colorlut_load).
+struct BrickLut {
+  float *d_bricks = nullptr;               // size^3 x 32 floats: {c, d} x 4 corner rows (24 floats) + 8 pad
+  uint32_t *d_axis = nullptr;              // 3 x 256 x {t, slot byte offset | window number << 15}
+  uint32_t *d_cellnum = nullptr;           // 3 x 256: per-axis contribution to the cell number x0 + S*y0 + S*S*z0 (miss path)
+  unsigned long long *d_counters = nullptr;  // [0] 256-pixel steps that took the careful path, [1] lanes that missed
+  int size = 0;
+  bool ok = false;                         // kernel applicable to this LUT (3D, size <= kBrickMaxSize, finite domain)
+  // content watch (brick_choose / brick_after_launch): the miss counters are copied to pinned host memory every few
+  // launches behind an event that is only ever polled, never waited for
+  unsigned long long *h_counters = nullptr;
+  hipEvent_t ev = nullptr;
+  bool pending = false;                    // a snapshot copy is in flight
+  unsigned long long px_since = 0;         // pixels launched through the brick kernel since the last snapshot
+  unsigned long long px_snapshot = 0;      // ... covered by the snapshot in flight
+  unsigned launches_since = 0;
+  bool hostile = false;                    // last snapshot: too many steps missed the cache -> three-pass kernel
+  unsigned retry_in = 0, retry_period = 0; // launches served by the other kernel before the brick kernel is tried again
+  double last_miss_fraction = 0.0;         // of the 256-pixel steps in the last snapshot
+};
+
+// Content watch for the interpolating path: true = use the brick kernel for this launch, false = the three-pass kernel.
+bool brick_choose(BrickLut &B);
+// after a brick launch of `pixels` pixels on ctx's stream: count it and, every few launches, start a non-blocking snapshot
+int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels);
+
+int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);
+void brick_release(BrickLut &B);
+bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch,
+                      int dst_stride, int n_frames, int width, int height);
+// hs == nullptr: colorlut alone; otherwise the fused hsvfilter -> colorlut chain. src == dst is allowed.
+int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
+                 const mi355_hsv_settings *hs);
+// synchronous read (and optional reset) of the miss counters
+int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);
+
+}  // namespace mi355

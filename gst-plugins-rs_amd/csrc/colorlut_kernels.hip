@@ -967,6 +967,7 @@ void lut_release(mi355_ctx *ctx) {
   if (ctx->lut.d_cells) (void)hipFree(ctx->lut.d_cells);
   if (ctx->lut.d_planar) (void)hipFree(ctx->lut.d_planar);
   if (ctx->lut.d_axis) (void)hipFree(ctx->lut.d_axis);
+  brick_release(ctx->lut.brick);
   ctx->lut = LutDevice{};
 }
 
@@ -1084,6 +1085,7 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
       L.lds_ok = true;
     }
   }
+  if (is3d && (rc = brick_upload(ctx, L.brick, (int)size, table, scale, offset))) return rc;
   L.loaded = true;
   return MI355_OK;
 }
@@ -1184,7 +1186,21 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
   if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
   size_t n_groups = 0;
-  if (lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups)) {
+  const bool three_pass_ok = lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups);
+  const int lv = ctx->lut_variant;
+  if (!ctx->force_generic && lv != 3 && lv != 1 && lv != 2 && ctx->fused_variant == 0 &&
+      brick_applicable(ctx->lut.brick, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height)) {
+    BrickLut &B = ctx->lut.brick;
+    const bool build = ctx->lut.building_table;
+    if (lv == 7 || !three_pass_ok || (!build && brick_choose(B))) {
+      ctx->lut.last_kernel = "colorlut3d_brick_kernel<HSV>";
+      int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs);
+      if (rc || build) return rc;
+      return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames);
+    }
+  }
+  if (three_pass_ok) {
+    ctx->lut.last_kernel = "colorlut3d_lds_kernel<HSV>";
     const HsvK hk{hs.hue_shift, hs.saturation_mul, hs.saturation_off, hs.value_mul, hs.value_off};
     const uint4 *s = (const uint4 *)d_src;
     uint4 *d = (uint4 *)d_dst;
@@ -1231,6 +1247,7 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
     const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
     if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
       constexpr int NT = 512;
+      ctx->lut.last_kernel = "colorlut1d_lds_kernel";
       auto kern = colorlut1d_lds_kernel<NT>;
       int rc = check_hip(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes),
                          "hipFuncSetAttribute(max dynamic LDS)");
@@ -1250,7 +1267,26 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
   }
   {
     size_t n_groups = 0;
-    if (rgba8 && lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups)) {
+    // MI355_FLAG_LUT_VARIANT among the interpolating kernels: 0 / 6 = brick-cache kernel with the content watch handing
+    // noise-like streams to the three-pass whole-plane kernel (brick_choose); 7 = brick kernel only; 3 = three-pass only;
+    // 1 / 2 = the three-pass kernel's late-prefetch / lean-state experiments.
+    const int v = ctx->lut_variant;
+    const bool three_pass_ok = rgba8 && lds3d_rgba_applicable(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_groups);
+    if (rgba8 && !ctx->force_generic && (v == 0 || v == 6 || v == 7 || v == 4 || v == 5) &&
+        brick_applicable(ctx->lut.brick, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height)) {
+      BrickLut &B = ctx->lut.brick;
+      // a table build runs over the all-colours frame, which is as hostile to the brick cache as noise: three-pass kernel
+      // when it applies, and no entry in the stream's content watch either way
+      const bool build = ctx->lut.building_table;
+      if (v == 7 || !three_pass_ok || (!build && brick_choose(B))) {
+        ctx->lut.last_kernel = "colorlut3d_brick_kernel";
+        int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr);
+        if (rc || build) return rc;
+        return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames);
+      }
+    }
+    if (three_pass_ok) {
+      ctx->lut.last_kernel = "colorlut3d_lds_kernel";
       const uint4 *s = (const uint4 *)d_src;
       uint4 *d = (uint4 *)d_dst;
       constexpr int NT = 1024, P4 = 3;
@@ -1273,6 +1309,7 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
     const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
     if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
       constexpr int NT = 1024, P2 = 4;
+      ctx->lut.last_kernel = "colorlut3d_lds64_kernel";
       Lut64K k64;
       for (int c = 0; c < 3; c++) { k64.scale[c] = L.scale[c]; k64.offset[c] = L.offset[c]; }
       k64.sm1 = (float)L.size - 1.0f;
@@ -1297,6 +1334,7 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
     }
   }
 
+  ctx->lut.last_kernel = "colorlut_rows_kernel";
   const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
   size_t blocks = (total + 255) / 256;
   const size_t cap = (size_t)ctx->n_cu * 8;
@@ -1345,8 +1383,12 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   uint8_t *t = (uint8_t *)L.d_table[which];
   L.table_morton[which] = -1;
   hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, L.d_table[which], morton);
+  L.building_table = true;
+  const char *serving = L.last_kernel;
   rc = which == 0 ? launch_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, MI355_FMT_RGBA)
                   : launch_hsv_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, *hs, true);
+  L.building_table = false;
+  L.last_kernel = serving;
   if (rc) return rc;
   L.table_morton[which] = morton;
   if (which == 1) L.table_hs = *hs;
@@ -1362,6 +1404,7 @@ static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t
 }
 
 static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton) {
+  ctx->lut.last_kernel = "colorlut_table_tiled_kernel";
   if (width % 4 == 0 && width >= 128 && rows < (1u << 30)) {
     const unsigned w4 = (unsigned)width / 4;
     // 256-pixel patches unless 128-pixel ones waste fewer masked lanes in the last column
@@ -1381,6 +1424,7 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
       return check_hip(ctx, hipGetLastError(), "colorlut table kernel launch");
     }
   }
+  ctx->lut.last_kernel = "colorlut_table_kernel";
   size_t grid = (size_t)ctx->n_cu * 16;
   const size_t max_blocks = n_vec / 512 + 1;  // a block's four waves take one 128-group chunk each per iteration
   if (grid > max_blocks) grid = max_blocks;

@@ -178,7 +178,8 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   REQUIRE_CTX(ctx);
   if (flag == MI355_FLAG_FORCE_GENERIC) { ctx->force_generic = value != 0; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_STAGGER && value >= 0 && value <= 4096) { ctx->lut_stagger = value; return MI355_OK; }
-  if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 6 && value != 3) { ctx->lut_variant = value; return MI355_OK; }
+  if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 7) { ctx->lut_variant = value; return MI355_OK; }
+  if (flag == MI355_FLAG_BRICK_TILES_PER_RUN && value >= 0 && value <= 4096) { ctx->brick_tiles_per_run = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 3) { ctx->hsv_table_mode = value; return MI355_OK; }
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
@@ -363,6 +364,23 @@ int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, d
                                : (ctx->lut_variant == 4 || ctx->lut_variant == 5 || (ctx->lut_variant == 0 && A.t_table > 0.0 && A.table));
   if (ms_per_mpx_compute) *ms_per_mpx_compute = A.t_compute * 250000.0;
   if (ms_per_mpx_table) *ms_per_mpx_table = A.t_table * 250000.0;
+  return MI355_OK;
+}
+
+const char *mi355_colorlut_last_kernel(mi355_ctx *ctx) {
+  if (!ctx) return "";
+  return ctx->lut.last_kernel ? ctx->lut.last_kernel : "";
+}
+
+int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *hostile, int reset) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  unsigned long long c[2] = {0, 0};
+  int rc = brick_read_counters(ctx, ctx->lut.brick, c, reset != 0);
+  if (rc) return rc;
+  if (counters) { counters[0] = c[0]; counters[1] = c[1]; }
+  if (last_miss_fraction) *last_miss_fraction = ctx->lut.brick.last_miss_fraction;
+  if (hostile) *hostile = ctx->lut.brick.hostile ? 1 : 0;
   return MI355_OK;
 }
 

@@ -7,6 +7,7 @@
 #include "../../include/mi355fx.h"
 
 #include "autopick.hpp"
+#include "colorlut_brick.hpp"
 
 namespace mi355 {
 
@@ -38,6 +39,9 @@ struct LutDevice {
   mi355_hsv_settings seen_hs{};    // settings of the previous fused call and for how many calls they have not changed
   unsigned seen_stable = 0;
   AutoPick pick[2];                // compute-kernel / table-kernel choice for the two entry points
+  BrickLut brick;                  // brick form of a 3D LUT for the brick-cache interpolating kernel (colorlut_brick.hip)
+  bool building_table = false;     // launch_*_compute is being run over the all-colours frame by table_ensure
+  const char *last_kernel = "";    // name of the kernel that served the last mi355_colorlut_* / mi355_hsv_colorlut_* launch
   bool loaded = false;
 };
 
@@ -86,6 +90,7 @@ struct mi355_ctx {
   int hsv_table_mode = 0; // MI355_FLAG_HSV_TABLE: 0 auto for GENERIC settings only (default), 1 auto for all, 2 table only, 3 off
   mi355::HsvTable hsv_table;
   int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
+  int brick_tiles_per_run = 0;  // MI355_FLAG_BRICK_TILES_PER_RUN (tuning; 0 = default)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

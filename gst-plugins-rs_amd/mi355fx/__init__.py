@@ -28,6 +28,7 @@ FLAG_FUSED_VARIANT = 3
 FLAG_LUT_VARIANT = 4
 FLAG_LUT_STAGGER = 5
 FLAG_HSV_TABLE = 6
+FLAG_BRICK_TILES_PER_RUN = 7
 
 
 class HsvSettings(C.Structure):
@@ -82,6 +83,8 @@ def load_library():
         "mi355_colorlut_unload": (i, [vp]),
         "mi355_selftest_autopick": (i, [i, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mi355_colorlut_kernel_choice": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "mi355_colorlut_last_kernel": (C.c_char_p, [vp]),
+        "mi355_colorlut_brick_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_int), i]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
         "mi355_hsv_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings)]),
@@ -259,6 +262,17 @@ class Context:
         k, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
         self._ck(self.L.mi355_colorlut_kernel_choice(self.h, int(fused), C.byref(k), C.byref(a), C.byref(b)))
         return bool(k.value), a.value, b.value
+
+    def colorlut_kernel_name(self):
+        """Name of the kernel that served the last colorlut / fused launch of this context."""
+        return (self.L.mi355_colorlut_last_kernel(self.h) or b"").decode()
+
+    def colorlut_brick_stats(self, reset=False):
+        """(careful-path steps, missed lanes, last miss fraction seen by the content watch, hostile flag)."""
+        c = (C.c_uint64 * 2)()
+        f, h = C.c_double(0), C.c_int(0)
+        self._ck(self.L.mi355_colorlut_brick_stats(self.h, c, C.byref(f), C.byref(h), int(reset)))
+        return int(c[0]), int(c[1]), f.value, bool(h.value)
 
     def colorlut_frame(self, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
         self._ck(self.L.mi355_colorlut_frame(self.h, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt]))

@@ -86,17 +86,19 @@ typedef enum mi355_flag {
    * memoised-table kernel (built on the device from the interpolating kernel, so bit-identical) are both timed on the
    * first four launches after a LUT load; afterwards the kind in use is re-timed every 8th-32nd launch and the other
    * one every 64-1024 launches, and the faster one serves the launches in between. mi355_hsv_colorlut_* does the same
-   * with a table of the composed function. 6 = interpolating kernel only; 1 / 2 = its late-prefetch / lean-state forms
-   * (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. Auto records, queries and
-   * occasionally waits for events on the context's stream: pin a variant (6 or 5) before capturing that stream
-   * into a hipGraph. */
+   * with a table of the composed function. 6 = interpolating kernels only: the brick-cache kernel (colorlut_brick.hip),
+   * with noise-like streams handed to the three-pass whole-plane kernel by a miss-counter watch that never blocks;
+   * 7 = brick-cache kernel only; 3 = three-pass kernel only; 1 / 2 = the three-pass kernel's late-prefetch / lean-state
+   * forms (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. Auto records and queries events
+   * on the context's stream: pin a variant (7, 3 or 5) before capturing that stream into a hipGraph. */
   MI355_FLAG_LUT_VARIANT = 4,
   /* hsvfilter on packed colour-first 4-byte frames through a memoised table: 0 (default) = auto choice as for colorlut,
    * but only for settings that need the literal GENERIC arithmetic (|hue-shift| > 360 or non-finite); 1 = auto choice
    * for all settings; 2 = table only; 3 = arithmetic kernels only */
   MI355_FLAG_HSV_TABLE = 6,
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
-  MI355_FLAG_FUSED_VARIANT = 3  /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
+  MI355_FLAG_FUSED_VARIANT = 3, /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
+  MI355_FLAG_BRICK_TILES_PER_RUN = 7 /* brick-cache kernel: 128 x 4 pixel tiles a wave walks down before its cache starts cold again (0 = default) */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 
@@ -161,6 +163,13 @@ int mi355_colorlut_unload(mi355_ctx *ctx);
  * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran). No reference
  * counterpart. */
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
+/* Name of the kernel that served the last mi355_colorlut_* / mi355_hsv_colorlut_* launch of this context ("" before the
+ * first one). Diagnostic; no reference counterpart. */
+const char *mi355_colorlut_last_kernel(mi355_ctx *ctx);
+/* Brick-cache kernel diagnostics (synchronous): counters[0] = 256-pixel steps that found a brick missing in the wave's
+ * LDS cache since the last reset, counters[1] = lanes that missed; *last_miss_fraction / *hostile = what the content
+ * watch last concluded. reset != 0 clears the device counters. No reference counterpart. */
+int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *hostile, int reset);
 /* Host-logic self test of the auto-choice policy against a scripted device (no GPU needed): call i has n_vec[i] 16-byte
  * pixel groups and, if measured, takes ms_compute[i] or ms_table[i] depending on the kind it ran; a measurement becomes
  * readable `lag` calls later. kind_out[i] = 0 interpolating / 1 table, measured_out[i] (optional) = launch was bracketed. */
