@@ -12,21 +12,24 @@
 // IEEE f32 subtraction, L2 / Infinity-Cache resident: 4.6 MB for 33^3). With the brick in registers a pixel costs
 //   4 x (c + d*tx)  +  2 x (a + (b-a)*ty)  +  1 x (a + (b-a)*tz)   per channel = 17 unfused f32 ops (reference: 21),
 // every one of them the reference's operation on the reference's operands: bit-identical for ANY table contents
-// (non-finite entries included: the differences and products are the same IEEE operations), any size <= 64.
+// (non-finite entries included: the differences and products are the same IEEE operations), any size <= 65.
 //
-// Where the bricks live. Natural-like pictures are locally coherent in colour: the pixels of a 128 x 4 patch fall into a
-// handful of neighbouring LUT cells. Each WAVE owns a direct-mapped cache of 64 bricks in LDS (slot = low 2 bits of x0,
-// y0, z0: any 4 x 4 x 4 window of cells maps to distinct slots; 112 B per slot so that slot s starts on 16-byte column
-// 7s mod 16 and the six 16-byte reads of neighbouring slots spread over the LDS banks; tag word = cell number) and walks
-// down a 128-pixel-wide strip of the picture so the cache stays warm from tile to tile. Per pixel: three 8-byte axis-table
-// reads ({t, packed slot/cell contribution} per input byte, computed on the host with the reference's coordinate
-// arithmetic), one tag read + compare, six ds_read_b128, 51 + ~16 VALU ops. A wave whose 256-pixel step has a miss takes
-// the careful path for that step: hit lanes read LDS, miss lanes read their brick's line from the global table (and one
-// elected lane per slot refills the cache) — per lane, no loop, so hostile content (noise: every pixel its own cell) is
-// slow but exact; the miss counters tell the host-side kernel choice (colorlut_kernels.hip) to use the three-pass
-// whole-plane kernel for such streams.
-// No block-level synchronisation anywhere after the prologue: waves run free, so HBM latency, L2 refills, LDS reads and
-// VALU work of the 16 waves of a CU overlap by themselves.
+// Where the bricks live. Natural-like pictures are locally coherent in colour: the pixels of a 128 x 2 patch fall into a
+// handful of neighbouring LUT cells, or into two such groups where the patch straddles an edge. Each WAVE owns a 2-way
+// set-associative cache of bricks in LDS: set = low bits of (x0, y0, z0) (4 x 4 x 2 or 4 x 4 x 4 sets, so neighbouring
+// cells never share a set), two ways per set (so two colour clusters do not evict each other), FIFO replacement;
+// a set is 208 B = two 96 B bricks + {tag0, tag1, owner, fifo}: 13 sixteen-byte columns, so neighbouring sets start on
+// different LDS bank groups. The wave walks down a 128-pixel-wide strip of the picture, so its cache stays warm from
+// tile to tile. Per pixel: three 8-byte axis-table reads ({t, packed set address | tag contribution} per input byte,
+// computed on the host with the reference's coordinate arithmetic), one 8-byte tag read, six ds_read_b128, 54 fast +
+// 14 other VALU ops. A 256-pixel step with a miss first FILLS: per pixel slot, one elected lane per set reads its brick's
+// line from the global table and writes it into the set (at most three rounds: a fill can evict a brick another lane
+// of the same step still needs); then every lane takes the fast path. A step that still misses after that (more than
+// two bricks per set among its pixels: noise) takes the slow path: hit lanes read the cache, miss lanes read the global
+// table directly — per lane, no loop, always exact. The miss counters tell the host-side content watch to hand
+// noise-like streams to the three-pass whole-plane kernel (colorlut_kernels.hip).
+// No block-level synchronisation after the prologue: waves run free, so HBM latency, L2 refills, LDS reads and VALU work
+// of the waves of a CU overlap by themselves.
 #include "internal.hpp"
 #include "hsv_device.hpp"
 #include "exact_math.hpp"
@@ -38,16 +41,26 @@
 
 namespace mi355 {
 
-constexpr int kBrickSlotBytes = 112;   // 96 B brick + tag word at +96 + owner word at +100 (+8 spare)
-constexpr int kBrickSlots = 64;        // per wave: 4 x 4 x 4 window
-constexpr int kBrickTagShift = 15;     // packed = LDS byte address of the slot (< 32768) | window number << 15
+constexpr int kBrickSetBytes = 208;    // brick way 0 at +0, way 1 at +96, tags at +192 / +196, owner at +200, fifo at +204
+constexpr int kBrickTagShift = 16;     // packed = LDS byte address of the set (< 65536) | tag << 16
 constexpr int kBrickAxisBytes = 3 * 256 * 8;
 constexpr int kBrickWaves = 4;         // waves per block
-constexpr int kBrickWaveBytes = kBrickSlots * kBrickSlotBytes;            // 7,168 B of slots per wave
-constexpr int kBrickAxisBase = kBrickWaves * kBrickWaveBytes;             // LDS: four slot regions, then the axis tables
-constexpr int kBrickHsvSelBase = kBrickAxisBase + kBrickAxisBytes;        // 8 dwords: hsvfilter sextant selectors (fused form)
-constexpr int kBrickLdsBytes = kBrickHsvSelBase + 32;                     // 34,848 B -> 4 blocks per CU
-static_assert(kBrickAxisBase <= (1 << kBrickTagShift), "slot addresses must fit below the tag field");
+constexpr int kBrickCounterSlots = 1024;
+constexpr size_t kBrickCounterBytes = 2 * kBrickCounterSlots * sizeof(unsigned long long);
+// ZB = set-index bits taken from z0: 1 -> 32 sets (6.5 KB per wave, 4 blocks per CU), 2 -> 64 sets (13 KB, 2 blocks per CU)
+// Set address = 208 x (x0 & 3) + 832 x (y0 & 3) + kBrickZStride x (z0 & (2^ZB - 1)). ds_read_b128 serves 16 lanes per LDS
+// cycle over 16 sixteen-byte columns; with 13 columns per set the 16 (x, y) residues start on 16 different columns, way 1
+// sits 6 columns after way 0, and the z stride adds 8 more: the two ways of a cell and of its x, y and z neighbours - the
+// bricks the lanes of a wave actually read together on natural-like content - occupy 16 different columns.
+constexpr int kBrickZStride = 16 * kBrickSetBytes + 128;
+constexpr int brick_wave_bytes(int zb) { return (1 << zb) * kBrickZStride; }
+constexpr int brick_axis_base(int zb) { return kBrickWaves * brick_wave_bytes(zb); }   // LDS: four wave regions, then the axis tables
+constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 dwords: cell-number contributions (fill path)
+constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 3 * 1024; }          // 8 dwords: hsvfilter sextant selectors
+constexpr int kBrickQueueCap = 30;                                                       // fill queue entries per wave ({cell, destination})
+constexpr int brick_queue_base(int zb) { return brick_sel_base(zb) + 32; }               // 4 x 256 B
+constexpr int brick_lds_bytes(int zb) { return brick_queue_base(zb) + kBrickWaves * 256; }
+static_assert(brick_axis_base(2) <= (1 << kBrickTagShift), "set addresses must fit below the tag field");
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -72,28 +85,30 @@ __device__ __forceinline__ void brick_round_into(uint32_t &packed, float y) {
   else asm("v_cvt_rpi_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(packed) : "v"(y));
 }
 
-template <int CH>
-__device__ __forceinline__ void brick_channel(const float (&v)[24], float tx, float ty, float tz, uint32_t &out) {
-  constexpr int ch = CH;
-  {
-    const float x00 = v[0 + ch] + v[3 + ch] * tx;    // (y0,z0)   imp.rs:518
-    const float x10 = v[6 + ch] + v[9 + ch] * tx;    // (y1,z0)   imp.rs:519
-    const float x01 = v[12 + ch] + v[15 + ch] * tx;  // (y0,z1)   imp.rs:520
-    const float x11 = v[18 + ch] + v[21 + ch] * tx;  // (y1,z1)   imp.rs:521
-    const float y0 = x00 + (x10 - x00) * ty;         // imp.rs:523
-    const float y1 = x01 + (x11 - x01) * ty;         // imp.rs:524
-    const float o = y0 + (y1 - y0) * tz;             // imp.rs:525
-    // float_to_u8 (imp.rs:537-539): inherent clamp (NaN passes, then `as u8` gives 0) == max-then-min (NaN -> 0) on the byte
-    brick_round_into<CH>(out, fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f);
-  }
-}
+typedef float f2_t __attribute__((ext_vector_type(2)));
 
-// lerps + float_to_u8 of one pixel from its brick v[24] (layout above); returns the three output bytes merged into `px`
-__device__ __forceinline__ uint32_t brick_pixel(const float (&v)[24], float tx, float ty, float tz, uint32_t px) {
+// Lerps + float_to_u8 of one pixel from its brick; returns the three output bytes merged into `px`.
+// Brick register layout (six 16-byte rows, built by brick_upload): rows 0..3 = {c.r, c.g, d.r, d.g} of the corner rows
+// q = (y0,z0), (y1,z0), (y0,z1), (y1,z1); row 4 = {c0.b, c2.b, d0.b, d2.b}; row 5 = {c1.b, c3.b, d1.b, d3.b}. Every operand
+// pair of the 7 lerps then sits in an aligned register pair, so the arithmetic is packed-f32 (v_pk_mul_f32 / v_pk_add_f32,
+// two IEEE results per instruction; never v_pk_fma: the reference's mul and add round separately): 24 packed + 3 scalar
+// instructions instead of 51. On gfx950 a wave64 VALU instruction occupies its SIMD for 4 cycles whether packed or not.
+__device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t px) {
+  const f2_t TX = {tx, tx}, TY = {ty, ty}, TZ = {tz, tz};
+  f2_t X[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) X[q] = f[q].xy + f[q].zw * TX;  // c + d * tx                 imp.rs:518-521
+  const f2_t Y0 = X[0] + (X[1] - X[0]) * TY;                  // (r,g) at z0                imp.rs:523
+  const f2_t Y1 = X[2] + (X[3] - X[2]) * TY;                  // (r,g) at z1                imp.rs:524
+  const f2_t Yb = X[4] + (X[5] - X[4]) * TY;                  // b at (z0, z1)
+  const f2_t O = Y0 + (Y1 - Y0) * TZ;                         // imp.rs:525
+  const float ob = Yb.x + (Yb.y - Yb.x) * tz;
+  // float_to_u8 (imp.rs:537-539): inherent clamp (NaN passes, then `as u8` gives 0) == max-then-min (NaN -> 0) on the byte
+  const f2_t O255 = __builtin_elementwise_min(__builtin_elementwise_max(O, (f2_t){0.0f, 0.0f}), (f2_t){1.0f, 1.0f}) * (f2_t){255.0f, 255.0f};
   uint32_t out = px;
-  brick_channel<0>(v, tx, ty, tz, out);
-  brick_channel<1>(v, tx, ty, tz, out);
-  brick_channel<2>(v, tx, ty, tz, out);
+  brick_round_into<0>(out, O255.x);
+  brick_round_into<1>(out, O255.y);
+  brick_round_into<2>(out, fminf(fmaxf(ob, 0.0f), 1.0f) * 255.0f);
   return out;
 }
 
@@ -108,30 +123,41 @@ typedef __attribute__((address_space(3))) f4_t lds_f4;
 __device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const lds_u32 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w32(uint32_t a, uint32_t v) { *(lds_u32 *)(lds_byte *)a = v; }
 __device__ __forceinline__ u2_t lds_r64(uint32_t a) { return *(const lds_u2 *)(lds_byte *)a; }
+__device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_byte *)a = v; }
 __device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)a = v; }
 
-template <int P, int HSV>  // P = 16-byte loads per lane and tile: a tile is 128 px x 2P rows
-__global__ __launch_bounds__(256, 4) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned rows,
-                                                                   unsigned n_strips, unsigned tiles_per_run, unsigned n_runs,
-                                                                   const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
-                                                                   const uint32_t *__restrict__ cellnum,
-                                                                   unsigned long long *__restrict__ counters, HsvK hk) {
+template <int P, int HSV, int ZB>  // P = 16-byte loads per lane and tile: a tile is 128 px x 2P rows
+__global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
+                                                                                 unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
+                                                                                 const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
+                                                                                 const uint32_t *__restrict__ cellnum,
+                                                                                 unsigned long long *__restrict__ counters, HsvK hk) {
   // All LDS of this kernel is the dynamic allocation and there are no static __shared__ objects, so the allocation starts
   // at LDS address 0. LDS is addressed by absolute byte address (address-space-3 pointers made from integers): every table
   // base then folds into the ds_read offset field instead of costing an add of the link-time base symbol per access.
-  const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)(uint32_t)kBrickHsvSelBase;
+  constexpr uint32_t AX = brick_axis_base(ZB), CELL = brick_cell_base(ZB), SEL = brick_sel_base(ZB), WB = brick_wave_bytes(ZB), SETS = 16u << ZB;
+  const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)SEL;
   if constexpr (HSV != kBrickNoHsv) {
-    if (threadIdx.x < 7)
-      lds_w32(kBrickHsvSelBase + 4 * threadIdx.x, HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3));
+    if (threadIdx.x < 7) lds_w32(SEL + 4 * threadIdx.x, HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3));
   }
-  for (int i = threadIdx.x; i < kBrickAxisBytes / 8; i += 256) *(lds_u2 *)(lds_byte *)(uint32_t)(kBrickAxisBase + 8 * i) = axis[i];
+  for (int i = threadIdx.x; i < kBrickAxisBytes / 8; i += 256) lds_w64(AX + 8 * i, axis[i]);
+  for (int i = threadIdx.x; i < 768; i += 256) lds_w32(CELL + 4 * i, cellnum[i]);
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t wave_base = __builtin_amdgcn_readfirstlane(wave * kBrickWaveBytes);
-  lds_w32(wave_base + lane * kBrickSlotBytes + 96, 0xffffffffu);  // 64 lanes, 64 slots: every tag invalid
+  const uint32_t queue = brick_queue_base(ZB) + wave * 256u;
+  const uint32_t e_l = lane / 6u, k_l = lane % 6u;  // fill pass: lane -> (queue entry, 16-byte piece of its brick)
+  uint32_t gen = 1;                                  // fill-round stamp (see the fifo word)
+  const uint32_t wave_base = __builtin_amdgcn_readfirstlane(wave * WB);
+  if (lane < SETS) {
+    const u2_t inval = {0xffffffffu, 0xffffffffu};
+    const uint32_t sa = wave_base + (lane & 15u) * kBrickSetBytes + (lane >> 4) * kBrickZStride;
+    lds_w64(sa + 192, inval);  // both tags invalid
+    lds_w32(sa + 204, 0u);     // next victim: way 0
+  }
   __syncthreads();
   const uint32_t three = 3;
 
+  const unsigned n_runs = n_runs_flags & 0x7fffffffu;  // bit 31: progress-based wave priorities
   const unsigned run = blockIdx.x * kBrickWaves + wave;
   if (run >= n_runs) return;
   // adjacent waves take adjacent strips of the same rows (a block covers 512 px x 2P rows: 2 KB row segments)
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(256, 4) void colorlut3d_brick_kernel(const u4_t *__
   const unsigned sub = lane >> 5, g = lane & 31;
   const unsigned col = strip * 32 + g;
   const bool col_ok = col < w4;
-  unsigned miss_steps = 0, miss_lanes = 0;
+  unsigned miss_steps = 0, slow_steps = 0;
 
   auto wave_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -148,20 +174,39 @@ __global__ __launch_bounds__(256, 4) void colorlut3d_brick_kernel(const u4_t *__
 
   const unsigned row_first = rr * tiles_per_run * (2 * P);
   u4_t cur[P], nxt[P];
+  // Loads are unconditional (out-of-picture lanes re-read a clamped in-picture address; only the stores are predicated):
+  // a load inside a branch makes the number of outstanding memory operations unknown to the compiler, which then waits
+  // for ALL of them - next tile's prefetch included - with s_waitcnt vmcnt(0) before touching the current tile.
+  const unsigned col_c = col_ok ? col : w4 - 1;
   auto load_tile = [&](unsigned row0, u4_t(&t)[P]) {
 #pragma unroll
     for (int j = 0; j < P; j++) {
       const unsigned r = row0 + 2 * j + sub;
-      u4_t v = {0, 0, 0, 0};
-      if (col_ok && r < rows) v = __builtin_nontemporal_load(src + (size_t)r * w4 + col);
-      t[j] = v;
+      t[j] = __builtin_nontemporal_load(src + (size_t)(r < rows ? r : rows - 1) * w4 + col_c);
     }
   };
   load_tile(row_first, cur);
+  const bool prio_quarters = (n_runs_flags >> 31) != 0;
+  unsigned prio_q = 0;
+  if (prio_quarters) __builtin_amdgcn_s_setprio(3);
   for (unsigned t = 0; t < tiles_per_run; t++) {
     const unsigned row0 = row_first + t * (2 * P);
     if (row0 >= rows) break;  // wave-uniform
-    if (t + 1 < tiles_per_run) load_tile(row0 + 2 * P, nxt);
+    // Fair share by hand. The SIMD arbitrates VALU issue by priority, then AGE: at equal priority the oldest of the four
+    // waves of a SIMD takes every slot it can use and finishes its run long before the youngest, which then works alone
+    // at a third of the issue rate (measured: average wave lifetime 66 % of the kernel time). A wave therefore lowers its
+    // priority as it advances (3, 2, 1, 0 by quarter of its run): whoever is behind outranks whoever is ahead, and the four
+    // finish within a quarter of a run of each other.
+    if (prio_quarters) {
+      const unsigned q = (4u * t) / tiles_per_run;
+      if (q != prio_q) {
+        prio_q = q;
+        if (q == 1) __builtin_amdgcn_s_setprio(2);
+        else if (q == 2) __builtin_amdgcn_s_setprio(1);
+        else if (q == 3) __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    load_tile(row0 + 2 * P, nxt);  // prefetch (clamped to the picture: the last tile of a run re-reads rows it does not use)
 #pragma unroll
     for (int j = 0; j < P; j++) {
       uint32_t px[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
@@ -172,70 +217,123 @@ __global__ __launch_bounds__(256, 4) void colorlut3d_brick_kernel(const u4_t *__
 #pragma unroll
         for (int i = 0; i < 4; i++) px[i] = hsvfilter_px<false, 0, 1, 2, 3>(px[i], hk, hsv_sel);
       }
-      // stage A: coordinates, slot, tag check
+      // stage A: coordinates, set, tag
       float tx[4], ty[4], tz[4];
-      uint32_t slot[4], tag[4];
-      bool miss = false;
+      uint32_t set[4], tag[4], baddr[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const u2_t ex = lds_r64(byte_times8<0>(px[i], three) + (uint32_t)kBrickAxisBase);
-        const u2_t ey = lds_r64(byte_times8<1>(px[i], three) + (uint32_t)(kBrickAxisBase + 2048));
-        const u2_t ez = lds_r64(byte_times8<2>(px[i], three) + (uint32_t)(kBrickAxisBase + 4096));
+        const u2_t ex = lds_r64(byte_times8<0>(px[i], three) + AX);
+        const u2_t ey = lds_r64(byte_times8<1>(px[i], three) + (AX + 2048u));
+        const u2_t ez = lds_r64(byte_times8<2>(px[i], three) + (AX + 4096u));
         tx[i] = __uint_as_float(ex.x);
         ty[i] = __uint_as_float(ey.x);
         tz[i] = __uint_as_float(ez.x);
         const uint32_t packed = (ex.y + ey.y) + (ez.y + wave_base);  // v_add_u32 + v_add3_u32
-        slot[i] = packed & ((1u << kBrickTagShift) - 1u);          // LDS byte address of the wave's slot for this cell
-        tag[i] = packed >> kBrickTagShift;                         // which 4x4x4 window of cells the slot must hold
-        miss |= lds_r32(slot[i] + 96u) != tag[i];
+        set[i] = packed & ((1u << kBrickTagShift) - 1u);           // LDS byte address of the wave's set for this cell
+        tag[i] = packed >> kBrickTagShift;                          // which cell of that residue class the brick must be
+      }
+      // tag check: both ways' tags in one 8-byte read; baddr = the way that holds the brick
+      auto check = [&]() -> bool {
+        bool miss = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const u2_t tg = lds_r64(set[i] + 192u);
+          const bool h1 = tg.y == tag[i];
+          baddr[i] = h1 ? set[i] + 96u : set[i];
+          miss |= !(h1 || tg.x == tag[i]);
+        }
+        return __any(miss);
+      };
+      bool slow = false;
+      if (__builtin_expect(check(), 0)) {
+        miss_steps++;
+        // Fill rounds. Enqueue: per pixel slot, one elected lane per missing set claims the victim way (FIFO), installs
+        // the tag at once (so that later pixel slots of this step see the brick as present and do not fetch it again) and
+        // appends {cell number, destination} to the wave's queue. A set accepts two installs per round - one per way - so
+        // no two queue entries of a round share a destination. Fetch: lanes 6e..6e+5 copy the six 16-byte pieces of entry
+        // e from the global brick table into LDS, ten bricks per pass, ONE L2 round trip per pass. Then every tag is
+        // checked again: a set asked for three different bricks by this step's pixels cannot hold them all, and after
+        // three rounds the step takes the slow path below.
+        int round = 0;
+        do {
+          uint32_t n = 0;  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            wave_sync();
+            const u2_t tg = lds_r64(set[i] + 192u);
+            const bool m = tg.x != tag[i] && tg.y != tag[i];
+            if (__any(m)) {
+              if (m) lds_w32(set[i] + 200u, lane);
+              wave_sync();
+              const bool own = m && lds_r32(set[i] + 200u) == lane;
+              const unsigned long long ob = __ballot(own);
+              const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(ob >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ob, 0u));
+              if (own && pos < (uint32_t)kBrickQueueCap) {
+                // fifo word: bit 0 = next victim way, bits 1-2 = installs in round `bits 3..`
+                const uint32_t fw = lds_r32(set[i] + 204u);
+                const uint32_t cnt = (fw >> 3) == gen ? ((fw >> 1) & 3u) : 0u;
+                if (cnt < 2u) {
+                  const uint32_t way = fw & 1u;
+                  const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
+                                        lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
+                  const u2_t qe = {cell, set[i] + 96u * way};
+                  lds_w64(queue + 8u * pos, qe);
+                  lds_w32(set[i] + 192u + 4u * way, tag[i]);
+                  lds_w32(set[i] + 204u, (way ^ 1u) | ((cnt + 1u) << 1) | (gen << 3));
+                } else {
+                  const u2_t qe = {0xffffffffu, 0u};  // claimed queue slot stays empty
+                  lds_w64(queue + 8u * pos, qe);
+                }
+              }
+              n += (uint32_t)__builtin_popcountll(ob);
+            }
+          }
+          if (n > (uint32_t)kBrickQueueCap) n = kBrickQueueCap;
+          n = __builtin_amdgcn_readfirstlane(n);
+          wave_sync();
+          for (uint32_t base = 0; base < n; base += 10u) {
+            const uint32_t e = base + e_l;
+            if (lane < 60u && e < n) {
+              const u2_t qe = lds_r64(queue + 8u * e);
+              if (qe.x != 0xffffffffu) lds_w128(qe.y + 16u * k_l, bricks[(size_t)qe.x * 8 + k_l]);
+            }
+          }
+          gen++;
+          wave_sync();
+          slow = check();
+        } while (slow && ++round < 3);
       }
       uint32_t out[4];
-      if (__builtin_expect(!__any(miss), 1)) {
+      if (__builtin_expect(!slow, 1)) {
         // fast path: every lane's four bricks are resident
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          float v[24];
+          f4_t f[6];
 #pragma unroll
-          for (int k = 0; k < 6; k++) {
-            const f4_t f = lds_r128(slot[i] + 16u * k);
-            v[4 * k + 0] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w;
-          }
-          out[i] = brick_pixel(v, tx[i], ty[i], tz[i], px[i]);
+          for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
+          out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
         }
       } else {
-        // careful path, pixel by pixel: hit lanes read the cache, miss lanes read the global brick table; then one
-        // elected miss lane per slot refills the cache (reads of this pixel come first in the wave's LDS order)
-        miss_steps++;
+        // slow path (more than two bricks per set among this step's pixels): hit lanes read the cache, miss lanes the global table
+        slow_steps++;
 #pragma unroll 1
         for (int i = 0; i < 4; i++) {
-          wave_sync();
-          const bool m = lds_r32(slot[i] + 96u) != tag[i];
-          miss_lanes += (unsigned)__builtin_popcountll(__ballot(m));
+          const u2_t tg = lds_r64(set[i] + 192u);
+          const bool h1 = tg.y == tag[i], h0 = tg.x == tag[i];
           f4_t f[6];
-          if (m) {
-            // cell number x0 + S*y0 + S*S*z0 from the per-axis contribution table (global, L1-resident; miss path only)
-            const uint32_t cell = cellnum[px[i] & 0xffu] + cellnum[256 + ((px[i] >> 8) & 0xffu)] + cellnum[512 + ((px[i] >> 16) & 0xffu)];
+          if (!(h0 || h1)) {
+            const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
+                                  lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
             const f4_t *gb = bricks + (size_t)cell * 8;
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = gb[k];
           } else {
+            const uint32_t a = h1 ? set[i] + 96u : set[i];
 #pragma unroll
-            for (int k = 0; k < 6; k++) f[k] = lds_r128(slot[i] + 16u * k);
+            for (int k = 0; k < 6; k++) f[k] = lds_r128(a + 16u * k);
           }
-          wave_sync();
-          if (m) lds_w32(slot[i] + 100u, lane);
-          wave_sync();
-          if (m && lds_r32(slot[i] + 100u) == lane) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) lds_w128(slot[i] + 16u * k, f[k]);
-            lds_w32(slot[i] + 96u, tag[i]);
-          }
-          float v[24];
-#pragma unroll
-          for (int k = 0; k < 6; k++) { v[4 * k + 0] = f[k].x; v[4 * k + 1] = f[k].y; v[4 * k + 2] = f[k].z; v[4 * k + 3] = f[k].w; }
-          out[i] = brick_pixel(v, tx[i], ty[i], tz[i], px[i]);
+          out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
         }
-        wave_sync();
       }
       const unsigned r = row0 + 2 * j + sub;
       if (col_ok && r < rows) {
@@ -246,9 +344,12 @@ __global__ __launch_bounds__(256, 4) void colorlut3d_brick_kernel(const u4_t *__
 #pragma unroll
     for (int j = 0; j < P; j++) cur[j] = nxt[j];
   }
+  // counters are spread over kBrickCounterSlots slots (the host adds them up): thousands of waves finishing together and
+  // adding to ONE address serialise in L2 at ~12 ns per atomic - a 0.1 ms tail on a 0.1 ms kernel
   if (counters && lane == 0 && miss_steps) {
-    atomicAdd(counters + 0, (unsigned long long)miss_steps);
-    atomicAdd(counters + 1, (unsigned long long)miss_lanes);
+    unsigned long long *c = counters + 2 * (run % kBrickCounterSlots);
+    atomicAdd(c + 0, (unsigned long long)miss_steps);
+    if (slow_steps) atomicAdd(c + 1, (unsigned long long)slow_steps);
   }
 }
 
@@ -297,25 +398,36 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
         const int ys[4] = {y, y1, y, y1}, zs[4] = {z, z, z1, z1};
         for (int q = 0; q < 4; q++) {
           const float *c0 = at(x, ys[q], zs[q]), *c1 = at(x1, ys[q], zs[q]);
+          float cq[3], dq[3];
           for (int ch = 0; ch < 3; ch++) {
             volatile float d = c1[ch] - c0[ch];  // the `(b - a)` of lerp4 (imp.rs:528-535), rounded to f32
-            b[6 * q + ch] = c0[ch];
-            b[6 * q + 3 + ch] = d;
+            cq[ch] = c0[ch];
+            dq[ch] = d;
           }
+          // register layout of brick_pixel: rows 0..3 = {c.r, c.g, d.r, d.g}; row 4 = b of q 0 and 2; row 5 = b of q 1 and 3
+          b[4 * q + 0] = cq[0]; b[4 * q + 1] = cq[1]; b[4 * q + 2] = dq[0]; b[4 * q + 3] = dq[1];
+          float *rb = b + 16 + 4 * (q & 1);
+          rb[(q >> 1)] = cq[2];
+          rb[2 + (q >> 1)] = dq[2];
         }
       }
-  std::vector<uint32_t> axis(3 * 256 * 2), cellnum(3 * 256);
-  for (int a = 0; a < 3; a++)
-    for (int v = 0; v < 256; v++) {
-      float t;
-      int i0;
-      brick_axis_entry(v, scale[a], offset[a], S, &t, &i0);
-      const uint32_t slot = (uint32_t)(i0 & 3) << (2 * a);                         // slot number: x bits 0-1, y 2-3, z 4-5
-      const uint32_t window = (uint32_t)(i0 >> 2) << (5 * a);                      // tag: 5 bits per axis (size <= 128)
-      std::memcpy(&axis[(size_t)(a * 256 + v) * 2 + 0], &t, 4);
-      axis[(size_t)(a * 256 + v) * 2 + 1] = slot * (uint32_t)kBrickSlotBytes + (window << kBrickTagShift);
-      cellnum[(size_t)a * 256 + v] = (uint32_t)i0 * (a == 0 ? 1u : (a == 1 ? (uint32_t)S : (uint32_t)S * S));
-    }
+  // axis tables for both cache geometries (ZB = 1, 2): [zb-1][axis][byte] = {t, set byte offset | tag contribution << 16}
+  std::vector<uint32_t> axis(2 * 3 * 256 * 2), cellnum(3 * 256);
+  for (int zb = 1; zb <= 2; zb++)
+    for (int a = 0; a < 3; a++)
+      for (int v = 0; v < 256; v++) {
+        float t;
+        int i0;
+        brick_axis_entry(v, scale[a], offset[a], S, &t, &i0);
+        const int bits = a == 2 ? zb : 2;                                              // set-index bits of this axis
+        const uint32_t r = (uint32_t)(i0 & ((1 << bits) - 1));                         // this axis' part of the set index
+        const uint32_t set_off = a == 0 ? r * kBrickSetBytes : (a == 1 ? r * 4u * kBrickSetBytes : r * (uint32_t)kBrickZStride);
+        const uint32_t tag = (uint32_t)(i0 >> bits) << (5 * a);                        // 5 + 5 + 6 tag bits (size <= 65)
+        uint32_t *e = &axis[((size_t)(zb - 1) * 768 + (size_t)a * 256 + v) * 2];
+        std::memcpy(&e[0], &t, 4);
+        e[1] = set_off + (tag << kBrickTagShift);
+        cellnum[(size_t)a * 256 + v] = (uint32_t)i0 * (a == 0 ? 1u : (a == 1 ? (uint32_t)S : (uint32_t)S * S));
+      }
   int rc = check_hip(ctx, hipMalloc((void **)&B.d_bricks, bricks.size() * sizeof(float)), "hipMalloc(lut bricks)");
   if (rc) return rc;
   if ((rc = check_hip(ctx, hipMemcpy(B.d_bricks, bricks.data(), bricks.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(lut bricks)"))) return rc;
@@ -323,10 +435,10 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
   if ((rc = check_hip(ctx, hipMemcpy(B.d_axis, axis.data(), axis.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(brick axis tables)"))) return rc;
   if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_cellnum, cellnum.size() * sizeof(uint32_t)), "hipMalloc(brick cell numbers)"))) return rc;
   if ((rc = check_hip(ctx, hipMemcpy(B.d_cellnum, cellnum.data(), cellnum.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(brick cell numbers)"))) return rc;
-  if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_counters, 2 * sizeof(unsigned long long)), "hipMalloc(brick counters)"))) return rc;
-  if ((rc = check_hip(ctx, hipMemset(B.d_counters, 0, 2 * sizeof(unsigned long long)), "hipMemset(brick counters)"))) return rc;
-  if ((rc = check_hip(ctx, hipHostMalloc((void **)&B.h_counters, 2 * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(brick counters)"))) return rc;
-  B.h_counters[0] = B.h_counters[1] = 0;
+  if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_counters, kBrickCounterBytes), "hipMalloc(brick counters)"))) return rc;
+  if ((rc = check_hip(ctx, hipMemset(B.d_counters, 0, kBrickCounterBytes), "hipMemset(brick counters)"))) return rc;
+  if ((rc = check_hip(ctx, hipHostMalloc((void **)&B.h_counters, kBrickCounterBytes, hipHostMallocDefault), "hipHostMalloc(brick counters)"))) return rc;
+  std::memset(B.h_counters, 0, kBrickCounterBytes);
   if ((rc = check_hip(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming), "hipEventCreate(brick)"))) return rc;
   B.size = S;
   B.ok = true;
@@ -343,57 +455,69 @@ bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch,
   return (size_t)n_frames * (size_t)height < (1u << 30);
 }
 
-template <int HSV>
+template <int HSV, int ZB>
 static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
   constexpr int P = 2;
   const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
   const unsigned n_strips = (w4 + 31) / 32;
   const unsigned tile_rows = (rows + 2 * P - 1) / (2 * P);
-  // run length: long enough to amortise the cold cache at the top of a run, short enough for >= 4 rounds of runs over the
-  // 16 waves x n_cu the chip holds (tail balance)
-  unsigned tpr = ctx->brick_tiles_per_run > 0 ? (unsigned)ctx->brick_tiles_per_run : 16;
-  const size_t wave_slots = (size_t)ctx->n_cu * 16;
-  while (tpr > 4 && (size_t)n_strips * ((tile_rows + tpr - 1) / tpr) < 4 * wave_slots) tpr /= 2;
+  // Run length: a wave's cache starts cold at the top of its run, so runs are as long as the launch allows while still
+  // giving every wave slot of the chip (n_cu x 16 or 8) one run: ONE round of runs, all of about the same length.
+  const size_t wave_slots = (size_t)ctx->n_cu * (ZB == 1 ? 16 : 8);
+  unsigned tpr = (unsigned)(((size_t)n_strips * tile_rows + wave_slots - 1) / wave_slots);
+  if (tpr < 8) tpr = 8;
+  if (tpr > 512) tpr = 512;
+  if (ctx->brick_tiles_per_run > 0) tpr = (unsigned)ctx->brick_tiles_per_run;
   const unsigned runs_per_strip = (tile_rows + tpr - 1) / tpr;
   const size_t n_runs = (size_t)n_strips * runs_per_strip;
   if (n_runs >= (1u << 31)) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame batch too large");
   const unsigned grid = (unsigned)((n_runs + kBrickWaves - 1) / kBrickWaves);
-  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV>), dim3(grid), dim3(256), kBrickLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, rows,
-                     n_strips, tpr, (unsigned)n_runs, (const f4_t *)B.d_bricks, (const u2_t *)B.d_axis, (const uint32_t *)B.d_cellnum, B.d_counters, hk);
+  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZB>), dim3(grid), dim3(256), brick_lds_bytes(ZB), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
+                     rows, n_strips, tpr, (unsigned)n_runs | (ctx->brick_prio ? 0x80000000u : 0u), (const f4_t *)B.d_bricks, (const u2_t *)B.d_axis + (size_t)(ZB - 1) * 768,
+                     (const uint32_t *)B.d_cellnum, B.d_counters, hk);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_brick kernel launch");
+}
+
+template <int HSV>
+static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
+  if (ctx->brick_sets == 64) return brick_launch_t<HSV, 2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+  return brick_launch_t<HSV, 1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
 }
 
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
                  const mi355_hsv_settings *hs) {
-  if (!hs) return brick_launch_t<kBrickNoHsv>(ctx, B, d_src, d_dst, n_frames, width, height, HsvK{});
+  if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, d_dst, n_frames, width, height, HsvK{});
   const HsvK hk{hs->hue_shift, hs->saturation_mul, hs->saturation_off, hs->value_mul, hs->value_off};
   switch (hsv_variant_for(*hs, false)) {
-    case -1: return brick_launch_t<-1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 0: return brick_launch_t<0>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 1: return brick_launch_t<1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 2: return brick_launch_t<2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 4: return brick_launch_t<4>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 5: return brick_launch_t<5>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    default: return brick_launch_t<6>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case -1: return brick_launch_z<-1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case 0: return brick_launch_z<0>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case 1: return brick_launch_z<1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case 2: return brick_launch_z<2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case 4: return brick_launch_z<4>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case 5: return brick_launch_z<5>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    default: return brick_launch_z<6>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
   }
 }
 
 // Content watch. The brick kernel is exact for any content but slow when most 256-pixel steps miss the cache (noise-like
 // frames: every pixel in its own LUT cell); the three-pass whole-plane kernel does not care about content. Every
 // kSnapEvery-th brick launch the miss counters are copied to pinned memory and reset, in stream order, behind an event
-// that later launches poll (never wait for). A snapshot with more than kHostileFraction of its steps on the careful path
-// hands the stream to the three-pass kernel for `retry_period` launches (64, doubling to 1024 while the verdict stays
+// that later launches poll (never wait for). A snapshot with more than kHostileSlow of its steps on the slow path (or more
+// than kHostileMiss of them needing fills) hands the stream to the three-pass kernel for `retry_period` launches (64, doubling to 1024 while the verdict stays
 // the same), after which the brick kernel gets kSnapEvery launches to prove itself again.
 constexpr unsigned kSnapEvery = 4;
-constexpr double kHostileFraction = 0.25;
+constexpr double kHostileSlow = 0.15, kHostileMiss = 0.6;
 
 static void brick_harvest(BrickLut &B) {
   if (!B.pending) return;
   if (hipEventQuery(B.ev) != hipSuccess) { (void)hipGetLastError(); return; }
   B.pending = false;
   const double steps = (double)B.px_snapshot / 256.0;
-  B.last_miss_fraction = steps > 0.0 ? (double)B.h_counters[0] / steps : 0.0;
-  if (B.last_miss_fraction > kHostileFraction) {
+  unsigned long long tot[2] = {0, 0};
+  for (int i = 0; i < kBrickCounterSlots; i++) { tot[0] += B.h_counters[2 * i]; tot[1] += B.h_counters[2 * i + 1]; }
+  B.last_miss_fraction = steps > 0.0 ? (double)tot[0] / steps : 0.0;
+  B.last_slow_fraction = steps > 0.0 ? (double)tot[1] / steps : 0.0;
+  if (B.last_slow_fraction > kHostileSlow || B.last_miss_fraction > kHostileMiss) {
     B.hostile = true;
     B.retry_period = B.retry_period ? (B.retry_period < 1024 ? B.retry_period * 2 : 1024) : 64;
     B.retry_in = B.retry_period;
@@ -416,9 +540,9 @@ int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels) {
   B.px_since += pixels;
   B.launches_since++;
   if (B.pending || B.launches_since < kSnapEvery) return MI355_OK;
-  int rc = check_hip(ctx, hipMemcpyAsync(B.h_counters, B.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "brick counters snapshot");
+  int rc = check_hip(ctx, hipMemcpyAsync(B.h_counters, B.d_counters, kBrickCounterBytes, hipMemcpyDeviceToHost, ctx->stream), "brick counters snapshot");
   if (rc) return rc;
-  if ((rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream), "brick counters reset"))) return rc;
+  if ((rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
   if ((rc = check_hip(ctx, hipEventRecord(B.ev, ctx->stream), "hipEventRecord(brick)"))) return rc;
   B.pending = true;
   B.px_snapshot = B.px_since;
@@ -430,10 +554,13 @@ int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels) {
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset) {
   out[0] = out[1] = 0;
   if (!B.d_counters) return MI355_OK;
-  int rc = check_hip(ctx, hipMemcpyAsync(out, B.d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "brick counters read");
+  std::vector<unsigned long long> tmp(2 * kBrickCounterSlots);
+  int rc = check_hip(ctx, hipMemcpyAsync(tmp.data(), B.d_counters, kBrickCounterBytes, hipMemcpyDeviceToHost, ctx->stream), "brick counters read");
   if (rc) return rc;
-  if (reset && (rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream), "brick counters reset"))) return rc;
-  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "brick counters sync");
+  if (reset && (rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
+  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "brick counters sync"))) return rc;
+  for (int i = 0; i < kBrickCounterSlots; i++) { out[0] += tmp[2 * i]; out[1] += tmp[2 * i + 1]; }
+  return MI355_OK;
 }
 
 }  // namespace mi355

@@ -14,9 +14,9 @@ constexpr int kBrickMaxSize = 65;  // size^3 lines of 128 B: 35 MB at 65 (the ta
 // Device-side brick form of a loaded 3D LUT (built by brick_upload at mi355_colorlut_load).
 struct BrickLut {
   float *d_bricks = nullptr;               // size^3 x 32 floats: {c, d} x 4 corner rows (24 floats) + 8 pad
-  uint32_t *d_axis = nullptr;              // 3 x 256 x {t, slot byte offset | window number << 15}
+  uint32_t *d_axis = nullptr;              // 2 geometries x 3 x 256 x {t, set byte offset | tag contribution << 16}
   uint32_t *d_cellnum = nullptr;           // 3 x 256: per-axis contribution to the cell number x0 + S*y0 + S*S*z0 (miss path)
-  unsigned long long *d_counters = nullptr;  // [0] 256-pixel steps that took the careful path, [1] lanes that missed
+  unsigned long long *d_counters = nullptr;  // 1024 slots x {256-pixel steps with a cache miss, steps that ended on the slow path}
   int size = 0;
   bool ok = false;                         // kernel applicable to this LUT (3D, size <= kBrickMaxSize, finite domain)
   // content watch (brick_choose / brick_after_launch): the miss counters are copied to pinned host memory every few
@@ -29,7 +29,8 @@ struct BrickLut {
   unsigned launches_since = 0;
   bool hostile = false;                    // last snapshot: too many steps missed the cache -> three-pass kernel
   unsigned retry_in = 0, retry_period = 0; // launches served by the other kernel before the brick kernel is tried again
-  double last_miss_fraction = 0.0;         // of the 256-pixel steps in the last snapshot
+  double last_miss_fraction = 0.0;         // of the 256-pixel steps in the last snapshot: steps that needed a fill
+  double last_slow_fraction = 0.0;         // ... steps that ended on the slow path
 };
 
 // Content watch for the interpolating path: true = use the brick kernel for this launch, false = the three-pass kernel.

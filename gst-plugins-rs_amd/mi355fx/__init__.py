@@ -29,6 +29,8 @@ FLAG_LUT_VARIANT = 4
 FLAG_LUT_STAGGER = 5
 FLAG_HSV_TABLE = 6
 FLAG_BRICK_TILES_PER_RUN = 7
+FLAG_BRICK_SETS = 8
+FLAG_BRICK_PRIO = 9
 
 
 class HsvSettings(C.Structure):
@@ -268,7 +270,7 @@ class Context:
         return (self.L.mi355_colorlut_last_kernel(self.h) or b"").decode()
 
     def colorlut_brick_stats(self, reset=False):
-        """(careful-path steps, missed lanes, last miss fraction seen by the content watch, hostile flag)."""
+        """(steps with a miss, steps on the slow path, last miss fraction seen by the content watch, hostile flag)."""
         c = (C.c_uint64 * 2)()
         f, h = C.c_double(0), C.c_int(0)
         self._ck(self.L.mi355_colorlut_brick_stats(self.h, c, C.byref(f), C.byref(h), int(reset)))

@@ -98,7 +98,9 @@ typedef enum mi355_flag {
   MI355_FLAG_HSV_TABLE = 6,
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3, /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
-  MI355_FLAG_BRICK_TILES_PER_RUN = 7 /* brick-cache kernel: 128 x 4 pixel tiles a wave walks down before its cache starts cold again (0 = default) */
+  MI355_FLAG_BRICK_TILES_PER_RUN = 7, /* brick-cache kernel: 128 x 4 pixel tiles a wave walks down before its cache starts cold again (0 = default) */
+  MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel: waves lower their issue priority as they advance through their run (1 = on, default) */
+  MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache, 32 (default; 16 waves per CU) or 64 (8 waves per CU); two ways each */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 
@@ -167,7 +169,7 @@ int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, d
  * first one). Diagnostic; no reference counterpart. */
 const char *mi355_colorlut_last_kernel(mi355_ctx *ctx);
 /* Brick-cache kernel diagnostics (synchronous): counters[0] = 256-pixel steps that found a brick missing in the wave's
- * LDS cache since the last reset, counters[1] = lanes that missed; *last_miss_fraction / *hostile = what the content
+ * LDS cache since the last reset, counters[1] = steps that still missed after the fill rounds (slow path); *last_miss_fraction / *hostile = what the content
  * watch last concluded. reset != 0 clears the device counters. No reference counterpart. */
 int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *hostile, int reset);
 /* Host-logic self test of the auto-choice policy against a scripted device (no GPU needed): call i has n_vec[i] 16-byte

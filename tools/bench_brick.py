@@ -22,8 +22,9 @@ def main():
     d_src, d_dst = ctx.alloc(base.size), ctx.alloc(base.size)
     variants = [int(v) for v in os.environ.get("VARIANTS", "7,3,5").split(",")]
     tprs = [int(v) for v in os.environ.get("TPR", "0").split(",")]
+    setss = [int(v) for v in os.environ.get("SETS", "32,64").split(",")]
     algo = 8.0 * W * H * N
-    print("%-8s %s" % ("amp", "  ".join("v%d[tpr %d] ms (frac)" % (v, t) for v in variants for t in (tprs if v == 7 else [0]))))
+    print("%-8s %s" % ("amp", "  ".join("v%d[tpr %d sets %d] ms (frac)" % (v, t, ns) for v in variants for t in (tprs if v == 7 else [0]) for ns in (setss if v == 7 else [0]))))
     for amp in [int(a) for a in os.environ.get("AMPS", "0,2,4,8,16,32,64,-1").split(",")]:
         if amp < 0:
             frames = np.stack([synth.noise_frame(W, H, seed=11 + i) for i in range(N)]).reshape(-1)
@@ -35,16 +36,18 @@ def main():
         ctx.h2d(d_src, frames)
         cells = []
         for v in variants:
-            for t in (tprs if v == 7 else [0]):
+            for t, ns in [(t, ns) for t in (tprs if v == 7 else [0]) for ns in (setss if v == 7 else [32])]:
                 ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
                 ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, v)
                 ctx.set_flag(mi355fx.FLAG_BRICK_TILES_PER_RUN, t)
+                ctx.set_flag(mi355fx.FLAG_BRICK_SETS, ns)
+                ctx.set_flag(mi355fx.FLAG_BRICK_PRIO, int(os.environ.get("PRIO", "1")))
                 run = lambda it: ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", it)
                 mi355fx.warm_clocks(lambda: run(1), ctx.synchronize, 0.2)
                 ctx.colorlut_brick_stats(reset=True)
                 ms = min(run(20) for _ in range(3))
-                steps, lanes, _, _ = ctx.colorlut_brick_stats(reset=True)
-                extra = " miss %.3f" % (steps / 60.0 / (W * H * N / 256)) if v == 7 else ""
+                steps, slow, _, _ = ctx.colorlut_brick_stats(reset=True)
+                extra = " miss %.3f slow %.3f" % (steps / 60.0 / (W * H * N / 256), slow / 60.0 / (W * H * N / 256)) if v == 7 else ""
                 cells.append("%.4f (%.3f)%s" % (ms, algo / (ms * 1e-3) / 8e12, extra))
         print("%-8s %s" % ("noise" if amp < 0 else amp, "  ".join(cells)), flush=True)
     ctx.free(d_src); ctx.free(d_dst); ctx.close()
