@@ -259,7 +259,15 @@ def main():
                         evs_.append((e0, e1))
                 return evs_
 
-            ramp(lambda n: region(scratch, n, False))
+            def ramp_body(n):
+                # the ramp's in-place hsvfilter passes would grind the scratch batches down to a fixed point (a different,
+                # colour-poor picture): refresh them from the pool every few steps so the ramp sees the leg's content too
+                for k0 in range(0, n, 2 * len(scratch)):
+                    for r, sb in enumerate(scratch):
+                        pool.fill(sb, 10_000 + r)
+                    region(scratch, min(2 * len(scratch), n - k0), False)
+
+            ramp(ramp_body)
             if fused:
                 # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
                 # launches of each kind: keep that learning phase out of the timed region (out-of-place: scratch stays pristine)

@@ -1,0 +1,74 @@
+// brickwatch.hpp — content watch of the interpolating colorlut path: which of the three exact kernels serves a stream.
+// HIP-free (policy only), unit-tested on the CPU through mi355_selftest_brickwatch (tests/test_brickwatch.py).
+//
+//   level 0  brick-cache kernel, 32 sets x 2 ways per wave (16 waves per CU): fastest on locally coherent content
+//   level 1  brick-cache kernel, 64 sets x 2 ways per wave (8 waves per CU): twice the cache per wave, for content whose
+//            256-pixel steps spread over more LUT cells (edges between two colour regions, moderate noise)
+//   level 2  three-pass whole-plane kernel: indifferent to content, slowest on coherent frames
+//
+// The brick kernels count the 256-pixel steps that needed cache fills ("miss") and those that could not be served from
+// the cache even after filling ("slow"). Every kSnapEvery-th launch at one level a snapshot of the counters becomes
+// available (asynchronously; the caller polls). A snapshot that is bad for its level moves the stream up a level at once;
+// a better level is probed again after `period` launches (64, doubling to 256 while the answer stays the same: a probe costs
+// four launches on the wrong kernel, i.e. at most a few percent, and a stream whose content calms down is back on the
+// faster kernel within a few hundred buffers).
+#pragma once
+
+namespace mi355 {
+
+struct BrickWatch {
+  int home = 0;            // level currently believed best
+  int probing = -1;        // level under probation (-1: none); launches use it until its snapshot arrives
+  unsigned retry_in = 0;   // launches left before the next lower level is probed
+  unsigned period = 0;     // current probe period
+  double last_miss = 0.0, last_slow = 0.0;
+  int last_level = 0;
+};
+
+constexpr unsigned kWatchSnapEvery = 4;
+constexpr unsigned kWatchPeriodMin = 64, kWatchPeriodMax = 256;
+
+inline bool watch_bad(int level, double miss, double slow) {
+  // Level 0 is left early: its misses come from the few strips whose content does not fit 32 sets, and the waves of those
+  // strips - not the average wave - set the kernel's duration (measured on 8x4K: 4.5 % miss steps 0.119 ms, 12 % 0.30 ms,
+  // against 0.138-0.145 ms for the 64-set geometry on either). Level 1 against the three-pass kernel's flat 0.24-0.25 ms:
+  // 31 % miss steps 0.20 ms, 45 % with 12 % slow steps 0.65 ms.
+  return level == 0 ? (slow > 0.01 || miss > 0.08) : (slow > 0.03 || miss > 0.40);
+}
+
+// level for the next launch (call once per launch)
+inline int watch_level(BrickWatch &W) {
+  if (W.probing >= 0) return W.probing;
+  if (W.home > 0) {
+    if (W.retry_in > 0) W.retry_in--;
+    else W.probing = W.home - 1;
+  }
+  return W.probing >= 0 ? W.probing : W.home;
+}
+
+// a snapshot taken over launches that all ran at `level` (0 or 1) has arrived
+inline void watch_snapshot(BrickWatch &W, int level, double miss, double slow) {
+  W.last_miss = miss; W.last_slow = slow; W.last_level = level;
+  const bool bad = watch_bad(level, miss, slow);
+  if (W.probing == level) {
+    W.probing = -1;
+    if (!bad) {               // the lower level is fine again: move down, forget the back-off
+      W.home = level;
+      W.period = 0;
+      W.retry_in = level > 0 ? kWatchPeriodMin : 0;
+      if (level > 0) W.period = kWatchPeriodMin;
+    } else {                  // still bad: stay, back off
+      W.period = W.period ? (W.period * 2 > kWatchPeriodMax ? kWatchPeriodMax : W.period * 2) : kWatchPeriodMin;
+      W.retry_in = W.period;
+    }
+    return;
+  }
+  if (level != W.home) return;  // stale snapshot of a level the stream has already left
+  if (bad) {
+    W.home = level + 1;
+    W.period = kWatchPeriodMin;
+    W.retry_in = W.period;
+  }
+}
+
+}  // namespace mi355

@@ -47,20 +47,25 @@ constexpr int kBrickAxisBytes = 3 * 256 * 8;
 constexpr int kBrickWaves = 4;         // waves per block
 constexpr int kBrickCounterSlots = 1024;
 constexpr size_t kBrickCounterBytes = 2 * kBrickCounterSlots * sizeof(unsigned long long);
-// ZB = set-index bits taken from z0: 1 -> 32 sets (6.5 KB per wave, 4 blocks per CU), 2 -> 64 sets (13 KB, 2 blocks per CU)
-// Set address = 208 x (x0 & 3) + 832 x (y0 & 3) + kBrickZStride x (z0 & (2^ZB - 1)). ds_read_b128 serves 16 lanes per LDS
+// ZN = number of z0 residues in the set index: 2 -> 32 sets (6.9 KB per wave, 4 blocks = 16 waves per CU), 3 -> 48 sets
+// (10.4 KB, 12 waves per CU), 4 -> 64 sets (13.8 KB, 8 waves per CU)
+// Set address = 208 x (x0 & 3) + 832 x (y0 & 3) + kBrickZStride x (z0 mod ZN). ds_read_b128 serves 16 lanes per LDS
 // cycle over 16 sixteen-byte columns; with 13 columns per set the 16 (x, y) residues start on 16 different columns, way 1
 // sits 6 columns after way 0, and the z stride adds 8 more: the two ways of a cell and of its x, y and z neighbours - the
 // bricks the lanes of a wave actually read together on natural-like content - occupy 16 different columns.
 constexpr int kBrickZStride = 16 * kBrickSetBytes + 128;
-constexpr int brick_wave_bytes(int zb) { return (1 << zb) * kBrickZStride; }
+// (ZN == 2: 7,040 B so that the (2, 4, 4) and (4, 2, 4) residue layouts fit as well as (4, 4, 2))
+constexpr int brick_wave_bytes(int zn) { return zn == 2 ? 7040 : zn * kBrickZStride; }
 constexpr int brick_axis_base(int zb) { return kBrickWaves * brick_wave_bytes(zb); }   // LDS: four wave regions, then the axis tables
 constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 dwords: cell-number contributions (fill path)
 constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 3 * 1024; }          // 8 dwords: hsvfilter sextant selectors
 constexpr int kBrickQueueCap = 30;                                                       // fill queue entries per wave ({cell, destination})
 constexpr int brick_queue_base(int zb) { return brick_sel_base(zb) + 32; }               // 4 x 256 B
-constexpr int brick_lds_bytes(int zb) { return brick_queue_base(zb) + kBrickWaves * 256; }
-static_assert(brick_axis_base(2) <= (1 << kBrickTagShift), "set addresses must fit below the tag field");
+constexpr int kBrickScratch = 6;                                                         // per-step overflow bricks per wave
+constexpr int brick_scratch_base(int zb) { return brick_queue_base(zb) + kBrickWaves * 256; }  // 4 x 6 x 96 B
+constexpr int brick_lds_bytes(int zb) { return brick_scratch_base(zb) + kBrickWaves * kBrickScratch * 96; }
+static_assert(4 * brick_lds_bytes(2) <= 160 * 1024 && 3 * brick_lds_bytes(3) <= 160 * 1024 && 2 * brick_lds_bytes(4) <= 160 * 1024, "blocks per CU");
+static_assert(brick_axis_base(4) <= (1 << kBrickTagShift), "set addresses must fit below the tag field");
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -101,10 +106,14 @@ __device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, fl
   const f2_t Y0 = X[0] + (X[1] - X[0]) * TY;                  // (r,g) at z0                imp.rs:523
   const f2_t Y1 = X[2] + (X[3] - X[2]) * TY;                  // (r,g) at z1                imp.rs:524
   const f2_t Yb = X[4] + (X[5] - X[4]) * TY;                  // b at (z0, z1)
-  const f2_t O = Y0 + (Y1 - Y0) * TZ;                         // imp.rs:525
+  // imp.rs:525, and float_to_u8's clamp (imp.rs:537-539) folded into the last add: the VOP3P clamp bit clamps both halves to
+  // [0, 1] and turns NaN into 0 (DX10_CLAMP is set for HSA kernels) - the inherent clamp lets NaN through and `as u8` then
+  // makes it 0: the same byte
+  const f2_t OZ = (Y1 - Y0) * TZ;
+  f2_t O;
+  asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(O) : "v"(Y0), "v"(OZ));
   const float ob = Yb.x + (Yb.y - Yb.x) * tz;
-  // float_to_u8 (imp.rs:537-539): inherent clamp (NaN passes, then `as u8` gives 0) == max-then-min (NaN -> 0) on the byte
-  const f2_t O255 = __builtin_elementwise_min(__builtin_elementwise_max(O, (f2_t){0.0f, 0.0f}), (f2_t){1.0f, 1.0f}) * (f2_t){255.0f, 255.0f};
+  const f2_t O255 = O * (f2_t){255.0f, 255.0f};
   uint32_t out = px;
   brick_round_into<0>(out, O255.x);
   brick_round_into<1>(out, O255.y);
@@ -127,16 +136,18 @@ __device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_by
 __device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)a = v; }
 
-template <int P, int HSV, int ZB>  // P = 16-byte loads per lane and tile: a tile is 128 px x 2P rows
-__global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
+template <int P, int HSV, int ZN, int G>  // P = 16-byte loads per lane and tile (a tile is 128 px x 2P rows), G of them per step
+__global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
                                                                                  unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
                                                                                  const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
                                                                                  const uint32_t *__restrict__ cellnum,
-                                                                                 unsigned long long *__restrict__ counters, HsvK hk) {
+                                                                                 unsigned long long *__restrict__ counters, HsvK hk, unsigned fold_axis) {
   // All LDS of this kernel is the dynamic allocation and there are no static __shared__ objects, so the allocation starts
   // at LDS address 0. LDS is addressed by absolute byte address (address-space-3 pointers made from integers): every table
   // base then folds into the ds_read offset field instead of costing an add of the link-time base symbol per access.
-  constexpr uint32_t AX = brick_axis_base(ZB), CELL = brick_cell_base(ZB), SEL = brick_sel_base(ZB), WB = brick_wave_bytes(ZB), SETS = 16u << ZB;
+  constexpr int NP = 4 * G;
+  static_assert(P % G == 0, "a tile is a whole number of steps");
+  constexpr uint32_t AX = brick_axis_base(ZN), CELL = brick_cell_base(ZN), SEL = brick_sel_base(ZN), SCR = brick_scratch_base(ZN), WB = brick_wave_bytes(ZN), SETS = 16u * ZN;
   const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)SEL;
   if constexpr (HSV != kBrickNoHsv) {
     if (threadIdx.x < 7) lds_w32(SEL + 4 * threadIdx.x, HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3));
@@ -144,13 +155,16 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
   for (int i = threadIdx.x; i < kBrickAxisBytes / 8; i += 256) lds_w64(AX + 8 * i, axis[i]);
   for (int i = threadIdx.x; i < 768; i += 256) lds_w32(CELL + 4 * i, cellnum[i]);
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t queue = brick_queue_base(ZB) + wave * 256u;
+  const uint32_t queue = brick_queue_base(ZN) + wave * 256u;
   const uint32_t e_l = lane / 6u, k_l = lane % 6u;  // fill pass: lane -> (queue entry, 16-byte piece of its brick)
   uint32_t gen = 1;                                  // fill-round stamp (see the fifo word)
   const uint32_t wave_base = __builtin_amdgcn_readfirstlane(wave * WB);
   if (lane < SETS) {
     const u2_t inval = {0xffffffffu, 0xffffffffu};
-    const uint32_t sa = wave_base + (lane & 15u) * kBrickSetBytes + (lane >> 4) * kBrickZStride;
+    // set residues per axis: (4, 4, ZN), or (2, 4, 4) / (4, 2, 4) when the host built the ZN == 2 tables with the 2 on x / y
+    const uint32_t m0 = (ZN == 2 && fold_axis == 0) ? 2u : 4u, m1 = (ZN == 2 && fold_axis == 1) ? 2u : 4u;
+    const uint32_t sa = wave_base + (lane % m0) * kBrickSetBytes + ((lane / m0) % m1) * (m0 * kBrickSetBytes) +
+                        (lane / (m0 * m1)) * (m0 * m1 * kBrickSetBytes + 128u);
     lds_w64(sa + 192, inval);  // both tags invalid
     lds_w32(sa + 204, 0u);     // next victim: way 0
   }
@@ -160,8 +174,11 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
   const unsigned n_runs = n_runs_flags & 0x7fffffffu;  // bit 31: progress-based wave priorities
   const unsigned run = blockIdx.x * kBrickWaves + wave;
   if (run >= n_runs) return;
-  // adjacent waves take adjacent strips of the same rows (a block covers 512 px x 2P rows: 2 KB row segments)
-  const unsigned strip = run % n_strips, rr = run / n_strips;
+  // the four waves of a block take four consecutive runs of ONE strip: strips differ in cost (a strip that straddles two
+  // colour regions refills its caches far more often), a block should not wait for one slow wave out of four
+  const unsigned runs_per_strip = (n_runs + n_strips - 1) / n_strips;
+  // (with 16 waves per CU the blocks of adjacent strips measure faster on coherent content: 2 KB row segments per block)
+  const unsigned strip = ZN == 2 ? run % n_strips : run / runs_per_strip, rr = ZN == 2 ? run / n_strips : run % runs_per_strip;
   const unsigned sub = lane >> 5, g = lane & 31;
   const unsigned col = strip * 32 + g;
   const bool col_ok = col < w4;
@@ -208,20 +225,23 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
     }
     load_tile(row0 + 2 * P, nxt);  // prefetch (clamped to the picture: the last tile of a run re-reads rows it does not use)
 #pragma unroll
-    for (int j = 0; j < P; j++) {
-      uint32_t px[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+    for (int j = 0; j < P; j += G) {
+      // one STEP = G 16-byte groups per lane = NP pixels per lane (64 NP pixels per wave), checked and filled together
+      uint32_t px[NP];
+#pragma unroll
+      for (int g2 = 0; g2 < G; g2++) { px[4 * g2 + 0] = cur[j + g2].x; px[4 * g2 + 1] = cur[j + g2].y; px[4 * g2 + 2] = cur[j + g2].z; px[4 * g2 + 3] = cur[j + g2].w; }
       if constexpr (HSV >= 0) {
-        hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(px[0], px[1], hk, hsv_sel);
-        hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(px[2], px[3], hk, hsv_sel);
+#pragma unroll
+        for (int i = 0; i < NP; i += 2) hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(px[i], px[i + 1], hk, hsv_sel);
       } else if constexpr (HSV == -1) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) px[i] = hsvfilter_px<false, 0, 1, 2, 3>(px[i], hk, hsv_sel);
+        for (int i = 0; i < NP; i++) px[i] = hsvfilter_px<false, 0, 1, 2, 3>(px[i], hk, hsv_sel);
       }
       // stage A: coordinates, set, tag
-      float tx[4], ty[4], tz[4];
-      uint32_t set[4], tag[4], baddr[4];
+      float tx[NP], ty[NP], tz[NP];
+      uint32_t set[NP], tag[NP], baddr[NP];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NP; i++) {
         const u2_t ex = lds_r64(byte_times8<0>(px[i], three) + AX);
         const u2_t ey = lds_r64(byte_times8<1>(px[i], three) + (AX + 2048u));
         const u2_t ez = lds_r64(byte_times8<2>(px[i], three) + (AX + 4096u));
@@ -230,13 +250,13 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
         tz[i] = __uint_as_float(ez.x);
         const uint32_t packed = (ex.y + ey.y) + (ez.y + wave_base);  // v_add_u32 + v_add3_u32
         set[i] = packed & ((1u << kBrickTagShift) - 1u);           // LDS byte address of the wave's set for this cell
-        tag[i] = packed >> kBrickTagShift;                          // which cell of that residue class the brick must be
+        tag[i] = packed;                                            // the whole word identifies the brick (the set bits are redundant there)
       }
       // tag check: both ways' tags in one 8-byte read; baddr = the way that holds the brick
       auto check = [&]() -> bool {
         bool miss = false;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NP; i++) {
           const u2_t tg = lds_r64(set[i] + 192u);
           const bool h1 = tg.y == tag[i];
           baddr[i] = h1 ? set[i] + 96u : set[i];
@@ -245,8 +265,9 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
         return __any(miss);
       };
       bool slow = false;
+      uint32_t lane_res = 0;  // bit i: this lane's pixel i is served from the global table (slow path only)
       if (__builtin_expect(check(), 0)) {
-        miss_steps++;
+        miss_steps += G;
         // Fill rounds. Enqueue: per pixel slot, one elected lane per missing set claims the victim way (FIFO), installs
         // the tag at once (so that later pixel slots of this step see the brick as present and do not fetch it again) and
         // appends {cell number, destination} to the wave's queue. A set accepts two installs per round - one per way - so
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
         do {
           uint32_t n = 0;  // wave-uniform
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
+          for (int i = 0; i < NP; i++) {
             wave_sync();
             const u2_t tg = lds_r64(set[i] + 192u);
             const bool m = tg.x != tag[i] && tg.y != tag[i];
@@ -301,44 +322,86 @@ __global__ __launch_bounds__(256, ZB == 1 ? 4 : 2) void colorlut3d_brick_kernel(
           gen++;
           wave_sync();
           slow = check();
-        } while (slow && ++round < 3);
+        } while (slow && ++round < 2);
+        if (slow) {
+          // Overflow. Some set is asked for more bricks by this step's pixels than its two ways hold. The bricks that did not
+          // fit go to the wave's SCRATCH slots, valid for this step only: per pixel slot, the first missing lane's brick is
+          // given the next scratch slot and every lane waiting for that same brick is pointed at it (one wave-uniform
+          // iteration per distinct brick); one more fetch pass brings them in. Lanes still without a brick when the scratch
+          // slots run out (noise-like steps) are served one by one from the global table in the per-pixel path below.
+          uint32_t n_ovf = 0;
+#pragma unroll
+          for (int i = 0; i < NP; i++) {
+            const u2_t tg = lds_r64(set[i] + 192u);
+            bool m = tg.x != tag[i] && tg.y != tag[i];
+            unsigned long long mb = __ballot(m);
+            if (mb) {
+              const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
+                                    lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
+              while (mb && n_ovf < (uint32_t)kBrickScratch) {
+                const int L = __builtin_ctzll(mb);
+                const uint32_t cellL = __builtin_amdgcn_readlane(cell, L);
+                const bool same = m && cell == cellL;
+                const uint32_t dst = SCR + wave * (kBrickScratch * 96u) + 96u * n_ovf;
+                if (same) baddr[i] = dst;
+                if (lane == 0) { const u2_t qe = {cellL, dst}; lds_w64(queue + 8u * n_ovf, qe); }
+                n_ovf++;
+                m = m && !same;
+                mb = __ballot(m);
+              }
+            }
+            if (m) lane_res |= 1u << i;  // this lane's pixel i has no brick in LDS
+          }
+          n_ovf = __builtin_amdgcn_readfirstlane(n_ovf);
+          wave_sync();
+          {
+            const uint32_t e = e_l;  // kBrickScratch <= 10: one pass
+            if (lane < 60u && e < n_ovf) {
+              const u2_t qe = lds_r64(queue + 8u * e);
+              lds_w128(qe.y + 16u * k_l, bricks[(size_t)qe.x * 8 + k_l]);
+            }
+          }
+          wave_sync();
+          slow = __any(lane_res != 0u);
+        }
       }
-      uint32_t out[4];
+      uint32_t out[NP];
       if (__builtin_expect(!slow, 1)) {
         // fast path: every lane's four bricks are resident
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NP; i++) {
           f4_t f[6];
 #pragma unroll
           for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
           out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
         }
       } else {
-        // slow path (more than two bricks per set among this step's pixels): hit lanes read the cache, miss lanes the global table
-        slow_steps++;
+        // slow path: pixel slots in which some lane is still without a brick after fills and scratch (noise-like content):
+        // those lanes read their brick's line from the global table, everyone else reads LDS (cache or scratch)
+        slow_steps += G;
 #pragma unroll 1
-        for (int i = 0; i < 4; i++) {
-          const u2_t tg = lds_r64(set[i] + 192u);
-          const bool h1 = tg.y == tag[i], h0 = tg.x == tag[i];
+        for (int i = 0; i < NP; i++) {
           f4_t f[6];
-          if (!(h0 || h1)) {
+          if ((lane_res >> i) & 1u) {
             const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
                                   lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
             const f4_t *gb = bricks + (size_t)cell * 8;
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = gb[k];
           } else {
-            const uint32_t a = h1 ? set[i] + 96u : set[i];
 #pragma unroll
-            for (int k = 0; k < 6; k++) f[k] = lds_r128(a + 16u * k);
+            for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
           }
           out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
         }
       }
-      const unsigned r = row0 + 2 * j + sub;
-      if (col_ok && r < rows) {
-        const u4_t o = {out[0], out[1], out[2], out[3]};
-        __builtin_nontemporal_store(o, dst + (size_t)r * w4 + col);
+#pragma unroll
+      for (int g2 = 0; g2 < G; g2++) {
+        const unsigned r = row0 + 2 * (j + g2) + sub;
+        if (col_ok && r < rows) {
+          const u4_t o = {out[4 * g2 + 0], out[4 * g2 + 1], out[4 * g2 + 2], out[4 * g2 + 3]};
+          __builtin_nontemporal_store(o, dst + (size_t)r * w4 + col);
+        }
       }
     }
 #pragma unroll
@@ -384,6 +447,7 @@ void brick_release(BrickLut &B) {
 
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]) {
   brick_release(B);
+  const int fold_axis = ctx->brick_fold_axis;
   if (S < 2 || S > kBrickMaxSize) return MI355_OK;  // not applicable: B.ok stays false
   for (int c = 0; c < 3; c++)
     if (!std::isfinite(scale[c]) || !std::isfinite(offset[c])) return MI355_OK;
@@ -411,19 +475,30 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
           rb[2 + (q >> 1)] = dq[2];
         }
       }
-  // axis tables for both cache geometries (ZB = 1, 2): [zb-1][axis][byte] = {t, set byte offset | tag contribution << 16}
-  std::vector<uint32_t> axis(2 * 3 * 256 * 2), cellnum(3 * 256);
-  for (int zb = 1; zb <= 2; zb++)
+  // axis tables for the three cache geometries (ZN = 2, 3, 4): [zn-2][axis][byte] = {t, set byte offset | tag contribution << 16}
+  std::vector<uint32_t> axis(3 * 3 * 256 * 2), cellnum(3 * 256);
+  for (int zn = 2; zn <= 4; zn++)
     for (int a = 0; a < 3; a++)
       for (int v = 0; v < 256; v++) {
         float t;
         int i0;
         brick_axis_entry(v, scale[a], offset[a], S, &t, &i0);
-        const int bits = a == 2 ? zb : 2;                                              // set-index bits of this axis
-        const uint32_t r = (uint32_t)(i0 & ((1 << bits) - 1));                         // this axis' part of the set index
-        const uint32_t set_off = a == 0 ? r * kBrickSetBytes : (a == 1 ? r * 4u * kBrickSetBytes : r * (uint32_t)kBrickZStride);
-        const uint32_t tag = (uint32_t)(i0 >> bits) << (5 * a);                        // 5 + 5 + 6 tag bits (size <= 65)
-        uint32_t *e = &axis[((size_t)(zb - 1) * 768 + (size_t)a * 256 + v) * 2];
+        // residues per axis in the set index: (4, 4, zn), or - zn == 2 only - the 2 on the axis fold_axis instead of z
+        int mods[3] = {4, 4, zn};
+        if (zn == 2 && fold_axis != 2) { mods[2] = 4; mods[fold_axis] = 2; }
+        const int mod = mods[a];
+        const uint32_t r = (uint32_t)(i0 % mod);
+        const uint32_t stride1 = (uint32_t)mods[0] * kBrickSetBytes;                   // y stride
+        const uint32_t stride2 = (uint32_t)mods[1] * stride1 + 128u;                   // z stride (+128: see kBrickZStride)
+        const uint32_t set_off = a == 0 ? r * kBrickSetBytes : (a == 1 ? r * stride1 : r * stride2);
+        // tag fields packed axis after axis, each as wide as its largest value (S - 1) / mod needs: 16 bits in all for S <= 65
+        auto bits_for = [&](int m) { int b = 0; while (((S - 1) / m) >> b) b++; return b; };
+        const int tag_shift = a == 0 ? 0 : (a == 1 ? bits_for(mods[0]) : bits_for(mods[0]) + bits_for(mods[1]));
+        if (bits_for(mods[0]) + bits_for(mods[1]) + bits_for(mods[2]) > 16 ||
+            (uint32_t)(mods[0] - 1) * kBrickSetBytes + (uint32_t)(mods[1] - 1) * stride1 + (uint32_t)(mods[2] - 1) * stride2 + kBrickSetBytes > (uint32_t)brick_wave_bytes(zn))
+          return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: brick cache geometry does not fit");
+        const uint32_t tag = (uint32_t)(i0 / mod) << tag_shift;
+        uint32_t *e = &axis[((size_t)(zn - 2) * 768 + (size_t)a * 256 + v) * 2];
         std::memcpy(&e[0], &t, 4);
         e[1] = set_off + (tag << kBrickTagShift);
         cellnum[(size_t)a * 256 + v] = (uint32_t)i0 * (a == 0 ? 1u : (a == 1 ? (uint32_t)S : (uint32_t)S * S));
@@ -441,6 +516,7 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
   std::memset(B.h_counters, 0, kBrickCounterBytes);
   if ((rc = check_hip(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming), "hipEventCreate(brick)"))) return rc;
   B.size = S;
+  B.fold_axis = fold_axis;
   B.ok = true;
   return MI355_OK;
 }
@@ -455,15 +531,16 @@ bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch,
   return (size_t)n_frames * (size_t)height < (1u << 30);
 }
 
-template <int HSV, int ZB>
+template <int HSV, int ZN>
 static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
-  constexpr int P = 2;
+  // tile = 128 px x 2P rows, prefetched one tile ahead: with 8 waves per CU a 4-row tile is consumed faster than HBM answers
+  constexpr int P = ZN == 4 ? 4 : 2;
   const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
   const unsigned n_strips = (w4 + 31) / 32;
   const unsigned tile_rows = (rows + 2 * P - 1) / (2 * P);
   // Run length: a wave's cache starts cold at the top of its run, so runs are as long as the launch allows while still
   // giving every wave slot of the chip (n_cu x 16 or 8) one run: ONE round of runs, all of about the same length.
-  const size_t wave_slots = (size_t)ctx->n_cu * (ZB == 1 ? 16 : 8);
+  const size_t wave_slots = (size_t)ctx->n_cu * 4 * (6 - ZN);
   unsigned tpr = (unsigned)(((size_t)n_strips * tile_rows + wave_slots - 1) / wave_slots);
   if (tpr < 8) tpr = 8;
   if (tpr > 512) tpr = 512;
@@ -472,42 +549,37 @@ static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_sr
   const size_t n_runs = (size_t)n_strips * runs_per_strip;
   if (n_runs >= (1u << 31)) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame batch too large");
   const unsigned grid = (unsigned)((n_runs + kBrickWaves - 1) / kBrickWaves);
-  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZB>), dim3(grid), dim3(256), brick_lds_bytes(ZB), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
-                     rows, n_strips, tpr, (unsigned)n_runs | (ctx->brick_prio ? 0x80000000u : 0u), (const f4_t *)B.d_bricks, (const u2_t *)B.d_axis + (size_t)(ZB - 1) * 768,
-                     (const uint32_t *)B.d_cellnum, B.d_counters, hk);
+  constexpr int G = ZN == 4 ? 2 : 1;  // 8 waves per CU have the registers for 8-pixel steps (more reads in flight per wave)
+  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G>), dim3(grid), dim3(256), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
+                     rows, n_strips, tpr, (unsigned)n_runs | (ctx->brick_prio ? 0x80000000u : 0u), (const f4_t *)B.d_bricks, (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768,
+                     (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis);
   return check_hip(ctx, hipGetLastError(), "colorlut3d_brick kernel launch");
 }
 
 template <int HSV>
-static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
-  if (ctx->brick_sets == 64) return brick_launch_t<HSV, 2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-  return brick_launch_t<HSV, 1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk, int sets) {
+  if (sets == 64) return brick_launch_t<HSV, 4>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+  if (sets == 48) return brick_launch_t<HSV, 3>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+  return brick_launch_t<HSV, 2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
 }
 
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
-                 const mi355_hsv_settings *hs) {
-  if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, d_dst, n_frames, width, height, HsvK{});
+                 const mi355_hsv_settings *hs, int sets) {
+  if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, d_dst, n_frames, width, height, HsvK{}, sets);
   const HsvK hk{hs->hue_shift, hs->saturation_mul, hs->saturation_off, hs->value_mul, hs->value_off};
   switch (hsv_variant_for(*hs, false)) {
-    case -1: return brick_launch_z<-1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 0: return brick_launch_z<0>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 1: return brick_launch_z<1>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 2: return brick_launch_z<2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 4: return brick_launch_z<4>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    case 5: return brick_launch_z<5>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-    default: return brick_launch_z<6>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+    case -1: return brick_launch_z<-1>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case 0: return brick_launch_z<0>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case 1: return brick_launch_z<1>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case 2: return brick_launch_z<2>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case 4: return brick_launch_z<4>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case 5: return brick_launch_z<5>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    default: return brick_launch_z<6>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
   }
 }
 
-// Content watch. The brick kernel is exact for any content but slow when most 256-pixel steps miss the cache (noise-like
-// frames: every pixel in its own LUT cell); the three-pass whole-plane kernel does not care about content. Every
-// kSnapEvery-th brick launch the miss counters are copied to pinned memory and reset, in stream order, behind an event
-// that later launches poll (never wait for). A snapshot with more than kHostileSlow of its steps on the slow path (or more
-// than kHostileMiss of them needing fills) hands the stream to the three-pass kernel for `retry_period` launches (64, doubling to 1024 while the verdict stays
-// the same), after which the brick kernel gets kSnapEvery launches to prove itself again.
-constexpr unsigned kSnapEvery = 4;
-constexpr double kHostileSlow = 0.15, kHostileMiss = 0.6;
-
+// Content watch mechanism (policy: brickwatch.hpp). Every kWatchSnapEvery-th brick launch at one level the miss counters
+// are copied to pinned memory and reset, in stream order, behind an event that later launches poll - never wait for.
 static void brick_harvest(BrickLut &B) {
   if (!B.pending) return;
   if (hipEventQuery(B.ev) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -515,37 +587,33 @@ static void brick_harvest(BrickLut &B) {
   const double steps = (double)B.px_snapshot / 256.0;
   unsigned long long tot[2] = {0, 0};
   for (int i = 0; i < kBrickCounterSlots; i++) { tot[0] += B.h_counters[2 * i]; tot[1] += B.h_counters[2 * i + 1]; }
-  B.last_miss_fraction = steps > 0.0 ? (double)tot[0] / steps : 0.0;
-  B.last_slow_fraction = steps > 0.0 ? (double)tot[1] / steps : 0.0;
-  if (B.last_slow_fraction > kHostileSlow || B.last_miss_fraction > kHostileMiss) {
-    B.hostile = true;
-    B.retry_period = B.retry_period ? (B.retry_period < 1024 ? B.retry_period * 2 : 1024) : 64;
-    B.retry_in = B.retry_period;
-  } else {
-    B.hostile = false;
-    B.retry_period = 0;
-  }
+  if (steps > 0.0) watch_snapshot(B.watch, B.level_snapshot, (double)tot[0] / steps, (double)tot[1] / steps);
 }
 
-bool brick_choose(BrickLut &B) {
+int brick_choose(BrickLut &B) {
   brick_harvest(B);
-  if (!B.hostile) return true;
-  if (B.retry_in > 0) { B.retry_in--; return false; }
-  // probation: brick kernel again until the next snapshot decides
-  B.hostile = false;
-  return true;
+  return watch_level(B.watch);
 }
 
-int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels) {
+int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level) {
+  int rc;
+  if (level != B.level_since) {
+    // first launch at a new level: what the counters hold belongs to the old one (stream order: this reset lands after the
+    // launch just made, whose own steps are thereby dropped from the count as well as from px_since)
+    if (B.level_since >= 0 && (rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
+    B.level_since = level;
+    B.px_since = 0;
+    B.launches_since = 0;
+    return MI355_OK;
+  }
   B.px_since += pixels;
-  B.launches_since++;
-  if (B.pending || B.launches_since < kSnapEvery) return MI355_OK;
-  int rc = check_hip(ctx, hipMemcpyAsync(B.h_counters, B.d_counters, kBrickCounterBytes, hipMemcpyDeviceToHost, ctx->stream), "brick counters snapshot");
-  if (rc) return rc;
+  if (++B.launches_since < kWatchSnapEvery || B.pending) return MI355_OK;
+  if ((rc = check_hip(ctx, hipMemcpyAsync(B.h_counters, B.d_counters, kBrickCounterBytes, hipMemcpyDeviceToHost, ctx->stream), "brick counters snapshot"))) return rc;
   if ((rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
   if ((rc = check_hip(ctx, hipEventRecord(B.ev, ctx->stream), "hipEventRecord(brick)"))) return rc;
   B.pending = true;
   B.px_snapshot = B.px_since;
+  B.level_snapshot = level;
   B.px_since = 0;
   B.launches_since = 0;
   return MI355_OK;

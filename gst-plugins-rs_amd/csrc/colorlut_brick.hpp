@@ -1,6 +1,7 @@
 // colorlut_brick.hpp — host-side handle of the brick-cache colorlut kernel (colorlut_brick.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "brickwatch.hpp"
 #include <cstddef>
 #include <cstdint>
 
@@ -18,6 +19,7 @@ struct BrickLut {
   uint32_t *d_cellnum = nullptr;           // 3 x 256: per-axis contribution to the cell number x0 + S*y0 + S*S*z0 (miss path)
   unsigned long long *d_counters = nullptr;  // 1024 slots x {256-pixel steps with a cache miss, steps that ended on the slow path}
   int size = 0;
+  int fold_axis = 2;                       // axis that has 2 residues in the 32-set geometry (2 = z)
   bool ok = false;                         // kernel applicable to this LUT (3D, size <= kBrickMaxSize, finite domain)
   // content watch (brick_choose / brick_after_launch): the miss counters are copied to pinned host memory every few
   // launches behind an event that is only ever polled, never waited for
@@ -27,16 +29,15 @@ struct BrickLut {
   unsigned long long px_since = 0;         // pixels launched through the brick kernel since the last snapshot
   unsigned long long px_snapshot = 0;      // ... covered by the snapshot in flight
   unsigned launches_since = 0;
-  bool hostile = false;                    // last snapshot: too many steps missed the cache -> three-pass kernel
-  unsigned retry_in = 0, retry_period = 0; // launches served by the other kernel before the brick kernel is tried again
-  double last_miss_fraction = 0.0;         // of the 256-pixel steps in the last snapshot: steps that needed a fill
-  double last_slow_fraction = 0.0;         // ... steps that ended on the slow path
+  int level_since = -1;                    // level of the launches counted in px_since (a change of level restarts the count)
+  int level_snapshot = 0;                  // level of the snapshot in flight
+  BrickWatch watch;                        // the policy (brickwatch.hpp)
 };
 
-// Content watch for the interpolating path: true = use the brick kernel for this launch, false = the three-pass kernel.
-bool brick_choose(BrickLut &B);
-// after a brick launch of `pixels` pixels on ctx's stream: count it and, every few launches, start a non-blocking snapshot
-int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels);
+// Content watch for the interpolating path: level for this launch (0 / 1 = brick kernel with 32 / 64 sets, 2 = three-pass).
+int brick_choose(BrickLut &B);
+// after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
+int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level);
 
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);
 void brick_release(BrickLut &B);
@@ -44,7 +45,7 @@ bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch,
                       int dst_stride, int n_frames, int width, int height);
 // hs == nullptr: colorlut alone; otherwise the fused hsvfilter -> colorlut chain. src == dst is allowed.
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
-                 const mi355_hsv_settings *hs);
+                 const mi355_hsv_settings *hs, int sets);  // sets: 32 or 64
 // synchronous read (and optional reset) of the miss counters
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);
 

@@ -1192,11 +1192,15 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
       brick_applicable(ctx->lut.brick, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height)) {
     BrickLut &B = ctx->lut.brick;
     const bool build = ctx->lut.building_table;
-    if (lv == 7 || !three_pass_ok || (!build && brick_choose(B))) {
-      ctx->lut.last_kernel = "colorlut3d_brick_kernel<HSV>";
-      int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs);
-      if (rc || build) return rc;
-      return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames);
+    const bool pinned = lv == 7 || !three_pass_ok || ctx->brick_sets != 0;
+    int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
+    if (level == 2 && !three_pass_ok) level = 1;
+    if (level < 2) {
+      const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
+      ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel<HSV> (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel<HSV> (48 sets)" : "colorlut3d_brick_kernel<HSV>");
+      int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs, sets);
+      if (rc || build || pinned) return rc;
+      return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
     }
   }
   if (three_pass_ok) {
@@ -1278,11 +1282,16 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       // a table build runs over the all-colours frame, which is as hostile to the brick cache as noise: three-pass kernel
       // when it applies, and no entry in the stream's content watch either way
       const bool build = ctx->lut.building_table;
-      if (v == 7 || !three_pass_ok || (!build && brick_choose(B))) {
-        ctx->lut.last_kernel = "colorlut3d_brick_kernel";
-        int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr);
-        if (rc || build) return rc;
-        return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames);
+      // MI355_FLAG_BRICK_SETS pins the cache geometry; 0 lets the content watch pick (and leave for the three-pass kernel)
+      const bool pinned = v == 7 || !three_pass_ok || ctx->brick_sets != 0;
+      int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
+      if (level == 2 && !three_pass_ok) level = 1;
+      if (level < 2) {
+        const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
+        ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel");
+        int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr, sets);
+        if (rc || build || pinned) return rc;
+        return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
       }
     }
     if (three_pass_ok) {
@@ -1605,6 +1614,31 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
 // measured, its interval is ms_compute[i] or ms_table[i] depending on the kind it ran, and the measurement becomes readable
 // `lag` calls later (or at once when the policy insists on waiting). kind_out[i] = 0 / 1, measured_out[i] = 0 / 1.
 // No device, no context: host logic only (tests/test_autopick.py).
+// Runs the content-watch policy (brickwatch.hpp) against a scripted stream: call i would produce the miss / slow fractions
+// miss0[i], slow0[i] on the 32-set brick kernel and miss1[i], slow1[i] on the 64-set one; a snapshot covers kWatchSnapEvery
+// consecutive launches at one level and becomes readable `lag` calls after its last launch. level_out[i] = 0 / 1 / 2.
+extern "C" int mi355_selftest_brickwatch(int n_calls, const double *miss0, const double *slow0, const double *miss1, const double *slow1, int lag,
+                                         int *level_out) {
+  if (n_calls < 0 || !miss0 || !slow0 || !miss1 || !slow1 || !level_out || lag < 0) return MI355_ERR_INVALID_ARG;
+  mi355::BrickWatch W;
+  int level_since = -1, launches_since = 0, pend_level = -1, pend_ready = 0;
+  double acc_m = 0, acc_s = 0, pend_m = 0, pend_s = 0;
+  for (int i = 0; i < n_calls; i++) {
+    if (pend_level >= 0 && i >= pend_ready) { mi355::watch_snapshot(W, pend_level, pend_m, pend_s); pend_level = -1; }
+    const int level = mi355::watch_level(W);
+    level_out[i] = level;
+    if (level == 2 || pend_level >= 0) continue;
+    if (level != level_since) { level_since = level; launches_since = 0; acc_m = acc_s = 0; }
+    acc_m += level ? miss1[i] : miss0[i];
+    acc_s += level ? slow1[i] : slow0[i];
+    if (++launches_since >= (int)mi355::kWatchSnapEvery) {
+      pend_level = level; pend_m = acc_m / launches_since; pend_s = acc_s / launches_since; pend_ready = i + 1 + lag;
+      launches_since = 0; acc_m = acc_s = 0;
+    }
+  }
+  return MI355_OK;
+}
+
 extern "C" int mi355_selftest_autopick(int n_calls, const uint64_t *n_vec, const double *ms_compute, const double *ms_table, int lag,
                                        int *kind_out, int *measured_out) {
   if (n_calls < 0 || !n_vec || !ms_compute || !ms_table || !kind_out || lag < 0) return MI355_ERR_INVALID_ARG;

@@ -180,8 +180,9 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_LUT_STAGGER && value >= 0 && value <= 4096) { ctx->lut_stagger = value; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 7) { ctx->lut_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_TILES_PER_RUN && value >= 0 && value <= 4096) { ctx->brick_tiles_per_run = value; return MI355_OK; }
+  if (flag == MI355_FLAG_BRICK_FOLD_AXIS && value >= 0 && value <= 2) { ctx->brick_fold_axis = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_PRIO && (value == 0 || value == 1)) { ctx->brick_prio = value; return MI355_OK; }
-  if (flag == MI355_FLAG_BRICK_SETS && (value == 32 || value == 64)) { ctx->brick_sets = value; return MI355_OK; }
+  if (flag == MI355_FLAG_BRICK_SETS && (value == 0 || value == 32 || value == 48 || value == 64)) { ctx->brick_sets = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 3) { ctx->hsv_table_mode = value; return MI355_OK; }
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
@@ -381,8 +382,8 @@ int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *las
   int rc = brick_read_counters(ctx, ctx->lut.brick, c, reset != 0);
   if (rc) return rc;
   if (counters) { counters[0] = c[0]; counters[1] = c[1]; }
-  if (last_miss_fraction) *last_miss_fraction = ctx->lut.brick.last_miss_fraction;
-  if (hostile) *hostile = ctx->lut.brick.hostile ? 1 : 0;
+  if (last_miss_fraction) *last_miss_fraction = ctx->lut.brick.watch.last_miss;
+  if (hostile) *hostile = ctx->lut.brick.watch.home;
   return MI355_OK;
 }
 

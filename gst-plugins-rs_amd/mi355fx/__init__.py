@@ -31,6 +31,7 @@ FLAG_HSV_TABLE = 6
 FLAG_BRICK_TILES_PER_RUN = 7
 FLAG_BRICK_SETS = 8
 FLAG_BRICK_PRIO = 9
+FLAG_BRICK_FOLD_AXIS = 10
 
 
 class HsvSettings(C.Structure):
@@ -87,6 +88,7 @@ def load_library():
         "mi355_colorlut_kernel_choice": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mi355_colorlut_last_kernel": (C.c_char_p, [vp]),
         "mi355_colorlut_brick_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_int), i]),
+        "mi355_selftest_brickwatch": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int)]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
         "mi355_hsv_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, C.POINTER(HsvSettings)]),
@@ -270,11 +272,11 @@ class Context:
         return (self.L.mi355_colorlut_last_kernel(self.h) or b"").decode()
 
     def colorlut_brick_stats(self, reset=False):
-        """(steps with a miss, steps on the slow path, last miss fraction seen by the content watch, hostile flag)."""
+        """(steps with a miss, steps on the slow path, last miss fraction seen by the content watch, level it settled on)."""
         c = (C.c_uint64 * 2)()
         f, h = C.c_double(0), C.c_int(0)
         self._ck(self.L.mi355_colorlut_brick_stats(self.h, c, C.byref(f), C.byref(h), int(reset)))
-        return int(c[0]), int(c[1]), f.value, bool(h.value)
+        return int(c[0]), int(c[1]), f.value, int(h.value)
 
     def colorlut_frame(self, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
         self._ck(self.L.mi355_colorlut_frame(self.h, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt]))

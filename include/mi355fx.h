@@ -99,8 +99,9 @@ typedef enum mi355_flag {
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3, /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
   MI355_FLAG_BRICK_TILES_PER_RUN = 7, /* brick-cache kernel: 128 x 4 pixel tiles a wave walks down before its cache starts cold again (0 = default) */
+  MI355_FLAG_BRICK_FOLD_AXIS = 10, /* brick-cache kernel, 32-set geometry: the axis (0 x, 1 y, 2 z = default) that gets 2 set residues instead of 4; read at mi355_colorlut_load */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel: waves lower their issue priority as they advance through their run (1 = on, default) */
-  MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache, 32 (default; 16 waves per CU) or 64 (8 waves per CU); two ways each */
+  MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 
@@ -169,9 +170,15 @@ int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, d
  * first one). Diagnostic; no reference counterpart. */
 const char *mi355_colorlut_last_kernel(mi355_ctx *ctx);
 /* Brick-cache kernel diagnostics (synchronous): counters[0] = 256-pixel steps that found a brick missing in the wave's
- * LDS cache since the last reset, counters[1] = steps that still missed after the fill rounds (slow path); *last_miss_fraction / *hostile = what the content
- * watch last concluded. reset != 0 clears the device counters. No reference counterpart. */
-int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *hostile, int reset);
+ * LDS cache since the last reset, counters[1] = steps that still missed after the fill rounds (slow path);
+ * *last_miss_fraction = miss fraction of the content watch's last snapshot, *level = the level it has settled on (0 brick
+ * kernel with 32 sets, 1 with 64 sets, 2 three-pass kernel). reset != 0 clears the device counters. No reference counterpart. */
+int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *level, int reset);
+/* Host-logic self test of the content-watch policy (csrc/brickwatch.hpp) against a scripted stream, no GPU needed: call i
+ * would show miss / slow step fractions miss0[i], slow0[i] on the 32-set brick kernel and miss1[i], slow1[i] on the 64-set
+ * one; snapshots become readable `lag` calls late. level_out[i] = 0 / 1 / 2 as above. */
+int mi355_selftest_brickwatch(int n_calls, const double *miss0, const double *slow0, const double *miss1, const double *slow1, int lag,
+                              int *level_out);
 /* Host-logic self test of the auto-choice policy against a scripted device (no GPU needed): call i has n_vec[i] 16-byte
  * pixel groups and, if measured, takes ms_compute[i] or ms_table[i] depending on the kind it ran; a measurement becomes
  * readable `lag` calls later. kind_out[i] = 0 interpolating / 1 table, measured_out[i] (optional) = launch was bracketed. */

@@ -1,0 +1,71 @@
+"""Content-watch policy of the interpolating colorlut path (csrc/brickwatch.hpp) against scripted streams, on the CPU:
+mi355_selftest_brickwatch feeds the policy the miss / slow step fractions each call would show on the 32-set and on the
+64-set brick kernel and reports the level (0 brick kernel 32 sets, 1 brick kernel 64 sets, 2 three-pass kernel) of every call."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _run(mi355lib, miss0, slow0, miss1, slow1, lag=2):
+    n = len(miss0)
+    arr = lambda v: (C.c_double * n)(*[float(x) for x in v])
+    out = (C.c_int * n)()
+    rc = mi355lib.mi355_selftest_brickwatch(n, arr(miss0), arr(slow0), arr(miss1), arr(slow1), lag, out)
+    assert rc == 0
+    return list(out)
+
+
+def test_coherent_content_stays_on_the_32_set_kernel(mi355lib):
+    n = 400
+    lv = _run(mi355lib, [0.045] * n, [0.0] * n, [0.04] * n, [0.0] * n)
+    assert set(lv) == {0}
+
+
+def test_edge_heavy_content_moves_to_64_sets_and_stays(mi355lib):
+    n = 400
+    lv = _run(mi355lib, [0.2] * n, [0.08] * n, [0.1] * n, [0.0] * n)
+    first1 = lv.index(1)
+    assert 4 <= first1 <= 8                      # one snapshot (4 launches) + lag
+    assert 2 not in lv
+    # level 0 is probed again after 64 launches, found bad, then after 128 ...
+    probes = [i for i in range(first1 + 1, n) if lv[i] == 0 and lv[i - 1] == 1]
+    assert len(probes) >= 2 and probes[1] - probes[0] > probes[0] - first1
+
+
+def test_noise_climbs_to_the_three_pass_kernel(mi355lib):
+    n = 300
+    lv = _run(mi355lib, [1.0] * n, [1.0] * n, [1.0] * n, [1.0] * n)
+    assert lv[0] == 0 and 1 in lv and 2 in lv
+    assert lv.index(2) <= 16
+    assert lv.count(2) > 0.8 * n                  # probes of level 1 are rare and short
+    assert 0 not in lv[lv.index(2):]              # never all the way down while level 1 is bad
+
+
+def test_stream_that_calms_down_walks_back_to_level_0(mi355lib):
+    n = 600
+    bad = 60
+    miss = [1.0] * bad + [0.03] * (n - bad)
+    slow = [1.0] * bad + [0.0] * (n - bad)
+    lv = _run(mi355lib, miss, slow, miss, slow)
+    assert 2 in lv[:bad]
+    assert lv[-1] == 0
+    i1 = max(i for i, v in enumerate(lv) if v == 2)
+    assert i1 < bad + 64 + 80                     # left the three-pass kernel at the first probe after the content changed
+
+
+def test_snapshot_lag_does_not_break_the_ladder(mi355lib):
+    n = 300
+    for lag in (0, 1, 7, 20):
+        lv = _run(mi355lib, [1.0] * n, [1.0] * n, [0.1] * n, [0.0] * n, lag=lag)
+        assert lv[-1] == 1 and 2 not in lv
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_levels_are_always_valid_under_random_content(mi355lib, seed):
+    rng = np.random.default_rng(seed)
+    n = 500
+    m0, s0, m1, s1 = rng.random(n), rng.random(n) * 0.2, rng.random(n) * 0.6, rng.random(n) * 0.08
+    lv = _run(mi355lib, m0, np.minimum(s0, m0), m1, np.minimum(s1, m1), lag=int(rng.integers(0, 6)))
+    assert set(lv) <= {0, 1, 2}
+    assert lv[0] == 0

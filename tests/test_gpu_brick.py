@@ -47,7 +47,7 @@ def _varying_alpha(ac):
     return ac
 
 
-@pytest.mark.parametrize("sets", [32, 64])
+@pytest.mark.parametrize("sets", [32, 48, 64])
 @pytest.mark.parametrize("size,domain", [(33, None), (2, None), (3, None), (17, None), (34, None), (65, None),
                                          (33, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))), (5, ((0.0, 0.0, 0.0), (2.0, 0.5, 1.0)))])
 def test_brick_kernel_allcolors(ctx, oracle, synth, size, domain, sets):
@@ -62,7 +62,7 @@ def test_brick_kernel_allcolors(ctx, oracle, synth, size, domain, sets):
     ctx.set_flag(mi355fx.FLAG_BRICK_SETS, sets)
     got = np.zeros_like(ac)
     ctx.colorlut_frame(ac, 4096 * 4, got, 4096 * 4, 4096, 4096, "RGBA")
-    assert ctx.colorlut_kernel_name() == "colorlut3d_brick_kernel"
+    assert ctx.colorlut_kernel_name().startswith("colorlut3d_brick_kernel")
     assert (got == exp).all(), _report(got, exp)
 
 
@@ -95,7 +95,7 @@ def test_brick_kernel_nonfinite_lut_entries(ctx, oracle):
     assert (got == exp).all(), _report(got, exp)
 
 
-@pytest.mark.parametrize("sets", [32, 64])
+@pytest.mark.parametrize("sets", [32, 48, 64])
 @pytest.mark.parametrize("content", ["smooth", "noise"])
 @pytest.mark.parametrize("in_place", [False, True])
 def test_brick_kernel_4k_batch(ctx, oracle, synth, content, in_place, sets):
@@ -115,7 +115,7 @@ def test_brick_kernel_4k_batch(ctx, oracle, synth, content, in_place, sets):
     ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 7)
     ctx.set_flag(mi355fx.FLAG_BRICK_SETS, sets)
     got = _device_lut(ctx, frames, 3840, 2160, in_place=in_place)
-    assert ctx.colorlut_kernel_name() == "colorlut3d_brick_kernel"
+    assert ctx.colorlut_kernel_name().startswith("colorlut3d_brick_kernel")
     assert (got.reshape(-1, 4) == exp).all(), _report(got, exp)
     steps, slow, _, _ = ctx.colorlut_brick_stats()
     total_steps = frames.size // 4 // 256
@@ -212,17 +212,17 @@ def test_content_watch_hands_noise_to_the_three_pass_kernel_and_back(ctx, oracle
         got = _device_lut(ctx, smooth, w, h)
         assert (got.reshape(-1, 4) == es).all()
         names.append(ctx.colorlut_kernel_name())
-    assert set(names) == {"colorlut3d_brick_kernel"}
+    assert all(n.startswith("colorlut3d_brick_kernel") for n in names), names   # 32 or 64 sets: the watch's call
     names = []
-    for _ in range(16):
+    for _ in range(20):
         got = _device_lut(ctx, noise, w, h)
         assert (got.reshape(-1, 4) == en).all()
         names.append(ctx.colorlut_kernel_name())
     assert names[-1] == "colorlut3d_lds_kernel", names
-    assert names.index("colorlut3d_lds_kernel") <= 10, names
+    assert "colorlut3d_brick_kernel (64 sets)" in names   # the ladder goes through the 64-set cache first
     names = []
-    for _ in range(80):  # probation after 64 launches of the other kernel
+    for _ in range(170):  # two probations (64 sets, then 32 sets), each after 64 launches of the level above
         got = _device_lut(ctx, smooth, w, h)
         assert (got.reshape(-1, 4) == es).all()
         names.append(ctx.colorlut_kernel_name())
-    assert names[-1] == "colorlut3d_brick_kernel", names[-10:]
+    assert names[-1].startswith("colorlut3d_brick_kernel"), names[-10:]

@@ -34,9 +34,13 @@ def main():
                 f[..., :3] += rng.integers(-amp, amp + 1, size=f[..., :3].shape, dtype=np.int16)
             frames = np.clip(f, 0, 255).astype(np.uint8).reshape(-1)
         ctx.h2d(d_src, frames)
+        if os.environ.get("PREHSV"):  # the chain's colorlut input: the frames after hsvfilter(hue-shift=90)
+            ctx.hsvfilter_frames_device(d_src, N, H * W * 4, W, H, W * 4, "RGBA", synth.HSV_SETTINGS["hue90"])
+            ctx.synchronize()
         cells = []
         for v in variants:
-            for t, ns in [(t, ns) for t in (tprs if v == 7 else [0]) for ns in (setss if v == 7 else [32])]:
+            for t, ns in [(t, ns) for t in (tprs if v == 7 else [0]) for ns in (setss if v == 7 else [0])]:
+                ctx.set_flag(mi355fx.FLAG_BRICK_FOLD_AXIS, int(os.environ.get("FOLD", "2")))
                 ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
                 ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, v)
                 ctx.set_flag(mi355fx.FLAG_BRICK_TILES_PER_RUN, t)
@@ -48,6 +52,8 @@ def main():
                 ms = min(run(20) for _ in range(3))
                 steps, slow, _, _ = ctx.colorlut_brick_stats(reset=True)
                 extra = " miss %.3f slow %.3f" % (steps / 60.0 / (W * H * N / 256), slow / 60.0 / (W * H * N / 256)) if v == 7 else ""
+                if v in (0, 6):
+                    extra = " [%s, watch level %d]" % (ctx.colorlut_kernel_name().replace("colorlut", ""), ctx.colorlut_brick_stats()[3])
                 cells.append("%.4f (%.3f)%s" % (ms, algo / (ms * 1e-3) / 8e12, extra))
         print("%-8s %s" % ("noise" if amp < 0 else amp, "  ".join(cells)), flush=True)
     ctx.free(d_src); ctx.free(d_dst); ctx.close()
