@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--hsv-blocks-per-cu", type=int, default=0, help="MI355_FLAG_HSV_BLOCKS_PER_CU (tuning; 0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST SCAFFOLDING, no GPU: tiny CPU frames and a fake context that sleeps instead of launching kernels, so that\n"
+                         "the N>1 control flow (gloo group, barriers, MAX over ranks, aggregation, rank-0 JSON) can be exercised by the CPU\n"
+                         "test suite (tests/test_bench_multirank.py); the line it prints says \"data\": \"stub\" and means nothing")
     return ap.parse_args()
 
 
@@ -147,6 +151,52 @@ def cpu_baseline(synth, settings, cube_text, seconds_target=12.0):
                  "sample": "%d 4K smooth frames as %d concurrent single-threaded streams" % (n2, nc)}
 
 
+def _install_stub(torch, mi355fx, rank):
+    """--stub: replace the device with the CPU and the context with a sleeper (test scaffolding for the N>1 control flow)."""
+    global W, H, FRAME_BYTES, BYTES_PER_FRAME_PER_KERNEL
+    W, H = 64, 16
+    FRAME_BYTES = W * H * 4
+    BYTES_PER_FRAME_PER_KERNEL = 2 * FRAME_BYTES
+    import contextlib
+
+    class Ev:
+        def __init__(self, enable_timing=True):
+            self.t = 0.0
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3 + 0.02
+
+    class St:
+        def __init__(self, device=None):
+            self.cuda_stream = 0
+
+    torch.cuda.Event = Ev
+    torch.cuda.Stream = St
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.mem_get_info = lambda *a, **k: (1 << 30, 1 << 30)
+    torch.cuda.empty_cache = lambda: None
+
+    class Ctx:
+        def __init__(self, device):
+            self.lat = 0.001 * (1 + rank)  # rank 1 is slower: the reported time must be the MAX over ranks
+
+        def set_stream(self, s): pass
+        def colorlut_load(self, *a): pass
+        def set_flag(self, *a): pass
+        def hsvfilter_frames_device(self, *a): time.sleep(self.lat)
+        def colorlut_frames_device(self, *a): time.sleep(self.lat)
+        def hsv_colorlut_frames_device(self, *a): time.sleep(self.lat)
+        def colorlut_kernel_choice(self, fused=False): return (False, 0.0, 0.0)
+        def colorlut_kernel_name(self): return "stub"
+        def close(self): pass
+
+    mi355fx.Context = Ctx
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -159,14 +209,17 @@ def main():
     import mi355fx
     from mi355fx import sharding, synth
 
-    if not torch.cuda.is_available():
+    if args.stub:
+        _install_stub(torch, mi355fx, rank)
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (torch.cuda unavailable); there is no CPU fallback")
     if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
         # test scaffolding only: exercise the N>1 control flow (barriers, max-over-ranks, aggregation) on a 1-GPU box by
         # putting every rank on device 0; the numbers of such a run mean nothing
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not args.stub:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         # Streams are independent (north_star: "no RCCL: there is no cross-stream collective"): the only cross-rank
@@ -381,7 +434,7 @@ def main():
             "metric": "4K RGBA frames/sec through hsvfilter+colorlut at 1 GPU; % HBM roofline",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "stub" if args.stub else "synthetic",
             "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
                        "frames_per_step": args.batch, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
@@ -414,7 +467,7 @@ def main():
         if extra:
             out["other_content"] = extra
         if not args.no_cpu_baseline:
-            one, mt = cpu_baseline(synth, settings, cube_text)
+            one, mt = cpu_baseline(synth, settings, cube_text, seconds_target=0.5 if args.stub else 12.0)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = mt
         print(json.dumps(out), flush=True)

@@ -231,6 +231,8 @@ int mi355_hsvfilter_frames_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames,
   if (!d_data) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: null data");
   if ((size_t)stride < (size_t)width * fmt.pixel_stride)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: stride smaller than width*pixel_stride");
+  if (n_frames > 1 && frame_pitch < (size_t)(height - 1) * (size_t)stride + (size_t)width * fmt.pixel_stride)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: frame_pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
   return launch_hsvfilter(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, *settings);
 }
@@ -404,6 +406,9 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
   if (!d_src || !d_dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: null data");
   if ((size_t)src_stride < (size_t)width * bpp || (size_t)dst_stride < (size_t)width * bpp)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: stride smaller than row bytes");
+  if (n_frames > 1 && (src_pitch < (size_t)(height - 1) * (size_t)src_stride + (size_t)width * bpp ||
+                       dst_pitch < (size_t)(height - 1) * (size_t)dst_stride + (size_t)width * bpp))
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
   return launch_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
 }
@@ -419,6 +424,9 @@ int mi355_hsv_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_
   if (!d_src || !d_dst) return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: null data");
   if ((size_t)src_stride < (size_t)width * 4 || (size_t)dst_stride < (size_t)width * 4)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: stride smaller than row bytes");
+  if (n_frames > 1 && (src_pitch < (size_t)(height - 1) * (size_t)src_stride + (size_t)width * 4 ||
+                       dst_pitch < (size_t)(height - 1) * (size_t)dst_stride + (size_t)width * 4))
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: frame pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
   return launch_hsv_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, *settings);
 }

@@ -10,6 +10,7 @@
 #include "mi355fx_host.h"
 
 #include <cerrno>
+#include <locale.h>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -126,7 +127,11 @@ bool parse_f32_token(sv t, float &out) {
   const std::string z(t);
   char *end = nullptr;
   errno = 0;
-  const float v = std::strtof(z.c_str(), &end);  // glibc: correctly rounded; overflow -> inf, like Rust
+  // Rust's str::parse::<f32> knows no locale; a GStreamer process has called setlocale(LC_ALL, "") (gst_init), and under a
+  // comma-decimal LC_NUMERIC plain strtof stops at the '.' of every .cube value. strtof_l with the "C" locale: glibc's
+  // correctly rounded conversion (overflow -> inf, underflow -> 0 / denormal, like Rust) whatever the process locale is.
+  static const locale_t c_locale = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+  const float v = c_locale ? strtof_l(z.c_str(), &end, c_locale) : std::strtof(z.c_str(), &end);
   if (end != z.c_str() + z.size()) return false;
   out = v;
   return true;

@@ -1,0 +1,53 @@
+"""bench.py's N>1 control flow end to end on the CPU: two ranks under torch.distributed.run with `--stub` (tiny CPU frames, a
+context that sleeps instead of launching kernels). Checks what the driver relies on: one JSON line from rank 0 only, n_gpus = 2,
+`value` = the units ALL ranks processed / the MAX-over-ranks time (rank 1 is made twice as slow), the timing group is gloo (no
+RCCL anywhere), and cpu_baseline is present at N > 1."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, steps=6, warmup=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", str(warmup),
+           "--stub", "--ramp-seconds", "0.02"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                     # rank 0 prints, nobody else
+    return json.loads(lines[0])
+
+
+def test_two_ranks_aggregate_over_the_slowest_rank():
+    d = _run(2)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["data"] == "stub" and d["scaling"] == "weak"
+    assert "gloo" in d["config"]["timing_group"] and "RCCL" in d["config"]["timing_group"]
+    # rank 1 sleeps 2 ms per launch, rank 0 1 ms: two launches per step -> a step takes >= 4 ms on the slowest rank
+    assert d["ms_per_step"] >= 4.0
+    frames = d["steps"] * d["config"]["frames_per_step"] * 2     # both ranks' frames
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_single_process_stub_has_all_legs():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--stub", "--ramp-seconds", "0.02"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    for key in ("interpolating_kernel_only", "fused_chain", "other_content", "cpu_baseline", "cpu_baseline_all_cores"):
+        assert key in d, key
+    assert d["config"]["sources"].startswith("pristine") and d["config"]["source_chunks"] >= 1

@@ -898,3 +898,27 @@ def test_hsvdetect_rgb24_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
     got = np.zeros_like(exp)
     ctx.hsvdetect_frame(src, 4096 * 3, in_fmt, got, 4096 * 4, out_fmt, 4096, st)
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_device_entry_points_reject_overlapping_frames(ctx, oracle, synth):
+    """n_frames > 1 with a frame pitch smaller than one frame would make launches read and write overlapping frames:
+    INVALID_ARG instead."""
+    import mi355fx
+    _load_cube(ctx, oracle, synth.cube_text_3d(5))
+    w, h = 64, 8
+    d = ctx.alloc(4 * w * h * 4)
+    try:
+        st = synth.HSV_SETTINGS["hue90"]
+        for call in (lambda: ctx.hsvfilter_frames_device(d, 2, w * 4 * (h - 1), w, h, w * 4, "RGBA", st),
+                     lambda: ctx.colorlut_frames_device(d, w * 4, w * 4, d, w * 4 * h, w * 4, 2, w, h, "RGBA"),
+                     lambda: ctx.colorlut_frames_device(d, w * 4 * h, w * 4, d, w * 4, w * 4, 2, w, h, "RGBA"),
+                     lambda: ctx.hsv_colorlut_frames_device(d, w * 4 * h, w * 4, d, 16, w * 4, 2, w, h, st)):
+            with pytest.raises(mi355fx.Mi355Error) as e:
+                call()
+            assert e.value.status == mi355fx.ERR_INVALID_ARG
+        # exactly one frame apart is fine, and a single frame ignores the pitch
+        ctx.hsvfilter_frames_device(d, 2, w * 4 * h, w, h, w * 4, "RGBA", st)
+        ctx.colorlut_frames_device(d, 0, w * 4, d, 0, w * 4, 1, w, h, "RGBA")
+        ctx.synchronize()
+    finally:
+        ctx.free(d)

@@ -285,3 +285,28 @@ def test_parsers_agree_on_fuzzed_cube_texts(parsers):
             assert np.array_equal(np.asarray(a["offset"]).view(np.uint32), np.asarray(b["offset"]).view(np.uint32))
 
     run()
+
+
+def test_host_parser_does_not_depend_on_the_process_locale(synth):
+    """A GStreamer process runs under setlocale(LC_ALL, ""); Rust's f32 parser knows no locale. The host parser must accept
+    the same '.'-decimal .cube text under a comma-decimal LC_NUMERIC (plain strtof stopped at the '.')."""
+    import ctypes
+    import locale
+    from mi355fx.cube import parse_cube
+    text = synth.cube_text_3d(5)
+    ref = parse_cube(text)
+    libc = ctypes.CDLL(None)
+    libc.setlocale.restype = ctypes.c_char_p
+    old = libc.setlocale(locale.LC_NUMERIC, None)
+    switched = None
+    for name in (b"de_DE.UTF-8", b"de_DE.utf8", b"fr_FR.UTF-8", b"de_DE", b"ru_RU.UTF-8"):
+        if libc.setlocale(locale.LC_NUMERIC, name):
+            switched = name
+            break
+    try:
+        got = parse_cube(text)  # must parse whatever LC_NUMERIC is
+        assert got.size == ref.size and (np.asarray(got.table) == np.asarray(ref.table)).all()
+    finally:
+        libc.setlocale(locale.LC_NUMERIC, old)
+    if switched is None:
+        pytest.skip("no comma-decimal locale installed in this image: parsed under the C locale only")

@@ -36,6 +36,23 @@ __global__ __launch_bounds__(1024) void k_r2(float *out, const uint32_t *offs, i
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// ds_read_b64 at 4-byte (not 8-byte) aligned addresses: the x0 / x0+1 corner pair of the plane in ONE 8-byte read. Legal only
+// with the LDS in unaligned-access mode (the ROCm default on gfx9); this measures what the hardware charges for it.
+__global__ __launch_bounds__(1024) void k_r64(float *out, const uint32_t *offs, int n_pat) {
+  extern __shared__ float lds[];
+  for (int i = threadIdx.x; i < 38000; i += 1024) lds[i] = i * 0.5f;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int i = 0; i < ITERS; i++) {
+    const uint32_t a = offs[((i + wave * 7) % n_pat) * 64 + lane];
+    float2 v0, v1, v2, v3;
+    asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:140\n ds_read_b64 %2, %4 offset:4644\n ds_read_b64 %3, %4 offset:4784\n s_waitcnt lgkmcnt(0)"
+                 : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(a));
+    acc += v0.x + v1.x + v2.x + v3.x + v0.y + v1.y + v2.y + v3.y;
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cu = p.multiProcessorCount;
@@ -45,6 +62,7 @@ int main() {
   const size_t lds = 156000;
   hipFuncSetAttribute((const void *)k_r32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipFuncSetAttribute((const void *)k_r2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void *)k_r64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const char *names[] = {"consecutive words", "all lanes same address", "8 neighbour cells (x+3y+9z banks)", "8 neighbour cells natural 33/1089 strides",
                          "random cells (noise)", "2 addresses", "64 distinct rows same bank (worst)"};
   for (int pat = 0; pat < 7; pat++) {
@@ -65,16 +83,34 @@ int main() {
       offs[k * 64 + l] = a;
     }
     hipMemcpy(doffs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice);
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-      if (which == 0) hipLaunchKernelGGL(k_r32, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat); else hipLaunchKernelGGL(k_r2, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat);
+      auto go = [&] {
+        if (which == 0) hipLaunchKernelGGL(k_r32, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat);
+        else if (which == 1) hipLaunchKernelGGL(k_r2, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat);
+        else hipLaunchKernelGGL(k_r64, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat);
+      };
+      go();
       hipEventRecord(e0);
-      if (which == 0) hipLaunchKernelGGL(k_r32, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat); else hipLaunchKernelGGL(k_r2, dim3(cu), dim3(1024), lds, 0, d, doffs, n_pat);
+      go();
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double dwords_per_cu = 16.0 * ITERS * 8;  // wave-level dword-reads per CU
-      printf("%-44s %-9s %.3f ms  -> %.2f clk per wave dword-read (nominal 2.4 GHz)\n", names[pat], which ? "read2_b32" : "read_b32", ms, ms * 1e-3 * 2.4e9 / dwords_per_cu);
+      printf("%-44s %-9s %.3f ms  -> %.2f clk per wave dword-read (nominal 2.4 GHz)\n", names[pat], which == 0 ? "read_b32" : (which == 1 ? "read2_b32" : "read_b64*"), ms, ms * 1e-3 * 2.4e9 / dwords_per_cu);
     }
+  }
+  // correctness of the misaligned 8-byte read: one wave reads pairs at odd word addresses
+  {
+    std::vector<uint32_t> offs(n_pat * 64);
+    for (size_t i = 0; i < offs.size(); i++) offs[i] = 4 * (2 * (i % 997) + 1);
+    hipMemcpy(doffs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_r64, dim3(1), dim3(1024), lds, 0, d, doffs, n_pat);
+    hipLaunchKernelGGL(k_r2, dim3(1), dim3(1024), lds, 0, d + 1024, doffs, n_pat);
+    std::vector<float> h(2048);
+    hipMemcpy(h.data(), d, 2048 * 4, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 1024; i++) bad += h[i] != h[1024 + i];
+    printf("misaligned ds_read_b64 vs ds_read2_b32 sums: %d of 1024 lanes differ\n", bad);
   }
   return 0;
 }
