@@ -711,11 +711,30 @@ static bool object_from_position(int pos, SpatialObject *o) {
   return false;  // FlowError::NotSupported -> "Unsupported channel position"
 }
 
-// Position::to_right_handed().to_vec3() (spatial.rs:58-66)
+// Position::{to_cartesian, to_left_handed, to_right_handed}().to_vec3() (audio/hrtf/src/spatial.rs:40-70); systems numbered as
+// GstHrtfCoordinateSystem: 0 Cartesian, 1 LeftHanded, 2 RightHanded. The known answers of spatial.rs:235-287 are replayed
+// against this function in tests/test_oracle_hrtf.py.
+extern "C" int mi355host_position_convert(int from, int to, const float in[3], float out[3]) {
+  if (from < 0 || from > 2 || to < 0 || to > 2 || !in || !out) return -1;
+  const float x = in[0], y = in[1], z = in[2];
+  if (from == to) { out[0] = x; out[1] = y; out[2] = z; return 0; }
+  if (to == 0) {         // to_cartesian (spatial.rs:40-48)
+    if (from == 1) { out[0] = z; out[1] = -x; out[2] = y; }
+    else { out[0] = -z; out[1] = -x; out[2] = y; }
+  } else if (to == 1) {  // to_left_handed (spatial.rs:51-59)
+    if (from == 0) { out[0] = -y; out[1] = z; out[2] = x; }
+    else { out[0] = x; out[1] = y; out[2] = -z; }
+  } else {               // to_right_handed (spatial.rs:62-70)
+    if (from == 0) { out[0] = -y; out[1] = z; out[2] = -x; }
+    else { out[0] = x; out[1] = y; out[2] = -z; }
+  }
+  return 0;
+}
+
+// Position::to_right_handed().to_vec3(): what HrtfRender hands the crate (hrtf/imp.rs:64-73)
 static void to_right_handed(const SpatialObject &o, float out[3]) {
-  if (o.coordinate_system == 0) { out[0] = -o.y; out[1] = o.z; out[2] = -o.x; }        // Cartesian
-  else if (o.coordinate_system == 1) { out[0] = o.x; out[1] = o.y; out[2] = -o.z; }    // LeftHanded
-  else { out[0] = o.x; out[1] = o.y; out[2] = o.z; }                                    // RightHanded
+  const float in[3] = {o.x, o.y, o.z};
+  (void)mi355host_position_convert(o.coordinate_system, 2, in, out);
 }
 
 bool HrtfRender::set_caps(int rate, int channels, const int *positions) {

@@ -24,6 +24,10 @@ const float *mi355h_cube_table(const mi355h_cube *c);
 size_t mi355h_cube_table_len(const mi355h_cube *c);
 void mi355h_cube_domain(const mi355h_cube *c, float scale[3], float offset[3]);
 
+/* Position::to_cartesian / to_left_handed / to_right_handed (audio/hrtf/src/spatial.rs:40-70); systems numbered as
+ * GstHrtfCoordinateSystem: 0 Cartesian, 1 LeftHanded, 2 RightHanded. Returns 0, or -1 on a bad argument. */
+int mi355host_position_convert(int from, int to, const float in[3], float out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -408,6 +408,19 @@ class HrtfExact:
         return out
 
 
+def position_convert(from_system, to_system, v):
+    """Position::{to_cartesian, to_left_handed, to_right_handed} (audio/hrtf/src/spatial.rs:40-70), restated; systems:
+    0 Cartesian, 1 LeftHanded, 2 RightHanded. Pinned by the reference's own known answers (spatial.rs:235-287)."""
+    x, y, z = (float(t) for t in v)
+    if from_system == to_system:
+        return (x, y, z)
+    if to_system == 0:
+        return (z, -x, y) if from_system == 1 else (-z, -x, y)
+    if to_system == 1:
+        return (-y, z, x) if from_system == 0 else (x, y, -z)
+    return (-y, z, -x) if from_system == 0 else (x, y, -z)
+
+
 def blockhash(frame, width, height, stride, channels):
     """image_hasher Blockhash (8x8) of a packed RGB/RGBA frame; ValueError when the integer fast path does not apply."""
     a = np.ascontiguousarray(frame, dtype=np.uint8)

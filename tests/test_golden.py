@@ -1,5 +1,7 @@
-"""Golden fixtures: the oracle must keep producing the committed CRCs (CPU), and the HIP path must
-produce the same CRCs (GPU) — a checksum-of-checksums tie between the two test tiers."""
+"""Golden fixtures. tests/golden/pixel_crc.json holds CRC-32s of full all-colours (2^24) frames produced by the NUMPY
+restatement (oracle/np_restate.py, written from the reference source independently of the C oracle). Three things must
+reproduce them: the numpy restatement itself (so it cannot drift unnoticed), the C oracle (CPU) and the HIP path (GPU) —
+two independently written CPU restatements and the device agree bit for bit on every colour."""
 import importlib.util
 import json
 import os
@@ -9,15 +11,44 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = json.load(open(os.path.join(HERE, "golden", "pixel_crc.json")))
+_DOC = json.load(open(os.path.join(HERE, "golden", "pixel_crc.json")))
+GOLDEN = _DOC["crc32"]
 
 
-def test_oracle_reproduces_committed_crcs():
+def _make_golden():
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-    got = {k: zlib.crc32(v) for k, v in mg.crc_cases().items()}
+    return mg
+
+
+def test_golden_provenance_is_the_numpy_restatement():
+    assert "np_restate" in _DOC["provenance"]["pixels"] and "2^24" in _DOC["provenance"]["pixels"]
+    assert len(GOLDEN) == 8
+
+
+def test_c_oracle_reproduces_committed_crcs():
+    """The C oracle (the checker of every GPU parity test) against CRCs it did not produce."""
+    got = {k: zlib.crc32(v) for k, v in _make_golden().crc_cases().items()}
     assert got == GOLDEN
+
+
+def test_numpy_restatement_reproduces_committed_crcs():
+    """The numpy restatement over all 2^24 colours, every case (about a minute): if it drifts, this fails, not the goldens."""
+    got = {k: zlib.crc32(v) for k, v in _make_golden().np_crc_cases().items()}
+    assert got == {k: v for k, v in GOLDEN.items() if k != "echo_config1_f32"}
+
+
+def test_exact_decimal_to_f32():
+    """f32_from_decimal (the goldens' LUT text reader) is correctly rounded where float()-then-cast rounds twice."""
+    mg = _make_golden()
+    import numpy as np
+    assert mg.f32_from_decimal("0.1") == np.float32(0.1) and mg.f32_from_decimal("1") == np.float32(1)
+    # 1 + 2^-24 + 2^-60 lies just above the midpoint of 1 and 1 + 2^-23: f32 must round up; via double it rounds to the
+    # midpoint first and then to even (down)
+    tok = "1.00000005960464477626738148115280148089681454002857208251953125"
+    assert mg.f32_from_decimal(tok) == np.nextafter(np.float32(1), np.float32(2))
+    assert np.float32(float(tok)) == np.float32(1)
 
 
 @pytest.mark.gpu

@@ -77,3 +77,36 @@ def test_fft_overlap_save_equals_exact_streaming_convolution(oracle, synth, leng
         scale = max(scale, float(np.abs(e).max()))
     assert scale > 0.1
     assert worst <= 2e-5 * max(scale, 1.0), (worst, scale)
+
+
+# ---- audio/hrtf/src/spatial.rs:235-287: the reference's known answers for the coordinate conversions, replayed against
+# the oracle restatement and against the product's host function (libmi355fx_host.so)
+SPATIAL_KATS = [  # (from, to, input, expected): 0 Cartesian, 1 LeftHanded, 2 RightHanded
+    (0, 1, (1.0, 2.0, 3.0), (-2.0, 3.0, 1.0)),    # cartesian_to_left_handed  (spatial.rs:235-252)
+    (0, 2, (1.0, 2.0, 3.0), (-2.0, 3.0, -1.0)),   # cartesian_to_right_handed (spatial.rs:254-270)
+    (1, 0, (1.0, 2.0, 3.0), (3.0, -1.0, 2.0)),    # left_handed_to_cartesian  (spatial.rs:272-287)
+]
+
+
+def test_spatial_known_answers_oracle(oracle):
+    for f, t, v, exp in SPATIAL_KATS:
+        assert oracle.position_convert(f, t, v) == exp
+
+
+def test_spatial_known_answers_host_library():
+    import ctypes as C
+    from mi355fx import cube
+    L = cube.load_host_library()
+    L.mi355host_position_convert.restype = C.c_int
+    L.mi355host_position_convert.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for f, t, v, exp in SPATIAL_KATS:
+        i, o = (C.c_float * 3)(*v), (C.c_float * 3)()
+        assert L.mi355host_position_convert(f, t, i, o) == 0
+        assert tuple(o) == exp
+    # round trips through every pair of systems are the identity (the three maps are signed permutations)
+    import itertools
+    for a, b in itertools.permutations(range(3), 2):
+        i, m, o = (C.c_float * 3)(0.25, -7.5, 3.0), (C.c_float * 3)(), (C.c_float * 3)()
+        assert L.mi355host_position_convert(a, b, i, m) == 0 and L.mi355host_position_convert(b, a, m, o) == 0
+        assert tuple(o) == tuple(i)
+    assert L.mi355host_position_convert(3, 0, (C.c_float * 3)(), (C.c_float * 3)()) == -1
