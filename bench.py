@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--lut-variant", type=int, default=0,
                     help="MI355_FLAG_LUT_VARIANT: 0 auto (default), 6 interpolating kernel only, 5 table kernel only")
     ap.add_argument("--hsv-blocks-per-cu", type=int, default=0, help="MI355_FLAG_HSV_BLOCKS_PER_CU (tuning; 0 = library default)")
+    ap.add_argument("--streams", type=int, default=32, help="concurrent streams of the secondary many-streams measurement (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
     ap.add_argument("--stub", action="store_true",
@@ -192,6 +193,7 @@ def _install_stub(torch, mi355fx, rank):
         def hsv_colorlut_frames_device(self, *a): time.sleep(self.lat)
         def colorlut_kernel_choice(self, fused=False): return (False, 0.0, 0.0)
         def colorlut_kernel_name(self): return "stub"
+        def synchronize(self): pass
         def close(self): pass
 
     mi355fx.Context = Ctx
@@ -270,9 +272,9 @@ def main():
                 marker["ms"] = vals[len(vals) // 2]
             return marker["ms"]
 
-        def hold_count(need):
+        def hold_count(need, nb):
             free, _total = torch.cuda.mem_get_info(dev)
-            cap = int(min(args.max_source_gib * 2 ** 30, 0.6 * free) // per_batch)
+            cap = int(min(args.max_source_gib * 2 ** 30, 0.6 * free) // (nb * FRAME_BYTES))
             return max(1, min(need, cap))
 
         def consume(pool, srcs, n_total, first_index, body):
@@ -289,14 +291,25 @@ def main():
                 done += n
             return fills
 
-        def measure(content, steps, warmup, record, fused=False):
-            """One leg: ramp on scratch batches, W warm-up steps and K timed steps, each on its own pristine batch."""
-            pool = SourcePool(torch, synth, dev, args.batch, content)
-            dsts = [torch.empty((args.batch, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
+        def measure(content, steps, warmup, record, fused=False, streams=None):
+            """One leg: ramp on scratch batches, W warm-up steps and K timed steps, each on its own pristine batch.
+            streams: list of per-stream contexts - frame i of every batch then belongs to stream i and is processed by
+            that stream's own context with one-frame launches (what N independent pipelines issue)."""
+            nb = len(streams) if streams else args.batch
+            pool = SourcePool(torch, synth, dev, nb, content)
+            dsts = [torch.empty((nb, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
             scratch = [pool.new(10_000 + r) for r in range(args.ring)]
             pitch = FRAME_BYTES
 
             def region(srcs_, n, rec, every=EVENT_EVERY):
+                if streams:
+                    for k in range(n):
+                        s_, d_ = srcs_[k % len(srcs_)], dsts[k % len(dsts)]
+                        for i, c in enumerate(streams):
+                            p_ = s_[i].data_ptr()
+                            c.hsvfilter_frames_device(p_, 1, pitch, W, H, W * 4, "RGBA", settings)
+                            c.colorlut_frames_device(p_, pitch, W * 4, d_[i].data_ptr(), pitch, W * 4, 1, W, H, "RGBA")
+                    return []
                 if not fused:
                     return run_region(torch, ctx, srcs_, dsts, settings, n, args.batch, rec, every)
                 evs_ = []
@@ -325,7 +338,7 @@ def main():
                 # the fused entry point builds its table only after 8 calls with unchanged hsv settings, then measures two
                 # launches of each kind: keep that learning phase out of the timed region (out-of-place: scratch stays pristine)
                 region(scratch, 14, False)
-            srcs = [torch.empty((args.batch, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(hold_count(steps + warmup))]
+            srcs = [torch.empty((nb, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(hold_count(steps + warmup, nb))]
             stats = {}
             evs, dts = [], []
 
@@ -404,6 +417,30 @@ def main():
                      "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
                      "colorlut_kernel": ctx.colorlut_kernel_name(), "source_stats": leg["source_stats"]}
 
+        streams_leg = None
+        if not args.no_extra and world == 1 and args.streams > 1:
+            # N independent streams per GPU (config 5 runs 32): one context + HIP stream per stream, one 4K frame per launch;
+            # the streams load the same LUT, so they share one memoised table (mi355_shared_table_count)
+            sctx, sstreams = [], []
+            for _ in range(args.streams):
+                c = mi355fx.Context(local_rank)
+                if not args.stub:
+                    st_ = torch.cuda.Stream(device=dev)
+                    c.set_stream(st_.cuda_stream)
+                    sstreams.append(st_)
+                c.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
+                if args.lut_variant:
+                    c.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
+                sctx.append(c)
+            torch.cuda.synchronize()
+            n_s = max(8, args.steps // 4)
+            leg = measure(args.content, n_s, 24, False, streams=sctx)
+            streams_leg = {"streams_per_gpu": args.streams, "frames_per_s": n_s * args.streams / leg["dt"], "launches": "one 4K frame per launch and stream",
+                           "colorlut_kernel": sctx[0].colorlut_kernel_name(),
+                           "memoised_tables_alive": mi355fx.load_library().mi355_shared_table_count() if not args.stub else 0}
+            for c in sctx:
+                c.close()
+
     fps = sharding.aggregate_throughput(args.steps * args.batch, world, dt)
     ms_per_step = dt / args.steps * 1e3
 
@@ -466,6 +503,8 @@ def main():
             out["fused_chain"] = fused
         if extra:
             out["other_content"] = extra
+        if streams_leg:
+            out["concurrent_streams"] = streams_leg
         if not args.no_cpu_baseline:
             one, mt = cpu_baseline(synth, settings, cube_text, seconds_target=0.5 if args.stub else 12.0)
             out["cpu_baseline"] = one

@@ -3,11 +3,12 @@
 // mi355_selftest_autopick (tests/test_autopick.py). The mechanism around it (events on the stream, table builds) lives in
 // colorlut_kernels.hip.
 //
-//   * learning: compute, compute, table, table - each launch measured and waited for, the first of each kind discarded
-//     (its interval holds one-off costs: code upload, cold caches);
+//   * learning: compute, compute, table, table - four measured launches, the first of each kind discarded (its interval
+//     holds one-off costs: code upload, cold caches). A measurement is only ever POLLED (hipEventQuery), never waited for:
+//     while one is in flight the launches go on, unmeasured, with the kind being learned, so on a host that enqueues far
+//     ahead of the device the learning simply spans more launches;
 //   * afterwards the kind with the smaller time per pixel group serves the launches (3 % hysteresis); every n-th launch
-//     of it is measured (n = 8..32, about one sample per 128 Mpixel), the result is read without blocking when complete
-//     and waited for once it is n-1 launches old;
+//     of it is measured (n = 8..32, about one sample per 128 Mpixel) unless the previous sample is still in flight;
 //   * the kind NOT in use is tried again after probe_period launches (64, doubling up to 1024 while the answer stays the
 //     same, back to 64 when it changes);
 //   * a change of launch size by more than 2x restarts the learning.
@@ -41,13 +42,6 @@ struct AutoDecision {
 inline unsigned auto_sample_every(size_t n_vec) {
   unsigned n = (unsigned)(((size_t)1 << 25) / (n_vec ? n_vec : 1));
   return n < 8 ? 8 : (n > 32 ? 32 : n);
-}
-
-// must the measurement in flight be waited for before this call proceeds?
-inline bool auto_must_wait(const AutoPolicy &A, size_t n_vec) {
-  if (A.pending_kind < 0) return false;
-  const unsigned max_lag = (A.learn < 4 || A.t_compute == 0.0 || A.t_table == 0.0) ? 0 : auto_sample_every(n_vec) - 1;
-  return A.calls - A.pending_call >= max_lag;
 }
 
 // the measurement in flight has completed: ms <= 0 means it could not be read

@@ -595,19 +595,23 @@ int brick_choose(BrickLut &B) {
   return watch_level(B.watch);
 }
 
+// before a brick launch at `level`: a change of level starts a new count (what the counters hold belongs to the old one)
+int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level) {
+  if (level == B.level_since) return MI355_OK;
+  int rc = MI355_OK;
+  if (B.level_since >= 0) rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset");
+  B.level_since = level;
+  B.px_since = 0;
+  B.launches_since = 0;
+  return rc;
+}
+
 int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level) {
   int rc;
-  if (level != B.level_since) {
-    // first launch at a new level: what the counters hold belongs to the old one (stream order: this reset lands after the
-    // launch just made, whose own steps are thereby dropped from the count as well as from px_since)
-    if (B.level_since >= 0 && (rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
-    B.level_since = level;
-    B.px_since = 0;
-    B.launches_since = 0;
-    return MI355_OK;
-  }
   B.px_since += pixels;
-  if (++B.launches_since < kWatchSnapEvery || B.pending) return MI355_OK;
+  // a probe of a lower level is judged on its first launch (it runs the kernel believed slower), the level in use on four
+  const unsigned need = B.watch.probing == level ? 1u : kWatchSnapEvery;
+  if (++B.launches_since < need || B.pending) return MI355_OK;
   if ((rc = check_hip(ctx, hipMemcpyAsync(B.h_counters, B.d_counters, kBrickCounterBytes, hipMemcpyDeviceToHost, ctx->stream), "brick counters snapshot"))) return rc;
   if ((rc = check_hip(ctx, hipMemsetAsync(B.d_counters, 0, kBrickCounterBytes, ctx->stream), "brick counters reset"))) return rc;
   if ((rc = check_hip(ctx, hipEventRecord(B.ev, ctx->stream), "hipEventRecord(brick)"))) return rc;

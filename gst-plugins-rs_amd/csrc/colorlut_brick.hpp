@@ -36,7 +36,8 @@ struct BrickLut {
 
 // Content watch for the interpolating path: level for this launch (0 / 1 = brick kernel with 32 / 64 sets, 2 = three-pass).
 int brick_choose(BrickLut &B);
-// after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
+// before / after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
+int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level);
 int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level);
 
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);

@@ -36,6 +36,9 @@
 
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 namespace mi355 {
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
 
 void lut_release(mi355_ctx *ctx) {
   for (int i = 0; i < 2; i++) {
-    if (ctx->lut.d_table[i]) (void)hipFree(ctx->lut.d_table[i]);
+    ctx->lut.table_ref[i].reset();  // the shared table goes when its last user does
     if (ctx->lut.pick[i].ev0) (void)hipEventDestroy(ctx->lut.pick[i].ev0);
     if (ctx->lut.pick[i].ev1) (void)hipEventDestroy(ctx->lut.pick[i].ev1);
   }
@@ -1086,6 +1089,22 @@ int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const 
     }
   }
   if (is3d && (rc = brick_upload(ctx, L.brick, (int)size, table, scale, offset))) return rc;
+  {
+    // identity of this LUT for the shared-table registry: kind, size, domain and two independent 64-bit hashes of the table
+    uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
+    const unsigned char *b = (const unsigned char *)table;
+    for (size_t i = 0; i < n_floats * sizeof(float); i++) {
+      h1 = (h1 ^ b[i]) * 1099511628211ull;
+      h2 = (h2 + b[i] + 1) * 0xff51afd7ed558ccdull;
+      h2 ^= h2 >> 29;
+    }
+    L.digest.assign((const char *)&h1, 8);
+    L.digest.append((const char *)&h2, 8);
+    L.digest.append((const char *)&is3d, sizeof(is3d));
+    L.digest.append((const char *)&size, sizeof(size));
+    L.digest.append((const char *)scale, 12);
+    L.digest.append((const char *)offset, 12);
+  }
   L.loaded = true;
   return MI355_OK;
 }
@@ -1198,7 +1217,9 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
     if (level < 2) {
       const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
       ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel<HSV> (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel<HSV> (48 sets)" : "colorlut3d_brick_kernel<HSV>");
-      int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs, sets);
+      int rc = (build || pinned) ? MI355_OK : brick_before_launch(ctx, B, level);
+      if (rc) return rc;
+      rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs, sets);
       if (rc || build || pinned) return rc;
       return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
     }
@@ -1289,7 +1310,9 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       if (level < 2) {
         const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
         ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel");
-        int rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr, sets);
+        int rc = (build || pinned) ? MI355_OK : brick_before_launch(ctx, B, level);
+        if (rc) return rc;
+        rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr, sets);
         if (rc || build || pinned) return rc;
         return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
       }
@@ -1380,25 +1403,88 @@ static bool rgba8_flat(const uint8_t *d_src, size_t src_pitch, int src_stride, c
 
 static bool same_hs(const mi355_hsv_settings &a, const mi355_hsv_settings &b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
-// Builds table `which` (0: colorlut, 1: hsvfilter -> colorlut under *hs) in the requested layout unless it is current:
-// the table buffer is filled with the colour of every slot and the exact compute path is run over it in place, all on
-// the context's stream with no host wait.
+// ---- memoised tables are shared between contexts
+// A table is a pure function of what it was built from (LUT contents and domain, index layout, hsv settings), so every
+// context of a process that asks for the same one on the same device gets the same 64 MiB: 32 streams with one LUT hold one
+// table, not 32 that evict each other from L2 and the Infinity Cache. The registry holds weak references; the context
+// that creates an entry enqueues the build on its own stream and records `ready` there, all under the registry lock, and
+// every other context makes its stream wait for that event once (hipStreamWaitEvent: no host wait). The table is freed
+// when its last user lets go.
+struct SharedTable {
+  uint32_t *d = nullptr;
+  hipEvent_t ready = nullptr;
+  int device = 0;
+  ~SharedTable() {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
+    if (d) (void)hipFree(d);
+    (void)hipSetDevice(cur);
+  }
+};
+static std::mutex g_tables_mu;
+static std::map<std::string, std::weak_ptr<SharedTable>> g_tables;
+
+// `build(table)` enqueues the kernels that fill a fresh table on ctx->stream. On return *out is usable on ctx->stream.
+template <class Build>
+static int shared_table_acquire(mi355_ctx *ctx, const std::string &key, std::shared_ptr<void> *ref, uint32_t **out, Build &&build) {
+  std::lock_guard<std::mutex> g(g_tables_mu);
+  for (auto it = g_tables.begin(); it != g_tables.end();) it = it->second.expired() ? g_tables.erase(it) : std::next(it);
+  const std::string full = std::string((const char *)&ctx->device, sizeof(ctx->device)) + key;
+  if (auto sp = g_tables[full].lock()) {
+    int rc = check_hip(ctx, hipStreamWaitEvent(ctx->stream, sp->ready, 0), "hipStreamWaitEvent(shared table)");
+    if (rc) return rc;
+    *out = sp->d;
+    *ref = sp;
+    return MI355_OK;
+  }
+  auto sp = std::make_shared<SharedTable>();
+  sp->device = ctx->device;
+  int rc = check_hip(ctx, hipMalloc((void **)&sp->d, (size_t)kTableEntries * 4), "hipMalloc(memoised table)");
+  if (rc) return rc;
+  if ((rc = check_hip(ctx, hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming), "hipEventCreate(shared table)"))) return rc;
+  if ((rc = build(sp->d))) return rc;
+  if ((rc = check_hip(ctx, hipEventRecord(sp->ready, ctx->stream), "hipEventRecord(shared table)"))) return rc;
+  g_tables[full] = sp;
+  *out = sp->d;
+  *ref = sp;
+  return MI355_OK;
+}
+
+extern "C" int mi355_shared_table_count(void) {
+  std::lock_guard<std::mutex> g(g_tables_mu);
+  int n = 0;
+  for (auto &kv : g_tables) n += kv.second.expired() ? 0 : 1;
+  return n;
+}
+
+// Makes table `which` (0: colorlut, 1: hsvfilter -> colorlut under *hs) in the requested layout current for this context:
+// shared with every context that loaded the same LUT (and, for 1, uses the same settings); built - table filled with the
+// colour of every slot, exact compute path run over it in place, on the stream, no host wait - only if nobody has it.
 static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_settings *hs) {
   LutDevice &L = ctx->lut;
-  if (L.d_table[which] && L.table_morton[which] == morton && (which == 0 || same_hs(L.table_hs, *hs))) return MI355_OK;
-  int rc;
-  if (!L.d_table[which] && (rc = check_hip(ctx, hipMalloc((void **)&L.d_table[which], (size_t)kTableEntries * 4), "hipMalloc(colorlut table)")))
-    return rc;
-  uint8_t *t = (uint8_t *)L.d_table[which];
+  std::string key(which ? "F" : "L");
+  key.push_back((char)('0' + morton));
+  key += L.digest;
+  if (which) key.append((const char *)hs, sizeof(*hs));
+  if (L.table_ref[which] && L.table_key[which] == key) return MI355_OK;
+  L.table_ref[which].reset();
+  L.d_table[which] = nullptr;
   L.table_morton[which] = -1;
-  hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, L.d_table[which], morton);
-  L.building_table = true;
-  const char *serving = L.last_kernel;
-  rc = which == 0 ? launch_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, MI355_FMT_RGBA)
-                  : launch_hsv_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, *hs, true);
-  L.building_table = false;
-  L.last_kernel = serving;
-  if (rc) return rc;
+  int rc = shared_table_acquire(ctx, key, &L.table_ref[which], &L.d_table[which], [&](uint32_t *tab) {
+    uint8_t *t = (uint8_t *)tab;
+    hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, tab, morton);
+    L.building_table = true;
+    const char *serving = L.last_kernel;
+    const int r = which == 0 ? launch_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, MI355_FMT_RGBA)
+                             : launch_hsv_colorlut_compute(ctx, t, 0, 4096 * 4, t, 0, 4096 * 4, 1, 4096, 4096, *hs, true);
+    L.building_table = false;
+    L.last_kernel = serving;
+    return r;
+  });
+  if (rc) { L.table_ref[which].reset(); L.d_table[which] = nullptr; return rc; }
+  L.table_key[which] = key;
   L.table_morton[which] = morton;
   if (which == 1) L.table_hs = *hs;
   return MI355_OK;
@@ -1446,12 +1532,12 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
 // which one is faster depends on the content (the table kernel's gathers need colour locality: 0.18 vs 0.25 ms per
 // 8x4K on natural-like frames, 1.2 vs 0.40 ms on uniform noise), on the LUT size (the table kernel does not care) and on
 // the launch size. Auto keeps a per-pixel-group time for each kind, measured with event pairs that are recorded around
-// every n-th launch (n = 8..32, about one sample per 128 Mpixel) and read back at the start of a later launch - without
-// blocking if the events have completed, and blocking once the sample is n-1 launches old, which bounds how far a host
-// that enqueues in bursts can run ahead of the decision while the device still has n-2 launches queued:
-//   * the first four eligible launches after a LUT load run compute, compute, table build + table, table, each waited
-//     for; the first launch of each kind is not used (its interval holds one-off costs: code upload, cold caches);
-//     from then on the kind with the smaller time serves the launches;
+// every n-th launch (n = 8..32, about one sample per 128 Mpixel) and read back at the start of a later launch, by polling
+// only (hipEventQuery): nothing here ever blocks the calling thread on the device:
+//   * after a LUT load four measured launches run compute, compute, table build + table, table (unmeasured launches of
+//     the same kind in between while a measurement is still in flight); the first measurement of each kind is not used
+//     (its interval holds one-off costs: code upload, cold caches); from then on the kind with the smaller time serves
+//     the launches;
 //   * the kind in use keeps being sampled, so content that turns hostile to the table (its time rises above the compute
 //     kernel's last time) flips the choice at the next sample;
 //   * the kind NOT in use is tried again after `probe_period` launches (64, doubling up to 1024 while the answer stays
@@ -1460,11 +1546,10 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
 // 1, 2, 6 = compute kernels only (6 = the default compute kernel), 4 / 5 = table kernel only (linear / Morton index).
 // The same policy, with its own state and table, serves the fused hsvfilter -> colorlut entry point.
 // The policy itself is autopick.hpp (HIP-free, unit-tested on the CPU); this is the mechanism around it.
-static void auto_harvest(AutoPick &A, size_t n_vec) {
+static void auto_harvest(AutoPick &A) {
   if (A.pending_kind < 0) return;
-  if (auto_must_wait(A, n_vec)) {
-    if (hipEventSynchronize(A.ev1) != hipSuccess) { (void)hipGetLastError(); auto_complete(A, 0.0); return; }
-  } else if (hipEventQuery(A.ev1) != hipSuccess) {
+  // poll, never wait: the streaming thread must not block on the device for a bookkeeping measurement
+  if (hipEventQuery(A.ev1) != hipSuccess) {
     (void)hipGetLastError();
     return;  // not finished yet: look again at a later call
   }
@@ -1481,7 +1566,7 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev0), "hipEventCreate"))) return rc;
     if ((rc = check_hip(ctx, hipEventCreate(&A.ev1), "hipEventCreate"))) return rc;
   }
-  auto_harvest(A, n_vec);
+  auto_harvest(A);
   const AutoDecision D = auto_decide(A, n_vec);
   if (D.kind == 1 && (rc = ensure())) {  // a table build stays outside the measurement
     // no memory for the 64 MiB table (or the build failed): this entry point stays on the compute kernel for good
@@ -1535,7 +1620,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
   else { L.seen_hs = hs; L.seen_stable = 0; }
-  const bool have = L.d_table[1] && L.table_morton[1] == 1 && same_hs(L.table_hs, hs);
+  const bool have = L.table_ref[1] && L.table_morton[1] == 1 && same_hs(L.table_hs, hs);
   if (!have && L.seen_stable < kStableCalls) return compute();
   if (!have && L.pick[1].learn > 2) {  // the table kernel's time belongs to the old table only loosely: measure it again
     L.pick[1].t_table = 0.0;
@@ -1557,7 +1642,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
 // 26.3-27.4 k to 24.6 k frames/s with both tables live.
 void hsv_table_release(mi355_ctx *ctx) {
   HsvTable &T = ctx->hsv_table;
-  if (T.d_table) (void)hipFree(T.d_table);
+  T.table_ref.reset();
   if (T.pick.ev0) (void)hipEventDestroy(T.pick.ev0);
   if (T.pick.ev1) (void)hipEventDestroy(T.pick.ev1);
   T = HsvTable{};
@@ -1566,11 +1651,17 @@ void hsv_table_release(mi355_ctx *ctx) {
 static int hsv_table_ensure(mi355_ctx *ctx, const PixFmt &fmt, const mi355_hsv_settings &hs) {
   HsvTable &T = ctx->hsv_table;
   if (T.valid && T.bgr == fmt.bgr && same_hs(T.hs, hs)) return MI355_OK;
-  int rc;
-  if (!T.d_table && (rc = check_hip(ctx, hipMalloc((void **)&T.d_table, (size_t)kTableEntries * 4), "hipMalloc(hsvfilter table)"))) return rc;
   T.valid = false;
-  hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, T.d_table, 1);
-  if ((rc = launch_hsvfilter_compute(ctx, (uint8_t *)T.d_table, 1, 0, 4096, 4096, 4096 * 4, fmt, hs))) return rc;
+  T.table_ref.reset();
+  T.d_table = nullptr;
+  std::string key("H");
+  key.push_back((char)('0' + fmt.bgr));
+  key.append((const char *)&hs, sizeof(hs));
+  int rc = shared_table_acquire(ctx, key, &T.table_ref, &T.d_table, [&](uint32_t *tab) {
+    hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, tab, 1);
+    return launch_hsvfilter_compute(ctx, (uint8_t *)tab, 1, 0, 4096, 4096, 4096 * 4, fmt, hs);
+  });
+  if (rc) { T.table_ref.reset(); T.d_table = nullptr; return rc; }
   T.valid = true;
   T.bgr = fmt.bgr;
   T.hs = hs;
@@ -1612,7 +1703,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
 
 // Runs the kernel-choice policy (autopick.hpp) against a scripted device: call i has n_vec[i] pixel groups; if it is
 // measured, its interval is ms_compute[i] or ms_table[i] depending on the kind it ran, and the measurement becomes readable
-// `lag` calls later (or at once when the policy insists on waiting). kind_out[i] = 0 / 1, measured_out[i] = 0 / 1.
+// `lag` calls later (the policy never waits). kind_out[i] = 0 / 1, measured_out[i] = 0 / 1.
 // No device, no context: host logic only (tests/test_autopick.py).
 // Runs the content-watch policy (brickwatch.hpp) against a scripted stream: call i would produce the miss / slow fractions
 // miss0[i], slow0[i] on the 32-set brick kernel and miss1[i], slow1[i] on the 64-set one; a snapshot covers kWatchSnapEvery
@@ -1631,7 +1722,7 @@ extern "C" int mi355_selftest_brickwatch(int n_calls, const double *miss0, const
     if (level != level_since) { level_since = level; launches_since = 0; acc_m = acc_s = 0; }
     acc_m += level ? miss1[i] : miss0[i];
     acc_s += level ? slow1[i] : slow0[i];
-    if (++launches_since >= (int)mi355::kWatchSnapEvery) {
+    if (++launches_since >= (W.probing == level ? 1 : (int)mi355::kWatchSnapEvery)) {
       pend_level = level; pend_m = acc_m / launches_since; pend_s = acc_s / launches_since; pend_ready = i + 1 + lag;
       launches_since = 0; acc_m = acc_s = 0;
     }
@@ -1646,7 +1737,7 @@ extern "C" int mi355_selftest_autopick(int n_calls, const uint64_t *n_vec, const
   double pending_ms = 0.0;
   for (int i = 0; i < n_calls; i++) {
     const size_t nv = (size_t)n_vec[i];
-    if (A.pending_kind >= 0 && (mi355::auto_must_wait(A, nv) || A.calls - A.pending_call >= (unsigned)lag)) mi355::auto_complete(A, pending_ms);
+    if (A.pending_kind >= 0 && A.calls - A.pending_call >= (unsigned)lag) mi355::auto_complete(A, pending_ms);
     const mi355::AutoDecision D = mi355::auto_decide(A, nv);
     kind_out[i] = D.kind;
     if (measured_out) measured_out[i] = D.measure ? 1 : 0;

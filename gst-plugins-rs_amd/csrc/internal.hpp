@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include "../../include/mi355fx.h"
 
@@ -33,7 +34,10 @@ struct LutDevice {
   bool lds_ok = false;        // LDS fast path legal for this LUT (fits, finite, bounded)
   // 2^24-entry memoised tables (RGBA8): see colorlut_table_kernel. [0] = colorlut alone, [1] = hsvfilter -> colorlut
   // under the hsv settings in table_hs.
-  uint32_t *d_table[2] = {nullptr, nullptr};
+  uint32_t *d_table[2] = {nullptr, nullptr};   // = table_ref[i]'s device pointer (shared between contexts, see SharedTable)
+  std::shared_ptr<void> table_ref[2];          // keeps the shared table alive while this context uses it
+  std::string table_key[2];                    // what the table in use was built from
+  std::string digest;                          // identifies the loaded LUT (contents, size, kind, domain) in table keys
   int table_morton[2] = {-1, -1};  // layout of the table: 0 linear, 1 Morton, -1 not built
   mi355_hsv_settings table_hs{};   // settings d_table[1] was built for
   mi355_hsv_settings seen_hs{};    // settings of the previous fused call and for how many calls they have not changed
@@ -48,7 +52,8 @@ struct LutDevice {
 // hsvfilter through a memoised table (colorlut_kernels.hip: launch_hsvfilter): the table of the element's per-pixel
 // function under `hs` for colour-first 4-byte formats (bgr selects the byte order the table was built for).
 struct HsvTable {
-  uint32_t *d_table = nullptr;
+  uint32_t *d_table = nullptr;         // = table_ref's device pointer
+  std::shared_ptr<void> table_ref;
   bool valid = false;
   int bgr = 0;
   mi355_hsv_settings hs{};       // settings the table was built for

@@ -86,6 +86,7 @@ def load_library():
         "mi355_colorlut_unload": (i, [vp]),
         "mi355_selftest_autopick": (i, [i, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mi355_colorlut_kernel_choice": (i, [vp, i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "mi355_shared_table_count": (i, []),
         "mi355_colorlut_last_kernel": (C.c_char_p, [vp]),
         "mi355_colorlut_brick_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_int), i]),
         "mi355_selftest_brickwatch": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int)]),

@@ -166,6 +166,9 @@ int mi355_colorlut_unload(mi355_ctx *ctx);
  * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran). No reference
  * counterpart. */
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
+/* Number of memoised 64 MiB tables alive in this process (tables are shared by all contexts that ask for the same
+ * function on the same device: same LUT and layout, same hsv settings). Diagnostic; no reference counterpart. */
+int mi355_shared_table_count(void);
 /* Name of the kernel that served the last mi355_colorlut_* / mi355_hsv_colorlut_* launch of this context ("" before the
  * first one). Diagnostic; no reference counterpart. */
 const char *mi355_colorlut_last_kernel(mi355_ctx *ctx);

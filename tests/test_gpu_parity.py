@@ -922,3 +922,37 @@ def test_device_entry_points_reject_overlapping_frames(ctx, oracle, synth):
         ctx.synchronize()
     finally:
         ctx.free(d)
+
+
+def test_memoised_tables_are_shared_between_contexts(oracle, synth, mi355lib):
+    """Contexts that load the same LUT use ONE 64 MiB table (32 streams with one LUT: one table, not 32); a different LUT
+    gets its own; tables go away with their last user; results stay exact throughout."""
+    import mi355fx
+    base = mi355lib.mi355_shared_table_count()
+    text_a, text_b = synth.cube_text_3d(33), synth.cube_text_3d(17, amp=0.09)
+    cube_a, cube_b = oracle.Cube.parse(text_a), oracle.Cube.parse(text_b)
+    frame = synth.smooth_frame(512, 64)
+    exp_a, exp_b = np.zeros_like(frame), np.zeros_like(frame)
+    oracle.colorlut_rgba8(cube_a, frame, 512 * 4, exp_a, 512 * 4, 512, 64)
+    oracle.colorlut_rgba8(cube_b, frame, 512 * 4, exp_b, 512 * 4, 512, 64)
+    ctxs = [mi355fx.Context(0) for _ in range(5)]
+    try:
+        for i, c in enumerate(ctxs):
+            cube = cube_b if i == 4 else cube_a
+            sc, of = cube.domain
+            c.colorlut_load(cube.is3d, cube.size, cube.table, sc, of)
+            c.set_flag(mi355fx.FLAG_LUT_VARIANT, 5)
+        for rep in range(2):
+            for i, c in enumerate(ctxs):
+                got = np.zeros_like(frame)
+                c.colorlut_frame(frame, 512 * 4, got, 512 * 4, 512, 64, "RGBA")
+                assert (got == (exp_b if i == 4 else exp_a)).all(), (rep, i)
+        assert mi355lib.mi355_shared_table_count() == base + 2
+        ctxs[4].close()
+        assert mi355lib.mi355_shared_table_count() == base + 1
+        ctxs[0].colorlut_unload()
+        assert mi355lib.mi355_shared_table_count() == base + 1      # three users left
+    finally:
+        for c in ctxs[:4]:
+            c.close()
+    assert mi355lib.mi355_shared_table_count() == base
