@@ -549,6 +549,23 @@ int mi355_ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsign
   BIND_DEVICE(ctx);
   return ebur128_setup(ctx, channels, rate, mode, channel_class);
 }
+int mi355_ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_setup_batch(ctx, n_streams, channels, rate, mode, channel_class);
+}
+int mi355_ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int sample_format) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_add_frames_batch(ctx, data, frames, sample_format, 0);
+}
+int mi355_ebur128_add_frames_batch_device(mi355_ctx *ctx, const void *d_data, size_t frames, int sample_format) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return ebur128_add_frames_batch(ctx, d_data, frames, sample_format, 1);
+}
+int mi355_ebur128_loudness_batch(mi355_ctx *ctx, int what, double *out) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return ebur128_query_batch(ctx, what, out); }
+int mi355_ebur128_peak_batch(mi355_ctx *ctx, int true_peak, double *out) { REQUIRE_CTX(ctx); return ebur128_peak_batch(ctx, true_peak, out); }
 int mi355_ebur128_reset(mi355_ctx *ctx) {
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);

@@ -59,7 +59,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
                                                         double *__restrict__ ring, size_t ring_frame0, unsigned channels,
                                                         const int *__restrict__ channel_class, double *__restrict__ vstate,
-                                                        unsigned long long *__restrict__ peak, EbFilterK k) {
+                                                        unsigned long long *__restrict__ peak, EbFilterK k, size_t src_ss, size_t ring_ss) {
+  // batch of independent streams: block y works on stream y (src_ss / ring_ss = elements between consecutive streams)
+  src += (size_t)blockIdx.y * src_ss;
+  ring += (size_t)blockIdx.y * ring_ss;
+  vstate += (size_t)blockIdx.y * channels * 4;
+  if (peak) peak += (size_t)blockIdx.y * 2 * channels;
   extern __shared__ double eb_sm[];          // [channels][kEbChunk + 4] : 4 carried v values, then x -> v in place
   __shared__ unsigned long long s_peak[64];
   const unsigned tid = threadIdx.x;
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ sr
 // eb_energy_final_kernel: fixed-order sum over the blocks, channel weights, division -> out[slot] (deterministic).
 constexpr unsigned kEbEnergyBlocks = 32;
 __global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *__restrict__ ring, size_t ring_frames, size_t end_frame,
-                                                                  size_t frames, unsigned channels, double *__restrict__ partial, unsigned slot) {
+                                                                  size_t frames, unsigned channels, double *__restrict__ partial, unsigned slot,
+                                                                  size_t ring_ss, unsigned slots_per_stream) {
+  ring += (size_t)blockIdx.y * ring_ss;
+  partial += (size_t)blockIdx.y * slots_per_stream * gridDim.x * channels;
   __shared__ double wave_sum[kEbNT / 64];
   const size_t per = (frames + gridDim.x - 1) / gridDim.x;
   const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < frames ? i0 + per : frames;
@@ -175,7 +183,10 @@ __global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *
 }
 
 __global__ __launch_bounds__(64) void eb_energy_final_kernel(const double *__restrict__ partial, unsigned blocks, size_t frames, unsigned channels,
-                                                             const int *__restrict__ channel_class, double *__restrict__ out, unsigned slot) {
+                                                             const int *__restrict__ channel_class, double *__restrict__ out, unsigned slot,
+                                                             unsigned slots_per_stream) {
+  partial += (size_t)blockIdx.x * slots_per_stream * blocks * channels;
+  out += (size_t)blockIdx.x * slots_per_stream;
   if (threadIdx.x != 0) return;
   double total = 0.0;
   for (unsigned c = 0; c < channels; c++) {
@@ -201,8 +212,11 @@ struct EbInterpK {
 template <typename T>
 __global__ __launch_bounds__(kEbNT) void eb_truepeak_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
                                                             float *__restrict__ tail, unsigned long long *__restrict__ peak,
-                                                            EbInterpK ik) {
+                                                            EbInterpK ik, size_t src_ss, unsigned channels) {
   const unsigned c = blockIdx.x;
+  src += (size_t)blockIdx.y * src_ss;
+  tail += (size_t)blockIdx.y * channels * ik.delay;
+  peak += (size_t)blockIdx.y * 2 * channels;
   const T *sp = src + (size_t)c * stride_c;
   float *tl = tail + (size_t)c * ik.delay;
   __shared__ double wave_max[kEbNT / 64];
@@ -245,14 +259,15 @@ __global__ __launch_bounds__(kEbNT) void eb_truepeak_kernel(const T *__restrict_
 // ---------------------------------------------------------------- host side state machine
 
 struct Ebur128State {
+  unsigned n_streams = 1;  // independent streams of identical configuration advancing in lock step (batch entry points)
   unsigned channels = 0, rate = 0, mode = 0;
   std::vector<int> channel_class;
   EbFilterK fk{};
   EbInterpK ik{};
   bool have_interp = false;
   size_t samples_in_100ms = 0, ring_frames = 0, index_frames = 0, needed_frames = 0, st_counter = 0;
-  unsigned long block_hist[kHistBins] = {0}, st_hist[kHistBins] = {0};
-  std::vector<double> sample_peak, true_peak;
+  std::vector<unsigned long> block_hist, st_hist;  // [n_streams][kHistBins]
+  std::vector<double> sample_peak, true_peak;      // [n_streams][channels]
   // device
   double *d_ring = nullptr, *d_vstate = nullptr, *d_energy = nullptr, *d_partial = nullptr;
   int *d_class = nullptr;
@@ -344,19 +359,22 @@ void ebur128_release(mi355_ctx *ctx) {
 }
 
 static int eb_reset_device(mi355_ctx *ctx, Ebur128State *st) {
-  int rc = check_hip(ctx, hipMemsetAsync(st->d_ring, 0, st->ring_frames * st->channels * sizeof(double), ctx->stream), "hipMemset(ebur128 ring)");
+  const size_t S = st->n_streams;
+  int rc = check_hip(ctx, hipMemsetAsync(st->d_ring, 0, S * st->ring_frames * st->channels * sizeof(double), ctx->stream), "hipMemset(ebur128 ring)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMemsetAsync(st->d_vstate, 0, st->channels * 4 * sizeof(double), ctx->stream), "hipMemset(ebur128 state)");
+  rc = check_hip(ctx, hipMemsetAsync(st->d_vstate, 0, S * st->channels * 4 * sizeof(double), ctx->stream), "hipMemset(ebur128 state)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMemsetAsync(st->d_peak, 0, 2 * st->channels * sizeof(unsigned long long), ctx->stream), "hipMemset(ebur128 peaks)");
+  rc = check_hip(ctx, hipMemsetAsync(st->d_peak, 0, S * 2 * st->channels * sizeof(unsigned long long), ctx->stream), "hipMemset(ebur128 peaks)");
   if (rc) return rc;
-  if (st->d_tail) rc = check_hip(ctx, hipMemsetAsync(st->d_tail, 0, st->channels * st->ik.delay * sizeof(float), ctx->stream), "hipMemset(ebur128 tail)");
+  if (st->d_tail) rc = check_hip(ctx, hipMemsetAsync(st->d_tail, 0, S * st->channels * st->ik.delay * sizeof(float), ctx->stream), "hipMemset(ebur128 tail)");
   return rc;
 }
 
-int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
+// n_streams independent meters of one configuration that are fed in lock step (ebur128_setup = one stream)
+int ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
   hist_tables();
   ebur128_release(ctx);
+  if (n_streams == 0 || n_streams > 65535) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: bad stream count");
   if (channels == 0 || channels > 64 || rate < 16 || rate > 2822400) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: bad channels/rate");
   // cumulative mode bits as in libebur128 (TRUE_PEAK -> SAMPLE_PEAK, LRA -> S, S/I -> M)
   if (mode & EB_TRUE_PEAK) mode |= EB_SAMPLE_PEAK;
@@ -364,6 +382,7 @@ int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mod
   if (mode & (EB_S | EB_I)) mode |= EB_M;
   Ebur128State *st = new Ebur128State();
   ctx->ebur128 = st;
+  st->n_streams = n_streams;
   st->channels = channels; st->rate = rate; st->mode = mode;
   st->channel_class.assign(channels, 1);
   for (unsigned c = 0; c < channels; c++) {
@@ -377,22 +396,25 @@ int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mod
   st->ring_frames = (size_t)rate * window / 1000;
   if (st->ring_frames % st->samples_in_100ms) st->ring_frames += st->samples_in_100ms - st->ring_frames % st->samples_in_100ms;
   st->needed_frames = st->samples_in_100ms * 4;
-  st->sample_peak.assign(channels, 0.0);
-  st->true_peak.assign(channels, 0.0);
+  const size_t S = n_streams;
+  st->block_hist.assign(S * kHistBins, 0ul);
+  st->st_hist.assign(S * kHistBins, 0ul);
+  st->sample_peak.assign(S * channels, 0.0);
+  st->true_peak.assign(S * channels, 0.0);
   if ((mode & EB_TRUE_PEAK) && rate < 192000) {
     interp_tables(49, rate < 96000 ? 4 : 2, &st->ik);
     st->have_interp = true;
   }
-  int rc = check_hip(ctx, hipMalloc((void **)&st->d_ring, st->ring_frames * channels * sizeof(double)), "hipMalloc(ebur128 ring)");
+  int rc = check_hip(ctx, hipMalloc((void **)&st->d_ring, S * st->ring_frames * channels * sizeof(double)), "hipMalloc(ebur128 ring)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMalloc((void **)&st->d_vstate, channels * 4 * sizeof(double)), "hipMalloc(ebur128 state)");
+  rc = check_hip(ctx, hipMalloc((void **)&st->d_vstate, S * channels * 4 * sizeof(double)), "hipMalloc(ebur128 state)");
   if (rc) return rc;
   rc = check_hip(ctx, hipMalloc((void **)&st->d_class, channels * sizeof(int)), "hipMalloc(ebur128 classes)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMalloc((void **)&st->d_peak, 2 * channels * sizeof(unsigned long long)), "hipMalloc(ebur128 peaks)");
+  rc = check_hip(ctx, hipMalloc((void **)&st->d_peak, S * 2 * channels * sizeof(unsigned long long)), "hipMalloc(ebur128 peaks)");
   if (rc) return rc;
   if (st->have_interp) {
-    rc = check_hip(ctx, hipMalloc((void **)&st->d_tail, channels * st->ik.delay * sizeof(float)), "hipMalloc(ebur128 tail)");
+    rc = check_hip(ctx, hipMalloc((void **)&st->d_tail, S * channels * st->ik.delay * sizeof(float)), "hipMalloc(ebur128 tail)");
     if (rc) return rc;
   }
   rc = check_hip(ctx, hipMemcpyAsync(st->d_class, st->channel_class.data(), channels * sizeof(int), hipMemcpyHostToDevice, ctx->stream),
@@ -403,85 +425,103 @@ int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mod
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
 
+int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
+  return ebur128_setup_batch(ctx, 1, channels, rate, mode, channel_class);
+}
+
 int ebur128_reset(mi355_ctx *ctx) {
   Ebur128State *st = (Ebur128State *)ctx->ebur128;
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
-  std::memset(st->block_hist, 0, sizeof st->block_hist);
-  std::memset(st->st_hist, 0, sizeof st->st_hist);
+  std::fill(st->block_hist.begin(), st->block_hist.end(), 0ul);
+  std::fill(st->st_hist.begin(), st->st_hist.end(), 0ul);
   st->index_frames = 0; st->needed_frames = st->samples_in_100ms * 4; st->st_counter = 0;
-  st->sample_peak.assign(st->channels, 0.0);
-  st->true_peak.assign(st->channels, 0.0);
+  std::fill(st->sample_peak.begin(), st->sample_peak.end(), 0.0);
+  std::fill(st->true_peak.begin(), st->true_peak.end(), 0.0);
   int rc = eb_reset_device(ctx, st);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
 
-// energy of the last `frames` ring frames -> d_energy[slot]
+// energy of the last `frames` ring frames of every stream -> d_energy[stream][slot]
 static void eb_launch_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, unsigned slot) {
-  hipLaunchKernelGGL(eb_energy_partial_kernel, dim3(kEbEnergyBlocks), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring, st->ring_frames,
-                     st->index_frames, frames, st->channels, st->d_partial, slot);
-  hipLaunchKernelGGL(eb_energy_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)st->d_partial, kEbEnergyBlocks, frames, st->channels,
-                     (const int *)st->d_class, st->d_energy, slot);
+  const size_t ring_ss = st->ring_frames * st->channels;
+  hipLaunchKernelGGL(eb_energy_partial_kernel, dim3(kEbEnergyBlocks, st->n_streams), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring,
+                     st->ring_frames, st->index_frames, frames, st->channels, st->d_partial, slot, ring_ss, (unsigned)st->energy_cap);
+  hipLaunchKernelGGL(eb_energy_final_kernel, dim3(st->n_streams), dim3(64), 0, ctx->stream, (const double *)st->d_partial, kEbEnergyBlocks, frames,
+                     st->channels, (const int *)st->d_class, st->d_energy, slot, (unsigned)st->energy_cap);
 }
 
+// src_ss: elements between the buffers of consecutive streams
 template <typename T>
-static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, size_t frame0, size_t n, size_t stride_f, size_t stride_c) {
+static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, size_t frame0, size_t n, size_t stride_f, size_t stride_c, size_t src_ss) {
   const T *p = d_src + frame0 * stride_f;
   unsigned long long *speak = (st->mode & EB_SAMPLE_PEAK) ? st->d_peak : nullptr;
   if (st->have_interp)
-    hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_tail,
-                       st->d_peak + st->channels, st->ik);
+    hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels, st->n_streams), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_tail,
+                       st->d_peak + st->channels, st->ik, src_ss, st->channels);
   const size_t filter_lds = (size_t)st->channels * (kEbChunk + 4) * sizeof(double);
   (void)hipFuncSetAttribute((const void *)eb_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds);
-  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1), dim3(256), filter_lds, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
-                     st->index_frames, st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk);
+  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1, st->n_streams), dim3(256), filter_lds, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
+                     st->index_frames, st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk, src_ss, st->ring_frames * st->channels);
 }
 
-// fmt: 0 s16, 1 s32, 2 f32, 3 f64. `planes`: nullptr for interleaved `data`, else `channels` plane pointers.
+static int eb_energy_capacity(mi355_ctx *ctx, Ebur128State *st, size_t events) {
+  if (st->energy_cap >= events) return MI355_OK;
+  if (st->d_energy) (void)hipFree(st->d_energy);
+  if (st->d_partial) (void)hipFree(st->d_partial);
+  st->d_energy = nullptr; st->d_partial = nullptr; st->energy_cap = 0;
+  int rc = check_hip(ctx, hipMalloc((void **)&st->d_energy, st->n_streams * events * sizeof(double)), "hipMalloc(ebur128 energies)");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMalloc((void **)&st->d_partial, st->n_streams * events * kEbEnergyBlocks * st->channels * sizeof(double)), "hipMalloc(ebur128 partial energies)");
+  if (rc) return rc;
+  st->energy_cap = events;
+  return MI355_OK;
+}
+
+// fmt: 0 s16, 1 s32, 2 f32, 3 f64. `planes`: nullptr for interleaved `data`, else `channels` plane pointers (one stream only).
+// Batch: `data` holds n_streams buffers of frames x channels interleaved samples back to back.
 template <typename T>
-static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, const T *const *planes, size_t frames) {
+static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, const T *const *planes, size_t frames, bool device_data) {
   if (frames == 0) return MI355_OK;
   const unsigned C = st->channels;
-  const size_t bytes = frames * C * sizeof(T);
-  if (st->d_in_bytes < bytes) {
-    if (st->d_in) (void)hipFree(st->d_in);
-    st->d_in = nullptr; st->d_in_bytes = 0;
-    int rc = check_hip(ctx, hipMalloc(&st->d_in, bytes), "hipMalloc(ebur128 input)");
-    if (rc) return rc;
-    st->d_in_bytes = bytes;
-  }
+  const size_t S = st->n_streams;
+  const size_t bytes = S * frames * C * sizeof(T);
+  const T *d_src = data;
   size_t stride_f, stride_c;
-  if (planes) {
-    for (unsigned c = 0; c < C; c++) {
-      int rc = check_hip(ctx, hipMemcpyAsync((T *)st->d_in + (size_t)c * frames, planes[c], frames * sizeof(T), hipMemcpyHostToDevice, ctx->stream),
-                         "hipMemcpyAsync(ebur128 plane)");
-      if (rc) return rc;
-    }
-    stride_f = 1; stride_c = frames;
-  } else {
-    int rc = check_hip(ctx, hipMemcpyAsync(st->d_in, data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(ebur128 input)");
-    if (rc) return rc;
+  if (device_data) {
     stride_f = C; stride_c = 1;
+  } else {
+    if (st->d_in_bytes < bytes) {
+      if (st->d_in) (void)hipFree(st->d_in);
+      st->d_in = nullptr; st->d_in_bytes = 0;
+      int rc = check_hip(ctx, hipMalloc(&st->d_in, bytes), "hipMalloc(ebur128 input)");
+      if (rc) return rc;
+      st->d_in_bytes = bytes;
+    }
+    if (planes) {
+      for (unsigned c = 0; c < C; c++) {
+        int rc = check_hip(ctx, hipMemcpyAsync((T *)st->d_in + (size_t)c * frames, planes[c], frames * sizeof(T), hipMemcpyHostToDevice, ctx->stream),
+                           "hipMemcpyAsync(ebur128 plane)");
+        if (rc) return rc;
+      }
+      stride_f = 1; stride_c = frames;
+    } else {
+      int rc = check_hip(ctx, hipMemcpyAsync(st->d_in, data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(ebur128 input)");
+      if (rc) return rc;
+      stride_f = C; stride_c = 1;
+    }
+    d_src = (const T *)st->d_in;
   }
+  const size_t src_ss = frames * C;
   // worst case one gating block + one short-term block per 100 ms
-  const size_t max_events = 2 * (frames / st->samples_in_100ms + 2);
-  if (st->energy_cap < max_events) {
-    if (st->d_energy) (void)hipFree(st->d_energy);
-    st->d_energy = nullptr; st->energy_cap = 0;
-    int rc = check_hip(ctx, hipMalloc((void **)&st->d_energy, max_events * sizeof(double)), "hipMalloc(ebur128 energies)");
-    if (rc) return rc;
-    st->energy_cap = max_events;
-    if (st->d_partial) (void)hipFree(st->d_partial);
-    st->d_partial = nullptr;
-    rc = check_hip(ctx, hipMalloc((void **)&st->d_partial, max_events * kEbEnergyBlocks * C * sizeof(double)), "hipMalloc(ebur128 partial energies)");
-    if (rc) return rc;
-  }
+  int rc = eb_energy_capacity(ctx, st, 2 * (frames / st->samples_in_100ms + 2));
+  if (rc) return rc;
   std::vector<int> event_kind;  // 0 = gating block (I), 1 = short-term block (LRA), in stream order
-  // ---- the add_frames loop of libebur128 (filter up to the next 100 ms boundary, then gate)
+  // ---- the add_frames loop of libebur128 (filter up to the next 100 ms boundary, then gate); identical for every stream
   size_t src_index = 0, left = frames;
   while (left > 0) {
     if (left >= st->needed_frames) {
-      eb_launch_segment<T>(ctx, st, (const T *)st->d_in, src_index, st->needed_frames, stride_f, stride_c);
+      eb_launch_segment<T>(ctx, st, d_src, src_index, st->needed_frames, stride_f, stride_c, src_ss);
       src_index += st->needed_frames;
       left -= st->needed_frames;
       st->index_frames += st->needed_frames;
@@ -500,18 +540,18 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
       st->needed_frames = st->samples_in_100ms;
       if (st->index_frames == st->ring_frames) st->index_frames = 0;
     } else {
-      eb_launch_segment<T>(ctx, st, (const T *)st->d_in, src_index, left, stride_f, stride_c);
+      eb_launch_segment<T>(ctx, st, d_src, src_index, left, stride_f, stride_c, src_ss);
       st->index_frames += left;
       if (st->mode & EB_LRA) st->st_counter += left;
       st->needed_frames -= left;
       left = 0;
     }
   }
-  int rc = check_hip(ctx, hipGetLastError(), "ebur128 kernel launch");
+  rc = check_hip(ctx, hipGetLastError(), "ebur128 kernel launch");
   if (rc) return rc;
-  std::vector<double> energies(event_kind.size());
-  std::vector<unsigned long long> peaks(2 * C);
-  if (!energies.empty()) {
+  std::vector<double> energies(S * st->energy_cap);
+  std::vector<unsigned long long> peaks(S * 2 * C);
+  if (!event_kind.empty()) {
     rc = check_hip(ctx, hipMemcpyAsync(energies.data(), st->d_energy, energies.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream),
                    "hipMemcpyAsync(ebur128 energies)");
     if (rc) return rc;
@@ -521,101 +561,146 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
   if (rc) return rc;
   rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
   if (rc) return rc;
-  for (size_t k = 0; k < energies.size(); k++) {
-    const double e = energies[k];
-    if (e >= g_hist_bound[0]) {
-      if (event_kind[k] == 0) st->block_hist[hist_index(e)]++;
-      else st->st_hist[hist_index(e)]++;
+  for (size_t s = 0; s < S; s++) {
+    for (size_t k = 0; k < event_kind.size(); k++) {
+      const double e = energies[s * st->energy_cap + k];
+      if (e >= g_hist_bound[0]) {
+        if (event_kind[k] == 0) st->block_hist[s * kHistBins + hist_index(e)]++;
+        else st->st_hist[s * kHistBins + hist_index(e)]++;
+      }
+    }
+    for (unsigned c = 0; c < C; c++) {  // device peaks are running maxima since the last reset
+      double sp, tp;
+      std::memcpy(&sp, &peaks[s * 2 * C + c], 8);
+      std::memcpy(&tp, &peaks[s * 2 * C + C + c], 8);
+      if (sp > st->sample_peak[s * C + c]) st->sample_peak[s * C + c] = sp;
+      if (tp > st->true_peak[s * C + c]) st->true_peak[s * C + c] = tp;
     }
   }
-  for (unsigned c = 0; c < C; c++) {  // device peaks are running maxima since the last reset
-    double sp, tp;
-    std::memcpy(&sp, &peaks[c], 8);
-    std::memcpy(&tp, &peaks[C + c], 8);
-    if (sp > st->sample_peak[c]) st->sample_peak[c] = sp;
-    if (tp > st->true_peak[c]) st->true_peak[c] = tp;
-  }
   return MI355_OK;
+}
+
+static int eb_add_dispatch(mi355_ctx *ctx, Ebur128State *st, const void *data, const void *const *planes, size_t frames, int fmt, bool device_data) {
+  switch (fmt) {
+    case 0: return eb_add_frames_t<int16_t>(ctx, st, (const int16_t *)data, (const int16_t *const *)planes, frames, device_data);
+    case 1: return eb_add_frames_t<int32_t>(ctx, st, (const int32_t *)data, (const int32_t *const *)planes, frames, device_data);
+    case 2: return eb_add_frames_t<float>(ctx, st, (const float *)data, (const float *const *)planes, frames, device_data);
+    case 3: return eb_add_frames_t<double>(ctx, st, (const double *)data, (const double *const *)planes, frames, device_data);
+    default: return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: bad sample format");
+  }
 }
 
 int ebur128_add_frames(mi355_ctx *ctx, const void *data, const void *const *planes, size_t frames, int fmt) {
   Ebur128State *st = (Ebur128State *)ctx->ebur128;
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (st->n_streams != 1) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: this meter is a batch, use the batch entry points");
   if (frames && !data && !planes) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null data");
-  switch (fmt) {
-    case 0: return eb_add_frames_t<int16_t>(ctx, st, (const int16_t *)data, (const int16_t *const *)planes, frames);
-    case 1: return eb_add_frames_t<int32_t>(ctx, st, (const int32_t *)data, (const int32_t *const *)planes, frames);
-    case 2: return eb_add_frames_t<float>(ctx, st, (const float *)data, (const float *const *)planes, frames);
-    case 3: return eb_add_frames_t<double>(ctx, st, (const double *)data, (const double *const *)planes, frames);
-    default: return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: bad sample format");
-  }
+  return eb_add_dispatch(ctx, st, data, planes, frames, fmt, false);
 }
 
-static int eb_window_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, double *out) {
-  if (frames > st->ring_frames) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: interval larger than the history window");
-  if (st->energy_cap < 1) {
-    int rc = check_hip(ctx, hipMalloc((void **)&st->d_energy, 16 * sizeof(double)), "hipMalloc(ebur128 energies)");
-    if (rc) return rc;
-    rc = check_hip(ctx, hipMalloc((void **)&st->d_partial, 16 * kEbEnergyBlocks * st->channels * sizeof(double)), "hipMalloc(ebur128 partial energies)");
-    if (rc) return rc;
-    st->energy_cap = 16;
-  }
-  eb_launch_energy(ctx, st, frames, 0u);
-  int rc = check_hip(ctx, hipMemcpyAsync(out, st->d_energy, sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(ebur128 energy)");
-  if (rc) return rc;
-  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
-}
-
-// what: 0 momentary, 1 short-term, 2 global, 3 relative threshold, 4 loudness range
-int ebur128_query(mi355_ctx *ctx, int what, double *out) {
+int ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int fmt, int device_data) {
   Ebur128State *st = (Ebur128State *)ctx->ebur128;
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
-  if (!out) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null output");
-  if (what == 0 || what == 1) {
-    if (what == 1 && !(st->mode & EB_S)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: short-term mode not enabled");
-    double e;
-    int rc = eb_window_energy(ctx, st, st->samples_in_100ms * (what == 0 ? 4 : 30), &e);
-    if (rc) return rc;
-    *out = e <= 0.0 ? -HUGE_VAL : to_loudness(e);
-    return MI355_OK;
-  }
+  if (frames && !data) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null data");
+  return eb_add_dispatch(ctx, st, data, nullptr, frames, fmt, device_data != 0);
+}
+
+// window energy of every stream -> out[n_streams]
+static int eb_window_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, std::vector<double> &out) {
+  if (frames > st->ring_frames) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: interval larger than the history window");
+  int rc = eb_energy_capacity(ctx, st, 16);
+  if (rc) return rc;
+  eb_launch_energy(ctx, st, frames, 0u);
+  std::vector<double> all(st->n_streams * st->energy_cap);
+  rc = check_hip(ctx, hipMemcpyAsync(all.data(), st->d_energy, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(ebur128 energy)");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
+  if (rc) return rc;
+  out.resize(st->n_streams);
+  for (size_t s = 0; s < st->n_streams; s++) out[s] = all[s * st->energy_cap];
+  return MI355_OK;
+}
+
+// histogram-derived values of stream s. what: 2 global, 3 relative threshold, 4 loudness range
+static double eb_hist_query(const Ebur128State *st, size_t s, int what) {
+  const unsigned long *bh = &st->block_hist[s * kHistBins], *sh = &st->st_hist[s * kHistBins];
   if (what == 2 || what == 3) {
-    if (!(st->mode & EB_I)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: global mode not enabled");
     double thr = 0.0; size_t n = 0;
-    for (int j = 0; j < kHistBins; j++) { thr += (double)st->block_hist[j] * g_hist_energy[j]; n += st->block_hist[j]; }
-    if (what == 3) { *out = n ? to_loudness(thr / (double)n * 0.1) : -70.0; return MI355_OK; }
-    if (!n) { *out = -HUGE_VAL; return MI355_OK; }
+    for (int j = 0; j < kHistBins; j++) { thr += (double)bh[j] * g_hist_energy[j]; n += bh[j]; }
+    if (what == 3) return n ? to_loudness(thr / (double)n * 0.1) : -70.0;
+    if (!n) return -HUGE_VAL;
     thr = thr / (double)n * 0.1;  // relative gate: -10 LU
     size_t start;
     if (thr < g_hist_bound[0]) start = 0;
     else { start = hist_index(thr); if (thr > g_hist_energy[start]) ++start; }
     double g = 0.0; n = 0;
-    for (size_t j = start; j < (size_t)kHistBins; j++) { g += (double)st->block_hist[j] * g_hist_energy[j]; n += st->block_hist[j]; }
-    *out = n ? to_loudness(g / (double)n) : -HUGE_VAL;
+    for (size_t j = start; j < (size_t)kHistBins; j++) { g += (double)bh[j] * g_hist_energy[j]; n += bh[j]; }
+    return n ? to_loudness(g / (double)n) : -HUGE_VAL;
+  }
+  size_t size = 0; double power = 0.0;
+  for (int j = 0; j < kHistBins; j++) { size += sh[j]; power += (double)sh[j] * g_hist_energy[j]; }
+  if (!size) return 0.0;
+  const double integrated = 0.01 * (power / (double)size);  // -20 LU
+  size_t index;
+  if (integrated < g_hist_bound[0]) index = 0;
+  else { index = hist_index(integrated); if (integrated > g_hist_energy[index]) ++index; }
+  size = 0;
+  for (size_t j = index; j < (size_t)kHistBins; j++) size += sh[j];
+  if (!size) return 0.0;
+  const size_t plow = (size_t)((double)(size - 1) * 0.1 + 0.5), phigh = (size_t)((double)(size - 1) * 0.95 + 0.5);
+  size_t acc = 0, j = index;
+  while (acc <= plow) acc += sh[j++];
+  const double l_en = g_hist_energy[j - 1];
+  while (acc <= phigh) acc += sh[j++];
+  const double h_en = g_hist_energy[j - 1];
+  return to_loudness(h_en) - to_loudness(l_en);
+}
+
+// what: 0 momentary, 1 short-term, 2 global, 3 relative threshold, 4 loudness range; out[n_streams]
+int ebur128_query_batch(mi355_ctx *ctx, int what, double *out) {
+  Ebur128State *st = (Ebur128State *)ctx->ebur128;
+  if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (!out) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null output");
+  if (what == 0 || what == 1) {
+    if (what == 1 && !(st->mode & EB_S)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: short-term mode not enabled");
+    std::vector<double> e;
+    int rc = eb_window_energy(ctx, st, st->samples_in_100ms * (what == 0 ? 4 : 30), e);
+    if (rc) return rc;
+    for (size_t s = 0; s < st->n_streams; s++) out[s] = e[s] <= 0.0 ? -HUGE_VAL : to_loudness(e[s]);
     return MI355_OK;
   }
-  if (what == 4) {
+  if (what == 2 || what == 3) {
+    if (!(st->mode & EB_I)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: global mode not enabled");
+  } else if (what == 4) {
     if (!(st->mode & EB_LRA)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: loudness-range mode not enabled");
-    size_t size = 0; double power = 0.0;
-    for (int j = 0; j < kHistBins; j++) { size += st->st_hist[j]; power += (double)st->st_hist[j] * g_hist_energy[j]; }
-    if (!size) { *out = 0.0; return MI355_OK; }
-    const double integrated = 0.01 * (power / (double)size);  // -20 LU
-    size_t index;
-    if (integrated < g_hist_bound[0]) index = 0;
-    else { index = hist_index(integrated); if (integrated > g_hist_energy[index]) ++index; }
-    size = 0;
-    for (size_t j = index; j < (size_t)kHistBins; j++) size += st->st_hist[j];
-    if (!size) { *out = 0.0; return MI355_OK; }
-    const size_t plow = (size_t)((double)(size - 1) * 0.1 + 0.5), phigh = (size_t)((double)(size - 1) * 0.95 + 0.5);
-    size_t acc = 0, j = index;
-    while (acc <= plow) acc += st->st_hist[j++];
-    const double l_en = g_hist_energy[j - 1];
-    while (acc <= phigh) acc += st->st_hist[j++];
-    const double h_en = g_hist_energy[j - 1];
-    *out = to_loudness(h_en) - to_loudness(l_en);
-    return MI355_OK;
+  } else {
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: unknown query");
   }
-  return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: unknown query");
+  for (size_t s = 0; s < st->n_streams; s++) out[s] = eb_hist_query(st, s, what);
+  return MI355_OK;
+}
+
+int ebur128_query(mi355_ctx *ctx, int what, double *out) {
+  Ebur128State *st = (Ebur128State *)ctx->ebur128;
+  if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (!out) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null output");
+  std::vector<double> v(st->n_streams);
+  int rc = ebur128_query_batch(ctx, what, v.data());
+  if (rc) return rc;
+  *out = v[0];
+  return MI355_OK;
+}
+
+// peaks of every stream: out[n_streams][channels]
+int ebur128_peak_batch(mi355_ctx *ctx, int true_peak, double *out) {
+  Ebur128State *st = (Ebur128State *)ctx->ebur128;
+  if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (!out) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null output");
+  if (true_peak && !(st->mode & EB_TRUE_PEAK)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: true-peak mode not enabled");
+  if (!true_peak && !(st->mode & EB_SAMPLE_PEAK)) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: sample-peak mode not enabled");
+  for (size_t i = 0; i < (size_t)st->n_streams * st->channels; i++)
+    out[i] = true_peak ? (st->true_peak[i] > st->sample_peak[i] ? st->true_peak[i] : st->sample_peak[i]) : st->sample_peak[i];
+  return MI355_OK;
 }
 
 int ebur128_peak(mi355_ctx *ctx, int true_peak, unsigned channel, double *out) {

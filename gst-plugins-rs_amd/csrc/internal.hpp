@@ -139,6 +139,10 @@ void lut_release(mi355_ctx *ctx);
 int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay, double intensity,
                 double feedback);
 int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+int ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+int ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int fmt, int device_data);
+int ebur128_query_batch(mi355_ctx *ctx, int what, double *out);
+int ebur128_peak_batch(mi355_ctx *ctx, int true_peak, double *out);
 int ebur128_reset(mi355_ctx *ctx);
 void ebur128_release(mi355_ctx *ctx);
 int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,

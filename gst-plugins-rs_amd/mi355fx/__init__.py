@@ -100,6 +100,11 @@ def load_library():
         "mi355_echo_process_device": (i, [vp, vp, sz, i, sz, C.c_double, C.c_double]),
         "mi355_echo_get_state": (i, [vp, vp, sz, C.POINTER(sz)]),
         "mi355_ebur128_setup": (i, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
+        "mi355_ebur128_setup_batch": (i, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
+        "mi355_ebur128_add_frames_batch": (i, [vp, vp, sz, i]),
+        "mi355_ebur128_add_frames_batch_device": (i, [vp, vp, sz, i]),
+        "mi355_ebur128_loudness_batch": (i, [vp, i, C.POINTER(C.c_double)]),
+        "mi355_ebur128_peak_batch": (i, [vp, i, C.POINTER(C.c_double)]),
         "mi355_ebur128_reset": (i, [vp]),
         "mi355_ebur128_teardown": (i, [vp]),
         "mi355_ebur128_add_frames": (i, [vp, vp, sz, i]),
@@ -496,6 +501,33 @@ class Context:
 
     def ebur128_reset(self):
         self._ck(self.L.mi355_ebur128_reset(self.h))
+
+    # batch of n_streams meters of one configuration, fed in lock step
+    def ebur128_setup_batch(self, n_streams, channels, rate, mode=63, channel_class=None):
+        cc = None
+        if channel_class is not None:
+            cc = (C.c_int * channels)(*[int(v) for v in channel_class])
+        self._ck(self.L.mi355_ebur128_setup_batch(self.h, n_streams, channels, rate, mode, cc))
+        self._eb_channels, self._eb_streams = channels, n_streams
+
+    def ebur128_add_frames_batch(self, data):
+        """data: (n_streams, frames, channels) array."""
+        a = np.ascontiguousarray(data)
+        assert a.ndim == 3 and a.shape[0] == self._eb_streams and a.shape[2] == self._eb_channels
+        self._ck(self.L.mi355_ebur128_add_frames_batch(self.h, a.ctypes.data, a.shape[1], self._EB_FMT[a.dtype]))
+
+    def ebur128_add_frames_batch_device(self, d_ptr, frames, fmt):
+        self._ck(self.L.mi355_ebur128_add_frames_batch_device(self.h, d_ptr, frames, fmt))
+
+    def ebur128_loudness_batch(self, what):
+        out = (C.c_double * self._eb_streams)()
+        self._ck(self.L.mi355_ebur128_loudness_batch(self.h, what, out))
+        return np.array(out)
+
+    def ebur128_peak_batch(self, true_peak=False):
+        out = (C.c_double * (self._eb_streams * self._eb_channels))()
+        self._ck(self.L.mi355_ebur128_peak_batch(self.h, int(true_peak), out))
+        return np.array(out).reshape(self._eb_streams, self._eb_channels)
 
     def ebur128_add_frames(self, data, planar=False):
         a = np.ascontiguousarray(data)

@@ -244,6 +244,19 @@ typedef enum mi355_ebur128_mode {
   MI355_EBUR128_LOUDNESS_RANGE = 8, MI355_EBUR128_SAMPLE_PEAK = 16, MI355_EBUR128_TRUE_PEAK = 32
 } mi355_ebur128_mode;
 int mi355_ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+/* Batch form: `n_streams` independent meters of ONE configuration fed in lock step, every kernel launched once for all of
+ * them (grid y = stream). One stream's K-weighting recurrence is serial; hundreds of streams are what fills the GPU
+ * (ebur128level is one instance per stream in the reference: ebur128level/imp.rs:682-745 runs per element; a transcoding
+ * farm runs hundreds of them). `data` of add_frames_batch: n_streams buffers of frames x channels interleaved samples,
+ * back to back (host pointer; _device: device pointer, asynchronous up to the read-back of the gating energies).
+ * loudness_batch: what = 0 momentary, 1 short-term, 2 global, 3 relative threshold, 4 loudness range -> out[n_streams];
+ * peak_batch -> out[n_streams][channels]. mi355_ebur128_reset / _teardown apply to the batch as a whole. Per-stream results
+ * are identical to n_streams separate single-stream meters (tests/test_gpu_ebur128.py). */
+int mi355_ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
+int mi355_ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int sample_format);
+int mi355_ebur128_add_frames_batch_device(mi355_ctx *ctx, const void *d_data, size_t frames, int sample_format);
+int mi355_ebur128_loudness_batch(mi355_ctx *ctx, int what, double *out);
+int mi355_ebur128_peak_batch(mi355_ctx *ctx, int true_peak, double *out);
 int mi355_ebur128_reset(mi355_ctx *ctx);
 int mi355_ebur128_teardown(mi355_ctx *ctx);
 int mi355_ebur128_add_frames(mi355_ctx *ctx, const void *data, size_t frames, int sample_format);

@@ -148,3 +148,56 @@ def test_modes_reset_and_errors(ctx, oracle):
     assert ctx.ebur128_loudness_global() == -np.inf and ctx.ebur128_relative_threshold() == -70.0
     assert ctx.ebur128_sample_peak(0) == 0.0 and ctx.ebur128_loudness_range() == 0.0
     ctx.ebur128_add_frames(np.zeros(0, np.float32))                            # empty buffer: no-op
+
+
+# ------------------------------------------------------------------ batch of streams
+
+@pytest.mark.parametrize("dtype,channels,rate", [(np.float32, 2, 48000), (np.int16, 6, 44100), (np.float64, 1, 96000)])
+def test_batch_equals_separate_meters(ctx, dtype, channels, rate):
+    """n_streams meters fed in lock step through the batch entry points give, stream for stream, exactly what separate
+    single-stream meters give (every loudness value, relative threshold, range and peak bit-identical): the batch only adds
+    a grid dimension, the per-stream arithmetic and its order are unchanged."""
+    import mi355fx
+    S, mode = 5, 63
+    rng = np.random.default_rng(11)
+    secs = 4.3
+    n = int(rate * secs)
+    t = np.arange(n) / rate
+    sig = np.empty((S, n, channels))
+    for s in range(S):
+        for c in range(channels):
+            sig[s, :, c] = (0.05 + 0.17 * s) * np.sin(2 * np.pi * (180.0 + 97 * s + 13 * c) * t) + 0.01 * rng.standard_normal(n)
+        sig[s, : n // 3] *= 0.2 + 0.1 * s   # level changes: gating and loudness range have something to do
+    if dtype == np.int16:
+        data = np.clip(sig * 32767, -32768, 32767).astype(np.int16)
+    else:
+        data = sig.astype(dtype)
+    chunk = rate // 7 + 3                      # ragged buffers: segments cross the 100 ms boundaries
+    # separate meters
+    singles = []
+    for s in range(S):
+        with mi355fx.Context(0) as c1:
+            c1.ebur128_setup(channels, rate, mode)
+            for a in range(0, n, chunk):
+                c1.ebur128_add_frames(data[s, a:a + chunk])
+            singles.append([c1.ebur128_loudness_momentary(), c1.ebur128_loudness_shortterm(), c1.ebur128_loudness_global(),
+                            c1.ebur128_relative_threshold(), c1.ebur128_loudness_range()] +
+                           [c1.ebur128_sample_peak(c) for c in range(channels)] + [c1.ebur128_true_peak(c) for c in range(channels)])
+    ctx.ebur128_setup_batch(S, channels, rate, mode)
+    for a in range(0, n, chunk):
+        ctx.ebur128_add_frames_batch(data[:, a:a + chunk])
+    got = [ctx.ebur128_loudness_batch(w) for w in range(5)]
+    sp, tp = ctx.ebur128_peak_batch(False), ctx.ebur128_peak_batch(True)
+    for s in range(S):
+        row = [got[w][s] for w in range(5)] + list(sp[s]) + list(tp[s])
+        assert row == singles[s], (s, row, singles[s])
+    # reset applies to all streams
+    ctx.ebur128_reset()
+    assert (ctx.ebur128_loudness_batch(2) == -np.inf).all() and (ctx.ebur128_peak_batch(False) == 0).all()
+
+
+def test_batch_and_single_entry_points_do_not_mix(ctx):
+    import mi355fx
+    ctx.ebur128_setup_batch(3, 2, 48000, 63)
+    with pytest.raises(mi355fx.Mi355Error):
+        ctx.ebur128_add_frames(np.zeros((480, 2), np.float32))
