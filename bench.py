@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=32, help="concurrent streams of the secondary many-streams measurement (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
+    ap.add_argument("--config", type=int, default=0,
+                    help="0 = the headline chain (default). 5 = BASELINE config 5: `--streams` concurrent 4K streams per GPU through the\n"
+                         "videocompare SSIM (dssim) engine, one comparison per stream and step; prints its own JSON line (comparisons/s)")
+    ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
     ap.add_argument("--stub", action="store_true",
                     help="TEST SCAFFOLDING, no GPU: tiny CPU frames and a fake context that sleeps instead of launching kernels, so that\n"
                          "the N>1 control flow (gloo group, barriers, MAX over ranks, aggregation, rank-0 JSON) can be exercised by the CPU\n"
@@ -199,6 +203,96 @@ def _install_stub(torch, mi355fx, rank):
     mi355fx.Context = Ctx
 
 
+def run_config5(args, rank, local_rank, world):
+    """BASELINE config 5: 256 concurrent 4K streams through videocompare's SSIM engine = 32 streams per GPU. Every stream is a
+    pair of resident 4K RGBA frames (the natural-like frame and the same frame + noise of sigma 2, SURVEY.md 8d synthetic (8));
+    a step = one comparison per stream the way HasherEngine does it (hash_image of both frames, then compare:
+    video/videofx/src/videocompare/hashed_image.rs:24-79). The streams are independent and sharded over the ranks; `--workers`
+    host threads per rank, each with its own context and HIP stream, take the rank's streams in turn (the calls release the
+    GIL and return a double, so a context is busy until its comparison is done). Timing: gloo barrier + MAX over ranks."""
+    import threading
+    import torch
+    import mi355fx
+    from mi355fx import sharding, synth
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        dist = dist_mod
+    n_streams, n_workers = args.streams, max(1, min(args.workers, args.streams))
+    rng = np.random.default_rng(1234 + rank)
+    base = synth.smooth_frame(W, H)
+    noisy = base.reshape(H, W, 4).astype(np.int16)
+    noisy[..., :3] += np.rint(rng.normal(0.0, 2.0, size=(H, W, 3))).astype(np.int16)
+    noisy = np.clip(noisy, 0, 255).astype(np.uint8).reshape(H, W * 4)
+    base[:, 3::4] = 255
+    noisy[:, 3::4] = 255
+    ctxs = [mi355fx.Context(local_rank) for _ in range(n_workers)]
+    frames = []   # per stream: (device reference frame, device secondary frame), all distinct by a row rotation
+    for s in range(n_streams):
+        c = ctxs[s % n_workers]
+        a, b = np.roll(base, 4 * 61 * s, axis=1).copy(), np.roll(noisy, 4 * 61 * s, axis=1).copy()
+        da, db = c.alloc(a.nbytes), c.alloc(b.nbytes)
+        c.h2d(da, a.reshape(-1)); c.h2d(db, b.reshape(-1))
+        frames.append((da, db))
+    results = [0.0] * n_streams
+
+    def serve(w, steps):
+        c = ctxs[w]
+        for _ in range(steps):
+            for s in range(w, n_streams, n_workers):
+                da, db = frames[s]
+                x = c.dssim_create_image_device(da, W * 4, W, H)
+                y = c.dssim_create_image_device(db, W * 4, W, H)
+                results[s] = c.dssim_compare(x, y)
+                c.dssim_free_image(x); c.dssim_free_image(y)
+
+    def run(steps):
+        ts = [threading.Thread(target=serve, args=(w, steps)) for w in range(n_workers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    t_end = time.perf_counter() + args.ramp_seconds
+    while time.perf_counter() < t_end:
+        run(1)
+    run(max(1, args.warmup))
+    dt = sharding.timed_region(lambda: run(args.steps), dist=dist, device_sync=torch.cuda.synchronize)
+    comps = sharding.aggregate_throughput(args.steps * n_streams, world, dt)
+    if rank == 0:
+        algo = 2 * FRAME_BYTES  # two 4K RGBA frames read per comparison (SURVEY.md 8d)
+        out = {"metric": "videocompare SSIM comparisons/sec, 32 concurrent 4K streams per GPU (BASELINE config 5)", "value": comps, "unit": "comparisons/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "videocompare hash-algorithm=dssim, 3840x2160 RGBA, hash both frames + compare per stream and step",
+                          "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "frames": "natural-like frame vs the same + N(0, 2) noise, resident",
+                          "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process",
+                          "real_time_need": "%d streams x 30 frames/s = %d comparisons/s per GPU" % (n_streams, 30 * n_streams)},
+               "roofline": {"bound": "hbm", "kernel": "dssim_* (create_image x2 + compare)", "achieved": comps / world * algo / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": comps / world * algo / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "algorithmic_bytes_per_comparison": algo},
+               "dssim_of_stream_0": results[0]}
+        if not args.no_cpu_baseline:
+            from oracle import dssim_restate as R
+            hw, hh = W // 2, H // 2
+            fa = np.ascontiguousarray(base.reshape(H, W, 4)[:hh, :hw]).reshape(hh, hw * 4)
+            fb = np.ascontiguousarray(noisy.reshape(H, W, 4)[:hh, :hw]).reshape(hh, hw * 4)
+            t0 = time.perf_counter()
+            v = R.compare(R.DssimImage(fa, hw, hh, hw * 4, 4), R.DssimImage(fb, hw, hh, hw * 4, 4))
+            d1 = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": 1.0 / (4.0 * d1), "unit": "comparisons/s", "cores": 1, "kind": "port",
+                                   "sample": "one 1920x1080 comparison by the numpy restatement (oracle/dssim_restate.py), scaled by 4 to 4K; dssim %.6f" % v}
+        print(json.dumps(out), flush=True)
+    for c in ctxs:
+        c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -206,6 +300,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+
+    if args.config == 5:
+        if world != args.gpus and world > 1:
+            args.gpus = world
+        return run_config5(args, rank, local_rank, world)
 
     import torch
     import mi355fx

@@ -98,3 +98,41 @@ def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
                     assert (got.view(np.uint32) == exp.view(np.uint32)).all(), (s, c, kind, int((got != exp).sum()))
     finally:
         ctx.dssim_free_image(g)
+
+
+def test_dssim_matches_restatement_at_4k(ctx, synth):
+    """BASELINE config 5's frame size: the natural-like 4K frame against itself + N(0, 2) noise and against a heavily
+    changed copy, device vs the numpy restatement (same tolerance as the smaller sizes)."""
+    from oracle import dssim_restate as D
+    w, h = 3840, 2160
+    rng = np.random.default_rng(5)
+    base = synth.smooth_frame(w, h)
+    base[:, 3::4] = 255
+    ga = ctx.dssim_create_image(base, w * 4, w, h)
+    oa = D.DssimImage(base, w, h, w * 4, 4)
+    try:
+        for sigma in (2.0, 25.0):
+            mod = base.reshape(h, w, 4).astype(np.int16)
+            mod[..., :3] += np.rint(rng.normal(0.0, sigma, size=(h, w, 3))).astype(np.int16)
+            mod = np.clip(mod, 0, 255).astype(np.uint8).reshape(h, w * 4)
+            mod[:, 3::4] = 255
+            gb = ctx.dssim_create_image(mod, w * 4, w, h)
+            got = ctx.dssim_compare(ga, gb)
+            ctx.dssim_free_image(gb)
+            exp = D.compare(oa, D.DssimImage(mod, w, h, w * 4, 4))
+            assert got == pytest.approx(exp, rel=1e-9, abs=1e-13), (sigma, got, exp)
+    finally:
+        ctx.dssim_free_image(ga)
+
+
+def test_config5_bench_leg_runs(tmp_path):
+    """bench.py --config 5 (32 concurrent 4K streams per GPU through the SSIM engine; here 4 streams, 2 workers, 2 steps):
+    one JSON line with comparisons/s, the roofline object and a plausible dssim value."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--streams", "4", "--workers", "2", "--steps", "2", "--warmup", "1",
+                        "--ramp-seconds", "0.05", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["unit"] == "comparisons/s" and d["value"] > 0 and d["config"]["streams_per_gpu"] == 4
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["dssim_of_stream_0"] < 0.1
