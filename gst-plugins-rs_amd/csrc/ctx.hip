@@ -145,6 +145,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   dssim_release(ctx);
   ebur128_release(ctx);
   hrtf_release(ctx);
+  sofa_release(ctx);
   if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
   for (int i = 0; i < 2; i++)
     if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -735,6 +736,40 @@ int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int 
   if (!image) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null image");
   BIND_DEVICE(ctx);
   return dssim_image_plane(ctx, image, scale, channel, kind, out, width, height);
+}
+
+/* ------------------------------------------------------------------ sofalizer */
+
+int mi355_sofa_setup(mi355_ctx *ctx, int channels, int filter_len, int partition_length, int block_length) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return sofa_setup(ctx, channels, filter_len, partition_length, block_length);
+}
+int mi355_sofa_set_filter(mi355_ctx *ctx, int channel, const float *left, const float *right, int delay_left, int delay_right) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return sofa_set_filter(ctx, channel, left, right, delay_left, delay_right);
+}
+int mi355_sofa_set_drop(mi355_ctx *ctx, int channel, int drop) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return sofa_set_drop(ctx, channel, drop); }
+int mi355_sofa_reset(mi355_ctx *ctx) { REQUIRE_CTX(ctx); BIND_DEVICE(ctx); return sofa_reset(ctx); }
+int mi355_sofa_teardown(mi355_ctx *ctx) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  sofa_release(ctx);
+  return MI355_OK;
+}
+int mi355_sofa_process_block(mi355_ctx *ctx, const float *in, float *out, const float *distance_gains) {
+  REQUIRE_CTX(ctx);
+  if (!in || !out || !distance_gains) return set_error(ctx, MI355_ERR_INVALID_ARG, "sofalizer: null argument");
+  BIND_DEVICE(ctx);
+  return sofa_process_block_host(ctx, in, out, distance_gains);
+}
+int mi355_sofa_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, const float *distance_gains) {
+  REQUIRE_CTX(ctx);
+  if (!d_in || !d_out || !distance_gains) return set_error(ctx, MI355_ERR_INVALID_ARG, "sofalizer: null argument");
+  BIND_DEVICE(ctx);
+  return sofa_process_block_device(ctx, d_in, d_out, distance_gains);
 }
 
 /* ------------------------------------------------------------------ hrtfrender */

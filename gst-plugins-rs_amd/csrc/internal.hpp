@@ -87,6 +87,7 @@ struct mi355_ctx {
   mi355::EchoDevice echo;
   void *ebur128 = nullptr;     // mi355::Ebur128State (ebur128_kernels.hip)
   void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
+  void *sofa = nullptr;        // mi355::SofaState (sofa_kernels.hip)
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
   void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
   bool force_generic = false;
@@ -166,6 +167,13 @@ int hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, c
 int hrtf_process_block_host(mi355_ctx *ctx, const float *in, float *out, const float *positions, const float *gains);
 int hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw);
 int hrtf_info(mi355_ctx *ctx, uint32_t *len, uint32_t *vertices, uint32_t *faces);
+int sofa_setup(mi355_ctx *ctx, int channels, int filter_len, int partition_len, int block_len);
+int sofa_set_filter(mi355_ctx *ctx, int channel, const float *left, const float *right, int delay_left, int delay_right);
+int sofa_set_drop(mi355_ctx *ctx, int channel, int drop);
+int sofa_reset(mi355_ctx *ctx);
+int sofa_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, const float *gains);
+int sofa_process_block_host(mi355_ctx *ctx, const float *in, float *out, const float *gains);
+void sofa_release(mi355_ctx *ctx);
 int ebur128_add_frames(mi355_ctx *ctx, const void *data, const void *const *planes, size_t frames, int fmt);
 int ebur128_query(mi355_ctx *ctx, int what, double *out);
 int ebur128_peak(mi355_ctx *ctx, int true_peak, unsigned channel, double *out);

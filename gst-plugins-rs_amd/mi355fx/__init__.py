@@ -137,6 +137,13 @@ def load_library():
         "mi355_dssim_free_image": (None, [vp, vp]),
         "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
+        "mi355_sofa_setup": (i, [vp, i, i, i, i]),
+        "mi355_sofa_set_filter": (i, [vp, i, f32p, f32p, i, i]),
+        "mi355_sofa_set_drop": (i, [vp, i, i]),
+        "mi355_sofa_reset": (i, [vp]),
+        "mi355_sofa_teardown": (i, [vp]),
+        "mi355_sofa_process_block": (i, [vp, f32p, f32p, f32p]),
+        "mi355_sofa_process_block_device": (i, [vp, vp, vp, f32p]),
         "mi355_hrtf_load_sphere": (i, [vp, vp, sz, C.c_uint32]),
         "mi355_hrtf_setup": (i, [vp, i, i, i]),
         "mi355_hrtf_reset": (i, [vp]),
@@ -422,6 +429,35 @@ class Context:
         v = C.c_double(0)
         self._ck(self.L.mi355_dssim_compare(self.h, a, b, C.byref(v)))
         return v.value
+
+    # ---- sofalizer
+    def sofa_setup(self, channels, filter_len, partition_length=64, block_length=256):
+        self._ck(self.L.mi355_sofa_setup(self.h, channels, filter_len, partition_length, block_length))
+        self._sofa = (channels, block_length)
+
+    def sofa_set_filter(self, channel, left, right, delay_left=0, delay_right=0):
+        fp = C.POINTER(C.c_float)
+        l, r = np.ascontiguousarray(left, np.float32), np.ascontiguousarray(right, np.float32)
+        self._ck(self.L.mi355_sofa_set_filter(self.h, channel, l.ctypes.data_as(fp), r.ctypes.data_as(fp), delay_left, delay_right))
+
+    def sofa_set_drop(self, channel, drop=True):
+        self._ck(self.L.mi355_sofa_set_drop(self.h, channel, int(drop)))
+
+    def sofa_reset(self):
+        self._ck(self.L.mi355_sofa_reset(self.h))
+
+    def sofa_teardown(self):
+        self._ck(self.L.mi355_sofa_teardown(self.h))
+
+    def sofa_process_block(self, block, gains):
+        """block: (block_length, channels) f32 -> (block_length, 2) f32."""
+        fp = C.POINTER(C.c_float)
+        ch, bl = self._sofa
+        x = np.ascontiguousarray(block, np.float32).reshape(bl, ch)
+        g = np.ascontiguousarray(gains, np.float32)
+        out = np.zeros((bl, 2), np.float32)
+        self._ck(self.L.mi355_sofa_process_block(self.h, x.ctypes.data_as(fp), out.ctypes.data_as(fp), g.ctypes.data_as(fp)))
+        return out
 
     # ---- hrtfrender
     def hrtf_load_sphere(self, data, rate):

@@ -355,6 +355,29 @@ int mi355_hrtf_sphere_info(mi355_ctx *ctx, uint32_t *hrir_len, uint32_t *n_verti
 /* Diagnostics: mesh face (or -1) and barycentric weights chosen per [channel][step] in the last block. */
 int mi355_hrtf_last_lookup(mi355_ctx *ctx, int *faces, float *uvw);
 
+/* ---------------------------------------------------------------- sofalizer
+ * Replaces the per-block loop of Sofalizer::process (audio/hrtf/src/sofa/imp.rs:234-300): de-interleave each channel,
+ * sofar's Renderer::process_block (uniformly partitioned convolution with `partition-length`, built in set_caps :793-798)
+ * and the channel-ordered mix `out[2i] += l * gain, out[2i+1] += r * gain` (:282-297). The element keeps what is not
+ * per-sample work: opening the SOFA file and looking up / interpolating the HRIR pair of a position (Sofar::filter in
+ * State::update_filters, :129-160) - it hands each pair over with mi355_sofa_set_filter when a source has moved by more
+ * than `update-threshold`, exactly where it calls Renderer::set_filter today - plus the adapter and drain logic.
+ *   setup       block_length must be a multiple of partition_length (else INVALID_ARG with the reference's message,
+ *               :775-781); partition_length a power of two in 8..2048 (UNSUPPORTED otherwise)
+ *   set_filter  filter_len taps per ear + whole-sample onset delays (>= 0); effective from the next block
+ *   set_drop    ChannelProcessor::Drop for LFE1 / LFE2 (:808-821)
+ *   reset       flush-stop (:840-848): input history cleared
+ *   process_block  in: block_length x channels interleaved f32; out: block_length x 2 interleaved f32
+ * The crate's arithmetic is not in the reference tree: parity is that of a streaming linear convolution, within 2e-6 of
+ * full scale against the time-domain oracle. */
+int mi355_sofa_setup(mi355_ctx *ctx, int channels, int filter_len, int partition_length, int block_length);
+int mi355_sofa_set_filter(mi355_ctx *ctx, int channel, const float *left, const float *right, int delay_left, int delay_right);
+int mi355_sofa_set_drop(mi355_ctx *ctx, int channel, int drop);
+int mi355_sofa_reset(mi355_ctx *ctx);
+int mi355_sofa_teardown(mi355_ctx *ctx);
+int mi355_sofa_process_block(mi355_ctx *ctx, const float *in, float *out, const float *distance_gains);
+int mi355_sofa_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, const float *distance_gains);
+
 /* ---------------------------------------------------------------- pinned memory + asynchronous host-buffer pipeline
  * For the GStreamer shim (precedent video/colorlut/src/d3d12colorlut/imp.rs:385-492 and
  * audio/audiofx/src/audiornnoise/imp.rs:323-348): mi355_host_alloc backs a GstAllocator / buffer pool offered in

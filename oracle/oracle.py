@@ -408,6 +408,44 @@ class HrtfExact:
         return out
 
 
+class SofaRenderer:
+    """Time-domain statement of what sofalizer's per-block loop computes (audio/hrtf/src/sofa/imp.rs:234-300): every
+    channel that is not dropped is convolved (streaming, linear) with its current HRIR pair - sofar's Renderer, a uniformly
+    partitioned FFT convolver whose sources are not in the reference tree (PARITY UNPINNED), computes exactly this up to
+    round-off - and mixed `out += y * gain` in channel order. Filters change at block boundaries; whole-sample onset
+    delays shift the taps; taps pushed beyond filter_len are cut (the renderer holds filter_len taps)."""
+
+    def __init__(self, channels, filter_len, block_len):
+        self.C, self.L, self.B = channels, filter_len, block_len
+        self.h = np.zeros((channels, 2, filter_len), np.float64)
+        self.drop = [False] * channels
+        self.hist = np.zeros((channels, filter_len - 1), np.float64)
+
+    def set_filter(self, c, left, right, delay_left=0, delay_right=0):
+        for e, (h, d) in enumerate(((left, delay_left), (right, delay_right))):
+            t = np.zeros(self.L, np.float64)
+            n = self.L - d
+            if n > 0:
+                t[d:] = np.asarray(h, np.float64)[:n]
+            self.h[c, e] = t
+
+    def reset(self):
+        self.hist[:] = 0.0
+
+    def process_block(self, block, gains):
+        x = np.asarray(block, np.float32).reshape(self.B, self.C).astype(np.float64)
+        out = np.zeros((self.B, 2), np.float32)
+        for c in range(self.C):
+            if self.drop[c]:
+                continue
+            sig = np.concatenate([self.hist[c], x[:, c]])
+            for e in range(2):
+                y = np.convolve(sig, self.h[c, e])[self.L - 1: self.L - 1 + self.B]
+                out[:, e] += (y.astype(np.float32) * np.float32(gains[c])).astype(np.float32)
+            self.hist[c] = sig[len(sig) - (self.L - 1):] if self.L > 1 else self.hist[c]
+        return out
+
+
 def position_convert(from_system, to_system, v):
     """Position::{to_cartesian, to_left_handed, to_right_handed} (audio/hrtf/src/spatial.rs:40-70), restated; systems:
     0 Cartesian, 1 LeftHanded, 2 RightHanded. Pinned by the reference's own known answers (spatial.rs:235-287)."""

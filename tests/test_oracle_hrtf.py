@@ -110,3 +110,24 @@ def test_spatial_known_answers_host_library():
         assert L.mi355host_position_convert(a, b, i, m) == 0 and L.mi355host_position_convert(b, a, m, o) == 0
         assert tuple(o) == tuple(i)
     assert L.mi355host_position_convert(3, 0, (C.c_float * 3)(), (C.c_float * 3)()) == -1
+
+
+def test_sofa_oracle_is_a_streaming_linear_convolution(oracle):
+    """The sofalizer oracle, block by block, equals one long np.convolve of the whole signal (per channel and ear), including
+    a whole-sample delay; a dropped channel contributes nothing."""
+    rng = np.random.default_rng(0)
+    C, L, B, n_blocks = 3, 40, 64, 5
+    r = oracle.SofaRenderer(C, L, B)
+    hs = [(rng.standard_normal(L).astype(np.float32), rng.standard_normal(L).astype(np.float32)) for _ in range(C)]
+    for c, (l, rr) in enumerate(hs):
+        r.set_filter(c, l, rr, delay_left=c, delay_right=0)
+    r.drop[1] = True
+    x = rng.standard_normal((n_blocks * B, C)).astype(np.float32)
+    g = np.array([0.5, 9.0, 2.0], np.float32)
+    out = np.concatenate([r.process_block(x[k * B:(k + 1) * B], g) for k in range(n_blocks)])
+    exp = np.zeros((n_blocks * B, 2))
+    for c in (0, 2):
+        hl = np.zeros(L); hl[c:] = hs[c][0][:L - c]
+        exp[:, 0] += np.convolve(x[:, c].astype(np.float64), hl)[: n_blocks * B] * g[c]
+        exp[:, 1] += np.convolve(x[:, c].astype(np.float64), hs[c][1].astype(np.float64))[: n_blocks * B] * g[c]
+    assert np.abs(out - exp).max() < 1e-4
