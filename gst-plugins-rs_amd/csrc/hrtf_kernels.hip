@@ -227,14 +227,49 @@ void hrtf_release(mi355_ctx *ctx) {
 static uint32_t rd_u32(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
 // HrirSphere::new(bytes, device_rate) (imp.rs:84-94)
+// Sample-rate conversion of one HRIR when the sphere file was measured at another rate than the stream runs at
+// (HrirSphere::new(bytes, rate), audio/hrtf/src/hrtf/imp.rs:83-93; the crate hands every HRIR to the `rubato` sinc
+// resampler, whose sources are not in the reference tree: PARITY UNPINNED, this is the published method, not its bits).
+// Band-limited interpolation: y[m] = sum_n h[n] * fc * sinc(fc * (t - n)) * w((t - n) / half), t = m / ratio,
+// fc = 0.95 * min(1, ratio) (cut-off relative to the input Nyquist rate, 5 % guard band), half = 128 / min(1, ratio)
+// input samples on either side (rubato's customary sinc_len = 256), w = squared 4-term Blackman-Harris window,
+// f64 accumulation, no added delay; out_len = round(len * ratio). Runs once per sphere load on the host.
+static std::vector<float> resample_hrir(const float *h, uint32_t len, double ratio, uint32_t out_len) {
+  const double pi = 3.14159265358979323846;
+  const double lo = ratio < 1.0 ? ratio : 1.0, fc = 0.95 * lo, half = 128.0 / lo;
+  std::vector<float> y(out_len);
+  for (uint32_t m = 0; m < out_len; m++) {
+    const double t = (double)m / ratio;
+    long n0 = (long)std::ceil(t - half), n1 = (long)std::floor(t + half);
+    if (n0 < 0) n0 = 0;
+    if (n1 > (long)len - 1) n1 = (long)len - 1;
+    double acc = 0.0;
+    for (long n = n0; n <= n1; n++) {
+      const double d = t - (double)n, x = pi * fc * d;
+      const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(x) / x;
+      const double u = 0.5 * (d / half + 1.0);  // 0..1 across the window
+      const double bh = 0.35875 - 0.48829 * std::cos(2.0 * pi * u) + 0.14128 * std::cos(4.0 * pi * u) - 0.01168 * std::cos(6.0 * pi * u);
+      acc += (double)h[n] * fc * sinc * bh * bh;
+    }
+    y[m] = (float)acc;
+  }
+  return y;
+}
+
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate) {
   if (!bytes || n < 20 || std::memcmp(bytes, "HRIR", 4) != 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: not an HRIR sphere (bad magic)");
-  const uint32_t rate = rd_u32(bytes + 4), len = rd_u32(bytes + 8), nv = rd_u32(bytes + 12), ni = rd_u32(bytes + 16);
-  if (len == 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: HRIR length is zero");
-  const size_t need = 20 + 4 * (size_t)ni + (size_t)nv * (12 + 8 * (size_t)len);
+  const uint32_t rate = rd_u32(bytes + 4), file_len = rd_u32(bytes + 8), nv = rd_u32(bytes + 12), ni = rd_u32(bytes + 16);
+  if (file_len == 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: HRIR length is zero");
+  const size_t need = 20 + 4 * (size_t)ni + (size_t)nv * (12 + 8 * (size_t)file_len);
   if (n < need) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: truncated HRIR sphere");
-  if (rate != device_rate)
-    return set_error(ctx, MI355_ERR_UNSUPPORTED, "hrtfrender: sphere sample rate differs from the stream rate (resampling not supported)");
+  if (rate == 0 || device_rate == 0) return set_error(ctx, MI355_ERR_INVALID_ARG, "hrtfrender: zero sample rate");
+  const bool resample = rate != device_rate;
+  const double ratio = (double)device_rate / (double)rate;
+  uint32_t len = file_len;
+  if (resample) {
+    const double l = std::floor((double)file_len * ratio + 0.5);
+    len = l < 1.0 ? 1u : (uint32_t)l;
+  }
   std::vector<uint32_t> idx(ni);
   for (uint32_t i = 0; i < ni; i++) {
     idx[i] = rd_u32(bytes + 20 + 4 * (size_t)i);
@@ -245,8 +280,17 @@ int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint3
   for (uint32_t v = 0; v < nv; v++) {
     std::memcpy(&pos[(size_t)v * 3], bytes + off, 12);  // little-endian host
     off += 12;
-    std::memcpy(&hr[(size_t)v * 2 * len], bytes + off, 8 * (size_t)len);
-    off += 8 * (size_t)len;
+    if (!resample) {
+      std::memcpy(&hr[(size_t)v * 2 * len], bytes + off, 8 * (size_t)len);
+    } else {
+      std::vector<float> raw(2 * (size_t)file_len);
+      std::memcpy(raw.data(), bytes + off, 8 * (size_t)file_len);
+      for (int ear = 0; ear < 2; ear++) {
+        const std::vector<float> y = resample_hrir(raw.data() + (size_t)ear * file_len, file_len, ratio, len);
+        std::memcpy(&hr[((size_t)v * 2 + ear) * len], y.data(), 4 * (size_t)len);
+      }
+    }
+    off += 8 * (size_t)file_len;
   }
   HrtfState *H = hrtf_of(ctx);
   if (!H) { H = new HrtfState(); ctx->hrtf = H; }
@@ -262,7 +306,7 @@ int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint3
   if ((rc = check_hip(ctx, hipMemcpy(H->d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice), "upload hrir positions"))) return rc;
   if (!idx.empty() && (rc = check_hip(ctx, hipMemcpy(H->d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice), "upload hrir indices"))) return rc;
   if ((rc = check_hip(ctx, hipMemcpy(H->d_hrir, hr.data(), hr.size() * 4, hipMemcpyHostToDevice), "upload hrir data"))) return rc;
-  H->rate = rate; H->len = len; H->n_vertices = nv; H->n_faces = ni / 3;
+  H->rate = device_rate; H->len = len; H->n_vertices = nv; H->n_faces = ni / 3;
   H->sphere_loaded = true;
   return MI355_OK;
 }

@@ -333,7 +333,9 @@ int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int 
  * into the `hrtf` crate (HrirSphere::new, HrtfProcessor::new, process_samples).
  *   mi355_hrtf_load_sphere : Settings::sphere(rate) -> HrirSphere::new(bytes, rate) (imp.rs:84-94). `bytes` is the
  *       crate's file format ("HRIR", u32 rate, u32 len, u32 n_vertices, u32 n_indices, indices, vertices). A sphere
- *       whose rate differs from `device_rate` returns MI355_ERR_UNSUPPORTED (the crate resamples it with rubato).
+ *       whose rate differs from `device_rate` is converted at load time, every HRIR by band-limited (windowed-sinc)
+ *       interpolation to round(len * device_rate / file_rate) taps - the crate does this with the `rubato` resampler, whose
+ *       sources are not in the reference tree: same method, parity unpinned (csrc/hrtf_kernels.hip: resample_hrir).
  *   mi355_hrtf_setup       : the ChannelProcessor vector of set_caps (imp.rs:662-680): one HrtfProcessor per input
  *       channel, zeroed tails, no previous vector/gain.
  *   mi355_hrtf_reset       : State::reset_processors (imp.rs:124-129).

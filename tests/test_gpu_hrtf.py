@@ -34,12 +34,11 @@ def test_load_errors(ctx):
         with pytest.raises(mi355fx.Mi355Error) as e:
             ctx.hrtf_load_sphere(bad, 44100)
         assert e.value.status == status
-    with pytest.raises(mi355fx.Mi355Error) as e:
-        ctx.hrtf_load_sphere(b, 48000)
-    assert e.value.status == mi355fx.ERR_UNSUPPORTED
     with pytest.raises(mi355fx.Mi355Error) as e:   # "Impulse response not set" (imp.rs:93)
         ctx.hrtf_setup(2, 512, 8)
     assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+    ctx.hrtf_load_sphere(b, 48000)   # a sphere at another rate is resampled (1 tap at 44.1 kHz -> round(48/44.1) = 1 tap)
+    assert ctx.hrtf_sphere_info() == (1, 187, 370)
 
 
 def _run(ctx, oracle, synth, length, channels, steps, block, n_blocks, seed, static=False):
@@ -139,3 +138,31 @@ def test_not_negotiated(ctx):
         ctx._hrtf_shape = (1, 64, 2)
         ctx.hrtf_process_block(np.zeros((64, 1), np.float32), np.zeros((1, 3), np.float32), np.ones(1, np.float32))
     assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+
+
+@pytest.mark.parametrize("file_rate,device_rate,length", [(44100, 48000, 200), (96000, 48000, 400), (44100, 44100, 64), (48000, 192000, 50)])
+def test_sphere_at_another_rate_is_resampled_at_load(ctx, oracle, synth, file_rate, device_rate, length):
+    """HrirSphere::new(bytes, rate) (audio/hrtf/src/hrtf/imp.rs:83-93) converts a sphere measured at another rate. The product
+    does it in mi355_hrtf_load_sphere (windowed-sinc interpolation, C++ loop); the oracle's numpy restatement of the same
+    method re-serialises the sphere at the stream rate. Rendering the same input through both must agree: the taps differ
+    only by f64 summation order (1e-6 of full scale)."""
+    import mi355fx
+    data = synth.hrir_sphere_bytes(_mesh(), length, rate=file_rate)
+    conv = oracle.resample_hrir_sphere_bytes(data, device_rate)
+    exp_len = max(1, int(np.floor(length * device_rate / file_rate + 0.5)))
+    ctx.hrtf_load_sphere(data, device_rate)
+    assert ctx.hrtf_sphere_info() == (exp_len, 187, 370)
+    channels, steps, block = 3, 4, 96
+    ctx.hrtf_setup(channels, block, steps)
+    rng = np.random.default_rng(length)
+    pos = rng.standard_normal((channels, 3)).astype(np.float32)
+    gains = rng.uniform(0.2, 1.0, channels).astype(np.float32)
+    xs = [rng.uniform(-1, 1, (steps * block, channels)).astype(np.float32) for _ in range(3)]
+    got = [ctx.hrtf_process_block(x, pos, gains) for x in xs]
+    with mi355fx.Context(0) as c2:
+        c2.hrtf_load_sphere(conv, device_rate)     # already at the stream rate: loaded as is
+        assert c2.hrtf_sphere_info() == (exp_len, 187, 370)
+        c2.hrtf_setup(channels, block, steps)
+        exp = [c2.hrtf_process_block(x, pos, gains) for x in xs]
+    scale = max(1.0, max(float(np.abs(e).max()) for e in exp))
+    assert max(float(np.abs(g - e).max()) for g, e in zip(got, exp)) <= 1e-6 * scale

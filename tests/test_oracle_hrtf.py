@@ -131,3 +131,26 @@ def test_sofa_oracle_is_a_streaming_linear_convolution(oracle):
         exp[:, 0] += np.convolve(x[:, c].astype(np.float64), hl)[: n_blocks * B] * g[c]
         exp[:, 1] += np.convolve(x[:, c].astype(np.float64), hs[c][1].astype(np.float64))[: n_blocks * B] * g[c]
     assert np.abs(out - exp).max() < 1e-4
+
+
+def test_resampling_preserves_a_band_limited_impulse_response(oracle):
+    """Property of the method (CPU, oracle side): a low-pass impulse response sampled at 44.1 kHz and converted to 48 kHz equals
+    the same continuous response sampled at 48 kHz (within the window's stop-band error)."""
+    import struct
+    flen, fr, dr = 400, 44100, 48000
+    t = (np.arange(flen) - 100) / fr
+    h = (np.sinc(2 * 6000.0 * t) * np.hanning(flen)).astype(np.float32)   # 6 kHz low-pass, far below both Nyquist rates
+    mesh = open(GOLDEN, "rb").read()
+    magic, rate, l0, nv, ni = struct.unpack_from("<4s4I", mesh, 0)
+    body, off = [struct.pack("<4s4I", b"HRIR", fr, flen, nv, ni), mesh[20:20 + 4 * ni]], 20 + 4 * ni
+    for _ in range(nv):
+        body.append(mesh[off:off + 12]); off += 12 + 8 * l0
+        body.append(h.tobytes()); body.append(h.tobytes())
+    conv = oracle.resample_hrir_sphere_bytes(b"".join(body), dr)
+    _, r2, l2, _, _ = struct.unpack_from("<4s4I", conv, 0)
+    assert r2 == dr and l2 == int(np.floor(flen * dr / fr + 0.5))
+    got = np.frombuffer(conv, "<f4", l2, 20 + 4 * ni + 12)
+    t2 = np.arange(l2) / dr - 100 / fr
+    win = np.interp(np.arange(l2) * fr / dr, np.arange(flen), np.hanning(flen))
+    exp = np.sinc(2 * 6000.0 * t2) * win
+    assert np.abs(got[20:-20] - exp[20:-20]).max() < 2e-3
