@@ -17,7 +17,7 @@ def test_every_entry_point_is_documented():
 
 def test_profile_artefacts_listed_exist():
     readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
-    files = set(re.findall(r"`(r01[a-z0-9_]*\.(?:json|csv|jsonl|txt))`", readme)) | {"pmc_latest.json"}
+    files = set(re.findall(r"`(r0[0-9][a-z0-9_]*\.(?:json|csv|jsonl|txt))`", readme)) | {"pmc_latest.json"}
     assert len(files) >= 6
     for f in files:
         assert os.path.exists(os.path.join(ROOT, "profiles", f)), f

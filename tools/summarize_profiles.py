@@ -67,7 +67,11 @@ def main():
             rec["l2_hit_rate"] = rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"])
     b0 = os.path.join(src, "bench.json")
     try:
-        out["frames_per_step"] = json.load(open(b0))["config"]["frames_per_step"]   # the PMC passes ran the same default workload
+        cfg = json.load(open(b0))["config"]
+        out["frames_per_step"] = cfg["frames_per_step"]   # the PMC passes ran the same default workload
+        out["content"] = cfg.get("content", "smooth")
+        out["pristine_sources"] = str(cfg.get("sources", "")).startswith("pristine")
+        out["collected"] = tag + ": tools/collect_profiles.sh"
     except (OSError, ValueError, KeyError):
         out["frames_per_step"] = None
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
