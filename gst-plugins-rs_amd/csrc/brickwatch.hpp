@@ -9,7 +9,7 @@
 // The brick kernels count the 256-pixel steps that needed cache fills ("miss") and those that could not be served from
 // the cache even after filling ("slow"). Every kSnapEvery-th launch at one level a snapshot of the counters becomes
 // available (asynchronously; the caller polls). A snapshot that is bad for its level moves the stream up a level at once;
-// a better level is probed again after `period` launches (64, doubling to 256 while the answer stays the same: a probe costs
+// a better level is probed - with a single launch - again after `period` launches (64, doubling to 256 while the answer stays the same: a probe costs
 // four launches on the wrong kernel, i.e. at most a few percent, and a stream whose content calms down is back on the
 // faster kernel within a few hundred buffers).
 #pragma once
@@ -18,7 +18,7 @@ namespace mi355 {
 
 struct BrickWatch {
   int home = 0;            // level currently believed best
-  int probing = -1;        // level under probation (-1: none); launches use it until its snapshot arrives
+  int probing = -1;        // level whose one-launch probe is in flight (-1: none)
   unsigned retry_in = 0;   // launches left before the next lower level is probed
   unsigned period = 0;     // current probe period
   double last_miss = 0.0, last_slow = 0.0;
@@ -36,14 +36,16 @@ inline bool watch_bad(int level, double miss, double slow) {
   return level == 0 ? (slow > 0.01 || miss > 0.08) : (slow > 0.03 || miss > 0.40);
 }
 
-// level for the next launch (call once per launch)
-inline int watch_level(BrickWatch &W) {
-  if (W.probing >= 0) return W.probing;
-  if (W.home > 0) {
-    if (W.retry_in > 0) W.retry_in--;
-    else W.probing = W.home - 1;
-  }
-  return W.probing >= 0 ? W.probing : W.home;
+// Level for the next launch (call once per launch). A probe of the next lower level is ONE launch: its counters are
+// snapshotted right behind it in stream order and the stream goes straight back to `home`; the verdict is applied whenever
+// the snapshot arrives. (A host that enqueues hundreds of launches ahead of the device would otherwise run the kernel
+// believed slower for as long as its queue is deep.) can_probe: no other snapshot is in flight.
+inline int watch_level(BrickWatch &W, bool can_probe) {
+  if (W.probing >= 0 || W.home == 0) return W.home;
+  if (W.retry_in > 0) { W.retry_in--; return W.home; }
+  if (!can_probe) return W.home;
+  W.probing = W.home - 1;
+  return W.probing;
 }
 
 // a snapshot taken over launches that all ran at `level` (0 or 1) has arrived

@@ -592,7 +592,7 @@ static void brick_harvest(BrickLut &B) {
 
 int brick_choose(BrickLut &B) {
   brick_harvest(B);
-  return watch_level(B.watch);
+  return watch_level(B.watch, !B.pending);
 }
 
 // before a brick launch at `level`: a change of level starts a new count (what the counters hold belongs to the old one)

@@ -1715,14 +1715,15 @@ extern "C" int mi355_selftest_brickwatch(int n_calls, const double *miss0, const
   int level_since = -1, launches_since = 0, pend_level = -1, pend_ready = 0;
   double acc_m = 0, acc_s = 0, pend_m = 0, pend_s = 0;
   for (int i = 0; i < n_calls; i++) {
-    if (pend_level >= 0 && i >= pend_ready) { mi355::watch_snapshot(W, pend_level, pend_m, pend_s); pend_level = -1; }
-    const int level = mi355::watch_level(W);
+    if (pend_level >= 0 && i >= pend_ready) { const int l = pend_level; pend_level = -1; mi355::watch_snapshot(W, l, pend_m, pend_s); }
+    const int level = mi355::watch_level(W, pend_level < 0);
     level_out[i] = level;
-    if (level == 2 || pend_level >= 0) continue;
+    if (level == 2) { level_since = 2; continue; }
     if (level != level_since) { level_since = level; launches_since = 0; acc_m = acc_s = 0; }
     acc_m += level ? miss1[i] : miss0[i];
     acc_s += level ? slow1[i] : slow0[i];
-    if (++launches_since >= (W.probing == level ? 1 : (int)mi355::kWatchSnapEvery)) {
+    launches_since++;
+    if (pend_level < 0 && launches_since >= (W.probing == level ? 1 : (int)mi355::kWatchSnapEvery)) {
       pend_level = level; pend_m = acc_m / launches_since; pend_s = acc_s / launches_since; pend_ready = i + 1 + lag;
       launches_since = 0; acc_m = acc_s = 0;
     }

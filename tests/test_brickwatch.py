@@ -69,3 +69,18 @@ def test_levels_are_always_valid_under_random_content(mi355lib, seed):
     lv = _run(mi355lib, m0, np.minimum(s0, m0), m1, np.minimum(s1, m1), lag=int(rng.integers(0, 6)))
     assert set(lv) <= {0, 1, 2}
     assert lv[0] == 0
+
+
+def test_probes_are_single_launches_even_when_the_host_runs_far_ahead(mi355lib):
+    """A host that enqueues 150 launches ahead of the device sees every snapshot 150 calls late. The first move up still
+    takes that long, but afterwards a probe of the lower level is ONE launch - not one queue depth of launches on the kernel
+    believed slower."""
+    n, lag = 1500, 150
+    lv = _run(mi355lib, [0.2] * n, [0.05] * n, [0.08] * n, [0.0] * n, lag=lag)
+    first1 = lv.index(1)
+    assert first1 <= lag + 6
+    tail = lv[first1:]
+    zeros = [i for i, v in enumerate(tail) if v == 0]
+    assert 2 <= len(zeros) <= 12                                   # a handful of probes in 1300 launches
+    assert all(b - a > 1 for a, b in zip(zeros, zeros[1:]))        # never two in a row
+    assert 2 not in lv
