@@ -29,11 +29,11 @@ constexpr unsigned kWatchSnapEvery = 4;
 constexpr unsigned kWatchPeriodMin = 64, kWatchPeriodMax = 256;
 
 inline bool watch_bad(int level, double miss, double slow) {
-  // Level 0 is left early: its misses come from the few strips whose content does not fit 32 sets, and the waves of those
-  // strips - not the average wave - set the kernel's duration (measured on 8x4K: 4.5 % miss steps 0.119 ms, 12 % 0.30 ms,
-  // against 0.138-0.145 ms for the 64-set geometry on either). Level 1 against the three-pass kernel's flat 0.24-0.25 ms:
-  // 31 % miss steps 0.20 ms, 45 % with 12 % slow steps 0.65 ms.
-  return level == 0 ? (slow > 0.01 || miss > 0.08) : (slow > 0.03 || miss > 0.40);
+  // Measured on 8x4K (profiles/r02_brick_sweep.txt; miss / slow = share of 256-pixel steps). Level 0 against level 1:
+  // 6 % miss steps 0.122 ms against 0.137; 13 % (the chain's post-hsvfilter frames) 0.151 against 0.138; 19 % 0.172
+  // against 0.147. Level 1 against the three-pass kernel's 0.23-0.27 ms: 29 % miss steps 0.226 ms (better), 35 % 0.278
+  // (worse), 53 % with 10 % slow steps 0.44.
+  return level == 0 ? (slow > 0.01 || miss > 0.09) : (slow > 0.02 || miss > 0.32);
 }
 
 // Level for the next launch (call once per launch). A probe of the next lower level is ONE launch: its counters are

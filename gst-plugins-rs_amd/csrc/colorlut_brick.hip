@@ -35,20 +35,48 @@
 #include "exact_math.hpp"
 #include "colorlut_brick.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace mi355 {
 
 constexpr int kBrickSetBytes = 208;    // brick way 0 at +0, way 1 at +96, tags at +192 / +196, owner at +200, fifo at +204
-constexpr int kBrickTagShift = 16;     // packed = LDS byte address of the set (< 65536) | tag << 16
+// Block shape. ONE block per CU, as many waves as the LDS holds caches for: 16 (32 sets), 12 (48 sets), 10 (64 sets). The
+// waves of a block share their work (see the deques in the kernel), so what matters is waves per CU, not blocks per CU.
+#ifndef BRICK_W64
+#define BRICK_W64 10
+#endif
+#ifndef BRICK_P64
+#define BRICK_P64 4
+#endif
+#ifndef BRICK_G64
+#define BRICK_G64 1
+#endif
+constexpr int brick_waves(int zn) { return zn == 4 ? BRICK_W64 : (zn == 3 ? 12 : 16); }
+#ifndef BRICK_SB32
+#define BRICK_SB32 2
+#endif
+#ifndef BRICK_SB64
+#define BRICK_SB64 2
+#endif
+constexpr int brick_group(int zn) { return zn == 4 ? BRICK_SB64 : (zn == 3 ? 4 : BRICK_SB32); }  // runs dealt out together (see the kernel)
+// packed word of the axis tables: LDS byte address of the set / 16 in the low 16 bits (every set address is a multiple of
+// 16 B; one SDWA shift turns WORD_0 into the byte address), tag in the high 16
+constexpr int kBrickTagShift = 16;
 constexpr int kBrickAxisBytes = 3 * 256 * 8;
-constexpr int kBrickWaves = 4;         // waves per block
 constexpr int kBrickCounterSlots = 1024;
 constexpr size_t kBrickCounterBytes = 2 * kBrickCounterSlots * sizeof(unsigned long long);
-// ZN = number of z0 residues in the set index: 2 -> 32 sets (6.9 KB per wave, 4 blocks = 16 waves per CU), 3 -> 48 sets
-// (10.4 KB, 12 waves per CU), 4 -> 64 sets (13.8 KB, 8 waves per CU)
+#ifdef BRICK_TIMING  // debug builds (tools/exp_brick_build.sh): per-run {start, end, miss | slow << 32, strip | rr << 32} after the counters
+constexpr size_t kBrickTimingBytes = 16384 * 4 * sizeof(unsigned long long);
+#else
+constexpr size_t kBrickTimingBytes = 0;
+#endif
+// ZN = number of z0 residues in the set index: 2 -> 32 sets (6.9 KB per wave, 16 waves per CU), 3 -> 48 sets
+// (10.4 KB, 12 waves per CU), 4 -> 64 sets (13.8 KB, 10 waves per CU)
 // Set address = 208 x (x0 & 3) + 832 x (y0 & 3) + kBrickZStride x (z0 mod ZN). ds_read_b128 serves 16 lanes per LDS
 // cycle over 16 sixteen-byte columns; with 13 columns per set the 16 (x, y) residues start on 16 different columns, way 1
 // sits 6 columns after way 0, and the z stride adds 8 more: the two ways of a cell and of its x, y and z neighbours - the
@@ -56,16 +84,17 @@ constexpr size_t kBrickCounterBytes = 2 * kBrickCounterSlots * sizeof(unsigned l
 constexpr int kBrickZStride = 16 * kBrickSetBytes + 128;
 // (ZN == 2: 7,040 B so that the (2, 4, 4) and (4, 2, 4) residue layouts fit as well as (4, 4, 2))
 constexpr int brick_wave_bytes(int zn) { return zn == 2 ? 7040 : zn * kBrickZStride; }
-constexpr int brick_axis_base(int zb) { return kBrickWaves * brick_wave_bytes(zb); }   // LDS: four wave regions, then the axis tables
-constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 dwords: cell-number contributions (fill path)
-constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 3 * 1024; }          // 8 dwords: hsvfilter sextant selectors
+constexpr int brick_axis_base(int zb) { return brick_waves(zb) * brick_wave_bytes(zb); }   // LDS: the wave regions, then the axis tables
+constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 bytes: lower cell index per axis and input byte (fill path)
+constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 768; }          // 8 dwords: hsvfilter sextant selectors
 constexpr int kBrickQueueCap = 30;                                                       // fill queue entries per wave ({cell, destination})
-constexpr int brick_queue_base(int zb) { return brick_sel_base(zb) + 32; }               // 4 x 256 B
+constexpr int brick_queue_base(int zb) { return brick_sel_base(zb) + 32; }               // 256 B per wave
 constexpr int kBrickScratch = 6;                                                         // per-step overflow bricks per wave
-constexpr int brick_scratch_base(int zb) { return brick_queue_base(zb) + kBrickWaves * 256; }  // 4 x 6 x 96 B
-constexpr int brick_lds_bytes(int zb) { return brick_scratch_base(zb) + kBrickWaves * kBrickScratch * 96; }
-static_assert(4 * brick_lds_bytes(2) <= 160 * 1024 && 3 * brick_lds_bytes(3) <= 160 * 1024 && 2 * brick_lds_bytes(4) <= 160 * 1024, "blocks per CU");
-static_assert(brick_axis_base(4) <= (1 << kBrickTagShift), "set addresses must fit below the tag field");
+constexpr int brick_scratch_base(int zb) { return brick_queue_base(zb) + brick_waves(zb) * 256; }  // 6 x 96 B per wave
+constexpr int brick_deque_base(int zb) { return brick_scratch_base(zb) + brick_waves(zb) * kBrickScratch * 96; }  // one word per wave: tiles {taken from the front, end}
+constexpr int brick_lds_bytes(int zb) { return brick_deque_base(zb) + 64; }
+static_assert(brick_lds_bytes(2) <= 160 * 1024 && brick_lds_bytes(3) <= 160 * 1024 && brick_lds_bytes(4) <= 160 * 1024, "one block per CU");
+static_assert(brick_waves(2) <= 16 && brick_waves(3) <= 16 && brick_waves(4) <= 16, "deque words / victim search");
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -78,6 +107,13 @@ __device__ __forceinline__ uint32_t byte_times8(uint32_t px, uint32_t three) {
   if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(o) : "v"(three), "v"(px));
   else if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o) : "v"(three), "v"(px));
   else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(o) : "v"(three), "v"(px));
+  return o;
+}
+
+// (packed & 0xffff) << 4: the set's LDS byte address out of the packed word, one SDWA shift
+__device__ __forceinline__ uint32_t word0_times16(uint32_t packed, uint32_t four) {
+  uint32_t o;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(o) : "v"(four), "v"(packed));
   return o;
 }
 
@@ -131,29 +167,36 @@ typedef __attribute__((address_space(3))) u2_t lds_u2;
 typedef __attribute__((address_space(3))) f4_t lds_f4;
 __device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const lds_u32 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w32(uint32_t a, uint32_t v) { *(lds_u32 *)(lds_byte *)a = v; }
+__device__ __forceinline__ uint32_t lds_r8(uint32_t a) { return *(const lds_byte *)a; }
+__device__ __forceinline__ void lds_w8(uint32_t a, uint32_t v) { *(lds_byte *)a = (unsigned char)v; }
 __device__ __forceinline__ u2_t lds_r64(uint32_t a) { return *(const lds_u2 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_byte *)a = v; }
 __device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)a = v; }
 
 template <int P, int HSV, int ZN, int G>  // P = 16-byte loads per lane and tile (a tile is 128 px x 2P rows), G of them per step
-__global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
+__global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
                                                                                  unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
                                                                                  const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
                                                                                  const uint32_t *__restrict__ cellnum,
-                                                                                 unsigned long long *__restrict__ counters, HsvK hk, unsigned fold_axis) {
+                                                                                 unsigned long long *__restrict__ counters, HsvK hk, unsigned fold_axis, unsigned lut_size) {
   // All LDS of this kernel is the dynamic allocation and there are no static __shared__ objects, so the allocation starts
   // at LDS address 0. LDS is addressed by absolute byte address (address-space-3 pointers made from integers): every table
   // base then folds into the ds_read offset field instead of costing an add of the link-time base symbol per access.
-  constexpr int NP = 4 * G;
+  constexpr int NP = 4 * G, NT = 64 * brick_waves(ZN);
   static_assert(P % G == 0, "a tile is a whole number of steps");
   constexpr uint32_t AX = brick_axis_base(ZN), CELL = brick_cell_base(ZN), SEL = brick_sel_base(ZN), SCR = brick_scratch_base(ZN), WB = brick_wave_bytes(ZN), SETS = 16u * ZN;
   const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)SEL;
   if constexpr (HSV != kBrickNoHsv) {
     if (threadIdx.x < 7) lds_w32(SEL + 4 * threadIdx.x, HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3));
   }
-  for (int i = threadIdx.x; i < kBrickAxisBytes / 8; i += 256) lds_w64(AX + 8 * i, axis[i]);
-  for (int i = threadIdx.x; i < 768; i += 256) lds_w32(CELL + 4 * i, cellnum[i]);
+  for (int i = threadIdx.x; i < kBrickAxisBytes / 8; i += NT) lds_w64(AX + 8 * i, axis[i]);
+  for (int i = threadIdx.x; i < 768; i += NT) lds_w8(CELL + i, cellnum[i]);
+  // cell number of a pixel (fill path only): x0 + S (y0 + S z0)
+  auto cell_of = [&](uint32_t p) -> uint32_t {
+    const uint32_t ix = lds_r8(CELL + (p & 0xffu)), iy = lds_r8(CELL + 256u + ((p >> 8) & 0xffu)), iz = lds_r8(CELL + 512u + ((p >> 16) & 0xffu));
+    return ix + lut_size * (iy + lut_size * iz);
+  };
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t queue = brick_queue_base(ZN) + wave * 256u;
   const uint32_t e_l = lane / 6u, k_l = lane % 6u;  // fill pass: lane -> (queue entry, 16-byte piece of its brick)
@@ -168,20 +211,46 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
     lds_w64(sa + 192, inval);  // both tags invalid
     lds_w32(sa + 204, 0u);     // next victim: way 0
   }
-  __syncthreads();
-  const uint32_t three = 3;
-
-  const unsigned n_runs = n_runs_flags & 0x7fffffffu;  // bit 31: progress-based wave priorities
-  const unsigned run = blockIdx.x * kBrickWaves + wave;
-  if (run >= n_runs) return;
-  // the four waves of a block take four consecutive runs of ONE strip: strips differ in cost (a strip that straddles two
-  // colour regions refills its caches far more often), a block should not wait for one slow wave out of four
+  // Work. The picture is cut into 128-pixel-wide strips and every strip into RUNS of tiles_per_run tiles. Runs are dealt out
+  // in groups of SB consecutive ones; a block takes the groups blockIdx, blockIdx + gridDim, ... (W / SB of them, from
+  // different parts of the picture, so that the CUs get work of about the same difficulty) and wave w OWNS one run. A
+  // wave walks down its run so that its cache stays warm from tile to tile - but runs differ in cost (one that straddles
+  // colour regions refills far more often; the SIMDs of a CU do not hold the same number of waves; the SIMD arbitrates by
+  // age), and a kernel that waits for its slowest wave loses 15-60 % to the tail. So every run is a DEQUE in LDS - one
+  // word {tiles taken from the front, end} - the owner takes tiles from the front (ds_add), a wave whose own run is done
+  // STEALS single tiles from the back of the run with the most tiles left (ds_cmpst), and keeps stealing from that run
+  // while it lasts (its cache warms up on the neighbouring rows). The waves of a CU then finish within a tile of each other.
+  constexpr uint32_t DQ = brick_deque_base(ZN), W = brick_waves(ZN), NONE = 0xffffffffu;
+  const unsigned n_runs = n_runs_flags & 0x3fffffffu;  // bit 31: stealing enabled, bit 30: progress-based priorities
+  const bool steal = (n_runs_flags >> 31) != 0, prio_quarters = ((n_runs_flags >> 30) & 1u) != 0;
   const unsigned runs_per_strip = (n_runs + n_strips - 1) / n_strips;
-  // (with 16 waves per CU the blocks of adjacent strips measure faster on coherent content: 2 KB row segments per block)
-  const unsigned strip = ZN == 2 ? run % n_strips : run / runs_per_strip, rr = ZN == 2 ? run / n_strips : run % runs_per_strip;
+  const unsigned tile_rows = (rows + 2 * P - 1) / (2 * P);  // tiles per strip
+  // run -> (strip, first tile). 32 sets: the runs of a block are the same rows of adjacent strips (2 KB row segments per
+  // block measure faster on coherent content); otherwise consecutive runs of one strip
+  auto run_pos = [&](unsigned run, unsigned &strip, unsigned &tile0) {
+    const unsigned rr = ZN == 2 ? run / n_strips : run % runs_per_strip;
+    strip = ZN == 2 ? run % n_strips : run / runs_per_strip;
+    tile0 = rr * tiles_per_run;
+  };
+  constexpr unsigned SB = brick_group(ZN);
+  auto run_of = [&](unsigned w) { return ((w / SB) * gridDim.x + blockIdx.x) * SB + w % SB; };
+  if (threadIdx.x < W) {
+    const unsigned run = run_of(threadIdx.x);
+    unsigned nt = 0;
+    if (run < n_runs) {
+      unsigned strip, tile0;
+      run_pos(run, strip, tile0);
+      if (tile0 < tile_rows) nt = tile_rows - tile0 < tiles_per_run ? tile_rows - tile0 : tiles_per_run;
+    }
+    lds_w32(DQ + 4 * threadIdx.x, nt << 16);
+  }
+  __syncthreads();
+  const uint32_t three = 3, four = 4;
+#ifdef BRICK_TIMING
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  unsigned tiles_done = 0, tiles_stolen = 0;
+#endif
   const unsigned sub = lane >> 5, g = lane & 31;
-  const unsigned col = strip * 32 + g;
-  const bool col_ok = col < w4;
   unsigned miss_steps = 0, slow_steps = 0;
 
   auto wave_sync = [] {
@@ -189,41 +258,99 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
     __builtin_amdgcn_wave_barrier();
   };
 
-  const unsigned row_first = rr * tiles_per_run * (2 * P);
+  // claim a tile: (owning wave << 16) | tile index within that wave's run, or NONE. Wave-uniform.
+  bool own_done = false;
+  uint32_t last_victim = NONE;
+  unsigned prio_q = 0;
+  if (prio_quarters) __builtin_amdgcn_s_setprio(3);
+  auto claim = [&]() -> uint32_t {
+    if (!own_done) {
+      uint32_t old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add((lds_u32 *)(lds_byte *)(DQ + 4u * wave), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if ((old & 0xffffu) < (old >> 16)) {
+        // Fair share by hand. The SIMD arbitrates VALU issue by priority, then AGE: at equal priority the oldest wave of a
+        // SIMD takes every slot it can use and is done with its run long before the youngest. A wave therefore lowers its
+        // priority as it advances (3, 2, 1, 0 by quarter of its run; 0 when it lives on stolen tiles): whoever is behind
+        // outranks whoever is ahead, so fewer tiles have to change hands (a stolen tile starts on a cold cache).
+        if (prio_quarters) {
+          const unsigned q = (4u * (old & 0xffffu)) / tiles_per_run;
+          if (q != prio_q) {
+            prio_q = q;
+            if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else if (q >= 3) __builtin_amdgcn_s_setprio(0);
+          }
+        }
+        return (wave << 16) | (old & 0xffffu);
+      }
+      own_done = true;
+      if (prio_quarters) __builtin_amdgcn_s_setprio(0);
+    }
+    if (!steal) return NONE;
+    for (;;) {
+      const uint32_t v = lane < W ? lds_r32(DQ + 4u * lane) : 0u;
+      const uint32_t f = v & 0xffffu, e = v >> 16;
+      uint32_t key = e > f ? (((e - f) << 6) | lane | (lane == last_victim ? 0x40000000u : 0u)) : 0u;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)key, o);
+        key = other > key ? other : key;
+      }
+      key = __builtin_amdgcn_readfirstlane(key);
+      if (key == 0u) return NONE;
+      const uint32_t vic = key & 63u;
+      const uint32_t vv = __builtin_amdgcn_readlane(v, vic);
+      uint32_t ok = 0;
+      if (lane == 0) {
+        uint32_t expected = vv;
+        ok = __hip_atomic_compare_exchange_strong((lds_u32 *)(lds_byte *)(DQ + 4u * vic), &expected, vv - 0x10000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+      }
+      ok = __builtin_amdgcn_readfirstlane(ok);
+      if (ok) {
+        last_victim = vic;
+#ifdef BRICK_TIMING
+        tiles_stolen++;
+#endif
+        return (vic << 16) | ((vv >> 16) - 1u);
+      }
+    }
+  };
+  auto tile_pos = [&](uint32_t id, unsigned &strip, unsigned &row0) {
+    unsigned tile0;
+    run_pos(run_of(id >> 16), strip, tile0);
+    row0 = (tile0 + (id & 0xffffu)) * (2 * P);
+  };
+
   u4_t cur[P], nxt[P];
   // Loads are unconditional (out-of-picture lanes re-read a clamped in-picture address; only the stores are predicated):
   // a load inside a branch makes the number of outstanding memory operations unknown to the compiler, which then waits
   // for ALL of them - next tile's prefetch included - with s_waitcnt vmcnt(0) before touching the current tile.
-  const unsigned col_c = col_ok ? col : w4 - 1;
-  auto load_tile = [&](unsigned row0, u4_t(&t)[P]) {
+  auto load_tile = [&](unsigned row0, unsigned col_c, u4_t(&t)[P]) {
 #pragma unroll
     for (int j = 0; j < P; j++) {
       const unsigned r = row0 + 2 * j + sub;
       t[j] = __builtin_nontemporal_load(src + (size_t)(r < rows ? r : rows - 1) * w4 + col_c);
     }
   };
-  load_tile(row_first, cur);
-  const bool prio_quarters = (n_runs_flags >> 31) != 0;
-  unsigned prio_q = 0;
-  if (prio_quarters) __builtin_amdgcn_s_setprio(3);
-  for (unsigned t = 0; t < tiles_per_run; t++) {
-    const unsigned row0 = row_first + t * (2 * P);
-    if (row0 >= rows) break;  // wave-uniform
-    // Fair share by hand. The SIMD arbitrates VALU issue by priority, then AGE: at equal priority the oldest of the four
-    // waves of a SIMD takes every slot it can use and finishes its run long before the youngest, which then works alone
-    // at a third of the issue rate (measured: average wave lifetime 66 % of the kernel time). A wave therefore lowers its
-    // priority as it advances (3, 2, 1, 0 by quarter of its run): whoever is behind outranks whoever is ahead, and the four
-    // finish within a quarter of a run of each other.
-    if (prio_quarters) {
-      const unsigned q = (4u * t) / tiles_per_run;
-      if (q != prio_q) {
-        prio_q = q;
-        if (q == 1) __builtin_amdgcn_s_setprio(2);
-        else if (q == 2) __builtin_amdgcn_s_setprio(1);
-        else if (q == 3) __builtin_amdgcn_s_setprio(0);
-      }
-    }
-    load_tile(row0 + 2 * P, nxt);  // prefetch (clamped to the picture: the last tile of a run re-reads rows it does not use)
+  uint32_t cur_id = claim();
+  unsigned strip = 0, row0 = 0;
+  if (cur_id != NONE) tile_pos(cur_id, strip, row0);
+  unsigned col = strip * 32 + g;
+  bool col_ok = col < w4;
+  load_tile(row0, col_ok ? col : w4 - 1, cur);
+  while (cur_id != NONE) {
+    // the next tile is claimed - and its loads issued - before this one is worked on
+    const uint32_t nxt_id = claim();
+    unsigned nstrip = strip, nrow0 = row0;
+    if (nxt_id != NONE) tile_pos(nxt_id, nstrip, nrow0);
+    const unsigned ncol = nstrip * 32 + g;
+    const bool ncol_ok = ncol < w4;
+    load_tile(nrow0, ncol_ok ? ncol : w4 - 1, nxt);
+#ifdef BRICK_TIMING
+    tiles_done++;
+#endif
 #pragma unroll
     for (int j = 0; j < P; j += G) {
       // one STEP = G 16-byte groups per lane = NP pixels per lane (64 NP pixels per wave), checked and filled together
@@ -248,8 +375,8 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
         tx[i] = __uint_as_float(ex.x);
         ty[i] = __uint_as_float(ey.x);
         tz[i] = __uint_as_float(ez.x);
-        const uint32_t packed = (ex.y + ey.y) + (ez.y + wave_base);  // v_add_u32 + v_add3_u32
-        set[i] = packed & ((1u << kBrickTagShift) - 1u);           // LDS byte address of the wave's set for this cell
+        const uint32_t packed = (ex.y + ey.y) + (ez.y + (wave_base >> 4));  // v_add_u32 + v_add3_u32
+        set[i] = word0_times16(packed, four);                       // LDS byte address of the wave's set for this cell
         tag[i] = packed;                                            // the whole word identifies the brick (the set bits are redundant there)
       }
       // tag check: both ways' tags in one 8-byte read; baddr = the way that holds the brick
@@ -295,8 +422,7 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
                 const uint32_t cnt = (fw >> 3) == gen ? ((fw >> 1) & 3u) : 0u;
                 if (cnt < 2u) {
                   const uint32_t way = fw & 1u;
-                  const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
-                                        lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
+                  const uint32_t cell = cell_of(px[i]);
                   const u2_t qe = {cell, set[i] + 96u * way};
                   lds_w64(queue + 8u * pos, qe);
                   lds_w32(set[i] + 192u + 4u * way, tag[i]);
@@ -336,8 +462,7 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
             bool m = tg.x != tag[i] && tg.y != tag[i];
             unsigned long long mb = __ballot(m);
             if (mb) {
-              const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
-                                    lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
+              const uint32_t cell = cell_of(px[i]);
               while (mb && n_ovf < (uint32_t)kBrickScratch) {
                 const int L = __builtin_ctzll(mb);
                 const uint32_t cellL = __builtin_amdgcn_readlane(cell, L);
@@ -383,8 +508,7 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
         for (int i = 0; i < NP; i++) {
           f4_t f[6];
           if ((lane_res >> i) & 1u) {
-            const uint32_t cell = lds_r32(CELL + ((px[i] & 0xffu) << 2)) + lds_r32(CELL + 1024u + (((px[i] >> 8) & 0xffu) << 2)) +
-                                  lds_r32(CELL + 2048u + (((px[i] >> 16) & 0xffu) << 2));
+            const uint32_t cell = cell_of(px[i]);
             const f4_t *gb = bricks + (size_t)cell * 8;
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = gb[k];
@@ -406,11 +530,25 @@ __global__ __launch_bounds__(256, 6 - ZN) void colorlut3d_brick_kernel(const u4_
     }
 #pragma unroll
     for (int j = 0; j < P; j++) cur[j] = nxt[j];
+    cur_id = nxt_id;
+    row0 = nrow0;
+    col = ncol;
+    col_ok = ncol_ok;
   }
   // counters are spread over kBrickCounterSlots slots (the host adds them up): thousands of waves finishing together and
   // adding to ONE address serialise in L2 at ~12 ns per atomic - a 0.1 ms tail on a 0.1 ms kernel
+  const unsigned wave_id = blockIdx.x * W + wave;
+#ifdef BRICK_TIMING
+  if (lane == 0 && wave_id < 16384) {
+    unsigned long long *tr = counters + 2 * kBrickCounterSlots + 4 * (size_t)wave_id;
+    tr[0] = t_start;
+    tr[1] = __builtin_amdgcn_s_memrealtime();
+    tr[2] = miss_steps | ((unsigned long long)slow_steps << 32);
+    tr[3] = tiles_done | ((unsigned long long)tiles_stolen << 32);
+  }
+#endif
   if (counters && lane == 0 && miss_steps) {
-    unsigned long long *c = counters + 2 * (run % kBrickCounterSlots);
+    unsigned long long *c = counters + 2 * (wave_id % kBrickCounterSlots);
     atomicAdd(c + 0, (unsigned long long)miss_steps);
     if (slow_steps) atomicAdd(c + 1, (unsigned long long)slow_steps);
   }
@@ -494,14 +632,14 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
         // tag fields packed axis after axis, each as wide as its largest value (S - 1) / mod needs: 16 bits in all for S <= 65
         auto bits_for = [&](int m) { int b = 0; while (((S - 1) / m) >> b) b++; return b; };
         const int tag_shift = a == 0 ? 0 : (a == 1 ? bits_for(mods[0]) : bits_for(mods[0]) + bits_for(mods[1]));
-        if (bits_for(mods[0]) + bits_for(mods[1]) + bits_for(mods[2]) > 16 ||
+        if (bits_for(mods[0]) + bits_for(mods[1]) + bits_for(mods[2]) > 32 - kBrickTagShift || set_off % 16u != 0u ||
             (uint32_t)(mods[0] - 1) * kBrickSetBytes + (uint32_t)(mods[1] - 1) * stride1 + (uint32_t)(mods[2] - 1) * stride2 + kBrickSetBytes > (uint32_t)brick_wave_bytes(zn))
           return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: brick cache geometry does not fit");
         const uint32_t tag = (uint32_t)(i0 / mod) << tag_shift;
         uint32_t *e = &axis[((size_t)(zn - 2) * 768 + (size_t)a * 256 + v) * 2];
         std::memcpy(&e[0], &t, 4);
-        e[1] = set_off + (tag << kBrickTagShift);
-        cellnum[(size_t)a * 256 + v] = (uint32_t)i0 * (a == 0 ? 1u : (a == 1 ? (uint32_t)S : (uint32_t)S * S));
+        e[1] = (set_off >> 4) + (tag << kBrickTagShift);
+        cellnum[(size_t)a * 256 + v] = (uint32_t)i0;
       }
   int rc = check_hip(ctx, hipMalloc((void **)&B.d_bricks, bricks.size() * sizeof(float)), "hipMalloc(lut bricks)");
   if (rc) return rc;
@@ -510,7 +648,7 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
   if ((rc = check_hip(ctx, hipMemcpy(B.d_axis, axis.data(), axis.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(brick axis tables)"))) return rc;
   if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_cellnum, cellnum.size() * sizeof(uint32_t)), "hipMalloc(brick cell numbers)"))) return rc;
   if ((rc = check_hip(ctx, hipMemcpy(B.d_cellnum, cellnum.data(), cellnum.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(brick cell numbers)"))) return rc;
-  if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_counters, kBrickCounterBytes), "hipMalloc(brick counters)"))) return rc;
+  if ((rc = check_hip(ctx, hipMalloc((void **)&B.d_counters, kBrickCounterBytes + kBrickTimingBytes), "hipMalloc(brick counters)"))) return rc;
   if ((rc = check_hip(ctx, hipMemset(B.d_counters, 0, kBrickCounterBytes), "hipMemset(brick counters)"))) return rc;
   if ((rc = check_hip(ctx, hipHostMalloc((void **)&B.h_counters, kBrickCounterBytes, hipHostMallocDefault), "hipHostMalloc(brick counters)"))) return rc;
   std::memset(B.h_counters, 0, kBrickCounterBytes);
@@ -534,25 +672,42 @@ bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch,
 template <int HSV, int ZN>
 static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
   // tile = 128 px x 2P rows, prefetched one tile ahead: with 8 waves per CU a 4-row tile is consumed faster than HBM answers
-  constexpr int P = ZN == 4 ? 4 : 2;
+  constexpr int P = ZN == 4 ? BRICK_P64 : 2;
   const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
   const unsigned n_strips = (w4 + 31) / 32;
   const unsigned tile_rows = (rows + 2 * P - 1) / (2 * P);
   // Run length: a wave's cache starts cold at the top of its run, so runs are as long as the launch allows while still
-  // giving every wave slot of the chip (n_cu x 16 or 8) one run: ONE round of runs, all of about the same length.
-  const size_t wave_slots = (size_t)ctx->n_cu * 4 * (6 - ZN);
+  // giving every wave of the chip (one block of W waves per CU) a run of its own: ONE round of runs, all of about the same
+  // length; what unevenness remains (content, SIMD sharing) the waves of a block even out among themselves (the deques).
+  constexpr unsigned W = brick_waves(ZN);
+  const size_t wave_slots = (size_t)ctx->n_cu * W;
   unsigned tpr = (unsigned)(((size_t)n_strips * tile_rows + wave_slots - 1) / wave_slots);
   if (tpr < 8) tpr = 8;
   if (tpr > 512) tpr = 512;
   if (ctx->brick_tiles_per_run > 0) tpr = (unsigned)ctx->brick_tiles_per_run;
   const unsigned runs_per_strip = (tile_rows + tpr - 1) / tpr;
   const size_t n_runs = (size_t)n_strips * runs_per_strip;
-  if (n_runs >= (1u << 31)) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame batch too large");
-  const unsigned grid = (unsigned)((n_runs + kBrickWaves - 1) / kBrickWaves);
-  constexpr int G = ZN == 4 ? 2 : 1;  // 8 waves per CU have the registers for 8-pixel steps (more reads in flight per wave)
-  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G>), dim3(grid), dim3(256), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
-                     rows, n_strips, tpr, (unsigned)n_runs | (ctx->brick_prio ? 0x80000000u : 0u), (const f4_t *)B.d_bricks, (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768,
-                     (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis);
+  if (n_runs >= (1u << 30)) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame batch too large");
+  // groups of SB runs, W / SB groups per block; small launches: as many blocks as there are groups, up to one per CU (the
+  // waves of a block that own nothing steal)
+  constexpr unsigned SB = brick_group(ZN), K = W / SB;
+  static_assert(W % SB == 0, "whole groups per block");
+  const size_t n_groups = (n_runs + SB - 1) / SB;
+  size_t grid = (n_groups + K - 1) / K;
+  const size_t spread = n_groups < (size_t)ctx->n_cu ? n_groups : (size_t)ctx->n_cu;
+  if (grid < spread) grid = spread;
+  constexpr int G = ZN == 4 ? BRICK_G64 : 1;
+  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G>), dim3((unsigned)grid), dim3(64 * W), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
+                     rows, n_strips, tpr, (unsigned)n_runs | ((unsigned)(ctx->brick_prio & 3) << 30), (const f4_t *)B.d_bricks,
+                     (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768, (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis, (unsigned)B.size);
+#ifdef BRICK_TIMING
+  if (const char *path = getenv("BRICK_TIMING_FILE")) {
+    std::vector<unsigned long long> tr(kBrickTimingBytes / 8);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(tr.data(), (const char *)B.d_counters + kBrickCounterBytes, kBrickTimingBytes, hipMemcpyDeviceToHost);
+    if (FILE *f = fopen(path, "wb")) { unsigned long long hdr[4] = {grid * W, tpr, n_strips, (unsigned long long)ZN}; fwrite(hdr, 8, 4, f); fwrite(tr.data(), 8, std::min<size_t>(tr.size(), grid * W * 4), f); fclose(f); }
+  }
+#endif
   return check_hip(ctx, hipGetLastError(), "colorlut3d_brick kernel launch");
 }
 

@@ -144,6 +144,36 @@ def test_brick_kernel_ragged_geometry(ctx, oracle, synth, w, h, n):
     assert (got == exp).all(), _report(got, exp)
 
 
+@pytest.mark.parametrize("sets", [32, 64])
+@pytest.mark.parametrize("share,tpr", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 3), (2, 500), (0, 2)])
+def test_brick_kernel_work_sharing_modes(ctx, oracle, synth, share, tpr, sets):
+    """The waves of a block share their runs (tile deques in LDS: FLAG_BRICK_PRIO bit 1 = stealing, bit 0 = progress-based
+    priorities). Every tile must be worked on exactly once whatever the mode and the run length: runs of one tile (every
+    wave lives on stolen tiles after its first), runs longer than the picture (one run per strip, the other waves of the
+    block steal all their work), frames of very different difficulty per strip (left half smooth, right half noise)."""
+    import mi355fx
+    cube = _load(ctx, oracle, synth.cube_text_3d(33, amp=0.05))
+    w, h, n = 1280, 203, 3
+    base = synth.smooth_frame(w, h)
+    frames = np.stack([np.roll(base, 4 * 11 * i, axis=1) for i in range(n)]).copy()
+    frames[:, :, w * 2:] = synth.noise_frame(w, h, seed=3)[:, w * 2:]
+    exp = np.zeros_like(frames)
+    for i in range(n):
+        oracle.colorlut_rgba8(cube, frames[i], w * 4, exp[i], w * 4, w, h)
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 7)
+    ctx.set_flag(mi355fx.FLAG_BRICK_SETS, sets)
+    ctx.set_flag(mi355fx.FLAG_BRICK_PRIO, share)
+    ctx.set_flag(mi355fx.FLAG_BRICK_TILES_PER_RUN, tpr)
+    try:
+        for in_place in (False, True):
+            got = _device_lut(ctx, frames, w, h, in_place=in_place).reshape(frames.shape)
+            assert (got == exp).all(), _report(got, exp)
+    finally:
+        ctx.set_flag(mi355fx.FLAG_BRICK_PRIO, 3)
+        ctx.set_flag(mi355fx.FLAG_BRICK_TILES_PER_RUN, 0)
+        ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)
+
+
 def test_brick_kernel_width_not_multiple_of_4_takes_another_kernel(ctx, oracle, synth):
     import mi355fx
     cube = _load(ctx, oracle, synth.cube_text_3d(33))

@@ -45,8 +45,11 @@ def main():
                 ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, v)
                 ctx.set_flag(mi355fx.FLAG_BRICK_TILES_PER_RUN, t)
                 ctx.set_flag(mi355fx.FLAG_BRICK_SETS, ns)
-                ctx.set_flag(mi355fx.FLAG_BRICK_PRIO, int(os.environ.get("PRIO", "1")))
-                run = lambda it: ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", it)
+                ctx.set_flag(mi355fx.FLAG_BRICK_PRIO, int(os.environ.get("PRIO", "3")))
+                if os.environ.get("FUSED"):  # the fused hsvfilter -> colorlut launch (compute kernels; the composed table is not built here)
+                    run = lambda it: ctx.time_hsv_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, synth.HSV_SETTINGS["hue90"], it)
+                else:
+                    run = lambda it: ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", it)
                 mi355fx.warm_clocks(lambda: run(1), ctx.synchronize, 0.2)
                 ctx.colorlut_brick_stats(reset=True)
                 ms = min(run(20) for _ in range(3))

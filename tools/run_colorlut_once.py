@@ -27,6 +27,9 @@ else:
     frames = np.clip(f, 0, 255).astype(np.uint8).reshape(-1)
 d_src, d_dst = ctx.alloc(frames.size), ctx.alloc(frames.size)
 ctx.h2d(d_src, frames)
+if os.environ.get("PREHSV"):  # the chain's colorlut input
+    ctx.hsvfilter_frames_device(d_src, N, H * W * 4, W, H, W * 4, "RGBA", synth.HSV_SETTINGS["hue90"])
+    ctx.synchronize()
 ms = ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", launches)
 print("variant %d: %.4f ms per launch, kernel %s" % (variant, ms, ctx.colorlut_kernel_name()))
 ctx.free(d_src); ctx.free(d_dst); ctx.close()
