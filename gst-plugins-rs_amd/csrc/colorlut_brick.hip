@@ -29,7 +29,9 @@
 // table directly — per lane, no loop, always exact. The miss counters tell the host-side content watch to hand
 // noise-like streams to the three-pass whole-plane kernel (colorlut_kernels.hip).
 // No block-level synchronisation after the prologue: waves run free, so HBM latency, L2 refills, LDS reads and VALU work
-// of the waves of a CU overlap by themselves.
+// of the waves of a CU overlap by themselves. One block per CU holds every wave the LDS has a cache for; the waves of a
+// block share their work through per-run tile deques in LDS (owners take from the front, finished waves steal from the
+// back), so that a CU's waves finish together whatever their runs contain.
 #include "internal.hpp"
 #include "hsv_device.hpp"
 #include "exact_math.hpp"
