@@ -186,6 +186,10 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   // at LDS address 0. LDS is addressed by absolute byte address (address-space-3 pointers made from integers): every table
   // base then folds into the ds_read offset field instead of costing an add of the link-time base symbol per access.
   constexpr int NP = 4 * G, NT = 64 * brick_waves(ZN);
+#ifndef BRICK_PIPE
+#define BRICK_PIPE 1
+#endif
+  constexpr bool PIPE = BRICK_PIPE != 0;
   static_assert(P % G == 0, "a tile is a whole number of steps");
   constexpr uint32_t AX = brick_axis_base(ZN), CELL = brick_cell_base(ZN), SEL = brick_sel_base(ZN), SCR = brick_scratch_base(ZN), WB = brick_wave_bytes(ZN), SETS = 16u * ZN;
   const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)SEL;
@@ -494,13 +498,28 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
       }
       uint32_t out[NP];
       if (__builtin_expect(!slow, 1)) {
-        // fast path: every lane's four bricks are resident
+        // fast path: every lane's four bricks are resident. The next pixel's brick is read while this one's is worked on (two
+        // register sets): a brick read left to its own devices waits out a full LDS round trip per pixel with nothing to issue
+        if constexpr (PIPE) {
+          f4_t f[2][6];
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-          f4_t f[6];
+          for (int k = 0; k < 6; k++) f[0][k] = lds_r128(baddr[0] + 16u * k);
 #pragma unroll
-          for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
-          out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
+          for (int i = 0; i < NP; i++) {
+            if (i + 1 < NP) {
+#pragma unroll
+              for (int k = 0; k < 6; k++) f[(i + 1) & 1][k] = lds_r128(baddr[i + 1] + 16u * k);
+            }
+            out[i] = brick_pixel(f[i & 1], tx[i], ty[i], tz[i], px[i]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NP; i++) {
+            f4_t f[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
+            out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
+          }
         }
       } else {
         // slow path: pixel slots in which some lane is still without a brick after fills and scratch (noise-like content):
