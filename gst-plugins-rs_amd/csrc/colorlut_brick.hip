@@ -65,6 +65,13 @@ constexpr int brick_waves(int zn) { return zn == 4 ? BRICK_W64 : (zn == 3 ? 12 :
 #ifndef BRICK_SB64
 #define BRICK_SB64 2
 #endif
+#ifndef BRICK_CHUNK32
+#define BRICK_CHUNK32 2
+#endif
+#ifndef BRICK_CHUNK64
+#define BRICK_CHUNK64 1
+#endif
+constexpr int brick_chunk(int zn) { return zn == 4 ? BRICK_CHUNK64 : BRICK_CHUNK32; }  // tiles claimed (or stolen) at a time
 constexpr int brick_group(int zn) { return zn == 4 ? BRICK_SB64 : (zn == 3 ? 4 : BRICK_SB32); }  // runs dealt out together (see the kernel)
 // packed word of the axis tables: LDS byte address of the set / 16 in the low 16 bits (every set address is a multiple of
 // 16 B; one SDWA shift turns WORD_0 into the byte address), tag in the high 16
@@ -94,7 +101,8 @@ constexpr int brick_queue_base(int zb) { return brick_sel_base(zb) + 32; }      
 constexpr int kBrickScratch = 6;                                                         // per-step overflow bricks per wave
 constexpr int brick_scratch_base(int zb) { return brick_queue_base(zb) + brick_waves(zb) * 256; }  // 6 x 96 B per wave
 constexpr int brick_deque_base(int zb) { return brick_scratch_base(zb) + brick_waves(zb) * kBrickScratch * 96; }  // one word per wave: tiles {taken from the front, end}
-constexpr int brick_lds_bytes(int zb) { return brick_deque_base(zb) + 64; }
+constexpr int brick_runpos_base(int zb) { return brick_deque_base(zb) + 64; }  // per run of the block: {strip, first tile}
+constexpr int brick_lds_bytes(int zb) { return brick_runpos_base(zb) + 128; }
 static_assert(brick_lds_bytes(2) <= 160 * 1024 && brick_lds_bytes(3) <= 160 * 1024 && brick_lds_bytes(4) <= 160 * 1024, "one block per CU");
 static_assert(brick_waves(2) <= 16 && brick_waves(3) <= 16 && brick_waves(4) <= 16, "deque words / victim search");
 
@@ -176,6 +184,16 @@ __device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_by
 __device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)a; }
 __device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)a = v; }
 
+// a wave-uniform global pointer the compiler will keep in SGPRs (global_load / global_store with an SGPR base and a 32-bit
+// VGPR offset); address space 1 is kept through the integer round trip, or the accesses become flat_*
+typedef __attribute__((address_space(1))) char gl_byte;
+typedef __attribute__((address_space(1))) u4_t gl_u4;
+__device__ __forceinline__ gl_byte *uniform_ptr(const void *p) {
+  const uint64_t b = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return (gl_byte *)(((uint64_t)hi << 32) | lo);
+}
+
 template <int P, int HSV, int ZN, int G>  // P = 16-byte loads per lane and tile (a tile is 128 px x 2P rows), G of them per step
 __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
                                                                                  unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   // word {tiles taken from the front, end} - the owner takes tiles from the front (ds_add), a wave whose own run is done
   // STEALS single tiles from the back of the run with the most tiles left (ds_cmpst), and keeps stealing from that run
   // while it lasts (its cache warms up on the neighbouring rows). The waves of a CU then finish within a tile of each other.
-  constexpr uint32_t DQ = brick_deque_base(ZN), W = brick_waves(ZN), NONE = 0xffffffffu;
+  constexpr uint32_t DQ = brick_deque_base(ZN), RP = brick_runpos_base(ZN), W = brick_waves(ZN), NONE = 0xffffffffu;
   const unsigned n_runs = n_runs_flags & 0x3fffffffu;  // bit 31: stealing enabled, bit 30: progress-based priorities
   const bool steal = (n_runs_flags >> 31) != 0, prio_quarters = ((n_runs_flags >> 30) & 1u) != 0;
   const unsigned runs_per_strip = (n_runs + n_strips - 1) / n_strips;
@@ -238,17 +256,19 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
     strip = ZN == 2 ? run % n_strips : run / runs_per_strip;
     tile0 = rr * tiles_per_run;
   };
-  constexpr unsigned SB = brick_group(ZN);
+  constexpr unsigned SB = brick_group(ZN), C = brick_chunk(ZN);
   auto run_of = [&](unsigned w) { return ((w / SB) * gridDim.x + blockIdx.x) * SB + w % SB; };
   if (threadIdx.x < W) {
     const unsigned run = run_of(threadIdx.x);
-    unsigned nt = 0;
+    unsigned nt = 0, strip = 0, tile0 = 0;
     if (run < n_runs) {
-      unsigned strip, tile0;
       run_pos(run, strip, tile0);
       if (tile0 < tile_rows) nt = tile_rows - tile0 < tiles_per_run ? tile_rows - tile0 : tiles_per_run;
     }
-    lds_w32(DQ + 4 * threadIdx.x, nt << 16);
+    lds_w32(DQ + 4 * threadIdx.x, ((nt + C - 1) / C) << 16);  // the deque counts chunks of C tiles
+    // (the divisions of run_pos are paid once per run here, not once per tile: there is no scalar integer divide)
+    const u2_t rp = {strip, tile0};
+    lds_w64(RP + 8 * threadIdx.x, rp);
   }
   __syncthreads();
   const uint32_t three = 3, four = 4;
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
     __builtin_amdgcn_wave_barrier();
   };
 
-  // claim a tile: (owning wave << 16) | tile index within that wave's run, or NONE. Wave-uniform.
+  // claim a chunk of C tiles: (owning wave << 16) | index of its first tile within that wave's run, or NONE. Wave-uniform.
   bool own_done = false;
   uint32_t last_victim = NONE;
   unsigned prio_q = 0;
@@ -280,15 +300,16 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
         // priority as it advances (3, 2, 1, 0 by quarter of its run; 0 when it lives on stolen tiles): whoever is behind
         // outranks whoever is ahead, so fewer tiles have to change hands (a stolen tile starts on a cold cache).
         if (prio_quarters) {
-          const unsigned q = (4u * (old & 0xffffu)) / tiles_per_run;
+          const unsigned t4 = 4u * C * (old & 0xffffu);
+          const unsigned q = (t4 >= tiles_per_run ? 1u : 0u) + (t4 >= 2u * tiles_per_run ? 1u : 0u) + (t4 >= 3u * tiles_per_run ? 1u : 0u);
           if (q != prio_q) {
             prio_q = q;
             if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
-            else if (q >= 3) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(0);
           }
         }
-        return (wave << 16) | (old & 0xffffu);
+        return (wave << 16) | (C * (old & 0xffffu));
       }
       own_done = true;
       if (prio_quarters) __builtin_amdgcn_s_setprio(0);
@@ -319,25 +340,32 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #ifdef BRICK_TIMING
         tiles_stolen++;
 #endif
-        return (vic << 16) | ((vv >> 16) - 1u);
+        return (vic << 16) | (C * ((vv >> 16) - 1u));
       }
     }
   };
+  unsigned tile0_of_cur = 0;  // first tile (within its strip) of the run the current chunk belongs to
   auto tile_pos = [&](uint32_t id, unsigned &strip, unsigned &row0) {
-    unsigned tile0;
-    run_pos(run_of(id >> 16), strip, tile0);
-    row0 = (tile0 + (id & 0xffffu)) * (2 * P);
+    const u2_t rp = lds_r64(RP + 8u * (id >> 16));  // wave-uniform address
+    strip = __builtin_amdgcn_readfirstlane(rp.x);
+    tile0_of_cur = __builtin_amdgcn_readfirstlane(rp.y);
+    row0 = (tile0_of_cur + (id & 0xffffu)) * (2 * P);
   };
 
   u4_t cur[P], nxt[P];
   // Loads are unconditional (out-of-picture lanes re-read a clamped in-picture address; only the stores are predicated):
   // a load inside a branch makes the number of outstanding memory operations unknown to the compiler, which then waits
   // for ALL of them - next tile's prefetch included - with s_waitcnt vmcnt(0) before touching the current tile.
+  // (addresses: wave-uniform 64-bit tile base in SGPRs + a 32-bit per-lane element offset - a tile may be anywhere now that
+  // tiles change hands, and a full 64-bit address computation per load and lane is a dozen VALU instructions)
   auto load_tile = [&](unsigned row0, unsigned col_c, u4_t(&t)[P]) {
+    gl_byte *base = uniform_ptr(src + (size_t)row0 * w4);
+    const unsigned room = rows - 1u - row0;  // rows left below the tile's first (row0 < rows always)
 #pragma unroll
     for (int j = 0; j < P; j++) {
-      const unsigned r = row0 + 2 * j + sub;
-      t[j] = __builtin_nontemporal_load(src + (size_t)(r < rows ? r : rows - 1) * w4 + col_c);
+      const unsigned ro = 2u * j + sub;
+      const uint32_t byte_off = ((ro < room ? ro : room) * w4 + col_c) * 16u;  // < 2^32: a tile spans 2P rows
+      t[j] = __builtin_nontemporal_load((const gl_u4 *)(base + byte_off));
     }
   };
   uint32_t cur_id = claim();
@@ -348,12 +376,20 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   load_tile(row0, col_ok ? col : w4 - 1, cur);
   while (cur_id != NONE) {
     // the next tile is claimed - and its loads issued - before this one is worked on
-    const uint32_t nxt_id = claim();
+    uint32_t nxt_id;
     unsigned nstrip = strip, nrow0 = row0;
-    if (nxt_id != NONE) tile_pos(nxt_id, nstrip, nrow0);
+    const uint32_t t1 = (cur_id & 0xffffu) + 1u;
+    if (C > 1 && t1 % C != 0u && t1 < tiles_per_run && tile0_of_cur + t1 < tile_rows) {
+      nxt_id = cur_id + 1u;  // the next tile of the chunk in hand
+      nrow0 = row0 + 2 * P;
+    } else {
+      nxt_id = claim();
+      if (nxt_id != NONE) tile_pos(nxt_id, nstrip, nrow0);
+    }
     const unsigned ncol = nstrip * 32 + g;
     const bool ncol_ok = ncol < w4;
     load_tile(nrow0, ncol_ok ? ncol : w4 - 1, nxt);
+    gl_byte *dst_tile = uniform_ptr(dst + (size_t)row0 * w4);
 #ifdef BRICK_TIMING
     tiles_done++;
 #endif
@@ -542,16 +578,18 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
       }
 #pragma unroll
       for (int g2 = 0; g2 < G; g2++) {
-        const unsigned r = row0 + 2 * (j + g2) + sub;
-        if (col_ok && r < rows) {
+        const unsigned ro = 2u * (j + g2) + sub;
+        if (col_ok && row0 + ro < rows) {
           const u4_t o = {out[4 * g2 + 0], out[4 * g2 + 1], out[4 * g2 + 2], out[4 * g2 + 3]};
-          __builtin_nontemporal_store(o, dst + (size_t)r * w4 + col);
+          const uint32_t byte_off = (ro * w4 + col) * 16u;
+          __builtin_nontemporal_store(o, (gl_u4 *)(dst_tile + byte_off));
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < P; j++) cur[j] = nxt[j];
     cur_id = nxt_id;
+    strip = nstrip;
     row0 = nrow0;
     col = ncol;
     col_ok = ncol_ok;

@@ -145,7 +145,7 @@ def test_brick_kernel_ragged_geometry(ctx, oracle, synth, w, h, n):
 
 
 @pytest.mark.parametrize("sets", [32, 64])
-@pytest.mark.parametrize("share,tpr", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 3), (2, 500), (0, 2)])
+@pytest.mark.parametrize("share,tpr", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 3), (3, 11), (3, 12), (2, 500), (0, 2)])
 def test_brick_kernel_work_sharing_modes(ctx, oracle, synth, share, tpr, sets):
     """The waves of a block share their runs (tile deques in LDS: FLAG_BRICK_PRIO bit 1 = stealing, bit 0 = progress-based
     priorities). Every tile must be worked on exactly once whatever the mode and the run length: runs of one tile (every

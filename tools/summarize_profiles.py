@@ -75,7 +75,9 @@ def main():
     except (OSError, ValueError, KeyError):
         out["frames_per_step"] = None
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    shutil.copy(os.path.join(dst, tag + "_pmc.json"), os.path.join(dst, "pmc_latest.json"))
+    # only the default bench.py command's counters feed roofline.traffic (tags like r02_interp are other commands)
+    if "_" not in tag:
+        shutil.copy(os.path.join(dst, tag + "_pmc.json"), os.path.join(dst, "pmc_latest.json"))
     b = os.path.join(src, "bench.json")
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
