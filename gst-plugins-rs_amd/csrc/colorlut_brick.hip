@@ -71,6 +71,15 @@ constexpr int brick_waves(int zn) { return zn == 4 ? BRICK_W64 : (zn == 3 ? 12 :
 #ifndef BRICK_CHUNK64
 #define BRICK_CHUNK64 1
 #endif
+// 32-set geometry: set = (x0 + 3 y0 + 9 z0) mod 32 instead of the (4, 4, 2) box of residues. The box puts cells two apart
+// in z into one set; the lattice of cells that collide under the linear hash has no vector shorter than 3 in any axis
+// (searched over all (a, b, c) mod 32): ANY 3 x 3 x 3 block of cells maps to 27 different sets, whichever axis of the LUT
+// the picture's gradients run along (hsvfilter's hue shift rotates them onto other axes). For 64 sets the (4, 4, 4) box
+// is already optimal in that sense.
+#ifndef BRICK_HASH32
+#define BRICK_HASH32 1
+#endif
+constexpr bool brick_hashed(int zn) { return zn == 2 && BRICK_HASH32 != 0; }
 constexpr int brick_chunk(int zn) { return zn == 4 ? BRICK_CHUNK64 : BRICK_CHUNK32; }  // tiles claimed (or stolen) at a time
 constexpr int brick_group(int zn) { return zn == 4 ? BRICK_SB64 : (zn == 3 ? 4 : BRICK_SB32); }  // runs dealt out together (see the kernel)
 // packed word of the axis tables: LDS byte address of the set / 16 in the low 16 bits (every set address is a multiple of
@@ -92,7 +101,7 @@ constexpr size_t kBrickTimingBytes = 0;
 // bricks the lanes of a wave actually read together on natural-like content - occupy 16 different columns.
 constexpr int kBrickZStride = 16 * kBrickSetBytes + 128;
 // (ZN == 2: 7,040 B so that the (2, 4, 4) and (4, 2, 4) residue layouts fit as well as (4, 4, 2))
-constexpr int brick_wave_bytes(int zn) { return zn == 2 ? 7040 : zn * kBrickZStride; }
+constexpr int brick_wave_bytes(int zn) { return zn == 2 ? (brick_hashed(2) ? 32 * kBrickSetBytes : 7040) : zn * kBrickZStride; }
 constexpr int brick_axis_base(int zb) { return brick_waves(zb) * brick_wave_bytes(zb); }   // LDS: the wave regions, then the axis tables
 constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 bytes: lower cell index per axis and input byte (fill path)
 constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 768; }          // 8 dwords: hsvfilter sextant selectors
@@ -230,8 +239,9 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
     const u2_t inval = {0xffffffffu, 0xffffffffu};
     // set residues per axis: (4, 4, ZN), or (2, 4, 4) / (4, 2, 4) when the host built the ZN == 2 tables with the 2 on x / y
     const uint32_t m0 = (ZN == 2 && fold_axis == 0) ? 2u : 4u, m1 = (ZN == 2 && fold_axis == 1) ? 2u : 4u;
-    const uint32_t sa = wave_base + (lane % m0) * kBrickSetBytes + ((lane / m0) % m1) * (m0 * kBrickSetBytes) +
-                        (lane / (m0 * m1)) * (m0 * m1 * kBrickSetBytes + 128u);
+    const uint32_t sa = brick_hashed(ZN) ? wave_base + lane * kBrickSetBytes
+                                         : wave_base + (lane % m0) * kBrickSetBytes + ((lane / m0) % m1) * (m0 * kBrickSetBytes) +
+                                               (lane / (m0 * m1)) * (m0 * m1 * kBrickSetBytes + 128u);
     lds_w64(sa + 192, inval);  // both tags invalid
     lds_w32(sa + 204, 0u);     // next victim: way 0
   }
@@ -417,9 +427,16 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
         tx[i] = __uint_as_float(ex.x);
         ty[i] = __uint_as_float(ey.x);
         tz[i] = __uint_as_float(ez.x);
-        const uint32_t packed = (ex.y + ey.y) + (ez.y + (wave_base >> 4));  // v_add_u32 + v_add3_u32
-        set[i] = word0_times16(packed, four);                       // LDS byte address of the wave's set for this cell
-        tag[i] = packed;                                            // the whole word identifies the brick (the set bits are redundant there)
+        if constexpr (brick_hashed(ZN)) {
+          // hashed 32-set geometry: the low byte sums the axes' set-number contributions (<= 93), the rest is the cell number
+          const uint32_t packed = ex.y + ey.y + ez.y;                            // v_add3_u32
+          set[i] = __umul24(packed & 31u, (uint32_t)kBrickSetBytes) + wave_base;           // v_and + v_mad_u32_u24
+          tag[i] = packed;
+        } else {
+          const uint32_t packed = (ex.y + ey.y) + (ez.y + (wave_base >> 4));  // v_add_u32 + v_add3_u32
+          set[i] = word0_times16(packed, four);                       // LDS byte address of the wave's set for this cell
+          tag[i] = packed;                                            // the whole word identifies the brick (the set bits are redundant there)
+        }
       }
       // tag check: both ways' tags in one 8-byte read; baddr = the way that holds the brick
       auto check = [&]() -> bool {
@@ -691,13 +708,19 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
         // tag fields packed axis after axis, each as wide as its largest value (S - 1) / mod needs: 16 bits in all for S <= 65
         auto bits_for = [&](int m) { int b = 0; while (((S - 1) / m) >> b) b++; return b; };
         const int tag_shift = a == 0 ? 0 : (a == 1 ? bits_for(mods[0]) : bits_for(mods[0]) + bits_for(mods[1]));
-        if (bits_for(mods[0]) + bits_for(mods[1]) + bits_for(mods[2]) > 32 - kBrickTagShift || set_off % 16u != 0u ||
+        if (brick_hashed(zn)) {
+          if ((size_t)S * S * S >= (1u << 24)) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: brick cache geometry does not fit");
+        } else if (bits_for(mods[0]) + bits_for(mods[1]) + bits_for(mods[2]) > 32 - kBrickTagShift || set_off % 16u != 0u ||
             (uint32_t)(mods[0] - 1) * kBrickSetBytes + (uint32_t)(mods[1] - 1) * stride1 + (uint32_t)(mods[2] - 1) * stride2 + kBrickSetBytes > (uint32_t)brick_wave_bytes(zn))
           return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: brick cache geometry does not fit");
         const uint32_t tag = (uint32_t)(i0 / mod) << tag_shift;
         uint32_t *e = &axis[((size_t)(zn - 2) * 768 + (size_t)a * 256 + v) * 2];
         std::memcpy(&e[0], &t, 4);
         e[1] = (set_off >> 4) + (tag << kBrickTagShift);
+        if (brick_hashed(zn)) {
+          const uint32_t mul = a == 0 ? 1u : (a == 1 ? 3u : 9u), cell = (uint32_t)i0 * (a == 0 ? 1u : (a == 1 ? (uint32_t)S : (uint32_t)S * S));
+          e[1] = (((uint32_t)i0 * mul) & 31u) | (cell << 8);  // three of these add up without carries: 93 < 256, S^3 < 2^24
+        }
         cellnum[(size_t)a * 256 + v] = (uint32_t)i0;
       }
   int rc = check_hip(ctx, hipMalloc((void **)&B.d_bricks, bricks.size() * sizeof(float)), "hipMalloc(lut bricks)");
