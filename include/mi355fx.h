@@ -99,7 +99,7 @@ typedef enum mi355_flag {
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3, /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
   MI355_FLAG_BRICK_TILES_PER_RUN = 7, /* brick-cache kernel: tiles (128 pixels x 4 or 8 rows) in a run, the part of a strip one wave owns (0 = default: one run per wave of the chip) */
-  MI355_FLAG_BRICK_FOLD_AXIS = 10, /* brick-cache kernel, 32-set geometry: the axis (0 x, 1 y, 2 z = default) that gets 2 set residues instead of 4; read at mi355_colorlut_load */
+  MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
 } mi355_flag;

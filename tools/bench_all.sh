@@ -13,4 +13,5 @@ for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_ebur128 
   python3 "$R/tools/$t.py" 2>/dev/null | grep '^{' | tail -1 | sed "s/^{/{\"tool\": \"$t\", /" >> "$OUT"
 done
 python3 "$R/tools/bench_hrtf.py" --taps 512 --no-cpu 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench_hrtf_512taps", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5", /' >> "$OUT"
 wc -l "$OUT" >&2
