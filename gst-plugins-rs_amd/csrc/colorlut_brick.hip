@@ -184,14 +184,14 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) u2_t lds_u2;
 typedef __attribute__((address_space(3))) f4_t lds_f4;
-__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const lds_u32 *)(lds_byte *)a; }
-__device__ __forceinline__ void lds_w32(uint32_t a, uint32_t v) { *(lds_u32 *)(lds_byte *)a = v; }
-__device__ __forceinline__ uint32_t lds_r8(uint32_t a) { return *(const lds_byte *)a; }
-__device__ __forceinline__ void lds_w8(uint32_t a, uint32_t v) { *(lds_byte *)a = (unsigned char)v; }
-__device__ __forceinline__ u2_t lds_r64(uint32_t a) { return *(const lds_u2 *)(lds_byte *)a; }
-__device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_byte *)a = v; }
-__device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)a; }
-__device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)a = v; }
+__device__ __forceinline__ uint32_t lds_r32(uint32_t a) { return *(const lds_u32 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w32(uint32_t a, uint32_t v) { *(lds_u32 *)(lds_byte *)(uintptr_t)a = v; }
+__device__ __forceinline__ uint32_t lds_r8(uint32_t a) { return *(const lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w8(uint32_t a, uint32_t v) { *(lds_byte *)(uintptr_t)a = (unsigned char)v; }
+__device__ __forceinline__ u2_t lds_r64(uint32_t a) { return *(const lds_u2 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w64(uint32_t a, u2_t v) { *(lds_u2 *)(lds_byte *)(uintptr_t)a = v; }
+__device__ __forceinline__ f4_t lds_r128(uint32_t a) { return *(const lds_f4 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w128(uint32_t a, f4_t v) { *(lds_f4 *)(lds_byte *)(uintptr_t)a = v; }
 
 // a wave-uniform global pointer the compiler will keep in SGPRs (global_load / global_store with an SGPR base and a 32-bit
 // VGPR offset); address space 1 is kept through the integer round trip, or the accesses become flat_*
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   constexpr bool PIPE = BRICK_PIPE != 0;
   static_assert(P % G == 0, "a tile is a whole number of steps");
   constexpr uint32_t AX = brick_axis_base(ZN), CELL = brick_cell_base(ZN), SEL = brick_sel_base(ZN), SCR = brick_scratch_base(ZN), WB = brick_wave_bytes(ZN), SETS = 16u * ZN;
-  const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)SEL;
+  const uint32_t *hsv_sel = (const uint32_t *)(lds_u32 *)(lds_byte *)(uintptr_t)SEL;
   if constexpr (HSV != kBrickNoHsv) {
     if (threadIdx.x < 7) lds_w32(SEL + 4 * threadIdx.x, HSV >= 0 ? hsv_sel_entry_floor(threadIdx.x, 0, 1, 2, 3) : hsv_sel_entry(threadIdx.x, 0, 1, 2, 3));
   }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   auto claim = [&]() -> uint32_t {
     if (!own_done) {
       uint32_t old = 0;
-      if (lane == 0) old = __hip_atomic_fetch_add((lds_u32 *)(lds_byte *)(DQ + 4u * wave), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) old = __hip_atomic_fetch_add((lds_u32 *)(lds_byte *)(uintptr_t)(DQ + 4u * wave), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       old = __builtin_amdgcn_readfirstlane(old);
       if ((old & 0xffffu) < (old >> 16)) {
         // Fair share by hand. The SIMD arbitrates VALU issue by priority, then AGE: at equal priority the oldest wave of a
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
       uint32_t ok = 0;
       if (lane == 0) {
         uint32_t expected = vv;
-        ok = __hip_atomic_compare_exchange_strong((lds_u32 *)(lds_byte *)(DQ + 4u * vic), &expected, vv - 0x10000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+        ok = __hip_atomic_compare_exchange_strong((lds_u32 *)(lds_byte *)(uintptr_t)(DQ + 4u * vic), &expected, vv - 0x10000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
       }
       ok = __builtin_amdgcn_readfirstlane(ok);
