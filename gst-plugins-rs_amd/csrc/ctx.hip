@@ -146,7 +146,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   ebur128_release(ctx);
   hrtf_release(ctx);
   sofa_release(ctx);
-  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
+  echo_release(ctx);
   for (int i = 0; i < 2; i++)
     if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -468,29 +468,29 @@ int mi355_colorlut_frame(mi355_ctx *ctx, const uint8_t *src, int src_stride, uin
 
 /* ------------------------------------------------------------------ rsaudioecho */
 
-int mi355_echo_setup(mi355_ctx *ctx, size_t ring_len) {
+int mi355_echo_setup(mi355_ctx *ctx, size_t ring_len) { return mi355_echo_setup_batch(ctx, 1, ring_len); }
+
+int mi355_echo_setup_batch(mi355_ctx *ctx, int n_streams, size_t ring_len) {
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
-  ctx->echo = EchoDevice{};
-  int rc = check_hip(ctx, hipMalloc((void **)&ctx->echo.d_ring, (ring_len ? ring_len : 1) * sizeof(double)), "hipMalloc(echo ring)");
-  if (rc) return rc;
-  rc = check_hip(ctx, hipMemset(ctx->echo.d_ring, 0, (ring_len ? ring_len : 1) * sizeof(double)), "hipMemset(echo ring)");
-  if (rc) return rc;
-  ctx->echo.ring_len = ring_len;
-  ctx->echo.pos = 0;
-  ctx->echo.configured = true;
-  return MI355_OK;
+  return echo_setup(ctx, n_streams, ring_len);
 }
 
 int mi355_echo_reset(mi355_ctx *ctx) {
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->echo.d_ring) (void)hipFree(ctx->echo.d_ring);
-  ctx->echo = EchoDevice{};
+  echo_release(ctx);
   return MI355_OK;
+}
+
+int mi355_echo_process_batch_device(mi355_ctx *ctx, void *d_data, size_t stream_stride, size_t n, int is_f64, const size_t *delay_samples,
+                                    const double *intensity, const double *feedback) {
+  REQUIRE_CTX(ctx);
+  if (!delay_samples || !intensity || !feedback) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: null parameter array");
+  if (n && !d_data) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: null data");
+  BIND_DEVICE(ctx);
+  return launch_echo_batch(ctx, d_data, stream_stride, n, is_f64, delay_samples, intensity, feedback);
 }
 
 int mi355_echo_process_device(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay_samples, double intensity,
@@ -530,15 +530,20 @@ int mi355_echo_process_f64(mi355_ctx *ctx, double *data, size_t n, size_t delay_
 }
 
 int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size_t *pos_out) {
+  return mi355_echo_get_state_batch(ctx, 0, ring_out, ring_len, pos_out);
+}
+
+int mi355_echo_get_state_batch(mi355_ctx *ctx, int stream, double *ring_out, size_t ring_len, size_t *pos_out) {
   REQUIRE_CTX(ctx);
   if (!ctx->echo.configured) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "rsaudioecho: not negotiated (setup not called)");
+  if (stream < 0 || stream >= ctx->echo.n_streams) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: no such stream in the batch");
   BIND_DEVICE(ctx);
   if (pos_out) *pos_out = ctx->echo.pos;
   if (ring_out) {
     const size_t n = ring_len < ctx->echo.ring_len ? ring_len : ctx->echo.ring_len;
     int rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (rc) return rc;
-    if (n) return check_hip(ctx, hipMemcpy(ring_out, ctx->echo.d_ring, n * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(echo ring)");
+    if (n) return check_hip(ctx, hipMemcpy(ring_out, ctx->echo.d_ring + (size_t)stream * ctx->echo.ring_len, n * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(echo ring)");
   }
   return MI355_OK;
 }

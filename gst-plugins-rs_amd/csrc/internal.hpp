@@ -65,9 +65,12 @@ struct HsvTable {
 };
 
 struct EchoDevice {
-  double *d_ring = nullptr;
+  double *d_ring = nullptr;   // n_streams rings of ring_len f64
   size_t ring_len = 0;
-  size_t pos = 0;
+  size_t pos = 0;             // shared: every stream of a batch advances by the same number of samples per call
+  int n_streams = 1;
+  void *d_par = nullptr, *h_par = nullptr;  // per-stream {D, intensity, feedback}: device copy, pinned host copy
+  hipEvent_t par_ev = nullptr;
   bool configured = false;
 };
 
@@ -137,6 +140,10 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
 int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float scale[3],
                const float offset[3]);
 void lut_release(mi355_ctx *ctx);
+int echo_setup(mi355_ctx *ctx, int n_streams, size_t ring_len);
+void echo_release(mi355_ctx *ctx);
+int launch_echo_batch(mi355_ctx *ctx, void *d_data, size_t stream_stride, size_t n, int is_f64, const size_t *delay, const double *intensity,
+                      const double *feedback);
 int launch_echo(mi355_ctx *ctx, void *d_data, size_t n, int is_f64, size_t delay, double intensity,
                 double feedback);
 int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);

@@ -99,6 +99,9 @@ def load_library():
         "mi355_echo_process_f64": (i, [vp, vp, sz, sz, C.c_double, C.c_double]),
         "mi355_echo_process_device": (i, [vp, vp, sz, i, sz, C.c_double, C.c_double]),
         "mi355_echo_get_state": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "mi355_echo_setup_batch": (i, [vp, i, sz]),
+        "mi355_echo_process_batch_device": (i, [vp, vp, sz, sz, i, vp, vp, vp]),
+        "mi355_echo_get_state_batch": (i, [vp, i, vp, sz, C.POINTER(sz)]),
         "mi355_ebur128_setup": (i, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
         "mi355_ebur128_setup_batch": (i, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
         "mi355_ebur128_add_frames_batch": (i, [vp, vp, sz, i]),
@@ -518,11 +521,21 @@ class Context:
         self._ck(fn(self.h, data.ctypes.data, data.size, delay_samples, float(intensity), float(feedback)))
         return data
 
-    def echo_state(self, ring_len):
+    def echo_state(self, ring_len, stream=0):
         ring = np.zeros(max(ring_len, 1), np.float64)
         pos = C.c_size_t(0)
-        self._ck(self.L.mi355_echo_get_state(self.h, ring.ctypes.data, ring_len, C.byref(pos)))
+        self._ck(self.L.mi355_echo_get_state_batch(self.h, stream, ring.ctypes.data, ring_len, C.byref(pos)))
         return ring, pos.value
+
+    def echo_setup_batch(self, n_streams, ring_len):
+        self._ck(self.L.mi355_echo_setup_batch(self.h, n_streams, ring_len))
+
+    def echo_process_batch_device(self, dptr, stream_stride, n, is_f64, delay_samples, intensity, feedback):
+        """n_streams slices of n samples, stream_stride elements apart, in place in device memory; per-stream parameter lists."""
+        d = np.ascontiguousarray(delay_samples, dtype=np.uint64)
+        a = np.ascontiguousarray(intensity, dtype=np.float64)
+        f = np.ascontiguousarray(feedback, dtype=np.float64)
+        self._ck(self.L.mi355_echo_process_batch_device(self.h, dptr, stream_stride, n, int(is_f64), d.ctypes.data, a.ctypes.data, f.ctypes.data))
 
 
     # ---- ebur128 (loudness meter)

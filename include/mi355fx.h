@@ -224,6 +224,15 @@ int mi355_echo_process_device(mi355_ctx *ctx, void *d_data, size_t n, int is_f64
                               size_t delay_samples, double intensity, double feedback);
 /* Test/diagnostic access to the element state (ring contents + write position). */
 int mi355_echo_get_state(mi355_ctx *ctx, double *ring_out, size_t ring_len, size_t *pos_out);
+/* Batches: `n_streams` independent AudioEcho instances (own ring, own delay / intensity / feedback - the per-call arrays
+ * have n_streams entries) advanced together by `n` interleaved samples per call, three launches for the whole batch
+ * instead of three per stream (one rsaudioecho buffer is a few thousand samples: a single stream is launch-bound).
+ * Stream s processes d_data + s * stream_stride elements (f32 or f64), in place, device memory. The single-stream
+ * entry points above are the n_streams == 1 case of the same kernels. */
+int mi355_echo_setup_batch(mi355_ctx *ctx, int n_streams, size_t ring_len);
+int mi355_echo_process_batch_device(mi355_ctx *ctx, void *d_data, size_t stream_stride, size_t n, int is_f64,
+                                    const size_t *delay_samples, const double *intensity, const double *feedback);
+int mi355_echo_get_state_batch(mi355_ctx *ctx, int stream, double *ring_out, size_t ring_len, size_t *pos_out);
 
 /* ---------------------------------------------------------------- ebur128 (loudness meter)
  * Replaces the `ebur128::EbuR128` object (third-party crate ebur128 0.1.10, Cargo.lock:3685-3686) that

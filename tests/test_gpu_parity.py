@@ -470,6 +470,48 @@ def test_echo_streaming_many_buffers(ctx, oracle, synth):
     assert pos == e.pos and ring[: e.ring_len].tobytes() == e.ring[: e.ring_len].tobytes()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_echo_batch_of_streams(ctx, oracle, synth, dtype):
+    """mi355_echo_*_batch: independent AudioEcho instances advanced together, each with its own delay / intensity / feedback
+    (feedback 0 and != 0 mixed in one batch, delay 0, a comb shorter than the buffer), ragged buffer sizes across calls,
+    padded stream stride. Every stream must equal its own oracle instance bit for bit, ring and position included."""
+    rate, ch, S = 48000, 2, 7
+    max_ns = 500 * 10 ** 6
+    es = [oracle.Echo(max_ns, rate, ch) for _ in range(S)]
+    ctx.echo_setup_batch(S, es[0].ring_len)
+    delays_ns = [250 * 10 ** 6, 0, 10 ** 6, 123456789, 499999999, 7 * 10 ** 6, 250 * 10 ** 6]
+    inten = [0.6, 0.3, 1.0, 0.7, 0.5, 0.9, 0.0]
+    fb = [0.4, 0.2, 0.99, 0.0, 0.0, 0.5, 0.0]
+    d = [oracle.lib().oracle_echo_delay_samples(t, max_ns, rate, ch) for t in delays_ns]
+    rng = np.random.default_rng(5)
+    stride = 96000 + 32
+    dev = ctx.alloc(S * stride * np.dtype(dtype).itemsize)
+    try:
+        for n in [960, 2, 96000, 0, 4801, 19200]:
+            x = rng.standard_normal((S, stride)).astype(dtype)
+            exp = x.copy()
+            for s in range(S):
+                row = np.ascontiguousarray(exp[s, :n])
+                es[s].process(row, delays_ns[s], inten[s], fb[s])
+                exp[s, :n] = row
+            ctx.h2d(dev, x.reshape(-1).view(np.uint8))
+            ctx.echo_process_batch_device(dev, stride, n, dtype == np.float64, d, inten, fb)
+            got = np.zeros_like(x)
+            ctx.synchronize()
+            ctx.d2h(got.reshape(-1).view(np.uint8), dev)
+            assert got.tobytes() == exp.tobytes(), "buffer of %d samples" % n   # padding beyond n untouched as well
+        for s in range(S):
+            ring, pos = ctx.echo_state(es[s].ring_len, stream=s)
+            assert pos == es[s].pos and ring[: es[s].ring_len].tobytes() == es[s].ring[: es[s].ring_len].tobytes(), s
+        with pytest.raises(Exception):   # the single-stream entry point on a batch
+            ctx.echo_process(np.zeros(4, np.float32), 1, 0.5, 0.0)
+        with pytest.raises(Exception):   # delay beyond the ring (RingBufferIter::new's assertion)
+            ctx.echo_process_batch_device(dev, stride, 16, dtype == np.float64, [es[0].ring_len + 1] * S, inten, fb)
+    finally:
+        ctx.free(dev)
+        ctx.echo_reset()
+
+
 def test_echo_not_negotiated(ctx):
     """transform_ip before setup is FlowError::NotNegotiated (audioecho/imp.rs:210)."""
     import mi355fx
