@@ -182,6 +182,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 7) { ctx->lut_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_TILES_PER_RUN && value >= 0 && value <= 4096) { ctx->brick_tiles_per_run = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_FOLD_AXIS && value >= 0 && value <= 2) { ctx->brick_fold_axis = value; return MI355_OK; }
+  if (flag == MI355_FLAG_DSSIM_TRANSLUCENT && (value == 0 || value == 1)) { ctx->dssim_translucent = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_PRIO && value >= 0 && value <= 3) { ctx->brick_prio = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_SETS && (value == 0 || value == 32 || value == 48 || value == 64)) { ctx->brick_sets = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 3) { ctx->hsv_table_mode = value; return MI355_OK; }

@@ -123,6 +123,7 @@ constexpr int kRw = kTw + 2 * kHalo, kRh = kTh + 2 * kHalo;  // 40 x 24 region
 
 struct DssimSrc {          // source of the scale's linear RGB
   const uint8_t *u8; int stride, channels; const float *lut;   // scale 0: packed sRGB(A) bytes + gamma table
+  int *translucent;                                             // set to 1 when an RGBA pixel with alpha < 255 is met
   const float4 *lin;                                           // other scales: premultiplied linear float4
 };
 
@@ -241,7 +242,10 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
       float r, g, b;
       if (S.u8) {
         const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
-        if (S.channels == 4) { const float a = (float)p[3] / 255.0f; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a; }
+        if (S.channels == 4) {
+          const float a = (float)p[3] / 255.0f; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
+          if (p[3] != 255 && *(volatile int *)S.translucent == 0) atomicOr(S.translucent, 1);
+        }
         else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
       } else {
         const float4 v = S.lin[(size_t)gy * w + gx];
@@ -634,6 +638,8 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   for (int k = 1; k < ns; k++) lin_px += (size_t)ws[k] * hs[k];
   void *scr = nullptr;
   if ((rc = dssim_scratch(ctx, 1, (lin_px + 16) * 16 + 1024, &scr))) { dssim_free_image(ctx, img); return rc; }
+  int *d_flag = (int *)((char *)scr + (lin_px + 16) * 16 + 512);  // "met a translucent pixel" (tail of the scratch)
+  if ((rc = check_hip(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream), "dssim: flag reset"))) { dssim_free_image(ctx, img); return rc; }
   float4 *lin[kDssimScales] = {nullptr};
   {
     float4 *q = (float4 *)scr;
@@ -662,6 +668,7 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     const DssimScale &s = img->s[k];
     if (k == 0) { j.S.u8 = d_frame; j.S.stride = stride; j.S.channels = channels; j.S.lut = d_lut; j.S.lin = nullptr; }
     else { j.S.u8 = nullptr; j.S.stride = 0; j.S.channels = 0; j.S.lut = nullptr; j.S.lin = lin[k]; }
+    j.S.translucent = d_flag;
     j.w = s.w; j.h = s.h;
     for (int c = 0; c < 3; c++) { j.O.img[c] = s.img[c]; j.O.mu[c] = s.mu[c]; j.O.sq[c] = s.sq[c]; }
     return j;
@@ -683,7 +690,16 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   }
   rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch");
   if (rc) { dssim_free_image(ctx, img); return rc; }
+  int translucent = 0;
+  if (channels == 4 && (rc = check_hip(ctx, hipMemcpyAsync(&translucent, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "dssim: flag D2H"))) { dssim_free_image(ctx, img); return rc; }
   if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) { dssim_free_image(ctx, img); return rc; }  // scratch is reused by the next call
+  if (translucent && !ctx->dssim_translucent) {
+    // The crate blends translucent pixels over a position-dependent background (dssim-core's to_lab for RGBA); that source is
+    // not in the reference tree, so the blend is not reproduced: the caller keeps its CPU path for such a frame rather than
+    // getting a different number. MI355_FLAG_DSSIM_TRANSLUCENT = 1 opts in to "premultiplied over black".
+    dssim_free_image(ctx, img);
+    return set_error(ctx, MI355_ERR_UNSUPPORTED, "dssim: frame has translucent pixels (alpha < 255); the crate's background blend is not reproduced - use the CPU path for this frame or set MI355_FLAG_DSSIM_TRANSLUCENT");
+  }
   *out = img;
   return MI355_OK;
 }

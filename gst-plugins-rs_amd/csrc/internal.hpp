@@ -100,7 +100,8 @@ struct mi355_ctx {
   mi355::HsvTable hsv_table;
   int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
   int brick_tiles_per_run = 0;  // MI355_FLAG_BRICK_TILES_PER_RUN (tuning; 0 = default)
-  int brick_fold_axis = 2;      // MI355_FLAG_BRICK_FOLD_AXIS (takes effect at the next mi355_colorlut_load)
+  int brick_fold_axis = 2;      // MI355_FLAG_BRICK_FOLD_AXIS (accepted, ignored)
+  int dssim_translucent = 0;    // MI355_FLAG_DSSIM_TRANSLUCENT: 1 = treat alpha < 255 as premultiplied over black instead of refusing the frame
   int brick_prio = 3;           // MI355_FLAG_BRICK_PRIO: bit 0 progress-based wave priorities, bit 1 tile stealing within a block
   int brick_sets = 0;           // MI355_FLAG_BRICK_SETS: 0 = content watch decides (default); 32 (4x4x2 sets, 16 waves per CU) or 64 (4x4x4 sets, 8 waves per CU) pinned
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)

@@ -32,6 +32,7 @@ FLAG_BRICK_TILES_PER_RUN = 7
 FLAG_BRICK_SETS = 8
 FLAG_BRICK_PRIO = 9
 FLAG_BRICK_FOLD_AXIS = 10
+FLAG_DSSIM_TRANSLUCENT = 11
 
 
 class HsvSettings(C.Structure):

@@ -65,10 +65,11 @@ def test_dssim_identical_4k_frames_exactly_zero_and_rgb(ctx):
 
 def test_dssim_errors(ctx):
     import mi355fx
-    f = np.zeros((16, 64), np.uint8)
+    f = np.zeros((16, 64), np.uint8); f[:, 3::4] = 255
+    g = np.zeros((32, 128), np.uint8); g[:, 3::4] = 255
     with pytest.raises(mi355fx.Mi355Error):
         ctx.dssim_create_image(f, 64, 16, 16, "BGRx")
-    a, b = ctx.dssim_create_image(f, 64, 16, 16), ctx.dssim_create_image(np.zeros((32, 128), np.uint8), 128, 32, 32)
+    a, b = ctx.dssim_create_image(f, 64, 16, 16), ctx.dssim_create_image(g, 128, 32, 32)
     try:
         with pytest.raises(mi355fx.Mi355Error):
             ctx.dssim_compare(a, b)
@@ -86,6 +87,8 @@ def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
     f = rng.integers(0, 256, (h, w * ch), dtype=np.uint8)
     if ch == 4:
         f[:, 3::4] = np.where(rng.random((h, w)) < 0.2, rng.integers(0, 256, (h, w)), 255)   # some translucent pixels (premultiplied)
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 1)   # opt in to "premultiplied over black" (what the restatement does as well)
     g = ctx.dssim_create_image(f, w * ch, w, h, fmt)
     o = D.DssimImage(f, w, h, w * ch, ch)
     try:
@@ -98,6 +101,36 @@ def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
                     assert (got.view(np.uint32) == exp.view(np.uint32)).all(), (s, c, kind, int((got != exp).sum()))
     finally:
         ctx.dssim_free_image(g)
+        ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 0)
+
+
+def test_dssim_refuses_translucent_frames_by_default(ctx):
+    """The crate blends translucent RGBA pixels over a position-dependent background; that arithmetic is not in the reference
+    tree, so by default a frame with any alpha < 255 is refused (MI355_ERR_UNSUPPORTED: the element keeps its crate path for
+    that frame) instead of getting a different number. Opaque RGBA, RGB, and the opt-in flag still work; one translucent
+    pixel anywhere - first row, last pixel, inside a tile - is enough."""
+    import mi355fx
+    w, h = 200, 120
+    rng = np.random.default_rng(1)
+    base = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
+    base[:, 3::4] = 255
+    g = ctx.dssim_create_image(base, w * 4, w, h, "RGBA")
+    ctx.dssim_free_image(g)
+    for (y, x) in [(0, 0), (h - 1, w - 1), (57, 101)]:
+        f = base.copy()
+        f[y, 4 * x + 3] = 254
+        with pytest.raises(mi355fx.Mi355Error) as e:
+            ctx.dssim_create_image(f, w * 4, w, h, "RGBA")
+        assert e.value.status == mi355fx.ERR_UNSUPPORTED and "translucent" in str(e.value)
+        ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 1)
+        try:
+            g = ctx.dssim_create_image(f, w * 4, w, h, "RGBA")
+            ctx.dssim_free_image(g)
+        finally:
+            ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 0)
+    rgb = rng.integers(0, 256, (h, w * 3), dtype=np.uint8)   # no alpha channel: nothing to refuse
+    g = ctx.dssim_create_image(rgb, w * 3, w, h, "RGB")
+    ctx.dssim_free_image(g)
 
 
 def test_dssim_matches_restatement_at_4k(ctx, synth):

@@ -371,8 +371,13 @@ def test_videocompare_several_pads_and_unsupported_algo(oracle):
     assert flow == 0 and posted and dist == [0.0]
     # test_use_dssim_to_find_similar_frames: Dssim engine, identical frames, threshold 0
     assert e.set_property("hash-algo", "dssim") and e.set_property("max-dist-threshold", 0.0)
-    flow, posted, dist = e.videocompare_aggregate([ref, ref.copy(), far], "RGBA", 96, 64, 384)
+    oref, ofar = ref.copy(), far.copy()
+    oref[:, 3::4] = 255; ofar[:, 3::4] = 255
+    flow, posted, dist = e.videocompare_aggregate([oref, oref.copy(), ofar], "RGBA", 96, 64, 384)
     assert flow == 0 and posted and dist[0] == 0.0 and dist[1] > 0.1
+    # translucent pixels: the device path refuses the frame (the crate's background blend is not reproduced) -> flow error
+    flow, posted, dist = e.videocompare_aggregate([ref, ref.copy()], "RGBA", 96, 64, 384)
+    assert flow != 0 and "translucent" in e.last_error
     assert not e.set_property("hash-algo", "nonsense")
 
 
