@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/configs_$TAG.jsonl
 mkdir -p "$R/gpurun_out"; : > "$OUT"
 python3 "$R/tools/bench_elements.py" 2>/dev/null > "$R/gpurun_out/configs_${TAG}_elements.txt"
-for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_ebur128 bench_echo bench_pipeline bench_streams; do
+for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_loudnorm_streams bench_ebur128 bench_echo bench_pipeline bench_streams; do
   echo "== $t" >&2
   python3 "$R/tools/$t.py" 2>/dev/null | grep '^{' | tail -1 | sed "s/^{/{\"tool\": \"$t\", /" >> "$OUT"
 done
