@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--rewarm-steps", type=int, default=150,
+                    help="untimed steps on scratch batches right before every timed bracket (the pristine batches' fills and statistics leave the GPU at low clocks)")
     ap.add_argument("--ramp-seconds", type=float, default=0.25,
                     help="untimed preamble before the W warm-up steps of each measured leg: the same launches for this long,\n"
                          "so that the GPU has left its idle clocks (a cold 50-step run measures 35 k frames/s, a warm one 43 k)")
@@ -312,6 +314,7 @@ def main():
 
     if args.stub:
         _install_stub(torch, mi355fx, rank)
+        args.rewarm_steps = min(args.rewarm_steps, 2)
     elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (torch.cuda unavailable); there is no CPU fallback")
     if os.environ.get("MI355_BENCH_TEST_SHARE_GPU"):
@@ -449,7 +452,14 @@ def main():
                     stats["first"] = batch_stats(torch, sl[0])
                 if first + n == warmup + steps:
                     stats["last"] = batch_stats(torch, sl[n - 1])
-                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record)), dist=dist, device_sync=torch.cuda.synchronize))
+                # Filling the pristine batches and taking their statistics (copies, a sort) leaves the GPU at low clocks; it then
+                # needs ~10 ms of this leg's work to be back at speed - 15 % of a 20-step timed region, nothing of a 300-step
+                # one. So the device is put back to work on the scratch batches right before the bracket (untimed, declared
+                # as config.rewarm_steps); the W warm-up steps on pristine batches have run before.
+                ramp_body(args.rewarm_steps)
+                # (short regions carry no event markers: ~5 us each on the stream, 2 % of 20 steps; the dedicated pass below
+                # then supplies every per-kernel sample)
+                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record and steps >= 64)), dist=dist, device_sync=torch.cuda.synchronize))
 
             consume(pool, srcs, warmup, 0, warm)
             chunks = consume(pool, srcs, steps, warmup, timed)
@@ -459,7 +469,11 @@ def main():
                 if len(evs) < 32:
                     # few in-region samples (small K): a dedicated bracketed pass on fresh pristine batches, every launch timed
                     extra = []
-                    consume(pool, srcs, 64, warmup + steps, lambda sl, n, first: extra.extend(region(sl, n, True, 1)))
+
+                    def bracketed(sl, n, first):
+                        ramp_body(args.rewarm_steps)
+                        extra.extend(region(sl, n, True, 1))
+                    consume(pool, srcs, 64, warmup + steps, bracketed)
                     torch.cuda.synchronize()
                     evs = evs + extra
                     res["samples"] = len(evs)
@@ -574,7 +588,7 @@ def main():
             "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
                        "frames_per_step": args.batch, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
-                       "lut_variant": args.lut_variant, "ramp_seconds": args.ramp_seconds, "event_marker_ms": marker_ms(),
+                       "lut_variant": args.lut_variant, "ramp_seconds": args.ramp_seconds, "rewarm_steps": args.rewarm_steps, "event_marker_ms": marker_ms(),
                        "sources": "pristine: every warm-up/timed step filters its own never-touched batch (in place)",
                        "source_batches_held": main_leg["held"], "source_chunks": main_leg["chunks"],
                        "source_stats": main_leg["source_stats"], "dst_ring_batches": args.ring,
