@@ -35,8 +35,13 @@ BYTES_PER_FRAME_PER_KERNEL = 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=75)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--pairs-per-step", type=int, default=4,
+                    help="(hsvfilter, colorlut) launch pairs per step, each on its own pristine batch of --batch frames: a step is\n"
+                         "pairs x batch = 32 frames. One pair is 0.19 ms; the driver times 20 steps, and a 3.8 ms bracket spends\n"
+                         "5-6 %% of itself starting and draining the queue (measured: 39.5 k frames/s at 20 steps of one pair against\n"
+                         "42.1 k at 300) - 20 steps of four pairs are 15 ms")
     ap.add_argument("--rewarm-steps", type=int, default=150,
                     help="untimed steps on scratch batches right before every timed bracket (the pristine batches' fills and statistics leave the GPU at low clocks)")
     ap.add_argument("--ramp-seconds", type=float, default=0.25,
@@ -398,6 +403,9 @@ def main():
             streams: list of per-stream contexts - frame i of every batch then belongs to stream i and is processed by
             that stream's own context with one-frame launches (what N independent pipelines issue)."""
             nb = len(streams) if streams else args.batch
+            # a step = `pairs` launch pairs (micro-steps), each on its own pristine batch; the stream leg's step is one frame per stream
+            pairs = 1 if streams else args.pairs_per_step
+            steps, warmup = steps * pairs, warmup * pairs
             pool = SourcePool(torch, synth, dev, nb, content)
             dsts = [torch.empty((nb, H, W * 4), dtype=torch.uint8, device=dev) for _ in range(args.ring)]
             scratch = [pool.new(10_000 + r) for r in range(args.ring)]
@@ -459,12 +467,13 @@ def main():
                 ramp_body(args.rewarm_steps)
                 # (short regions carry no event markers: ~5 us each on the stream, 2 % of 20 steps; the dedicated pass below
                 # then supplies every per-kernel sample)
-                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record and steps >= 64)), dist=dist, device_sync=torch.cuda.synchronize))
+                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record and steps >= 64)), dist=dist, device_sync=torch.cuda.synchronize,
+                                                 keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
 
             consume(pool, srcs, warmup, 0, warm)
             chunks = consume(pool, srcs, steps, warmup, timed)
             dt = sum(dts)
-            res = {"dt": dt, "chunks": chunks, "held": len(srcs), "source_stats": stats, "samples": len(evs)}
+            res = {"dt": dt, "chunks": chunks, "held": len(srcs), "source_stats": stats, "samples": len(evs), "frames": steps * nb, "launch_pairs": steps}
             if record:
                 if len(evs) < 32:
                     # few in-region samples (small K): a dedicated bracketed pass on fresh pristine batches, every launch timed
@@ -505,13 +514,13 @@ def main():
             leg = measure(args.content, n_i, 4, True)
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
             h_i, l_i = leg["ms"]
-            interp = {"frames_per_s": sharding.aggregate_throughput(n_i * args.batch, world, leg["dt"]), "colorlut_kernel": ctx.colorlut_kernel_name(),
+            interp = {"frames_per_s": sharding.aggregate_throughput(leg["frames"], world, leg["dt"]), "colorlut_kernel": ctx.colorlut_kernel_name(),
                       "colorlut_ms_per_launch": l_i, "colorlut_GBps": lb / (l_i * 1e-3) / 1e9,
                       "colorlut_frac_of_hbm_peak": lb / (l_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "hsvfilter_ms_per_launch": h_i}
         fused = None
         if not args.no_extra and world == 1:
             leg = measure(args.content, args.steps, args.warmup, True, fused=True)
-            fused_fps = sharding.aggregate_throughput(args.steps * args.batch, world, leg["dt"])
+            fused_fps = sharding.aggregate_throughput(leg["frames"], world, leg["dt"])
             fused_ms = leg["ms"][0]
             f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
             fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
@@ -526,7 +535,7 @@ def main():
             n_o = max(10, args.steps // 2)
             # warm-up long enough for the colorlut kernel choice to follow the change of content (sampled every 8th launch)
             leg = measure(other, n_o, 18, True)
-            extra = {"content": other, "frames_per_s": n_o * args.batch / leg["dt"],
+            extra = {"content": other, "frames_per_s": leg["frames"] / leg["dt"],
                      "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
                      "colorlut_kernel": ctx.colorlut_kernel_name(), "source_stats": leg["source_stats"]}
 
@@ -548,13 +557,13 @@ def main():
             torch.cuda.synchronize()
             n_s = max(8, args.steps // 4)
             leg = measure(args.content, n_s, 24, False, streams=sctx)
-            streams_leg = {"streams_per_gpu": args.streams, "frames_per_s": n_s * args.streams / leg["dt"], "launches": "one 4K frame per launch and stream",
+            streams_leg = {"streams_per_gpu": args.streams, "frames_per_s": leg["frames"] / leg["dt"], "launches": "one 4K frame per launch and stream",
                            "colorlut_kernel": sctx[0].colorlut_kernel_name(),
                            "memoised_tables_alive": mi355fx.load_library().mi355_shared_table_count() if not args.stub else 0}
             for c in sctx:
                 c.close()
 
-    fps = sharding.aggregate_throughput(args.steps * args.batch, world, dt)
+    fps = sharding.aggregate_throughput(main_leg["frames"], world, dt)
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
@@ -572,7 +581,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc.get("frames_per_step") == args.batch and pmc.get("content", "smooth") == args.content and pmc.get("pristine_sources"):
+            if pmc.get("frames_per_launch", pmc.get("frames_per_step")) == args.batch and pmc.get("content", "smooth") == args.content and pmc.get("pristine_sources"):
                 for kname, rec in pmc.get("kernels", {}).items():
                     if kname.startswith(dom.split(" ")[0].split("<")[0]):
                         traffic = rec["hbm_bytes"]
@@ -586,7 +595,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "stub" if args.stub else "synthetic",
             "config": {"workload": "hsvfilter(hue-shift=90) -> colorlut(33^3 trilinear), 3840x2160 RGBA, two kernels",
-                       "frames_per_step": args.batch, "content": args.content,
+                       "frames_per_step": args.batch * args.pairs_per_step, "frames_per_launch": args.batch,
+                       "launches_per_step": 2 * args.pairs_per_step, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
                        "lut_variant": args.lut_variant, "ramp_seconds": args.ramp_seconds, "rewarm_steps": args.rewarm_steps, "event_marker_ms": marker_ms(),
                        "sources": "pristine: every warm-up/timed step filters its own never-touched batch (in place)",

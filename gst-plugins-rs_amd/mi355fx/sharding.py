@@ -16,13 +16,18 @@ def streams_for_rank(n_streams, rank, world):
     return list(range(rank, n_streams, world))
 
 
-def timed_region(run, dist=None, device_sync=None, reduce_device=None):
-    """barrier + sync, run(), sync + barrier; returns the MAX elapsed seconds over all ranks."""
+def timed_region(run, dist=None, device_sync=None, reduce_device=None, keep_busy=None):
+    """barrier + sync, run(), sync + barrier; returns the MAX elapsed seconds over all ranks.
+    keep_busy: optional callable that ENQUEUES (does not wait for) a few milliseconds of untimed device work; it is called
+    right before the opening barrier so that the device does not sit idle - and drop its clocks - while the ranks meet (a
+    host-side barrier over 8 processes takes about a millisecond); the sync that follows the barrier drains it."""
     def sync():
         if device_sync is not None:
             device_sync()
 
     sync()
+    if keep_busy is not None:
+        keep_busy()
     if dist is not None:
         dist.barrier()
     sync()

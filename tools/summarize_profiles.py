@@ -69,6 +69,7 @@ def main():
     try:
         cfg = json.load(open(b0))["config"]
         out["frames_per_step"] = cfg["frames_per_step"]   # the PMC passes ran the same default workload
+        out["frames_per_launch"] = cfg.get("frames_per_launch", cfg["frames_per_step"])
         out["content"] = cfg.get("content", "smooth")
         out["pristine_sources"] = str(cfg.get("sources", "")).startswith("pristine")
         out["collected"] = tag + ": tools/collect_profiles.sh"
