@@ -104,7 +104,7 @@ def batch_stats(torch, b):
 EVENT_EVERY = 4  # steps between per-kernel event samples inside the timed region
 
 
-def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVENT_EVERY):
+def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVENT_EVERY, served=None):
     """`steps` steps on ctx's stream (== torch current stream); step k filters srcs[k % len(srcs)] in place and maps it into
     dsts[k % len(dsts)]. With `record`, every `every`-th step has its two launches bracketed by in-stream events (the
     timestamps cost a few microseconds each and keep consecutive kernels from overlapping their tails, so bracketing every
@@ -122,6 +122,9 @@ def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVE
         if sample:
             e1.record()
         ctx.colorlut_frames_device(s.data_ptr(), pitch, W * 4, d.data_ptr(), pitch, W * 4, batch, W, H, "RGBA")
+        if served is not None:   # which colorlut kernel the library picked for this launch (a host-side query, no device work)
+            name = ctx.colorlut_kernel_name()
+            served[name] = served.get(name, 0) + 1
         if sample:
             e2.record()
             evs.append((e0, e1, e2))
@@ -404,6 +407,7 @@ def main():
             that stream's own context with one-frame launches (what N independent pipelines issue)."""
             nb = len(streams) if streams else args.batch
             # a step = `pairs` launch pairs (micro-steps), each on its own pristine batch; the stream leg's step is one frame per stream
+            served, in_timed = {}, [False]   # colorlut kernels picked during the timed region (and the bracketed pass)
             pairs = 1 if streams else args.pairs_per_step
             steps, warmup = steps * pairs, warmup * pairs
             pool = SourcePool(torch, synth, dev, nb, content)
@@ -421,7 +425,7 @@ def main():
                             c.colorlut_frames_device(p_, pitch, W * 4, d_[i].data_ptr(), pitch, W * 4, 1, W, H, "RGBA")
                     return []
                 if not fused:
-                    return run_region(torch, ctx, srcs_, dsts, settings, n, args.batch, rec, every)
+                    return run_region(torch, ctx, srcs_, dsts, settings, n, args.batch, rec, every, served=served if in_timed[0] else None)
                 evs_ = []
                 for k in range(n):
                     s_, d_ = srcs_[k % len(srcs_)], dsts[k % len(dsts)]
@@ -467,13 +471,16 @@ def main():
                 ramp_body(args.rewarm_steps)
                 # (short regions carry no event markers: ~5 us each on the stream, 2 % of 20 steps; the dedicated pass below
                 # then supplies every per-kernel sample)
-                dts.append(sharding.timed_region(lambda: evs.extend(region(sl, n, record and steps >= 64)), dist=dist, device_sync=torch.cuda.synchronize,
-                                                 keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
+                def body():
+                    in_timed[0] = True
+                    evs.extend(region(sl, n, record and steps >= 64))
+                    in_timed[0] = False
+                dts.append(sharding.timed_region(body, dist=dist, device_sync=torch.cuda.synchronize, keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
 
             consume(pool, srcs, warmup, 0, warm)
             chunks = consume(pool, srcs, steps, warmup, timed)
             dt = sum(dts)
-            res = {"dt": dt, "chunks": chunks, "held": len(srcs), "source_stats": stats, "samples": len(evs), "frames": steps * nb, "launch_pairs": steps}
+            res = {"dt": dt, "chunks": chunks, "held": len(srcs), "source_stats": stats, "samples": len(evs), "frames": steps * nb, "launch_pairs": steps, "colorlut_kernels_served": served}
             if record:
                 if len(evs) < 32:
                     # few in-region samples (small K): a dedicated bracketed pass on fresh pristine batches, every launch timed
@@ -501,6 +508,7 @@ def main():
 
         cal = torch.zeros(FRAME_BYTES, dtype=torch.uint8, device=dev)
         main_leg = measure(args.content, args.steps, args.warmup, True)
+        main_kernel_name = ctx.colorlut_kernel_name()   # the kernel that served the main leg's last colorlut launch
         dt = main_leg["dt"]
         hsv_ms, lut_ms = main_leg["ms"]
         lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
@@ -515,6 +523,7 @@ def main():
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
             h_i, l_i = leg["ms"]
             interp = {"frames_per_s": sharding.aggregate_throughput(leg["frames"], world, leg["dt"]), "colorlut_kernel": ctx.colorlut_kernel_name(),
+                      "colorlut_kernels_served": leg["colorlut_kernels_served"],
                       "colorlut_ms_per_launch": l_i, "colorlut_GBps": lb / (l_i * 1e-3) / 1e9,
                       "colorlut_frac_of_hbm_peak": lb / (l_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "hsvfilter_ms_per_launch": h_i}
         fused = None
@@ -569,7 +578,7 @@ def main():
     if rank == 0:
         # dominant kernel = the longer of the two launches
         per_launch_bytes = lb
-        lut_name = "colorlut_table_tiled_kernel" if lut_tab else "colorlut3d (interpolating)"
+        lut_name = "colorlut_table_tiled_kernel" if lut_tab else main_kernel_name
         if lut_ms >= hsv_ms:
             dom, dom_ms = lut_name, lut_ms
         else:
@@ -581,7 +590,8 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc.get("frames_per_launch", pmc.get("frames_per_step")) == args.batch and pmc.get("content", "smooth") == args.content and pmc.get("pristine_sources"):
+            if (pmc.get("frames_per_launch", pmc.get("frames_per_step")) == args.batch and pmc.get("content", "smooth") == args.content
+                    and pmc.get("pristine_sources") and pmc.get("lut_variant", 0) == args.lut_variant):
                 for kname, rec in pmc.get("kernels", {}).items():
                     if kname.startswith(dom.split(" ")[0].split("<")[0]):
                         traffic = rec["hbm_bytes"]
@@ -613,7 +623,7 @@ def main():
                         "hsvfilter_GBps": per_launch_bytes / (hsv_ms * 1e-3) / 1e9,
                         "colorlut_GBps": per_launch_bytes / (lut_ms * 1e-3) / 1e9,
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
-                        "colorlut_kernel": lut_name,
+                        "colorlut_kernel": lut_name, "colorlut_kernels_served": main_leg["colorlut_kernels_served"],
                         "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt},
                         "hsvfilter_kernel": "colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel",
                         "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt},

@@ -70,6 +70,7 @@ def main():
         cfg = json.load(open(b0))["config"]
         out["frames_per_step"] = cfg["frames_per_step"]   # the PMC passes ran the same default workload
         out["frames_per_launch"] = cfg.get("frames_per_launch", cfg["frames_per_step"])
+        out["lut_variant"] = cfg.get("lut_variant", 0)
         out["content"] = cfg.get("content", "smooth")
         out["pristine_sources"] = str(cfg.get("sources", "")).startswith("pristine")
         out["collected"] = tag + ": tools/collect_profiles.sh"
