@@ -174,6 +174,49 @@ def test_brick_kernel_work_sharing_modes(ctx, oracle, synth, share, tpr, sets):
         ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)
 
 
+def test_brick_kernels_of_concurrent_contexts(mi355lib, oracle, synth):
+    """Four contexts on four host threads, each with its own HIP stream, LUT and frames, launching the brick kernel (both
+    geometries in turn) at the same time: a brick block takes a whole CU, so the kernels of different streams interleave
+    block by block. Every output must still equal the oracle's (nothing is shared between the contexts' caches, deques and
+    counters)."""
+    import threading
+    import mi355fx
+    w, h, n = 1920, 1080, 2
+    jobs = []
+    for k in range(4):
+        cube = oracle.Cube.parse(synth.cube_text_3d([33, 17, 65, 9][k], amp=0.05 + 0.01 * k))
+        frames = np.stack([np.roll(synth.smooth_frame(w, h, seed=40 + k), 4 * 37 * i, axis=1) for i in range(n)]).copy()
+        exp = np.zeros_like(frames)
+        for i in range(n):
+            oracle.colorlut_rgba8(cube, frames[i], w * 4, exp[i], w * 4, w, h, nthreads=2)
+        jobs.append((cube, frames, exp))
+    errors = []
+    barrier = threading.Barrier(4)
+
+    def worker(k):
+        cube, frames, exp = jobs[k]
+        c = mi355fx.Context(0)
+        try:
+            sc, of = cube.domain
+            c.colorlut_load(cube.is3d, cube.size, cube.table, sc, of)
+            c.set_flag(mi355fx.FLAG_LUT_VARIANT, 7)
+            barrier.wait()
+            for it in range(6):
+                c.set_flag(mi355fx.FLAG_BRICK_SETS, 64 if (it + k) % 2 else 32)
+                got = _device_lut(c, frames, w, h).reshape(frames.shape)
+                if not (got == exp).all():
+                    errors.append("context %d launch %d: %s" % (k, it, _report(got, exp)))
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append("context %d: %r" % (k, e))
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+
+
 def test_brick_kernel_width_not_multiple_of_4_takes_another_kernel(ctx, oracle, synth):
     import mi355fx
     cube = _load(ctx, oracle, synth.cube_text_3d(33))
