@@ -34,8 +34,9 @@ def test_two_ranks_aggregate_over_the_slowest_rank():
     d = _run(2)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["data"] == "stub" and d["scaling"] == "weak"
     assert "gloo" in d["config"]["timing_group"] and "RCCL" in d["config"]["timing_group"]
-    # rank 1 sleeps 2 ms per launch, rank 0 1 ms: two launches per step -> a step takes >= 4 ms on the slowest rank
-    assert d["ms_per_step"] >= 4.0
+    # rank 1 sleeps 2 ms per launch, rank 0 1 ms: a step is four (hsvfilter, colorlut) pairs = 8 launches -> >= 16 ms on the slowest rank
+    assert d["config"]["launches_per_step"] == 8 and d["config"]["frames_per_step"] == 4 * d["config"]["frames_per_launch"]
+    assert d["ms_per_step"] >= 16.0
     frames = d["steps"] * d["config"]["frames_per_step"] * 2     # both ranks' frames
     assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
@@ -51,3 +52,15 @@ def test_single_process_stub_has_all_legs():
     for key in ("interpolating_kernel_only", "fused_chain", "other_content", "cpu_baseline", "cpu_baseline_all_cores"):
         assert key in d, key
     assert d["config"]["sources"].startswith("pristine") and d["config"]["source_chunks"] >= 1
+    # the driver's contract (one JSON line with these keys) and the two objects this tier adds
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u8"
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for key in ("ramp_seconds", "rewarm_steps", "event_marker_ms"):   # everything untimed that precedes the bracket is declared
+        assert key in d["config"], key
+    assert sum(d["kernels"]["colorlut_kernels_served"].values()) == d["steps"] * d["config"]["launches_per_step"] // 2
