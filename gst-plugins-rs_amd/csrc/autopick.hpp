@@ -10,7 +10,10 @@
 //   * afterwards the kind with the smaller time per pixel group serves the launches (3 % hysteresis); every n-th launch
 //     of it is measured (n = 8..32, about one sample per 128 Mpixel) unless the previous sample is still in flight;
 //   * the kind NOT in use is tried again after probe_period launches (64, doubling up to 1024 while the answer stays the
-//     same, back to 64 when it changes);
+//     same, back to 64 when it changes). A probe is TWO consecutive launches of that kind, the second one measured: what the
+//     kind not in use keeps in the caches (the table's lines, the brick table) has been evicted by the launches in between,
+//     and a single cold launch of the table kernel measures 0.156 ms against 0.09-0.11 ms warm - enough to lose against the
+//     interpolating kernel for ever once a disturbance has flipped the choice (measured: 34 k frames/s instead of 41 k);
 //   * a change of launch size by more than 2x restarts the learning.
 #pragma once
 #include <cstddef>
@@ -29,6 +32,7 @@ struct AutoPolicy {
   unsigned pending_call = 0;              // `calls` when the sample in flight was recorded
   bool pending_probe = false, pending_discard = false;
   unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
+  bool probe_second = false;              // the previous launch was the warming half of a probe: this one is the measured half
   bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
 };
 
@@ -78,7 +82,18 @@ inline AutoDecision auto_decide(AutoPolicy &A, size_t n_vec) {
     if (A.pending_kind < 0) A.learn++;
   } else {
     D.kind = A.table ? 1 : 0;
-    if (++A.since_probe >= A.probe_period && A.pending_kind < 0) { D.kind ^= 1; D.probe = true; A.since_probe = 0; }
+    bool warming = false;
+    if (A.probe_second) {  // second half of a probe: measured if nothing else is in flight (otherwise the probe is lost)
+      A.probe_second = false;
+      D.kind ^= 1;
+      D.probe = true;
+    } else if (++A.since_probe >= A.probe_period && A.pending_kind < 0) {  // first half: warms the other kind's working set
+      A.since_probe = 0;
+      A.probe_second = true;
+      D.kind ^= 1;
+      warming = true;
+    }
+    if (warming) { A.calls++; return D; }  // never measured: it is neither a sample of the kind in use nor a fair one of the other
   }
   D.measure = A.pending_kind < 0 && (D.probe || (A.calls % auto_sample_every(n_vec)) == 0);
   A.calls++;

@@ -43,12 +43,15 @@ def test_first_launch_of_each_kind_is_discarded(mi355lib):
 def test_probe_of_the_other_kind_backs_off(mi355lib):
     n = 2600
     kind, meas = run(mi355lib, [NV] * n, [0.25] * n, [0.12] * n)
-    probes = [i for i in range(4, n) if kind[i] == 0]
-    assert probes, "the kind not in use must be tried again"
+    other = [i for i in range(4, n) if kind[i] == 0]
+    assert other, "the kind not in use must be tried again"
+    # a probe is two consecutive launches of the other kind: the first warms its working set and is not measured, the second is
+    assert len(other) % 2 == 0 and all(b == a + 1 for a, b in zip(other[0::2], other[1::2]))
+    assert all(meas[i] == 0 for i in other[0::2]) and all(meas[i] == 1 for i in other[1::2])
+    probes = other[0::2]
     gaps = np.diff([4] + probes)
     assert 60 <= gaps[0] <= 70
     assert all(g2 >= g1 for g1, g2 in zip(gaps, gaps[1:])) and gaps[-1] <= 1030   # 64, 128, 256, 512, 1024, 1024 ...
-    assert all(meas[i] for i in probes)
 
 
 def test_content_change_flips_within_a_sample_interval(mi355lib):
@@ -65,6 +68,29 @@ def test_content_change_flips_within_a_sample_interval(mi355lib):
     assert kind2[-1] == 1
 
 
+def test_a_cold_first_launch_does_not_bias_the_probe(mi355lib):
+    """What the kind not in use keeps in the caches is gone by the time it is probed: its first launch after a pause is slow
+    (the table kernel: 0.156 ms cold against 0.10 warm, the interpolating kernel 0.131). A one-launch probe would measure the
+    cold launch and never let the table back in once something had flipped the choice; the two-launch probe measures the
+    second, warm one."""
+    n = 600
+    ms_c = [0.131] * n
+    ms_t = [0.100] * n
+    for i in range(8, 100):
+        ms_t[i] = 0.20            # a disturbance while the table is in use (content, a neighbour): the choice flips to compute
+    kind0, _ = run(mi355lib, [NV] * n, ms_c, ms_t)
+    assert (kind0[40:100] == 0).sum() > 50
+    # from then on every table launch that follows a compute launch is cold, every table launch that follows a table launch warm
+    kind = None
+    for _ in range(3):        # the scripted times depend on the decisions: iterate to the fixed point
+        prev = kind0 if kind is None else kind
+        ms_t2 = list(ms_t)
+        for i in range(100, n):
+            ms_t2[i] = 0.156 if prev[i - 1] == 0 else 0.100
+        kind, _ = run(mi355lib, [NV] * n, ms_c, ms_t2)
+    assert (kind[300:] == 1).sum() > 280, "the table must win back once the disturbance is over"
+
+
 def test_hysteresis_no_flip_flop_on_equal_kernels(mi355lib):
     rng = np.random.default_rng(0)
     n = 3000
@@ -72,8 +98,8 @@ def test_hysteresis_no_flip_flop_on_equal_kernels(mi355lib):
     ms_t = 0.200 * (1 + rng.uniform(-0.01, 0.01, n))
     kind, _ = run(mi355lib, [NV] * n, ms_c, ms_t)
     steady = kind[4:]
-    # ignore single-launch probes: count changes of the kind that serves runs of >= 2 launches
-    runs = [k for k, g in zip(steady[:-1], steady[1:]) if k == g]
+    # ignore the two-launch probes: count changes of the kind that serves runs of >= 3 launches
+    runs = [k for k, g, h in zip(steady[:-2], steady[1:-1], steady[2:]) if k == g == h]
     assert np.count_nonzero(np.diff(runs)) <= 2
 
 
@@ -116,13 +142,13 @@ def test_learning_spans_more_launches_when_results_arrive_late(mi355lib):
         assert list(m[:4]) == [0, lag + 1, 2 * (lag + 1), 3 * (lag + 1)], (lag, m[:6])
         assert (np.diff(m) >= lag + 1).all()
         steady = kind[5 * (lag + 1):200]
-        assert kind[0] == 0 and (steady == 1).sum() >= len(steady) - 3, (lag, kind[:40])   # all but the odd probe of the other kind
+        assert kind[0] == 0 and (steady == 1).sum() >= len(steady) - 6, (lag, kind[:40])   # all but the odd two-launch probe of the other kind
 
 
 def test_property_steady_timings_pick_the_faster_kind(mi355lib):
     """Hypothesis: for any constant pair of timings at least 10 % apart, any launch size and any read-back lag, every
-    launch after the learning phase runs the faster kind except single probe launches of the other one, which are
-    measured and at least 64 launches apart."""
+    launch after the learning phase runs the faster kind except two-launch probes of the other one (the first launch warms
+    and is not measured, the second is measured unless another measurement is still in flight), at least 64 launches apart."""
     from hypothesis import given, settings, strategies as st
 
     @settings(max_examples=150, deadline=None)
@@ -136,8 +162,10 @@ def test_property_steady_timings_pick_the_faster_kind(mi355lib):
         if n <= learned:
             return
         assert kind[0] == 0
-        other = [i for i in range(learned, n) if kind[i] != want]
-        assert all(meas[i] for i in other), "a launch of the slower kind that is not a measured probe"
-        assert all(b - a >= 60 for a, b in zip([3 * (lag + 1)] + other, other)), other[:5]
+        other = [i for i in range(learned, n - 1) if kind[i] != want]
+        starts = [i for i in other if i - 1 not in other]
+        assert all(i + 1 in other or i + 1 >= n - 1 for i in starts) and len(other) <= 2 * len(starts), "probes of the slower kind come in pairs"
+        assert all(meas[i] == 0 for i in starts), "the warming half of a probe is never measured"
+        assert all(b - a >= 60 for a, b in zip([3 * (lag + 1)] + starts, starts)), starts[:5]
 
     prop()
