@@ -180,12 +180,33 @@ __device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, 
   }
 }
 
+// The 3 x 3 blur of a 2 x 2 block of outputs from its 4 x 4 window, the two outputs of a row as one packed-f32 pair:
+// v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations per instruction (never fused: -ffp-contract=off), so every output is
+// accumulated over its nine taps in the same order, with the same roundings, as the scalar loop - in half the instructions.
+typedef float dssim_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dssim_blur_2x2(const float (&v)[4][4], float (&o)[2][2]) {
+  const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
+#pragma unroll
+  for (int oy = 0; oy < 2; oy++) {
+    dssim_f2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int dyy = 0; dyy < 3; dyy++)
+#pragma unroll
+      for (int dxx = 0; dxx < 3; dxx++) {
+        const dssim_f2 p = {v[oy + dyy][dxx], v[oy + dyy][dxx + 1]};
+        const dssim_f2 k = {K[dyy * 3 + dxx], K[dyy * 3 + dxx]};
+        acc = acc + p * k;
+      }
+    o[oy][0] = acc.x;
+    o[oy][1] = acc.y;
+  }
+}
+
 // Interior regions, register-tiled: a lane produces a 2 x 2 block of outputs from one 4 x 4 window (16 LDS reads instead
 // of 36), each output accumulated over its nine taps in the usual order. DUAL also produces the blur of the squares from
 // the same window (the squares are formed once per cell: the same values as squaring per tap).
 template <int M, bool DUAL>
 __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, float *dst_sq) {
-  const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
   constexpr int cw = (kRw - 2 * M) / 2, ch = (kRh - 2 * M) / 2;
   static_assert((kRw - 2 * M) % 2 == 0 && (kRh - 2 * M) % 2 == 0, "even pass extents");
   for (int e = threadIdx.x; e < cw * ch; e += 256) {
@@ -197,33 +218,22 @@ __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, flo
     for (int r = 0; r < 4; r++)
 #pragma unroll
       for (int c = 0; c < 4; c++) v[r][c] = p[r * kRw + c];
+    float o[2][2];
+    dssim_blur_2x2(v, o);
 #pragma unroll
     for (int oy = 0; oy < 2; oy++)
 #pragma unroll
-      for (int ox = 0; ox < 2; ox++) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int dyy = 0; dyy < 3; dyy++)
-#pragma unroll
-          for (int dxx = 0; dxx < 3; dxx++) acc = acc + v[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
-        dst[(ly + oy) * kRw + lx + ox] = acc;
-      }
+      for (int ox = 0; ox < 2; ox++) dst[(ly + oy) * kRw + lx + ox] = o[oy][ox];
     if (DUAL) {
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int c = 0; c < 4; c++) v[r][c] = v[r][c] * v[r][c];
+      dssim_blur_2x2(v, o);
 #pragma unroll
       for (int oy = 0; oy < 2; oy++)
 #pragma unroll
-        for (int ox = 0; ox < 2; ox++) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int dyy = 0; dyy < 3; dyy++)
-#pragma unroll
-            for (int dxx = 0; dxx < 3; dxx++) acc = acc + v[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
-          dst_sq[(ly + oy) * kRw + lx + ox] = acc;
-        }
+        for (int ox = 0; ox < 2; ox++) dst_sq[(ly + oy) * kRw + lx + ox] = o[oy][ox];
     }
   }
 }
@@ -286,22 +296,17 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
         for (int r = 0; r < 4; r++)
 #pragma unroll
           for (int q = 0; q < 4; q++) { va[r][q] = s_a[j0 + r * kRw + q]; vb[r][q] = s_b[j0 + r * kRw + q]; }
+        float om[2][2], os[2][2];
+        dssim_blur_2x2(va, om);
+        dssim_blur_2x2(vb, os);
 #pragma unroll
         for (int oy = 0; oy < 2; oy++)
 #pragma unroll
           for (int ox = 0; ox < 2; ox++) {
-            float am = 0.0f, as = 0.0f;
-#pragma unroll
-            for (int dyy = 0; dyy < 3; dyy++)
-#pragma unroll
-              for (int dxx = 0; dxx < 3; dxx++) {
-                am = am + va[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
-                as = as + vb[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
-              }
             const size_t o = (size_t)(y0 + ly + oy) * w + (x0 + lx + ox);
             O.img[c][o] = s_lab[c][(ly + oy) * kRw + lx + ox];
-            O.mu[c][o] = am;
-            O.sq[c][o] = as;
+            O.mu[c][o] = om[oy][ox];
+            O.sq[c][o] = os[oy][ox];
           }
       }
     } else
@@ -399,17 +404,12 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
         for (int r = 0; r < 4; r++)
 #pragma unroll
           for (int q = 0; q < 4; q++) v[r][q] = s_p[c][j0 + r * kCw + q];
+        float o[2][2];
+        dssim_blur_2x2(v, o);
 #pragma unroll
         for (int oy = 0; oy < 2; oy++)
 #pragma unroll
-          for (int ox = 0; ox < 2; ox++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int dyy = 0; dyy < 3; dyy++)
-#pragma unroll
-              for (int dxx = 0; dxx < 3; dxx++) acc = acc + v[oy + dyy][ox + dxx] * K[dyy * 3 + dxx];
-            s_q[c][(ly + oy) * kCw + lx + ox] = acc;
-          }
+          for (int ox = 0; ox < 2; ox++) s_q[c][(ly + oy) * kCw + lx + ox] = o[oy][ox];
       }
     }
   } else
