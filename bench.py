@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--lut-variant", type=int, default=0,
                     help="MI355_FLAG_LUT_VARIANT: 0 auto (default), 6 interpolating kernel only, 5 table kernel only")
     ap.add_argument("--hsv-blocks-per-cu", type=int, default=0, help="MI355_FLAG_HSV_BLOCKS_PER_CU (tuning; 0 = library default)")
+    ap.add_argument("--ctx-flag", action="append", default=[], metavar="FLAG=VALUE",
+                    help="mi355_ctx_set_flag on the main context (numeric MI355_FLAG_* id = value); A/B knob, repeatable")
     ap.add_argument("--streams", type=int, default=32, help="concurrent streams of the secondary many-streams measurement (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other-content) measurement")
@@ -358,6 +360,9 @@ def main():
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
         if args.hsv_blocks_per_cu:
             ctx.set_flag(mi355fx.FLAG_HSV_BLOCKS_PER_CU, args.hsv_blocks_per_cu)
+        for kv in args.ctx_flag:
+            k_, v_ = kv.split("=")
+            ctx.set_flag(int(k_), int(v_))
 
         def ramp(run_n):
             """Untimed: keep the device busy with the leg's own launches for --ramp-seconds (clock ramp-up)."""
@@ -373,7 +378,9 @@ def main():
             if "ms" not in marker:
                 pairs = []
                 for _ in range(32):
-                    ctx.hsvfilter_frames_device(cal.data_ptr(), 1, FRAME_BYTES, W, H, W * 4, "RGBA", settings)  # keep the queue busy
+                    # keep the queue busy; byte order xRGB = another instantiation (hsvfilter_flat_kernel<5, 1, false>), so that these
+                    # 1-frame launches do not dilute the 8-frame launches' average in a rocprofv3 kernel trace of this command
+                    ctx.hsvfilter_frames_device(cal.data_ptr(), 1, FRAME_BYTES, W, H, W * 4, "xRGB", settings)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(); b.record()
                     pairs.append((a, b))
@@ -608,7 +615,7 @@ def main():
                        "frames_per_step": args.batch * args.pairs_per_step, "frames_per_launch": args.batch,
                        "launches_per_step": 2 * args.pairs_per_step, "content": args.content,
                        "algorithmic_bytes_per_frame": 2 * BYTES_PER_FRAME_PER_KERNEL, "streams_per_gpu": 1,
-                       "lut_variant": args.lut_variant, "ramp_seconds": args.ramp_seconds, "rewarm_steps": args.rewarm_steps, "event_marker_ms": marker_ms(),
+                       "lut_variant": args.lut_variant, "ctx_flags": args.ctx_flag, "ramp_seconds": args.ramp_seconds, "rewarm_steps": args.rewarm_steps, "event_marker_ms": marker_ms(),
                        "sources": "pristine: every warm-up/timed step filters its own never-touched batch (in place)",
                        "source_batches_held": main_leg["held"], "source_chunks": main_leg["chunks"],
                        "source_stats": main_leg["source_stats"], "dst_ring_batches": args.ring,

@@ -1675,7 +1675,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   auto compute = [&]() { return launch_hsvfilter_compute(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, hs); };
   size_t n_vec = 0;
   // mode 0 (default): only settings that need the GENERIC arithmetic (3x slower than the FAST kernels) are candidates
-  const bool candidate = ctx->hsv_table_mode == 1 || ctx->hsv_table_mode == 2 || (ctx->hsv_table_mode == 0 && hsv_variant_for(hs, false) < 0);
+  const bool candidate = ctx->hsv_table_mode == 1 || ctx->hsv_table_mode == 2 || (ctx->hsv_table_mode == 0 && hsv_variant_for(hs, false, true) < 0);
   const bool table_ok = candidate && !ctx->force_generic && fmt.pixel_stride == 4 && fmt.first == 0 &&
                         rgba8_flat(d_data, frame_pitch, stride, d_data, frame_pitch, stride, n_frames, width, height, &n_vec);
   T.last_table = false;

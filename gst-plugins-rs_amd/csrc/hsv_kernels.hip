@@ -24,46 +24,78 @@ namespace mi355 {
 
 // ---------------------------------------------------------------- hsvfilter kernels
 
+// Four pixels of one lane through the filter. FAST variants: two calls of the pair routine with the block's HsvLds;
+// GENERIC: the pair routine's settings-independent from_rgb (exact for every colour, all-colours tests) followed by the
+// literal fmodf / `/ 60` / sextant chain, which is what non-finite and out-of-range hue shifts need.
+template <int VARIANT, int RPOS, int GPOS, int BPOS, int NPOS>
+__device__ __forceinline__ void hsvfilter_quad(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, const HsvK &k, const HsvLds *lds) {
+  if constexpr (VARIANT >= 0) {
+    hsvfilter_px2_lds<RPOS, GPOS, BPOS, NPOS, hsv_shift_of(VARIANT), hsv_sv_ident_of(VARIANT)>(a, b, k, lds);
+    hsvfilter_px2_lds<RPOS, GPOS, BPOS, NPOS, hsv_shift_of(VARIANT), hsv_sv_ident_of(VARIANT)>(c, d, k, lds);
+  } else {
+    hsvfilter_px2_generic<RPOS, GPOS, BPOS, NPOS>(a, b, k, lds);
+    hsvfilter_px2_generic<RPOS, GPOS, BPOS, NPOS>(c, d, k, lds);
+  }
+}
+
 // Flat streaming kernel for 4-byte formats on contiguous storage (stride == width*4 and frames
 // back to back): each lane owns 16 B (4 pixels) per iteration -> global_load/store_dwordx4.
-// VARIANT: -1 = GENERIC arithmetic; otherwise FAST with SHIFT = VARIANT & 3, SV_IDENT = VARIANT >> 2.
+// VARIANT: -1 = GENERIC arithmetic; otherwise FAST, see hsv_shift_of / hsv_sv_ident_of.
+// Plain loads and stores on purpose: with the non-temporal hint on both, this kernel alone is 5 % faster (0.086 against
+// 0.091 ms for the bare read-modify-write of 8 x 4K frames, tools/hsv_mem_probe.hip), but its output then bypasses the
+// Infinity Cache and the element behind it reads from HBM: colorlut 0.115 instead of 0.087 ms, the chain 38.5 k instead of
+// 44.4 k frames/s (r03, bench.py). One load in flight per lane: two measured the same or slower once the arithmetic had
+// shrunk (63 VGPRs, 8 waves per SIMD cover the latency).
 template <int VARIANT, int FIRST, bool BGR>
 __global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__ data, size_t n_vec,
                                                              HsvK k) {
   constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
   constexpr int NPOS = FIRST == 0 ? 3 : 0;
-  constexpr bool FAST = VARIANT >= 0;
-  __shared__ uint32_t sel_tab[8];
-  if (threadIdx.x < 7)
-    sel_tab[threadIdx.x] = FAST ? hsv_sel_entry_floor(threadIdx.x, RPOS, GPOS, BPOS, NPOS)
-                                : hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
+  __shared__ HsvLds lds;
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  auto one = [&](uint4 &p) {
-    if constexpr (FAST) {
-      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p.x, p.y, k, sel_tab);
-      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p.z, p.w, k, sel_tab);
-    } else {
-      p.x = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.x, k, sel_tab);
-      p.y = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.y, k, sel_tab);
-      p.z = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.z, k, sel_tab);
-      p.w = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p.w, k, sel_tab);
-    }
-  };
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // two independent 16 B loads in flight per lane (four measured slower: register pressure)
-  for (; i + stride < n_vec; i += 2 * stride) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     uint4 p = data[i];
-    uint4 q = data[i + stride];
-    one(p);
+    hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
     data[i] = p;
-    one(q);
-    data[i + stride] = q;
   }
-  if (i < n_vec) {
-    uint4 p = data[i];
-    one(p);
-    data[i] = p;
+}
+
+// 4-byte formats with padded rows and / or frame pitches (what real caps negotiate when upstream aligns strides):
+// the same 16 B per lane, addressed as (frame, row, 4-pixel group). Needs base, stride and pitch to be multiples of 16;
+// the last group of a row may hold 1-3 pixels: its padding bytes are read, filtered as pixels and NOT written back
+// (only `line[..width*4]` of a row is touched, hsvfilter/imp.rs:94-97).
+template <int VARIANT, int FIRST, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_strided_kernel(uint8_t *__restrict__ data, int n_frames, size_t frame_pitch, int width,
+                                                                int height, int stride, HsvK k) {
+  constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
+  constexpr int NPOS = FIRST == 0 ? 3 : 0;
+  __shared__ HsvLds lds;
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
+  __syncthreads();
+  const uint32_t groups = ((uint32_t)width + 3u) >> 2;  // per row
+  const size_t rows = (size_t)height * (size_t)n_frames;
+  const size_t total = rows * groups;
+  const size_t gstride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const size_t rowi = i / groups;
+    const uint32_t g = (uint32_t)(i - rowi * groups);
+    const size_t f = rowi / (size_t)height;
+    const size_t row = rowi - f * (size_t)height;
+    uint8_t *at = data + f * frame_pitch + row * (size_t)stride + (size_t)g * 16;
+    const int left = width - (int)(g * 4);  // pixels of this group inside the row
+    if (left >= 4) {
+      uint4 p = *(const uint4 *)at;
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
+      *(uint4 *)at = p;
+    } else {
+      // the row's bytes end inside this group: read only what belongs to the row
+      uint32_t px[4] = {0, 0, 0, 0};
+      for (int j = 0; j < left; j++) px[j] = ((const uint32_t *)at)[j];
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(px[0], px[1], px[2], px[3], k, &lds);
+      for (int j = 0; j < left; j++) ((uint32_t *)at)[j] = px[j];
+    }
   }
 }
 
@@ -74,25 +106,14 @@ struct Rgb24x4 { uint32_t d0, d1, d2; };
 template <int VARIANT, bool BGR>
 __global__ __launch_bounds__(256) void hsvfilter_rgb24_kernel(Rgb24x4 *__restrict__ data, size_t n_grp, HsvK k) {
   constexpr int RPOS = BGR ? 2 : 0, GPOS = 1, BPOS = BGR ? 0 : 2, NPOS = 3;
-  constexpr bool FAST = VARIANT >= 0;
-  __shared__ uint32_t sel_tab[8];
-  if (threadIdx.x < 7)
-    sel_tab[threadIdx.x] = FAST ? hsv_sel_entry_floor(threadIdx.x, RPOS, GPOS, BPOS, NPOS)
-                                : hsv_sel_entry(threadIdx.x, RPOS, GPOS, BPOS, NPOS);
+  __shared__ HsvLds lds;
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grp; i += stride) {
     const Rgb24x4 v = data[i];
     uint32_t p0 = v.d0, p1 = (v.d0 >> 24) | (v.d1 << 8), p2 = (v.d1 >> 16) | (v.d2 << 16), p3 = v.d2 >> 8;
-    if constexpr (FAST) {
-      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p0, p1, k, sel_tab);
-      hsvfilter_px2_fast<RPOS, GPOS, BPOS, NPOS, VARIANT & 3, (VARIANT >> 2) != 0>(p2, p3, k, sel_tab);
-    } else {
-      p0 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p0, k, sel_tab);
-      p1 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p1, k, sel_tab);
-      p2 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p2, k, sel_tab);
-      p3 = hsvfilter_px<false, RPOS, GPOS, BPOS, NPOS>(p3, k, sel_tab);
-    }
+    hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p0, p1, p2, p3, k, &lds);
     Rgb24x4 o;
     o.d0 = (p0 & 0x00ffffffu) | (p1 << 24);
     o.d1 = ((p1 >> 8) & 0x0000ffffu) | (p2 << 16);
@@ -107,7 +128,7 @@ static void launch_rgb24(mi355_ctx *ctx, Rgb24x4 *d, size_t n_grp, const HsvK &k
   else hipLaunchKernelGGL((hsvfilter_rgb24_kernel<VARIANT, false>), dim3(grid), dim3(256), 0, ctx->stream, d, n_grp, k);
 }
 
-// General kernel: any stride / pixel stride (3 or 4) / triple offset, one pixel per lane, byte
+// General kernel: any stride / pixel stride (3 or 4) / triple offset / alignment, one pixel per lane, byte
 // accesses. Only `line[..width*pixel_stride]` of each row is touched (hsvfilter/imp.rs:94-97).
 template <bool FAST>
 __global__ __launch_bounds__(256) void hsvfilter_rows_kernel(uint8_t *__restrict__ data, int n_frames,
@@ -153,47 +174,59 @@ static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, i
   else hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
 }
 
+template <int VARIANT>
+static void launch_strided(mi355_ctx *ctx, uint8_t *d, int n_frames, size_t frame_pitch, int width, int height, int stride, const HsvK &k,
+                           int first, int bgr, int grid) {
+  dim3 g(grid), b(256);
+  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 0, false>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);
+  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 0, true>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);
+  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 1, false>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);
+  else hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);
+}
+
+// Calls F<VARIANT>(args...) for the run-time variant number (hsv_variant_for).
+#define MI355_HSV_VARIANT_SWITCH(variant, F, ...)   \
+  switch (variant) {                                \
+    case -1: F<-1>(__VA_ARGS__); break;             \
+    case 0: F<0>(__VA_ARGS__); break;               \
+    case 1: F<1>(__VA_ARGS__); break;               \
+    case 2: F<2>(__VA_ARGS__); break;               \
+    case 4: F<4>(__VA_ARGS__); break;               \
+    case 5: F<5>(__VA_ARGS__); break;               \
+    case 6: F<6>(__VA_ARGS__); break;               \
+    case 8: F<8>(__VA_ARGS__); break;               \
+    case 9: F<9>(__VA_ARGS__); break;               \
+    case 12: F<12>(__VA_ARGS__); break;             \
+    default: F<13>(__VA_ARGS__); break;             \
+  }
+
 int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
                      int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s) {
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;  // nothing to do
   const HsvK k{s.hue_shift, s.saturation_mul, s.saturation_off, s.value_mul, s.value_off};
-  const int variant = hsv_variant_for(s, ctx->force_generic);
-  const bool fast = variant >= 0;
+  const int variant = hsv_variant_for(s, ctx->force_generic, true);
   const size_t row_bytes = (size_t)width * (size_t)fmt.pixel_stride;
-  const bool contiguous = fmt.pixel_stride == 4 && (size_t)stride == row_bytes &&
-                          (n_frames == 1 || frame_pitch == row_bytes * (size_t)height);
+  const bool packed_rows = (size_t)stride == row_bytes && (n_frames == 1 || frame_pitch == row_bytes * (size_t)height);
   const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
-  if (contiguous && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
+  if (fmt.pixel_stride == 4 && packed_rows && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
     const size_t n_vec = total_bytes / 16;
     const int grid = grid_for(ctx, n_vec, 256, ctx->hsv_blocks_per_cu);
     uint4 *d = (uint4 *)d_data;
-    switch (variant) {
-      case -1: launch_flat<-1>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      case 0: launch_flat<0>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      case 1: launch_flat<1>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      case 2: launch_flat<2>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      case 4: launch_flat<4>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      case 5: launch_flat<5>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-      default: launch_flat<6>(ctx, d, n_vec, k, fmt.first, fmt.bgr, grid); break;
-    }
-  } else if (fmt.pixel_stride == 3 && fmt.first == 0 && (size_t)stride == row_bytes &&
-             (n_frames == 1 || frame_pitch == row_bytes * (size_t)height) && ((uintptr_t)d_data % 4 == 0) && (total_bytes % 12 == 0)) {
+    MI355_HSV_VARIANT_SWITCH(variant, launch_flat, ctx, d, n_vec, k, fmt.first, fmt.bgr, grid)
+  } else if (fmt.pixel_stride == 4 && ((uintptr_t)d_data % 16 == 0) && stride % 16 == 0 && (n_frames == 1 || frame_pitch % 16 == 0)) {
+    const size_t n_grp = (size_t)((width + 3) / 4) * (size_t)height * (size_t)n_frames;
+    const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
+    MI355_HSV_VARIANT_SWITCH(variant, launch_strided, ctx, d_data, n_frames, frame_pitch, width, height, stride, k, fmt.first, fmt.bgr, grid)
+  } else if (fmt.pixel_stride == 3 && fmt.first == 0 && packed_rows && ((uintptr_t)d_data % 4 == 0) && (total_bytes % 12 == 0)) {
     const size_t n_grp = total_bytes / 12;
     const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
     Rgb24x4 *d = (Rgb24x4 *)d_data;
-    switch (variant) {
-      case -1: launch_rgb24<-1>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      case 0: launch_rgb24<0>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      case 1: launch_rgb24<1>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      case 2: launch_rgb24<2>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      case 4: launch_rgb24<4>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      case 5: launch_rgb24<5>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-      default: launch_rgb24<6>(ctx, d, n_grp, k, fmt.bgr, grid); break;
-    }
+    MI355_HSV_VARIANT_SWITCH(variant, launch_rgb24, ctx, d, n_grp, k, fmt.bgr, grid)
   } else {
     const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
     const int grid = grid_for(ctx, total, 256, 32);
-    if (fast)
+    // one pixel per lane: the single-pixel FAST routine knows the narrow shift classes only
+    if (hsv_variant_for(s, ctx->force_generic, false) >= 0)
       hipLaunchKernelGGL((hsvfilter_rows_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, d_data, n_frames,
                          frame_pitch, width, height, stride, fmt.pixel_stride, fmt.first, fmt.bgr, k);
     else
@@ -252,6 +285,9 @@ __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__rest
                                                              HsvDetK k, uint32_t out_sel) {
   constexpr int RPOS = IN_FIRST + (IN_BGR ? 2 : 0), GPOS = IN_FIRST + 1, BPOS = IN_FIRST + (IN_BGR ? 0 : 2);
   const float off = 180.0f - k.hue_ref;  // ref_hue_offset (hsvdetector/imp.rs:140)
+  __shared__ HsvLds lds;  // value / reciprocal tables of the pair routine (the sextant entries are not used here)
+  hsv_lds_fill<0, 1, 2, 3>(&lds);
+  __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     const uint4 p = src[i];
@@ -260,11 +296,8 @@ __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__rest
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
       f2 h, s, v;
-      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS>(in[j], in[j + 1], h, s, v);
-      f2 sh = h + splat2(off);
-      const f2 u = sh - splat2(360.0f);
-      sh.x = (u.x >= 0.0f) ? u.x : sh.x;
-      sh.y = (u.y >= 0.0f) ? u.y : sh.y;
+      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS, 1>(in[j], in[j + 1], h, s, v, &lds);
+      const f2 sh = sub360_if_reached2(h + splat2(off));
       const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = v - splat2(k.val_ref);
       const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
       const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;
@@ -284,6 +317,9 @@ __global__ __launch_bounds__(256) void hsvdetect_rgb24_kernel(const Rgb24x4 *__r
                                                               uint32_t out_sel) {
   constexpr int RPOS = IN_BGR ? 2 : 0, GPOS = 1, BPOS = IN_BGR ? 0 : 2;
   const float off = 180.0f - k.hue_ref;
+  __shared__ HsvLds lds;
+  hsv_lds_fill<0, 1, 2, 3>(&lds);
+  __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_grp; i += stride) {
     const Rgb24x4 v = src[i];
@@ -292,11 +328,8 @@ __global__ __launch_bounds__(256) void hsvdetect_rgb24_kernel(const Rgb24x4 *__r
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
       f2 h, s, vv;
-      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS>(in[j], in[j + 1], h, s, vv);
-      f2 sh = h + splat2(off);
-      const f2 u = sh - splat2(360.0f);
-      sh.x = (u.x >= 0.0f) ? u.x : sh.x;
-      sh.y = (u.y >= 0.0f) ? u.y : sh.y;
+      hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS, 1>(in[j], in[j + 1], h, s, vv, &lds);
+      const f2 sh = sub360_if_reached2(h + splat2(off));
       const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = vv - splat2(k.val_ref);
       const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
       const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;

@@ -94,6 +94,77 @@ void replay_hsvfilter_fast(uint32_t *px, size_t n, const float st[5], int rcp_mo
   }
 }
 
+/* ---------------------------------------------------------------- round-3 form of the FAST pixel algorithm
+ * (csrc/hsv_device.hpp: hsvfilter_px2_fast). Differences from the round-2 form replayed above, each of which must leave
+ * every output byte unchanged:
+ *   - value = n/255 and its reciprocal come from a 256-entry table (LDS on the device) holding the IEEE quotients, so
+ *     chroma/value is refined from a CORRECTLY ROUNDED reciprocal; only 1/chroma still comes from v_rcp_f32 (rcp_mode);
+ *   - zero denominators: chroma + 1e-30f (== chroma for every non-zero chroma, which is >= 1/255 - ulp) instead of fmaxf;
+ *   - "x < 0 ? x + 360 : x" and "t >= 360 ? t - 360 : t" are ONE unsigned-integer minimum of the two candidates' bit
+ *     patterns (a negative float is a huge unsigned number);
+ *   - hp % 2 - 1 == hp - odd with odd = 2*floor(hp/2) + 1 read from the sextant table next to the byte selector
+ *     (both are one rounding of the same real number);
+ *   - 360 < |hue_shift| <= 2^22 ("wide" classes 3 / 4) no longer needs the literal fmodf kernel: fmod(|t|, 360) is
+ *     computed exactly with one fma around floor(|t| * (1/360)) and two exact wraps. */
+static uint32_t fbits(float x) { uint32_t b; memcpy(&b, &x, 4); return b; }
+static float minu(float a, float b) { return fbits(a) < fbits(b) ? a : b; }
+static float exact_fmod360_abs(float a) { /* fmodf(a, 360) for 0 <= a < 2^23 */
+  const float f0 = floorf(a * 0x1.6c16c2p-9f); /* RN(1/360); f0 is within one of floor(a/360) */
+  float r = fmaf(-f0, 360.0f, a);              /* exact: a multiple of ulp(a) below 720 in magnitude */
+  r = minu(r, r + 360.0f);                     /* r in [-360,0) -> +360 (exact) */
+  r = minu(r, r - 360.0f);                     /* r in [360,720) -> -360 (exact) */
+  return r;
+}
+
+void replay_hsvfilter_fast2(uint32_t *px, size_t n, const float st[5], int rcp_mode) {
+  const float hs = st[0], sm = st[1], so = st[2], vm = st[3], vo = st[4];
+  const float ahs = fabsf(hs);
+  const int shift_class = hs == 0.0f ? 0 : (ahs <= 360.0f ? (hs > 0.0f ? 1 : 2) : (hs > 0.0f ? 3 : 4));
+  const int sv_ident = sm == 1.0f && so == 0.0f && vm == 1.0f && vo == 0.0f;
+  float tab_v[256], tab_y[256];
+  for (int i = 0; i < 256; i++) { tab_v[i] = (float)i / 255.0f; tab_y[i] = i ? 1.0f / tab_v[i] : 0.0f; }
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t p = px[i];
+    const uint32_t r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
+    uint32_t M8, a8, b8, addi;
+    if (r >= g && r >= b) { M8 = r; a8 = g; b8 = b; addi = 0; }
+    else if (g >= b) { M8 = g; a8 = b; b8 = r; addi = 2; }
+    else { M8 = b; a8 = r; b8 = g; addi = 4; }
+    const float value = tab_v[M8], yv = tab_y[M8];
+    const float af = replay_div255((float)a8), bf = replay_div255((float)b8);
+    const float minv = fminf(af, bf);
+    const float chroma = value - minv;
+    const float num = af - bf;
+    const float dq = chroma + 1e-30f;
+    const float yq = rcp_model(dq, rcp_mode);
+    float q = num * yq, sat = chroma * yv;
+    q = fmaf(fmaf(-q, dq, num), yq, q);
+    sat = fmaf(fmaf(-sat, value, chroma), yv, sat);
+    float h = 60.0f * ((float)addi + q);
+    h = minu(h, h + 360.0f);
+    float t = h;
+    if (shift_class == 1) { t = h + hs; t = minu(t, t - 360.0f); }
+    else if (shift_class == 2) { t = h + hs; t = minu(t, t + 360.0f); }
+    else if (shift_class == 3) { t = exact_fmod360_abs(h + hs); }
+    else if (shift_class == 4) { t = 360.0f - exact_fmod360_abs(-(h + hs)); }
+    float s = sat, v = value;
+    if (!sv_ident) {
+      s = fminf(fmaxf(sm * sat + so, 0.0f), 1.0f);
+      v = fminf(fmaxf(vm * value + vo, 0.0f), 1.0f);
+    }
+    const float c = v * s;
+    const float hp = replay_div60(t);
+    const int k = (int)hp; /* floor, 0..6 */
+    const float odd = (float)(2 * (k >> 1) + 1);
+    const float w = hp - odd;
+    const float x = c * (1.0f - fabsf(w));
+    const float m = v - c;
+    const uint32_t cand[3] = {(uint32_t)((c + m) * 255.0f), (uint32_t)((x + m) * 255.0f), (uint32_t)(m * 255.0f)};
+    const uint32_t ro = cand[kFloorCodes[k][0]], go = cand[kFloorCodes[k][1]], bo = cand[kFloorCodes[k][2]];
+    px[i] = (p & 0xff000000u) | ro | (go << 8) | (bo << 16);
+  }
+}
+
 /* colorlut FAST output conversion: v_cvt_rpi_i32_f32(clamp01(o)*255) = floor(y + 0.5) computed exactly */
 uint32_t replay_float_to_u8_fast(float o) {
   float c = fminf(fmaxf(o, 0.0f), 1.0f);

@@ -22,6 +22,7 @@ def replay():
         getattr(L, name).restype = C.c_float
         getattr(L, name).argtypes = [C.c_float]
     L.replay_hsvfilter_fast.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
+    L.replay_hsvfilter_fast2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.c_int]
     L.replay_float_to_u8_fast.restype = C.c_uint32
     L.replay_float_to_u8_fast.argtypes = [C.c_float]
     L.replay_float_to_u8_ref.restype = C.c_uint32
@@ -62,6 +63,26 @@ def test_fast_hsvfilter_algorithm_matches_oracle_on_all_colours(replay, oracle, 
     got = ac.copy().reshape(-1).view(np.uint32)
     s = (C.c_float * 5)(*[float(v) for v in st])
     replay.replay_hsvfilter_fast(got.ctypes.data, got.size, s, 0)
+    assert (got.view(np.uint8) == exp).all()
+
+
+R3_SETTINGS = {"neg": (-200.25, 0.8, 0.1, 1.1, -0.05), "wide+": (725.5, 1.0, 0.0, 1.0, 0.0), "wide-": (-400.5, 1.1, 0.0, 0.9, 0.01),
+               "just over 360": (360.00003, 1.0, 0.0, 1.0, 0.0), "just under -360": (-360.00003, 1.0, 0.0, 1.0, 0.0),
+               "2^22": (4194304.0, 1.0, 0.0, 1.0, 0.0), "-2 x 360": (-720.0, 1.0, 0.0, 1.0, 0.0)}
+
+
+@pytest.mark.parametrize("setting", ["defaults", "hue90", "mixed"] + sorted(R3_SETTINGS))
+def test_round3_fast_hsvfilter_algorithm_matches_oracle_on_all_colours(replay, oracle, synth, setting):
+    """The round-3 form of the FAST pixel algorithm (csrc/hsv_device.hpp: value and its correctly rounded reciprocal from
+    a table, chroma + 1e-30 for the zero denominator, sign wraps as one unsigned minimum, hp - odd for hp % 2 - 1, exact
+    one-fma fmod for 360 < |hue-shift| <= 2^22) == the oracle on all 2^24 colours."""
+    st = synth.HSV_SETTINGS.get(setting) or R3_SETTINGS[setting]
+    ac = synth.allcolors()
+    exp = ac.copy().reshape(-1)
+    oracle.hsvfilter(exp, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    got = ac.copy().reshape(-1).view(np.uint32)
+    s = (C.c_float * 5)(*[float(v) for v in st])
+    replay.replay_hsvfilter_fast2(got.ctypes.data, got.size, s, 0)
     assert (got.view(np.uint8) == exp).all()
 
 

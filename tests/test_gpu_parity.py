@@ -66,6 +66,53 @@ def test_hsvfilter_allcolors_generic_settings(ctx, oracle, synth, st):
     assert (got == exp).all(), _mismatch_report(got, exp)
 
 
+WIDE_SHIFTS = [(720.0, 1.0, 0.0, 1.0, 0.0), (-400.5, 1.1, 0.0, 0.9, 0.01), (360.00003, 1.0, 0.0, 1.0, 0.0),
+               (-360.00003, 1.0, 0.0, 1.0, 0.0), (4194304.0, 1.0, 0.0, 1.0, 0.0), (-123456.7, 0.7, 0.2, 1.0, 0.0),
+               (-720.0, 1.0, 0.0, 1.0, 0.0), (1080.0, 1.0, 0.0, 1.0, 0.0), (4194304.5, 1.0, 0.0, 1.0, 0.0),
+               (-4194304.0, 1.0, 0.0, 1.0, 0.0)]
+
+
+@pytest.mark.parametrize("st", WIDE_SHIFTS)
+def test_hsvfilter_allcolors_wide_hue_shift(ctx, oracle, synth, st):
+    """360 < |hue_shift| <= 2^22 runs the FAST arithmetic with an exact one-fma fmod (round 3; these settings used to
+    take the literal kernel); the reference's `% 360` then `< 0 -> + 360` on every colour, both signs, exact multiples
+    of 360 (fmod gives -0 for a negative one) and the class boundaries (2^22 + 0.5 is GENERIC again)."""
+    ac = synth.allcolors()
+    exp = ac.copy().reshape(-1)
+    oracle.hsvfilter(exp, 4096, 4096 * 4, 4, 0, False, st, nthreads=8)
+    got = ac.copy().reshape(-1)
+    ctx.hsvfilter_frame_ip(got, 4096, 4096 * 4, "RGBA", st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("fmt,w,h,stride,n", [("RGBA", 1918, 9, 7680, 1), ("BGRx", 1921, 5, 7696, 3), ("xRGB", 637, 33, 2560, 2),
+                                              ("ABGR", 4, 4, 64, 2), ("ARGB", 3, 2, 16, 1), ("RGBx", 3840, 17, 15424, 2)])
+@pytest.mark.parametrize("setting", ["hue90", "generic"])
+def test_hsvfilter_padded_rows_16_byte_aligned(ctx, oracle, synth, fmt, w, h, stride, n, setting):
+    """4-byte formats whose stride / frame pitch are padded to multiples of 16 (what aligned allocators negotiate) run
+    the strided 16-B-per-lane kernel (round 3), not the one-pixel-per-lane rows kernel: widths that end inside a
+    4-pixel group, padding and inter-frame gaps untouched."""
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    st = synth.HSV_SETTINGS["hue90"] if setting == "hue90" else (float("inf"), 1.0, 0.0, 1.0, 0.0)
+    pitch = stride * h + 48
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=pitch * n, dtype=np.uint8)
+    exp = frames.copy()
+    for f in range(n):
+        oracle.hsvfilter(exp[f * pitch: f * pitch + stride * h], w, stride, ps, first, bool(bgr), st)
+    d = ctx.alloc(frames.nbytes)
+    try:
+        ctx.h2d(d, frames)
+        ctx.hsvfilter_frames_device(d, n, pitch, w, h, stride, fmt, st)
+        ctx.synchronize()
+        got = np.empty_like(frames)
+        ctx.d2h(got, d)
+    finally:
+        ctx.free(d)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
 def test_hsvfilter_generic_kernel_equals_fast_kernel(ctx, oracle, synth):
     """A/B of the two kernels on the same input (FORCE_GENERIC flag)."""
     import mi355fx
@@ -233,14 +280,15 @@ def test_hsvfilter_auto_table_per_buffer_launches(ctx, oracle, synth):
 
 
 def test_hsvfilter_generic_settings_get_the_table_by_default(ctx, oracle, synth):
-    """Default flags: settings outside the FAST envelope (literal GENERIC arithmetic, 3x slower) are served from the
-    memoised table once they have been stable and the table kernel has measured faster; FAST settings never are."""
+    """Default flags: settings outside the FAST envelope (non-finite hue shift: literal GENERIC arithmetic) are candidates
+    for the memoised table once they have been stable, and are served by whichever kind measured faster; FAST settings -
+    since round 3 that includes 360 < |hue-shift| <= 2^22 - never are."""
     w, h, n = 1920, 1080, 8
     frames = np.stack([synth.smooth_frame(w, h, seed=60 + i) for i in range(n)]).reshape(-1)
     d = ctx.alloc(frames.nbytes)
     got = np.zeros_like(frames)
     try:
-        for st, expect_table in (((725.5, 1.1, 0.0, 0.9, 0.0), True), (synth.HSV_SETTINGS["hue90"], False)):
+        for st, candidate in (((float("inf"), 1.1, 0.0, 0.9, 0.0), True), ((725.5, 1.1, 0.0, 0.9, 0.0), False), (synth.HSV_SETTINGS["hue90"], False)):
             exp = frames.copy()
             for f in range(n):
                 oracle.hsvfilter(exp[f * w * h * 4:(f + 1) * w * h * 4], w, w * 4, 4, 0, True, st, nthreads=8)
@@ -251,8 +299,8 @@ def test_hsvfilter_generic_settings_get_the_table_by_default(ctx, oracle, synth)
                 ctx.d2h(got, d)
                 assert (got == exp).all(), "call %d" % k
             on_table, t_c, t_t = ctx.colorlut_kernel_choice(fused=2)
-            if expect_table:
-                assert t_c > 0.0 and t_t > 0.0 and on_table and t_t < t_c, (on_table, t_c, t_t)
+            if candidate:
+                assert t_c > 0.0 and t_t > 0.0 and on_table == (t_t < t_c), (on_table, t_c, t_t)
             else:
                 assert not on_table
     finally:
