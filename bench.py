@@ -83,8 +83,19 @@ class SourcePool:
     N_BASE = 4
 
     def __init__(self, torch, synth, dev, batch, content):
-        gen = synth.smooth_frame if content == "smooth" else synth.noise_frame
         self.torch, self.batch = torch, batch
+
+        def gen(w, h, seed):
+            if content == "noise":
+                return synth.noise_frame(w, h, seed=seed)
+            f = synth.smooth_frame(w, h, seed=seed)
+            if content.startswith("smooth+"):   # "smooth+4": the natural-like frame plus uniform noise of +-4 per colour channel
+                amp = int(content.split("+")[1])
+                rng = np.random.default_rng(seed + 1000)
+                px = f.reshape(h, w, 4).astype(np.int16)
+                px[..., :3] += rng.integers(-amp, amp + 1, size=(h, w, 3), dtype=np.int16)
+                f = np.clip(px, 0, 255).astype(np.uint8).reshape(h, w * 4)
+            return f
         self.bases = [torch.from_numpy(gen(W, H, seed=synth.SEED + 17 * r)).to(dev) for r in range(self.N_BASE)]  # (H, W*4) u8
 
     def fill(self, buf, index):
@@ -215,6 +226,19 @@ def _install_stub(torch, mi355fx, rank):
     mi355fx.Context = Ctx
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources, the C ABI header and this file: ties a committed PMC profile to the code it was taken from
+    (the GPU boxes get a snapshot without .git, so a commit id cannot be read there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "gst-plugins-rs_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gst-plugins-rs_amd", "csrc", "*.hpp")))
+    for f in files + [os.path.join(ROOT, "include", "mi355fx.h"), os.path.abspath(__file__)]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def run_config5(args, rank, local_rank, world):
     """BASELINE config 5: 256 concurrent 4K streams through videocompare's SSIM engine = 32 streams per GPU. Every stream is a
     pair of resident 4K RGBA frames (the natural-like frame and the same frame + noise of sigma 2, SURVEY.md 8d synthetic (8));
@@ -274,6 +298,16 @@ def run_config5(args, rank, local_rank, world):
     run(max(1, args.warmup))
     dt = sharding.timed_region(lambda: run(args.steps), dist=dist, device_sync=torch.cuda.synchronize)
     comps = sharding.aggregate_throughput(args.steps * n_streams, world, dt)
+    if getattr(args, "as_leg", False):
+        for s_, (da, db) in enumerate(frames):
+            ctxs[s_ % n_workers].free(da)
+            ctxs[s_ % n_workers].free(db)
+        for c in ctxs:
+            c.close()
+        return {"comparisons_per_s": comps, "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "steps": args.steps,
+                "seconds": dt, "real_time_need": 30 * n_streams, "frac_of_hbm_peak": comps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_comparison": 2 * FRAME_BYTES, "dssim_of_stream_0": results[0],
+                "what": "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, hash both frames + compare per stream and step"}
     if rank == 0:
         algo = 2 * FRAME_BYTES  # two 4K RGBA frames read per comparison
         out = {"metric": "videocompare SSIM comparisons/sec, 32 concurrent 4K streams per GPU (BASELINE config 5)", "value": comps, "unit": "comparisons/s",
@@ -543,7 +577,10 @@ def main():
                      "kernel": "colorlut_table_tiled_kernel (composed hsv+lut table)" if f_tab else "fused compute kernel",
                      "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
                      "algorithmic_bytes_per_launch": lb, "GBps": lb / (fused_ms * 1e-3) / 1e9,
-                     "frac_of_hbm_peak": lb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     # two different quantities: the kernel inside its event bracket, and the leg's wall-clock throughput
+                     # (launch gaps included) against the 8 B/pixel roofline of 120,563 frames/s
+                     "kernel_frac_of_hbm_peak": lb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "throughput_frac_of_hbm_peak": fused_fps * BYTES_PER_FRAME_PER_KERNEL / 1e9 / HBM_PEAK_GBS,
                      "note": "one launch per batch, 8 B/px algorithmic (SURVEY 8d fused accounting); bit-identical to the two-kernel chain"}
         extra = None
         if not args.no_extra and world == 1:
@@ -579,8 +616,31 @@ def main():
             for c in sctx:
                 c.close()
 
+        sweep = None
+        if not args.no_extra and world == 1:
+            # what the chain does on other content statistics, auto kernel choice (default flags) and the arithmetic brick /
+            # three-pass path pinned (variant 6): natural-like frame + uniform noise of +-amp per channel, and uniform noise
+            sweep = {}
+            n_c = max(8, args.steps // 5)
+            for label, content in (("amp0", "smooth"), ("amp4", "smooth+4"), ("amp8", "smooth+8"), ("uniform", "noise")):
+                row = {}
+                for tag, variant in (("auto", 0), ("interpolating", 6)):
+                    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+                    leg = measure(content, n_c, 18, True)
+                    row[tag] = {"frames_per_s": leg["frames"] / leg["dt"], "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
+                                "colorlut_frac_of_hbm_peak": lb / (leg["ms"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "colorlut_kernels_served": leg["colorlut_kernels_served"]}
+                row["distinct_colours_frame0"] = leg["source_stats"]["first"]["distinct_colours_frame0"]
+                sweep[label] = row
+            ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
+
     fps = sharding.aggregate_throughput(main_leg["frames"], world, dt)
     ms_per_step = dt / args.steps * 1e3
+    config5 = None
+    if not args.no_extra and world == 1 and not args.stub and args.streams > 1:
+        # BASELINE config 5 (32 concurrent 4K streams per GPU through the SSIM engine) as a short leg of the default line
+        leg_args = argparse.Namespace(**vars(args))
+        leg_args.as_leg, leg_args.streams, leg_args.workers, leg_args.steps, leg_args.warmup = True, 32, 8, 48, 4
+        config5 = run_config5(leg_args, rank, local_rank, 1)
 
     if rank == 0:
         # dominant kernel = the longer of the two launches
@@ -598,7 +658,8 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if (pmc.get("frames_per_launch", pmc.get("frames_per_step")) == args.batch and pmc.get("content", "smooth") == args.content
-                    and pmc.get("pristine_sources") and pmc.get("lut_variant", 0) == args.lut_variant):
+                    and pmc.get("pristine_sources") and pmc.get("lut_variant", 0) == args.lut_variant
+                    and pmc.get("source_fingerprint") == source_fingerprint()):   # taken from THIS code, or null
                 for kname, rec in pmc.get("kernels", {}).items():
                     if kname.startswith(dom.split(" ")[0].split("<")[0]):
                         traffic = rec["hbm_bytes"]
@@ -621,7 +682,7 @@ def main():
                        "source_stats": main_leg["source_stats"], "dst_ring_batches": args.ring,
                        "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "source_fingerprint": source_fingerprint(),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms,
                          "avg_launch_ms_raw_bracket": main_leg["raw_ms"][1] if lut_ms >= hsv_ms else main_leg["raw_ms"][0],
                          "launch_samples": main_leg["samples"]},
@@ -645,6 +706,10 @@ def main():
             out["other_content"] = extra
         if streams_leg:
             out["concurrent_streams"] = streams_leg
+        if sweep:
+            out["content_sweep"] = sweep
+        if config5:
+            out["config5"] = config5
         if not args.no_cpu_baseline:
             one, mt = cpu_baseline(synth, settings, cube_text, seconds_target=0.5 if args.stub else 12.0)
             out["cpu_baseline"] = one

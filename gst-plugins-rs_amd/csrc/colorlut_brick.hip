@@ -102,7 +102,10 @@ constexpr size_t kBrickTimingBytes = 0;
 constexpr int kBrickZStride = 16 * kBrickSetBytes + 128;
 // (ZN == 2: 7,040 B so that the (2, 4, 4) and (4, 2, 4) residue layouts fit as well as (4, 4, 2))
 constexpr int brick_wave_bytes(int zn) { return zn == 2 ? (brick_hashed(2) ? 32 * kBrickSetBytes : 7040) : zn * kBrickZStride; }
-constexpr int brick_axis_base(int zb) { return brick_waves(zb) * brick_wave_bytes(zb); }   // LDS: the wave regions, then the axis tables
+// LDS map: the small tables FIRST (their addresses then fit the 16-bit offset field of ds_read / ds_write: an axis-table
+// read is one SDWA shift + the read; round 2 had the wave regions first and the axis tables at 104 KB, which cost one
+// v_add_u32 per read - three per pixel), then the waves' brick caches.
+constexpr int brick_axis_base(int) { return 0; }                                          // 3 x 256 x {t, packed}
 constexpr int brick_cell_base(int zb) { return brick_axis_base(zb) + kBrickAxisBytes; }  // 3 x 256 bytes: lower cell index per axis and input byte (fill path)
 constexpr int brick_sel_base(int zb) { return brick_cell_base(zb) + 768; }          // 8 dwords: hsvfilter sextant selectors
 constexpr int kBrickQueueCap = 30;                                                       // fill queue entries per wave ({cell, destination})
@@ -111,7 +114,9 @@ constexpr int kBrickScratch = 6;                                                
 constexpr int brick_scratch_base(int zb) { return brick_queue_base(zb) + brick_waves(zb) * 256; }  // 6 x 96 B per wave
 constexpr int brick_deque_base(int zb) { return brick_scratch_base(zb) + brick_waves(zb) * kBrickScratch * 96; }  // one word per wave: tiles {taken from the front, end}
 constexpr int brick_runpos_base(int zb) { return brick_deque_base(zb) + 64; }  // per run of the block: {strip, first tile}
-constexpr int brick_lds_bytes(int zb) { return brick_runpos_base(zb) + 128; }
+constexpr int brick_cache_base(int zb) { return (brick_runpos_base(zb) + 128 + 255) & ~255; }  // the wave regions (a multiple of 256 B: the column arithmetic above)
+constexpr int brick_lds_bytes(int zb) { return brick_cache_base(zb) + brick_waves(zb) * brick_wave_bytes(zb); }
+static_assert(brick_scratch_base(2) + brick_waves(2) * kBrickScratch * 96 < 65536 && brick_scratch_base(4) + brick_waves(4) * kBrickScratch * 96 < 65536, "table offsets fit ds offsets");
 static_assert(brick_lds_bytes(2) <= 160 * 1024 && brick_lds_bytes(3) <= 160 * 1024 && brick_lds_bytes(4) <= 160 * 1024, "one block per CU");
 static_assert(brick_waves(2) <= 16 && brick_waves(3) <= 16 && brick_waves(4) <= 16, "deque words / victim search");
 
@@ -153,7 +158,19 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 // pair of the 7 lerps then sits in an aligned register pair, so the arithmetic is packed-f32 (v_pk_mul_f32 / v_pk_add_f32,
 // two IEEE results per instruction; never v_pk_fma: the reference's mul and add round separately): 24 packed + 3 scalar
 // instructions instead of 51. On gfx950 a wave64 VALU instruction occupies its SIMD for 4 cycles whether packed or not.
+#ifndef BRICK_DUMMY_VALU  // sensitivity probes (tools/exp_brick_build.sh): n extra VALU instructions / extra 16-byte LDS reads per pixel
+#define BRICK_DUMMY_VALU 0
+#endif
+#ifndef BRICK_DUMMY_LDS
+#define BRICK_DUMMY_LDS 0
+#endif
 __device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t px) {
+  if constexpr (BRICK_DUMMY_VALU > 0) {
+    uint32_t sink = px;
+#pragma unroll
+    for (int d = 0; d < BRICK_DUMMY_VALU; d++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(sink) : "v"(px));
+    asm volatile("" ::"v"(sink));
+  }
   const f2_t TX = {tx, tx}, TY = {ty, ty}, TZ = {tz, tz};
   f2_t X[6];
 #pragma unroll
@@ -167,12 +184,15 @@ __device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, fl
   const f2_t OZ = (Y1 - Y0) * TZ;
   f2_t O;
   asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(O) : "v"(Y0), "v"(OZ));
-  const float ob = Yb.x + (Yb.y - Yb.x) * tz;
+  // blue: the same clamp as an output modifier of the z-lerp's add (VOP3 clamp: [0, 1], NaN -> 0)
+  const float obz = (Yb.y - Yb.x) * tz;
+  float ob;
+  asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(ob) : "v"(Yb.x), "v"(obz));
   const f2_t O255 = O * (f2_t){255.0f, 255.0f};
   uint32_t out = px;
   brick_round_into<0>(out, O255.x);
   brick_round_into<1>(out, O255.y);
-  brick_round_into<2>(out, fminf(fmaxf(ob, 0.0f), 1.0f) * 255.0f);
+  brick_round_into<2>(out, ob * 255.0f);
   return out;
 }
 
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   const uint32_t queue = brick_queue_base(ZN) + wave * 256u;
   const uint32_t e_l = lane / 6u, k_l = lane % 6u;  // fill pass: lane -> (queue entry, 16-byte piece of its brick)
   uint32_t gen = 1;                                  // fill-round stamp (see the fifo word)
-  const uint32_t wave_base = __builtin_amdgcn_readfirstlane(wave * WB);
+  const uint32_t wave_base = __builtin_amdgcn_readfirstlane((uint32_t)brick_cache_base(ZN) + wave * WB);
   if (lane < SETS) {
     const u2_t inval = {0xffffffffu, 0xffffffffu};
     // set residues per axis: (4, 4, ZN), or (2, 4, 4) / (4, 2, 4) when the host built the ZN == 2 tables with the 2 on x / y
@@ -416,26 +436,33 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #pragma unroll
         for (int i = 0; i < NP; i++) px[i] = hsvfilter_px<false, 0, 1, 2, 3>(px[i], hk, hsv_sel);
       }
-      // stage A: coordinates, set, tag
+      // stage A: coordinates, set, tag. All twelve axis reads of the step are issued before the first one is used (one LDS
+      // round trip for the step, not one per pixel: the compiler keeps the order it is given and waits with lgkmcnt(0))
       float tx[NP], ty[NP], tz[NP];
       uint32_t set[NP], tag[NP], baddr[NP];
+      {
+        u2_t ex[NP], ey[NP], ez[NP];
 #pragma unroll
-      for (int i = 0; i < NP; i++) {
-        const u2_t ex = lds_r64(byte_times8<0>(px[i], three) + AX);
-        const u2_t ey = lds_r64(byte_times8<1>(px[i], three) + (AX + 2048u));
-        const u2_t ez = lds_r64(byte_times8<2>(px[i], three) + (AX + 4096u));
-        tx[i] = __uint_as_float(ex.x);
-        ty[i] = __uint_as_float(ey.x);
-        tz[i] = __uint_as_float(ez.x);
-        if constexpr (brick_hashed(ZN)) {
-          // hashed 32-set geometry: the low byte sums the axes' set-number contributions (<= 93), the rest is the cell number
-          const uint32_t packed = ex.y + ey.y + ez.y;                            // v_add3_u32
-          set[i] = __umul24(packed & 31u, (uint32_t)kBrickSetBytes) + wave_base;           // v_and + v_mad_u32_u24
-          tag[i] = packed;
-        } else {
-          const uint32_t packed = (ex.y + ey.y) + (ez.y + (wave_base >> 4));  // v_add_u32 + v_add3_u32
-          set[i] = word0_times16(packed, four);                       // LDS byte address of the wave's set for this cell
-          tag[i] = packed;                                            // the whole word identifies the brick (the set bits are redundant there)
+        for (int i = 0; i < NP; i++) {
+          ex[i] = lds_r64(byte_times8<0>(px[i], three) + AX);
+          ey[i] = lds_r64(byte_times8<1>(px[i], three) + (AX + 2048u));
+          ez[i] = lds_r64(byte_times8<2>(px[i], three) + (AX + 4096u));
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          tx[i] = __uint_as_float(ex[i].x);
+          ty[i] = __uint_as_float(ey[i].x);
+          tz[i] = __uint_as_float(ez[i].x);
+          if constexpr (brick_hashed(ZN)) {
+            // hashed 32-set geometry: the low byte sums the axes' set-number contributions (<= 93), the rest is the cell number
+            const uint32_t packed = ex[i].y + ey[i].y + ez[i].y;                     // v_add3_u32
+            set[i] = __umul24(packed & 31u, (uint32_t)kBrickSetBytes) + wave_base;  // v_and + v_mad_u32_u24
+            tag[i] = packed;
+          } else {
+            const uint32_t packed = (ex[i].y + ey[i].y) + (ez[i].y + (wave_base >> 4));  // v_add_u32 + v_add3_u32
+            set[i] = word0_times16(packed, four);                                        // LDS byte address of the wave's set for this cell
+            tag[i] = packed;                                                             // the whole word identifies the brick (the set bits are redundant there)
+          }
         }
       }
       // tag check: both ways' tags in one 8-byte read; baddr = the way that holds the brick
@@ -562,6 +589,10 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
             if (i + 1 < NP) {
 #pragma unroll
               for (int k = 0; k < 6; k++) f[(i + 1) & 1][k] = lds_r128(baddr[i + 1] + 16u * k);
+            }
+            if constexpr (BRICK_DUMMY_LDS > 0) {
+#pragma unroll
+              for (int d = 0; d < BRICK_DUMMY_LDS; d++) { const f4_t x = lds_r128(baddr[i] + 16u * (d % 6)); asm volatile("" ::"v"(x)); }
             }
             out[i] = brick_pixel(f[i & 1], tx[i], ty[i], tz[i], px[i]);
           }

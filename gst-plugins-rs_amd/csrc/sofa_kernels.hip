@@ -10,7 +10,7 @@
 // mi355_sofa_set_filter: reading SOFA/HDF5 files is not part of the per-buffer path.
 // sofar's sources are not in the reference tree (Cargo dependency `sofar`, features "dsp"): PARITY UNPINNED. What a
 // uniformly partitioned convolver computes is a streaming linear convolution, y = x * h per ear, with h changing at block
-// boundaries; that is the contract here, checked against a time-domain oracle (oracle/sofa_oracle.c) within 2e-6 of
+// boundaries; that is the contract here, checked against a time-domain oracle (oracle/oracle.py: SofaRenderer) within 2e-6 of
 // full scale (f32 FFT round-off), not bit for bit.
 //
 // Algorithm (uniformly partitioned overlap-save, partition P, FFT size N = 2P, K = ceil(L / P) filter partitions):

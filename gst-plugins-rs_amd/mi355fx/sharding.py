@@ -3,8 +3,9 @@
 Every element instance owns its state (settings, LUT, echo ring — e.g. video/hsv/src/hsvfilter/imp.rs:54-57,
 audio/audiofx/src/audioecho/imp.rs:57-66) and streams never exchange data, so the
 partition is stream -> GPU and the only cross-rank traffic is the timing reduction of the benchmark
-(barrier + MAX over ranks). `torch.distributed` (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU
-tests) is used for exactly that and nothing else.
+(barrier + MAX over ranks). `torch.distributed` is used for exactly that and nothing else, over a CPU ("gloo") group on
+the GPU box as well as in the CPU tests: neither the data path nor the harness opens an RCCL communicator (north_star:
+"no RCCL: there is no cross-stream collective").
 """
 import time
 

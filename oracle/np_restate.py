@@ -136,3 +136,34 @@ def colorlut1d(c8, comp, size, planes, scale, offset):
     t = (x - i0.astype(F)).astype(F)
     lut = planes[comp]
     return _float_to_u8((lut[i0] + ((lut[i1] - lut[i0]) * t).astype(F)).astype(F))
+
+
+# ---- rsaudioecho (audio/audiofx/src/audioecho/imp.rs:69-85, ring_buffer.rs:37-82), written from the reference source
+# independently of oracle/echo_oracle.c: the sample loop there is serial; here the recurrence is evaluated a whole delay
+# period at a time (sample i only depends on ring entries written >= D samples earlier), in float64 like the reference.
+class Echo:
+    def __init__(self, max_delay_ns, rate, channels):
+        # AudioFilterImpl::setup (imp.rs:246-259): size = (max_delay * rate).seconds(), times channels
+        self.rate, self.channels = rate, channels
+        self.ring = np.zeros((max_delay_ns * rate // 10 ** 9) * channels, np.float64)
+        self.pos = 0
+
+    def process(self, data, delay_ns, intensity, feedback):
+        """In place on an interleaved float32 / float64 array; delay already clamped to max-delay by the caller (imp.rs:207)."""
+        size = self.ring.size
+        delay = delay_ns * self.channels * self.rate // 10 ** 9          # imp.rs:74-77 (`.seconds()` truncates)
+        assert size >= delay and size != 0                               # ring_buffer.rs:41-42
+        # read == write index when delay is 0 or size: the sample read is the one written `size` samples ago (ring_buffer.rs:44-45)
+        period = delay if 0 < delay < size else size
+        n, done = data.size, 0
+        while done < n:
+            m = min(period, n - done)
+            w = (self.pos + np.arange(m)) % size
+            r = (w + size - delay) % size
+            e = self.ring[r]                                             # all written at least one period ago
+            inp = data[done:done + m].astype(np.float64)
+            data[done:done + m] = (inp + intensity * e).astype(data.dtype)   # imp.rs:81,83
+            self.ring[w] = inp + feedback * e                            # imp.rs:82
+            self.pos = (self.pos + m) % size
+            done += m
+        return data

@@ -34,9 +34,10 @@ def test_c_oracle_reproduces_committed_crcs():
 
 
 def test_numpy_restatement_reproduces_committed_crcs():
-    """The numpy restatement over all 2^24 colours, every case (about a minute): if it drifts, this fails, not the goldens."""
+    """The numpy restatement over all 2^24 colours, every case (about a minute), and its block-wise echo loop on config 1:
+    if it drifts, this fails, not the goldens."""
     got = {k: zlib.crc32(v) for k, v in _make_golden().np_crc_cases().items()}
-    assert got == {k: v for k, v in GOLDEN.items() if k != "echo_config1_f32"}
+    assert got == GOLDEN
 
 
 def test_exact_decimal_to_f32():

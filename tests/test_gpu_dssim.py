@@ -159,13 +159,13 @@ def test_dssim_matches_restatement_at_4k(ctx, synth):
 
 
 def test_config5_bench_leg_runs(tmp_path):
-    """bench.py --config 5 (32 concurrent 4K streams per GPU through the SSIM engine; here 4 streams, 2 workers, 2 steps):
-    one JSON line with comparisons/s, the roofline object and a plausible dssim value."""
+    """bench.py --config 5 at BASELINE's shape: 32 concurrent 4K streams per GPU through the SSIM engine, 8 worker contexts
+    (2 timed steps = 64 comparisons): one JSON line with comparisons/s, the roofline object and a plausible dssim value."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--streams", "4", "--workers", "2", "--steps", "2", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--streams", "32", "--workers", "8", "--steps", "2", "--warmup", "1",
                         "--ramp-seconds", "0.05", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["unit"] == "comparisons/s" and d["value"] > 0 and d["config"]["streams_per_gpu"] == 4
+    assert d["unit"] == "comparisons/s" and d["value"] > 0 and d["config"]["streams_per_gpu"] == 32 and d["config"]["worker_contexts_per_gpu"] == 8
     assert d["roofline"]["bound"] == "hbm" and 0 < d["dssim_of_stream_0"] < 0.1

@@ -73,6 +73,8 @@ def main():
         out["lut_variant"] = cfg.get("lut_variant", 0)
         out["content"] = cfg.get("content", "smooth")
         out["pristine_sources"] = str(cfg.get("sources", "")).startswith("pristine")
+        # which code the counters were taken from: bench.py only reports them as roofline.traffic for the same fingerprint
+        out["source_fingerprint"] = json.load(open(b0))["roofline"].get("source_fingerprint")
         out["collected"] = tag + ": tools/collect_profiles.sh"
     except (OSError, ValueError, KeyError):
         out["frames_per_step"] = None
