@@ -874,6 +874,13 @@ int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level) {
   return rc;
 }
 
+// a launch outside the watch's accounting - the three-pass kernel while the stream is at level 2, a pinned or table-build
+// brick launch (which adds to d_counters without adding to px_since): whatever the counters hold no longer belongs to one
+// level's launches, so the next watched launch starts a new count (counters reset in stream order, brick_before_launch).
+// Without this a one-launch probe of level 1 after a stretch at level 2 was judged on counters and pixels left over from
+// before the stream moved up (the selftest model always did this; the real path did not).
+void brick_mark_unwatched(BrickLut &B) { B.level_since = 2; }
+
 int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level) {
   int rc;
   B.px_since += pixels;

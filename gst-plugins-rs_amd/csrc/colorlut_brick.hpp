@@ -38,6 +38,7 @@ struct BrickLut {
 int brick_choose(BrickLut &B);
 // before / after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
 int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level);
+void brick_mark_unwatched(BrickLut &B);
 int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level);
 
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);

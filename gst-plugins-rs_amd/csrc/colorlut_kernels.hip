@@ -1214,6 +1214,7 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
     const bool pinned = lv == 7 || !three_pass_ok || ctx->brick_sets != 0;
     int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
     if (level == 2 && !three_pass_ok) level = 1;
+    if (level == 2 || build || pinned) brick_mark_unwatched(B);
     if (level < 2) {
       const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
       ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel<HSV> (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel<HSV> (48 sets)" : "colorlut3d_brick_kernel<HSV>");
@@ -1307,6 +1308,7 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       const bool pinned = v == 7 || !three_pass_ok || ctx->brick_sets != 0;
       int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
       if (level == 2 && !three_pass_ok) level = 1;
+      if (level == 2 || build || pinned) brick_mark_unwatched(B);
       if (level < 2) {
         const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
         ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel");
@@ -1426,7 +1428,11 @@ struct SharedTable {
 static std::mutex g_tables_mu;
 static std::map<std::string, std::weak_ptr<SharedTable>> g_tables;
 
-// `build(table)` enqueues the kernels that fill a fresh table on ctx->stream. On return *out is usable on ctx->stream.
+// `build(table)` enqueues the kernels that fill a table on ctx->stream. On return *out is usable on ctx->stream.
+// *ref may hold the table this context used under ANOTHER key (new hsv settings, a reloaded LUT). If nobody else has that
+// table it is rebuilt in place under the new key, in stream order - everything that read the old contents was enqueued on
+// this stream earlier - instead of being destroyed (hipEventSynchronize + hipFree + a fresh 64 MiB hipMalloc on the
+// streaming thread: device-wide waits in a path that otherwise never blocks its caller).
 template <class Build>
 static int shared_table_acquire(mi355_ctx *ctx, const std::string &key, std::shared_ptr<void> *ref, uint32_t **out, Build &&build) {
   std::lock_guard<std::mutex> g(g_tables_mu);
@@ -1439,13 +1445,22 @@ static int shared_table_acquire(mi355_ctx *ctx, const std::string &key, std::sha
     *ref = sp;
     return MI355_OK;
   }
-  auto sp = std::make_shared<SharedTable>();
-  sp->device = ctx->device;
-  int rc = check_hip(ctx, hipMalloc((void **)&sp->d, (size_t)kTableEntries * 4), "hipMalloc(memoised table)");
-  if (rc) return rc;
-  if ((rc = check_hip(ctx, hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming), "hipEventCreate(shared table)"))) return rc;
-  if ((rc = build(sp->d))) return rc;
-  if ((rc = check_hip(ctx, hipEventRecord(sp->ready, ctx->stream), "hipEventRecord(shared table)"))) return rc;
+  std::shared_ptr<SharedTable> sp;
+  if (*ref && ref->use_count() == 1) {
+    // sole user (strong references are only ever taken under this lock): keep the buffer, give it the new key
+    sp = std::static_pointer_cast<SharedTable>(*ref);
+    for (auto it = g_tables.begin(); it != g_tables.end();) it = it->second.lock() == sp ? g_tables.erase(it) : std::next(it);
+  } else {
+    ref->reset();
+    sp = std::make_shared<SharedTable>();
+    sp->device = ctx->device;
+    int rc = check_hip(ctx, hipMalloc((void **)&sp->d, (size_t)kTableEntries * 4), "hipMalloc(memoised table)");
+    if (rc) return rc;
+    if ((rc = check_hip(ctx, hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming), "hipEventCreate(shared table)"))) return rc;
+  }
+  int rc = build(sp->d);
+  if (rc) { ref->reset(); return rc; }
+  if ((rc = check_hip(ctx, hipEventRecord(sp->ready, ctx->stream), "hipEventRecord(shared table)"))) { ref->reset(); return rc; }
   g_tables[full] = sp;
   *out = sp->d;
   *ref = sp;
@@ -1469,9 +1484,9 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   key += L.digest;
   if (which) key.append((const char *)hs, sizeof(*hs));
   if (L.table_ref[which] && L.table_key[which] == key) return MI355_OK;
-  L.table_ref[which].reset();
-  L.d_table[which] = nullptr;
+  L.d_table[which] = nullptr;  // (the reference stays: shared_table_acquire reuses the buffer if nobody else holds it)
   L.table_morton[which] = -1;
+  L.table_key[which].clear();
   int rc = shared_table_acquire(ctx, key, &L.table_ref[which], &L.d_table[which], [&](uint32_t *tab) {
     uint8_t *t = (uint8_t *)tab;
     hipLaunchKernelGGL(table_domain_kernel, dim3(kTableEntries / 256), dim3(256), 0, ctx->stream, tab, morton);
@@ -1652,8 +1667,7 @@ static int hsv_table_ensure(mi355_ctx *ctx, const PixFmt &fmt, const mi355_hsv_s
   HsvTable &T = ctx->hsv_table;
   if (T.valid && T.bgr == fmt.bgr && same_hs(T.hs, hs)) return MI355_OK;
   T.valid = false;
-  T.table_ref.reset();
-  T.d_table = nullptr;
+  T.d_table = nullptr;  // (the reference stays: shared_table_acquire reuses the buffer if nobody else holds it)
   std::string key("H");
   key.push_back((char)('0' + fmt.bgr));
   key.append((const char *)&hs, sizeof(hs));

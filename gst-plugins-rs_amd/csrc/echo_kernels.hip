@@ -115,6 +115,10 @@ static int echo_run(mi355_ctx *ctx, T *d_data, size_t n, size_t stream_stride, c
   // parameters: pinned host copy -> device, in stream order (a call may change delay / intensity / feedback)
   std::memcpy(E.h_par, par_host, S * sizeof(EchoPar));
   if ((rc = check_hip(ctx, hipMemcpyAsync(E.d_par, E.h_par, S * sizeof(EchoPar), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(echo parameters)"))) return rc;
+  // the pinned parameter block may be rewritten by the next call once THIS COPY has been consumed: the event sits right
+  // behind the copy, not behind the kernels (behind them, the next call's hipEventSynchronize would wait for the whole
+  // previous buffer and serialise host and device)
+  if ((rc = check_hip(ctx, hipEventRecord(E.par_ev, ctx->stream), "hipEventRecord(echo)"))) return rc;
   bool any_nofb = false;
   size_t most = 1;  // widest parallel extent of the main kernel over the streams
   for (unsigned s = 0; s < S; s++) {
@@ -128,8 +132,6 @@ static int echo_run(mi355_ctx *ctx, T *d_data, size_t n, size_t stream_stride, c
   hipLaunchKernelGGL(echo_commit_kernel, dim3(gb, S), dim3(256), 0, ctx->stream, E.d_ring, (const double *)w, n, size, E.pos);
   rc = check_hip(ctx, hipGetLastError(), "echo kernel launch");
   if (rc) return rc;
-  // the pinned parameter block may be rewritten by the next call only after this copy has been consumed
-  if ((rc = check_hip(ctx, hipEventRecord(E.par_ev, ctx->stream), "hipEventRecord(echo)"))) return rc;
   E.pos = (E.pos + n) % size;  // RingBufferIter::drop (ring_buffer.rs:78-82)
   return MI355_OK;
 }
