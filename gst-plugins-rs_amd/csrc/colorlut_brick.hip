@@ -224,7 +224,7 @@ __device__ __forceinline__ gl_byte *uniform_ptr(const void *p) {
 }
 
 template <int P, int HSV, int ZN, int G>  // P = 16-byte loads per lane and tile (a tile is 128 px x 2P rows), G of them per step
-__global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4,
+__global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
                                                                                  unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
                                                                                  const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
                                                                                  const uint32_t *__restrict__ cellnum,
@@ -389,12 +389,12 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
   // (addresses: wave-uniform 64-bit tile base in SGPRs + a 32-bit per-lane element offset - a tile may be anywhere now that
   // tiles change hands, and a full 64-bit address computation per load and lane is a dozen VALU instructions)
   auto load_tile = [&](unsigned row0, unsigned col_c, u4_t(&t)[P]) {
-    gl_byte *base = uniform_ptr(src + (size_t)row0 * w4);
+    gl_byte *base = uniform_ptr(src + (size_t)row0 * sw4);  // sw4 / dw4: row strides in 16-byte groups (== w4 for packed rows)
     const unsigned room = rows - 1u - row0;  // rows left below the tile's first (row0 < rows always)
 #pragma unroll
     for (int j = 0; j < P; j++) {
       const unsigned ro = 2u * j + sub;
-      const uint32_t byte_off = ((ro < room ? ro : room) * w4 + col_c) * 16u;  // < 2^32: a tile spans 2P rows
+      const uint32_t byte_off = ((ro < room ? ro : room) * sw4 + col_c) * 16u;  // < 2^32: a tile spans 2P rows
       t[j] = __builtin_nontemporal_load((const gl_u4 *)(base + byte_off));
     }
   };
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
     const unsigned ncol = nstrip * 32 + g;
     const bool ncol_ok = ncol < w4;
     load_tile(nrow0, ncol_ok ? ncol : w4 - 1, nxt);
-    gl_byte *dst_tile = uniform_ptr(dst + (size_t)row0 * w4);
+    gl_byte *dst_tile = uniform_ptr(dst + (size_t)row0 * dw4);
 #ifdef BRICK_TIMING
     tiles_done++;
 #endif
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
         const unsigned ro = 2u * (j + g2) + sub;
         if (col_ok && row0 + ro < rows) {
           const u4_t o = {out[4 * g2 + 0], out[4 * g2 + 1], out[4 * g2 + 2], out[4 * g2 + 3]};
-          const uint32_t byte_off = (ro * w4 + col) * 16u;
+          const uint32_t byte_off = (ro * dw4 + col) * 16u;
           __builtin_nontemporal_store(o, (gl_u4 *)(dst_tile + byte_off));
         }
       }
@@ -775,15 +775,17 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
 bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch,
                       int dst_stride, int n_frames, int width, int height) {
   if (!B.ok || width < 4 || width % 4 != 0) return false;
+  // rows may be padded (strides that are multiples of 16 B - what aligned allocators negotiate); a batch must then be one
+  // tall picture: frames `stride * height` apart
   const size_t row_bytes = (size_t)width * 4;
-  const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
-                          (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
-  if (!contiguous || (uintptr_t)d_src % 16 != 0 || (uintptr_t)d_dst % 16 != 0) return false;
-  return (size_t)n_frames * (size_t)height < (1u << 30);
+  if ((size_t)src_stride < row_bytes || (size_t)dst_stride < row_bytes || src_stride % 16 != 0 || dst_stride % 16 != 0) return false;
+  if (n_frames != 1 && (src_pitch != (size_t)src_stride * (size_t)height || dst_pitch != (size_t)dst_stride * (size_t)height)) return false;
+  if ((uintptr_t)d_src % 16 != 0 || (uintptr_t)d_dst % 16 != 0) return false;
+  return (size_t)n_frames * (size_t)height < (1u << 30) && (size_t)src_stride * 4 < (1u << 28) && (size_t)dst_stride * 4 < (1u << 28);
 }
 
 template <int HSV, int ZN>
-static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk) {
+static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height, const HsvK &hk) {
   // tile = 128 px x 2P rows, prefetched one tile ahead: with 8 waves per CU a 4-row tile is consumed faster than HBM answers
   constexpr int P = ZN == 4 ? BRICK_P64 : 2;
   const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
@@ -811,7 +813,7 @@ static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_sr
   if (grid < spread) grid = spread;
   constexpr int G = ZN == 4 ? BRICK_G64 : 1;
   hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G>), dim3((unsigned)grid), dim3(64 * W), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
-                     rows, n_strips, tpr, (unsigned)n_runs | ((unsigned)(ctx->brick_prio & 3) << 30), (const f4_t *)B.d_bricks,
+                     (unsigned)src_stride / 16, (unsigned)dst_stride / 16, rows, n_strips, tpr, (unsigned)n_runs | ((unsigned)(ctx->brick_prio & 3) << 30), (const f4_t *)B.d_bricks,
                      (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768, (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis, (unsigned)B.size);
 #ifdef BRICK_TIMING
   if (const char *path = getenv("BRICK_TIMING_FILE")) {
@@ -825,24 +827,24 @@ static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_sr
 }
 
 template <int HSV>
-static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height, const HsvK &hk, int sets) {
-  if (sets == 64) return brick_launch_t<HSV, 4>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-  if (sets == 48) return brick_launch_t<HSV, 3>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
-  return brick_launch_t<HSV, 2>(ctx, B, d_src, d_dst, n_frames, width, height, hk);
+static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height, const HsvK &hk, int sets) {
+  if (sets == 64) return brick_launch_t<HSV, 4>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk);
+  if (sets == 48) return brick_launch_t<HSV, 3>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk);
+  return brick_launch_t<HSV, 2>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk);
 }
 
-int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
+int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height,
                  const mi355_hsv_settings *hs, int sets) {
-  if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, d_dst, n_frames, width, height, HsvK{}, sets);
+  if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{}, sets);
   const HsvK hk{hs->hue_shift, hs->saturation_mul, hs->saturation_off, hs->value_mul, hs->value_off};
   switch (hsv_variant_for(*hs, false)) {
-    case -1: return brick_launch_z<-1>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    case 0: return brick_launch_z<0>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    case 1: return brick_launch_z<1>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    case 2: return brick_launch_z<2>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    case 4: return brick_launch_z<4>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    case 5: return brick_launch_z<5>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
-    default: return brick_launch_z<6>(ctx, B, d_src, d_dst, n_frames, width, height, hk, sets);
+    case -1: return brick_launch_z<-1>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    case 0: return brick_launch_z<0>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    case 1: return brick_launch_z<1>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    case 2: return brick_launch_z<2>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    case 4: return brick_launch_z<4>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    case 5: return brick_launch_z<5>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
+    default: return brick_launch_z<6>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, hk, sets);
   }
 }
 

@@ -46,7 +46,7 @@ void brick_release(BrickLut &B);
 bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch,
                       int dst_stride, int n_frames, int width, int height);
 // hs == nullptr: colorlut alone; otherwise the fused hsvfilter -> colorlut chain. src == dst is allowed.
-int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, uint8_t *d_dst, int n_frames, int width, int height,
+int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height,
                  const mi355_hsv_settings *hs, int sets);  // sets: 32 or 64
 // synchronous read (and optional reset) of the miss counters
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);

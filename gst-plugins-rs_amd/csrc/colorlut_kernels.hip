@@ -910,8 +910,8 @@ __global__ __launch_bounds__(256) void colorlut_table_kernel(const uint4 *__rest
 // 30 TB/s of line traffic = the L2's bandwidth). tools/table_gather_probe.py.
 // The frames are contiguous, so the batch is one picture of `rows` = n_frames * height rows of w4 pixel groups.
 template <bool MORTON, int TW4>  // TW4 = patch width in pixel groups (64 = 256 px); a wave's patch is TW4*4 px x 128/TW4 rows
-__global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned w4, unsigned rows,
-                                                                   unsigned n_cols, const uint32_t *__restrict__ table) {
+__global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
+                                                                   unsigned rows, unsigned n_cols, const uint32_t *__restrict__ table) {
   __shared__ uint32_t s_spread[256];
   __shared__ uint32_t s_strip[4][512];
   if (MORTON) {
@@ -941,7 +941,8 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   const unsigned col = tx * TW4 + g;
   const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
   const bool ok0 = col < w4 && r0 < rows, ok1 = col < w4 && r1 < rows;
-  const size_t i0 = (size_t)r0 * w4 + col, i1 = (size_t)r1 * w4 + col;
+  // sw4 / dw4: row strides in 16-byte groups (== w4 for packed rows; larger when the rows are padded)
+  const size_t i0 = (size_t)r0 * sw4 + col, i1 = (size_t)r1 * sw4 + col, o0 = (size_t)r0 * dw4 + col, o1 = (size_t)r1 * dw4 + col;
   u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
   if (ok0) p = __builtin_nontemporal_load(s4 + i0);
   if (ok1) q = __builtin_nontemporal_load(s4 + i1);
@@ -957,8 +958,8 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
   wave_sync();
   const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
-  if (ok0) __builtin_nontemporal_store(r0v, d4 + i0);
-  if (ok1) __builtin_nontemporal_store(r1v, d4 + i1);
+  if (ok0) __builtin_nontemporal_store(r0v, d4 + o0);
+  if (ok1) __builtin_nontemporal_store(r1v, d4 + o1);
 }
 
 void lut_release(mi355_ctx *ctx) {
@@ -1220,7 +1221,7 @@ static int launch_hsv_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, siz
       ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel<HSV> (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel<HSV> (48 sets)" : "colorlut3d_brick_kernel<HSV>");
       int rc = (build || pinned) ? MI355_OK : brick_before_launch(ctx, B, level);
       if (rc) return rc;
-      rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, &hs, sets);
+      rc = brick_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, &hs, sets);
       if (rc || build || pinned) return rc;
       return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
     }
@@ -1314,7 +1315,7 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
         ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel");
         int rc = (build || pinned) ? MI355_OK : brick_before_launch(ctx, B, level);
         if (rc) return rc;
-        rc = brick_launch(ctx, B, d_src, d_dst, n_frames, width, height, nullptr, sets);
+        rc = brick_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, nullptr, sets);
         if (rc || build || pinned) return rc;
         return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
       }
@@ -1391,15 +1392,35 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
 }
 
 
-// geometry test shared by the table path and the auto-selector: contiguous RGBA8 frames, 16 B aligned
-static bool rgba8_flat(const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
-                       int width, int height, size_t *n_vec) {
+// geometry test shared by the table path and the auto-selector: RGBA8 frames on 16-byte-aligned storage, either packed
+// (rows and frames back to back: one flat array of pixel groups) or with padded rows (strides that are multiples of 16 B,
+// frames `stride * height` apart so that a batch is one tall picture: the tiled kernel takes row strides)
+struct Rgba8Geom {
+  size_t n_vec = 0;      // pixel groups (4 px) of the batch
+  unsigned sw4 = 0, dw4 = 0;  // row strides in 16-byte groups
+  bool packed = false;
+};
+static bool rgba8_geom(const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
+                       int width, int height, Rgba8Geom *g) {
   const size_t row_bytes = (size_t)width * 4;
-  const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
-                          (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+  if (((uintptr_t)d_src % 16 != 0) || ((uintptr_t)d_dst % 16 != 0)) return false;
+  const bool packed = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                      (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
   const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
-  if (!(contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0))) return false;
-  *n_vec = total_bytes / 16;
+  if (packed) {
+    if (total_bytes % 16 != 0) return false;
+    g->n_vec = total_bytes / 16;
+    g->sw4 = g->dw4 = (unsigned)(row_bytes / 16);
+    g->packed = true;
+    return true;
+  }
+  // padded rows: only what the tiled kernel takes (whole 16-byte groups per row, width >= 128)
+  if (width % 4 != 0 || width < 128 || (size_t)src_stride < row_bytes || (size_t)dst_stride < row_bytes || src_stride % 16 != 0 || dst_stride % 16 != 0) return false;
+  if (n_frames != 1 && (src_pitch != (size_t)src_stride * (size_t)height || dst_pitch != (size_t)dst_stride * (size_t)height)) return false;
+  g->n_vec = total_bytes / 16;
+  g->sw4 = (unsigned)src_stride / 16;
+  g->dw4 = (unsigned)dst_stride / 16;
+  g->packed = false;
   return true;
 }
 
@@ -1505,15 +1526,16 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   return MI355_OK;
 }
 
-static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton);
-static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton,
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton);
+static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
                         const mi355_hsv_settings *hs) {
   int rc = table_ensure(ctx, which, morton, hs);
   if (rc) return rc;
-  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, n_vec, width, rows, morton);
+  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, geo, width, rows, morton);
 }
 
-static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, size_t n_vec, int width, size_t rows, int morton) {
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton) {
+  const size_t n_vec = geo.n_vec;
   ctx->lut.last_kernel = "colorlut_table_tiled_kernel";
   if (width % 4 == 0 && width >= 128 && rows < (1u << 30)) {
     const unsigned w4 = (unsigned)width / 4;
@@ -1525,7 +1547,7 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
     if (n_tiles < (1u << 31)) {
       const size_t grid = n_tiles;
 #define MI355_LT(M, T) hipLaunchKernelGGL((colorlut_table_tiled_kernel<M, T>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint4 *)d_src, \
-                                          (uint4 *)d_dst, w4, (unsigned)rows, n_cols, t)
+                                          (uint4 *)d_dst, w4, geo.sw4, geo.dw4, (unsigned)rows, n_cols, t)
       if (morton && tw4 == 64) MI355_LT(true, 64);
       else if (morton) MI355_LT(true, 32);
       else if (tw4 == 64) MI355_LT(false, 64);
@@ -1534,6 +1556,7 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
       return check_hip(ctx, hipGetLastError(), "colorlut table kernel launch");
     }
   }
+  if (!geo.packed) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: table kernel geometry");  // rgba8_geom only admits padded rows the tiled kernel takes
   ctx->lut.last_kernel = "colorlut_table_kernel";
   size_t grid = (size_t)ctx->n_cu * 16;
   const size_t max_blocks = n_vec / 512 + 1;  // a block's four waves take one 128-group chunk each per iteration
@@ -1606,15 +1629,16 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   LutDevice &L = ctx->lut;
   if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
-  size_t n_vec = 0;
+  Rgba8Geom geo;
   const bool table_ok = format == MI355_FMT_RGBA && !ctx->force_generic &&
-                        rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
+                        rgba8_geom(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &geo);
+  const size_t n_vec = geo.n_vec;
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, n_vec, width, (size_t)n_frames * height, v == 5 ? 1 : 0, nullptr);
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 5 ? 1 : 0, nullptr);
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
-                     [&]() { return launch_table(ctx, 0, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, nullptr); });
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr); });
 }
 
 // The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
@@ -1627,11 +1651,12 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   LutDevice &L = ctx->lut;
   if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
-  size_t n_vec = 0;
-  const bool table_ok = !ctx->force_generic && rgba8_flat(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &n_vec);
+  Rgba8Geom geo;
+  const bool table_ok = !ctx->force_generic && rgba8_geom(d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, &geo);
+  const size_t n_vec = geo.n_vec;
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_hsv_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, hs, false); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, v == 5 ? 1 : 0, &hs);
+  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 5 ? 1 : 0, &hs);
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
   else { L.seen_hs = hs; L.seen_stable = 0; }
@@ -1642,7 +1667,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
     L.pick[1].learn = 2;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
-                     [&]() { return launch_table(ctx, 1, d_src, d_dst, n_vec, width, (size_t)n_frames * height, 1, &hs); });
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs); });
 }
 
 // hsvfilter alone is a function of the colour too, and MI355_FLAG_HSV_TABLE = 1 / 2 runs it through the same machinery
@@ -1687,18 +1712,19 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   if (n_frames <= 0 || width <= 0 || height <= 0) return MI355_OK;
   HsvTable &T = ctx->hsv_table;
   auto compute = [&]() { return launch_hsvfilter_compute(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, hs); };
-  size_t n_vec = 0;
+  Rgba8Geom geo;
   // mode 0 (default): only settings that need the GENERIC arithmetic (3x slower than the FAST kernels) are candidates
   const bool candidate = ctx->hsv_table_mode == 1 || ctx->hsv_table_mode == 2 || (ctx->hsv_table_mode == 0 && hsv_variant_for(hs, false, true) < 0);
   const bool table_ok = candidate && !ctx->force_generic && fmt.pixel_stride == 4 && fmt.first == 0 &&
-                        rgba8_flat(d_data, frame_pitch, stride, d_data, frame_pitch, stride, n_frames, width, height, &n_vec);
+                        rgba8_geom(d_data, frame_pitch, stride, d_data, frame_pitch, stride, n_frames, width, height, &geo);
+  const size_t n_vec = geo.n_vec;
   T.last_table = false;
   if (!table_ok) return compute();
   const size_t rows = (size_t)n_frames * height;
   if (ctx->hsv_table_mode == 2) {
     int rc = hsv_table_ensure(ctx, fmt, hs);
     T.last_table = true;
-    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1);
+    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1);
   }
   if (n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, T.seen_hs) && fmt.bgr == T.seen_bgr) { if (T.seen_stable < kStableCalls) T.seen_stable++; }
@@ -1710,7 +1736,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
     T.pick.learn = 2;
   }
   return auto_launch(ctx, T.pick, n_vec, compute, [&]() { return hsv_table_ensure(ctx, fmt, hs); },
-                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, n_vec, width, rows, 1); });
+                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1); });
 }
 
 }  // namespace mi355

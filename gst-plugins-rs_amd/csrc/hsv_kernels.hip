@@ -122,6 +122,69 @@ __global__ __launch_bounds__(256) void hsvfilter_rgb24_kernel(Rgb24x4 *__restric
   }
 }
 
+// The same formats with fully coalesced memory accesses (round 3; the 12-byte-per-lane form above moves 42-57 % of the
+// HBM peak, its dwordx3 accesses leave every fourth dword slot of the memory pipeline empty): a wave takes 3 KB = 1024 pixels
+// per iteration as three 16-byte loads per lane (lane l: bytes [16 l, 16 l + 16) of each 1 KB third), passes them through
+// a wave-private 3 KB LDS strip so that lane l owns the 48 contiguous bytes of pixels 16 l .. 16 l + 15 (ds_read_b128 at a
+// 48-byte lane stride: the 16 lanes of a pass start on 16 different 4-bank groups), filters them with the pair routine
+// and sends them back the same way. The caller gives whole 3 KB chunks; the remainder goes to the kernel above.
+template <int VARIANT, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_rgb24x16_kernel(uint4 *__restrict__ data, size_t n_chunks, HsvK k) {
+  constexpr int RPOS = BGR ? 2 : 0, GPOS = 1, BPOS = BGR ? 0 : 2, NPOS = 3;
+  __shared__ HsvLds lds;
+  __shared__ uint4 strip[4][192];
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
+  __syncthreads();
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint4 *x = strip[wave];
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const size_t n_waves = (size_t)gridDim.x * 4;
+  size_t c = (size_t)blockIdx.x * 4 + wave;
+  if (c >= n_chunks) return;
+  uint4 a0 = data[c * 192 + lane], a1 = data[c * 192 + 64 + lane], a2 = data[c * 192 + 128 + lane];
+  for (; c < n_chunks; c += n_waves) {
+    uint4 *base = data + c * 192;
+    // the next chunk's loads are in flight while this one is worked on (16 pixels per lane are ~600 VALU instructions:
+    // without the prefetch a wave has nothing outstanding for four fifths of its time)
+    const size_t cn = c + n_waves < n_chunks ? c + n_waves : c;
+    const uint4 n0 = data[cn * 192 + lane], n1 = data[cn * 192 + 64 + lane], n2 = data[cn * 192 + 128 + lane];
+    x[lane] = a0;
+    x[64 + lane] = a1;
+    x[128 + lane] = a2;
+    wave_sync();
+    uint4 v[3] = {x[3 * lane], x[3 * lane + 1], x[3 * lane + 2]};  // 12 dwords = 16 pixels
+    wave_sync();
+    uint32_t *d = (uint32_t *)v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // four pixels = three dwords at a time
+      const uint32_t d0 = d[3 * q], d1 = d[3 * q + 1], d2 = d[3 * q + 2];
+      uint32_t p0 = d0, p1 = (d0 >> 24) | (d1 << 8), p2 = (d1 >> 16) | (d2 << 16), p3 = d2 >> 8;
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p0, p1, p2, p3, k, &lds);
+      d[3 * q] = (p0 & 0x00ffffffu) | (p1 << 24);
+      d[3 * q + 1] = ((p1 >> 8) & 0x0000ffffu) | (p2 << 16);
+      d[3 * q + 2] = ((p2 >> 16) & 0x000000ffu) | (p3 << 8);
+    }
+    x[3 * lane] = v[0];
+    x[3 * lane + 1] = v[1];
+    x[3 * lane + 2] = v[2];
+    wave_sync();
+    base[lane] = x[lane];
+    base[64 + lane] = x[64 + lane];
+    base[128 + lane] = x[128 + lane];
+    wave_sync();
+    a0 = n0; a1 = n1; a2 = n2;
+  }
+}
+
+template <int VARIANT>
+static void launch_rgb24x16(mi355_ctx *ctx, uint4 *d, size_t n_chunks, const HsvK &k, int bgr, int grid) {
+  if (bgr) hipLaunchKernelGGL((hsvfilter_rgb24x16_kernel<VARIANT, true>), dim3(grid), dim3(256), 0, ctx->stream, d, n_chunks, k);
+  else hipLaunchKernelGGL((hsvfilter_rgb24x16_kernel<VARIANT, false>), dim3(grid), dim3(256), 0, ctx->stream, d, n_chunks, k);
+}
+
 template <int VARIANT>
 static void launch_rgb24(mi355_ctx *ctx, Rgb24x4 *d, size_t n_grp, const HsvK &k, int bgr, int grid) {
   if (bgr) hipLaunchKernelGGL((hsvfilter_rgb24_kernel<VARIANT, true>), dim3(grid), dim3(256), 0, ctx->stream, d, n_grp, k);
@@ -218,10 +281,18 @@ int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size
     const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
     MI355_HSV_VARIANT_SWITCH(variant, launch_strided, ctx, d_data, n_frames, frame_pitch, width, height, stride, k, fmt.first, fmt.bgr, grid)
   } else if (fmt.pixel_stride == 3 && fmt.first == 0 && packed_rows && ((uintptr_t)d_data % 4 == 0) && (total_bytes % 12 == 0)) {
-    const size_t n_grp = total_bytes / 12;
-    const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
-    Rgb24x4 *d = (Rgb24x4 *)d_data;
-    MI355_HSV_VARIANT_SWITCH(variant, launch_rgb24, ctx, d, n_grp, k, fmt.bgr, grid)
+    // whole 3 KB chunks (1024 pixels) through the coalescing kernel when the base is 16-byte aligned, the rest 12 bytes per lane
+    const size_t n_chunks = ((uintptr_t)d_data % 16 == 0) ? total_bytes / 3072 : 0;
+    if (n_chunks) {
+      const int grid = grid_for(ctx, n_chunks * 64, 256, ctx->hsv_blocks_per_cu / 2);
+      MI355_HSV_VARIANT_SWITCH(variant, launch_rgb24x16, ctx, (uint4 *)d_data, n_chunks, k, fmt.bgr, grid)
+    }
+    const size_t n_grp = (total_bytes - n_chunks * 3072) / 12;
+    if (n_grp) {
+      const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
+      Rgb24x4 *d = (Rgb24x4 *)(d_data + n_chunks * 3072);
+      MI355_HSV_VARIANT_SWITCH(variant, launch_rgb24, ctx, d, n_grp, k, fmt.bgr, grid)
+    }
   } else {
     const size_t total = (size_t)width * (size_t)height * (size_t)n_frames;
     const int grid = grid_for(ctx, total, 256, 32);

@@ -163,6 +163,23 @@ def test_hsvfilter_ragged_and_padded(ctx, oracle, synth, fmt, w, h, pad):
     assert (got == exp).all(), _mismatch_report(got, exp)
 
 
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("w,h", [(1000, 7), (4096, 3), (1024, 1), (340, 3), (1028, 5)])
+@pytest.mark.parametrize("setting", ["mixed", "wide", "generic"])
+def test_hsvfilter_rgb24_chunks_and_tails(ctx, oracle, synth, fmt, w, h, setting):
+    """3-byte formats: whole 3 KB chunks (1024 pixels) go through the coalescing kernel (three 16-byte loads per lane, LDS
+    transpose), what is left through the 12-bytes-per-lane one; sizes with no whole chunk, only whole chunks, and both."""
+    from mi355fx import FMT_LAYOUT
+    ps, first, bgr = FMT_LAYOUT[fmt]
+    st = {"mixed": synth.HSV_SETTINGS["mixed"], "wide": (777.25, 1.0, 0.0, 1.0, 0.0), "generic": (float("nan"), 1.0, 0.0, 1.0, 0.0)}[setting]
+    frame = synth.noise_frame(w * 3, h, seed=w + h, channels=1).reshape(-1).copy()
+    exp = frame.copy()
+    oracle.hsvfilter(exp, w, w * 3, ps, first, bool(bgr), st)
+    got = frame.copy()
+    ctx.hsvfilter_frame_ip(got, w, w * 3, fmt, st)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
 def test_hsvfilter_empty_and_errors(ctx, synth):
     import mi355fx
     st = synth.HSV_SETTINGS["hue90"]
@@ -417,6 +434,51 @@ def test_colorlut_independent_strides_and_untouched_padding(ctx, oracle, synth):
     oracle.colorlut_rgba8(cube, src, ss, exp, ds, w, h)
     ctx.colorlut_frame(src, ss, got, ds, w, h, "RGBA")
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("variant", [0, 5, 6, 7])
+@pytest.mark.parametrize("w,h,spad,dpad,n", [(640, 37, 64, 128, 1), (1920, 16, 16, 16, 2), (132, 9, 112, 0, 3)])
+def test_colorlut_padded_rows_take_the_fast_kernels(ctx, oracle, synth, variant, w, h, spad, dpad, n):
+    """RGBA frames whose strides are padded to multiples of 16 B (independent for source and destination,
+    colorlut/imp.rs:275-286) run the brick / memoised-table kernels with a row-stride argument (round 3) instead of the rows
+    kernels; a batch is frames `stride * height` apart. Padding and the destination's padding stay untouched; fused chain too."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    ss, ds = w * 4 + spad, w * 4 + dpad
+    rng = np.random.default_rng(w + variant)
+    base = synth.smooth_frame(w, h, seed=9).reshape(h, w * 4)
+    src = rng.integers(0, 256, size=(n, h, ss), dtype=np.uint8)
+    for f in range(n):
+        src[f, :, :w * 4] = np.roll(base, 4 * f, axis=1)
+    src = src.reshape(-1)
+    st = synth.HSV_SETTINGS["hue90"]
+    for fused in (False, True):
+        exp = np.full(n * h * ds, 0xEE, np.uint8)
+        for f in range(n):
+            s_f = src[f * h * ss:(f + 1) * h * ss].copy()
+            if fused:
+                oracle.hsvfilter(s_f, w, ss, 4, 0, False, st)
+            oracle.colorlut_rgba8(cube, s_f, ss, exp[f * h * ds:(f + 1) * h * ds], ds, w, h)
+        d_src, d_dst = ctx.alloc(src.nbytes), ctx.alloc(exp.nbytes)
+        ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
+        try:
+            ctx.h2d(d_src, src)
+            got = np.full(n * h * ds, 0xEE, np.uint8)
+            for rep in range(12 if variant == 0 else 1):   # auto: let the choice settle and change kernels on the way
+                ctx.h2d(d_dst, np.full(n * h * ds, 0xEE, np.uint8))
+                if fused:
+                    ctx.hsv_colorlut_frames_device(d_src, h * ss, ss, d_dst, h * ds, ds, n, w, h, st)
+                else:
+                    ctx.colorlut_frames_device(d_src, h * ss, ss, d_dst, h * ds, ds, n, w, h, "RGBA")
+                ctx.synchronize()
+                ctx.d2h(got, d_dst)
+                assert (got == exp).all(), (fused, rep, _mismatch_report(got, exp))
+            if not fused and variant in (5, 7):
+                assert ctx.colorlut_kernel_name().startswith("colorlut_table_tiled_kernel" if variant == 5 else "colorlut3d_brick_kernel")
+        finally:
+            ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
+            ctx.free(d_src)
+            ctx.free(d_dst)
 
 
 def test_colorlut_without_lut_fails_like_reference(ctx):
