@@ -123,9 +123,22 @@ constexpr int kRw = kTw + 2 * kHalo, kRh = kTh + 2 * kHalo;  // 40 x 24 region
 
 struct DssimSrc {          // source of the scale's linear RGB
   const uint8_t *u8; int stride, channels; const float *lut;   // scale 0: packed sRGB(A) bytes + gamma table
-  int *translucent;                                             // set to 1 when an RGBA pixel with alpha < 255 is met
+  int pattern;                                                  // translucent pixels: 1 = over the crate's coloured pattern, 0 = over black
   const float4 *lin;                                           // other scales: premultiplied linear float4
 };
+
+// Translucent pixels (premultiplied linear r, g, b with alpha a < 1): dssim composes them on a coloured, position-dependent
+// background "to better judge dissimilarity with various backgrounds" - each channel gets the missing coverage 1 - a where
+// a bit of n = (x + 11) ^ (y + 11) is set (r: 16, g: 8, b: 32), in the coordinates of the scale being converted. Written
+// from memory of dssim-core's to_lab for RGBA (sources not in the reference tree): PARITY UNPINNED like the rest of this
+// engine. For a == 1 the term is + 0.0f: opaque frames - what videocompare's tests and config 5 feed - are unaffected.
+__device__ __forceinline__ void dssim_pattern(float &r, float &g, float &b, float a, int gx, int gy) {
+  const int n = (gx + 11) ^ (gy + 11);
+  const float t = 1.0f - a;
+  if (n & 16) r = r + t;
+  if (n & 8) g = g + t;
+  if (n & 32) b = b + t;
+}
 
 __device__ __forceinline__ void dssim_lab_px(float r, float g, float b, float &L, float &A, float &B) {
   const float dx = 0.9505f, dy = 1.0f, dz = 1.089f;
@@ -254,12 +267,13 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
         const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
         if (S.channels == 4) {
           const float a = (float)p[3] / 255.0f; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
-          if (p[3] != 255 && *(volatile int *)S.translucent == 0) atomicOr(S.translucent, 1);
+          if (S.pattern) dssim_pattern(r, g, b, a, gx, gy);
         }
         else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
       } else {
         const float4 v = S.lin[(size_t)gy * w + gx];
         r = v.x; g = v.y; b = v.z;
+        if (S.pattern) dssim_pattern(r, g, b, v.w, gx, gy);
       }
       dssim_lab_px(r, g, b, L, A, B);
     }
@@ -594,11 +608,12 @@ static int dssim_scratch(mi355_ctx *ctx, int slot, size_t bytes, void **out) {
 
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img) {
   if (!img) return;
-  (void)hipStreamSynchronize(ctx->stream);
+  // no host wait: the pool goes back to THIS context's free list and is handed out again by a later create_image on the same
+  // stream, i.e. behind every kernel that still reads it (an image is created, compared and freed through one context)
   if (img->pool) {
     DssimCache *c = dssim_cache(ctx);
     if (c->free_pools.size() < 8) c->free_pools.push_back({img->pool, img->pool_bytes});
-    else (void)hipFree(img->pool);
+    else { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(img->pool); }
   }
   delete img;
 }
@@ -638,8 +653,6 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   for (int k = 1; k < ns; k++) lin_px += (size_t)ws[k] * hs[k];
   void *scr = nullptr;
   if ((rc = dssim_scratch(ctx, 1, (lin_px + 16) * 16 + 1024, &scr))) { dssim_free_image(ctx, img); return rc; }
-  int *d_flag = (int *)((char *)scr + (lin_px + 16) * 16 + 512);  // "met a translucent pixel" (tail of the scratch)
-  if ((rc = check_hip(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream), "dssim: flag reset"))) { dssim_free_image(ctx, img); return rc; }
   float4 *lin[kDssimScales] = {nullptr};
   {
     float4 *q = (float4 *)scr;
@@ -668,7 +681,7 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     const DssimScale &s = img->s[k];
     if (k == 0) { j.S.u8 = d_frame; j.S.stride = stride; j.S.channels = channels; j.S.lut = d_lut; j.S.lin = nullptr; }
     else { j.S.u8 = nullptr; j.S.stride = 0; j.S.channels = 0; j.S.lut = nullptr; j.S.lin = lin[k]; }
-    j.S.translucent = d_flag;
+    j.S.pattern = (channels == 4 && !ctx->dssim_translucent) ? 1 : 0;
     j.w = s.w; j.h = s.h;
     for (int c = 0; c < 3; c++) { j.O.img[c] = s.img[c]; j.O.mu[c] = s.mu[c]; j.O.sq[c] = s.sq[c]; }
     return j;
@@ -690,16 +703,8 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
   }
   rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch");
   if (rc) { dssim_free_image(ctx, img); return rc; }
-  int translucent = 0;
-  if (channels == 4 && (rc = check_hip(ctx, hipMemcpyAsync(&translucent, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "dssim: flag D2H"))) { dssim_free_image(ctx, img); return rc; }
-  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) { dssim_free_image(ctx, img); return rc; }  // scratch is reused by the next call
-  if (translucent && !ctx->dssim_translucent) {
-    // The crate blends translucent pixels over a position-dependent background (dssim-core's to_lab for RGBA); that source is
-    // not in the reference tree, so the blend is not reproduced: the caller keeps its CPU path for such a frame rather than
-    // getting a different number. MI355_FLAG_DSSIM_TRANSLUCENT = 1 opts in to "premultiplied over black".
-    dssim_free_image(ctx, img);
-    return set_error(ctx, MI355_ERR_UNSUPPORTED, "dssim: frame has translucent pixels (alpha < 255); the crate's background blend is not reproduced - use the CPU path for this frame or set MI355_FLAG_DSSIM_TRANSLUCENT");
-  }
+  // No host wait here: the scratch (linear images of scales 1..) is reused by the next call on this context, which is behind
+  // these kernels in stream order; compare() ends with the only synchronisation of a comparison.
   *out = img;
   return MI355_OK;
 }

@@ -3,7 +3,10 @@
  * hsvfilter/mod.rs:20-27 (rank NONE), five gfloat properties with the full float range, mutable in PLAYING :122-160,
  * metadata :263-268, caps {RGBx,xRGB,BGRx,xBGR,RGBA,ARGB,BGRA,ABGR,RGB,BGR} :274-311, AlwaysInPlace / no passthrough
  * :315-320, transform_frame_ip :323-376 -> mi355_hsvfilter_frame_ip (the per-pixel loop :76-120 runs on the GPU).
- * Added by the shim: propose_allocation offers pinned buffers (gst_mi355_propose_pinned_pool). */
+ * Added by the shim: propose_allocation offers pinned buffers (gst_mi355_propose_pinned_pool); and when the DIRECT
+ * downstream peer is this shim's colorlut on RGBA frames (custom query "mi355-fuse-hsv"), the element leaves the pixels
+ * alone and tags the buffer with its settings snapshot (GstMi355HsvMeta): colorlut then runs the fused
+ * hsvfilter -> colorlut kernel - one upload, one launch, one download for the pair instead of two PCIe round trips. */
 #include "gstmi355common.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_hsv_filter_debug);
@@ -17,6 +20,8 @@ struct _GstHsvFilter {
   GMutex lock;                /* settings: set from application threads, snapshotted once per frame (imp.rs:85) */
   mi355_hsv_settings settings;
   mi355_ctx *ctx;             /* created in start(), destroyed in stop() */
+  gboolean fuse_checked;      /* the peer has been asked since the last (re)negotiation */
+  gboolean fuse;              /* downstream is our colorlut: defer the filter to its fused kernel */
 };
 
 G_DEFINE_TYPE(GstHsvFilter, gst_hsv_filter, GST_TYPE_VIDEO_FILTER)
@@ -78,8 +83,25 @@ static gboolean gst_hsv_filter_stop(GstBaseTransform *trans) {
 static gboolean gst_hsv_filter_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query) {
   GstHsvFilter *self = GST_HSV_FILTER(trans);
   if (!GST_BASE_TRANSFORM_CLASS(gst_hsv_filter_parent_class)->propose_allocation(trans, decide_query, query)) return FALSE;
-  if (self->ctx) (void)gst_mi355_propose_pinned_pool(trans, self->ctx, query);
+  if (self->ctx) (void)gst_mi355_propose_pinned_pool(trans, query);
   return TRUE;
+}
+
+/* (re)negotiation: ask the peer again on the next frame */
+static gboolean gst_hsv_filter_set_info(GstVideoFilter *filter, GstCaps *incaps, GstVideoInfo *in_info, GstCaps *outcaps, GstVideoInfo *out_info) {
+  GstHsvFilter *self = GST_HSV_FILTER(filter);
+  self->fuse_checked = FALSE;
+  self->fuse = FALSE;
+  return TRUE;
+}
+
+static gboolean gst_hsv_filter_peer_fuses(GstHsvFilter *self) {
+  if (g_getenv("MI355_GST_NO_FUSE")) return FALSE;
+  GstQuery *q = gst_query_new_custom(GST_QUERY_CUSTOM, gst_structure_new_empty(GST_MI355_FUSE_QUERY_NAME));
+  /* gst_pad_peer_query goes to the pad linked to our source pad, nobody further: only a direct colorlut neighbour answers */
+  const gboolean ok = gst_pad_peer_query(GST_BASE_TRANSFORM_SRC_PAD(self), q);
+  gst_query_unref(q);
+  return ok;
 }
 
 /* VideoFilterImpl::transform_frame_ip (imp.rs:323-376): the base class hands a writable frame (AlwaysInPlace). */
@@ -91,6 +113,15 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
   g_mutex_unlock(&self->lock);
   const int fmt = gst_mi355_format(GST_VIDEO_FRAME_FORMAT(frame));
   if (fmt < 0) return GST_FLOW_NOT_NEGOTIATED; /* the reference's match ends in unreachable!() (imp.rs:374) */
+  if (!self->fuse_checked) {
+    self->fuse = fmt == MI355_FMT_RGBA && gst_hsv_filter_peer_fuses(self);
+    self->fuse_checked = TRUE;
+    GST_INFO_OBJECT(self, "hsvfilter %s", self->fuse ? "deferred to the downstream colorlut (fused kernel)" : "runs its own kernel");
+  }
+  if (self->fuse) {
+    /* the settings of THIS frame travel with it; colorlut applies them in the fused launch */
+    return gst_buffer_add_mi355_hsv_meta(frame->buffer, &s) ? GST_FLOW_OK : GST_FLOW_ERROR;
+  }
   guint8 *data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
   const int stride = GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
   /* plane_data().len() of the reference = the mapped plane: stride x height rows (imp.rs:87-97 walks chunks of `stride`) */
@@ -140,6 +171,7 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass) {
   trans->propose_allocation = gst_hsv_filter_propose_allocation;
   trans->passthrough_on_same_caps = FALSE;     /* imp.rs:318 */
   trans->transform_ip_on_passthrough = FALSE;  /* imp.rs:319 */
+  vfilter->set_info = gst_hsv_filter_set_info;
   vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; /* only _ip installed == BaseTransformMode::AlwaysInPlace */
   GST_DEBUG_CATEGORY_INIT(gst_hsv_filter_debug, "hsvfilter", 0, "HSV transformation filter (MI355X)");
 }

@@ -1,11 +1,14 @@
 /* gst/gstmi355allocator.c — GstAllocator over mi355_host_alloc (page-locked host memory). Buffers of a pool built on it
  * map to pointers the library can hipMemcpyAsync from / to directly (47 GB/s each way), instead of going
- * through a pageable staging copy. */
+ * through a pageable staging copy. Also here: the GstMi355HsvMeta registration shared by the two plugins. */
 #include "gstmi355common.h"
 
 struct _GstMi355Allocator {
   GstAllocator parent;
-  mi355_ctx *ctx; /* borrowed: the element outlives its pools (it drops them in stop) */
+  /* OWN context, created with the allocator and destroyed in finalize. (Round 2 borrowed the element's: the pool offered in
+   * propose_allocation belongs to the UPSTREAM element, its buffers are freed whenever upstream lets go of them - after this
+   * element's stop() has destroyed that context on a READY <-> PAUSED cycle: use after free. ADVICE r02.) */
+  mi355_ctx *ctx;
 };
 G_DEFINE_TYPE(GstMi355Allocator, gst_mi355_allocator, GST_TYPE_ALLOCATOR)
 
@@ -17,6 +20,7 @@ typedef struct {
 static GstMemory *gst_mi355_allocator_alloc(GstAllocator *allocator, gsize size, GstAllocationParams *params) {
   GstMi355Allocator *self = GST_MI355_ALLOCATOR(allocator);
   const gsize maxsize = size + params->prefix + params->padding;
+  if (!self->ctx) return NULL;
   gpointer data = mi355_host_alloc(self->ctx, maxsize); /* page-aligned: satisfies any params->align */
   if (!data) return NULL;
   GstMi355Memory *m = g_new0(GstMi355Memory, 1);
@@ -30,6 +34,7 @@ static GstMemory *gst_mi355_allocator_alloc(GstAllocator *allocator, gsize size,
 static void gst_mi355_allocator_free(GstAllocator *allocator, GstMemory *memory) {
   GstMi355Allocator *self = GST_MI355_ALLOCATOR(allocator);
   GstMi355Memory *m = (GstMi355Memory *)memory;
+  /* every memory holds a reference on its allocator, so self (and self->ctx) are alive here */
   (void)mi355_host_free(self->ctx, m->data);
   g_free(m);
 }
@@ -37,10 +42,18 @@ static void gst_mi355_allocator_free(GstAllocator *allocator, GstMemory *memory)
 static gpointer gst_mi355_mem_map(GstMemory *mem, gsize maxsize, GstMapFlags flags) { return ((GstMi355Memory *)mem)->data; }
 static void gst_mi355_mem_unmap(GstMemory *mem) {}
 
+static void gst_mi355_allocator_finalize(GObject *object) {
+  GstMi355Allocator *self = GST_MI355_ALLOCATOR(object);
+  if (self->ctx) mi355_ctx_destroy(self->ctx);
+  self->ctx = NULL;
+  G_OBJECT_CLASS(gst_mi355_allocator_parent_class)->finalize(object);
+}
+
 static void gst_mi355_allocator_class_init(GstMi355AllocatorClass *klass) {
   GstAllocatorClass *a = GST_ALLOCATOR_CLASS(klass);
   a->alloc = gst_mi355_allocator_alloc;
   a->free = gst_mi355_allocator_free;
+  G_OBJECT_CLASS(klass)->finalize = gst_mi355_allocator_finalize;
 }
 
 static void gst_mi355_allocator_init(GstMi355Allocator *self) {
@@ -52,42 +65,104 @@ static void gst_mi355_allocator_init(GstMi355Allocator *self) {
   GST_OBJECT_FLAG_SET(self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 
-GstAllocator *gst_mi355_allocator_new(mi355_ctx *ctx) {
+GstAllocator *gst_mi355_allocator_new(void) {
   GstMi355Allocator *self = g_object_new(GST_TYPE_MI355_ALLOCATOR, NULL);
-  self->ctx = ctx;
+  int status = 0;
+  self->ctx = mi355_ctx_create(0, &status); /* device choice: HIP_VISIBLE_DEVICES, one process per GPU */
   gst_object_ref_sink(self);
+  if (!self->ctx) {
+    gst_object_unref(self);
+    return NULL;
+  }
   return GST_ALLOCATOR_CAST(self);
+}
+
+GstBufferPool *gst_mi355_pinned_pool_new(GstCaps *caps, const GstVideoInfo *info) {
+  GstAllocator *alloc = gst_mi355_allocator_new();
+  if (!alloc) return NULL;
+  GstAllocationParams params;
+  gst_allocation_params_init(&params);
+  params.align = 15; /* 16-byte rows: the flat kernels take whole uint4 groups */
+  GstBufferPool *pool = gst_video_buffer_pool_new();
+  GstStructure *config = gst_buffer_pool_get_config(pool);
+  gst_buffer_pool_config_set_params(config, caps, GST_VIDEO_INFO_SIZE(info), 2, 0);
+  gst_buffer_pool_config_set_allocator(config, alloc, &params);
+  gst_buffer_pool_config_add_option(config, GST_BUFFER_POOL_OPTION_VIDEO_META);
+  gst_object_unref(alloc); /* the config holds its own reference */
+  if (!gst_buffer_pool_set_config(pool, config)) {
+    gst_object_unref(pool);
+    return NULL;
+  }
+  return pool;
 }
 
 /* propose_allocation: offer upstream a GstVideoBufferPool whose buffers live in pinned memory (the shape of
  * video/colorlut/src/d3d12colorlut/imp.rs:385-424: parse the caps of the query, build a pool, add it and the metas). */
-gboolean gst_mi355_propose_pinned_pool(GstBaseTransform *trans, mi355_ctx *ctx, GstQuery *query) {
+gboolean gst_mi355_propose_pinned_pool(GstBaseTransform *trans, GstQuery *query) {
   GstCaps *caps = NULL;
   gboolean need_pool = FALSE;
   GstVideoInfo info;
   gst_query_parse_allocation(query, &caps, &need_pool);
   if (!caps || !gst_video_info_from_caps(&info, caps)) return FALSE;
-  GstAllocator *alloc = gst_mi355_allocator_new(ctx);
+  GstAllocator *alloc = gst_mi355_allocator_new();
+  if (!alloc) return FALSE;
   GstAllocationParams params;
   gst_allocation_params_init(&params);
-  params.align = 15; /* 16-byte rows: the flat kernels take whole uint4 groups */
+  params.align = 15;
   gst_query_add_allocation_param(query, alloc, &params);
+  gst_object_unref(alloc);
   if (need_pool) {
-    GstBufferPool *pool = gst_video_buffer_pool_new();
-    GstStructure *config = gst_buffer_pool_get_config(pool);
-    gst_buffer_pool_config_set_params(config, caps, GST_VIDEO_INFO_SIZE(&info), 2, 0);
-    gst_buffer_pool_config_set_allocator(config, alloc, &params);
-    gst_buffer_pool_config_add_option(config, GST_BUFFER_POOL_OPTION_VIDEO_META);
-    if (!gst_buffer_pool_set_config(pool, config)) {
-      gst_object_unref(pool);
-      gst_object_unref(alloc);
-      return FALSE;
-    }
+    GstBufferPool *pool = gst_mi355_pinned_pool_new(caps, &info);
+    if (!pool) return FALSE;
     gst_query_add_allocation_pool(query, pool, GST_VIDEO_INFO_SIZE(&info), 2, 0);
     gst_object_unref(pool);
   }
   gst_query_add_allocation_meta(query, GST_VIDEO_META_API_TYPE, NULL);
-  gst_object_unref(alloc);
   (void)trans;
   return TRUE;
+}
+
+/* ---- GstMi355HsvMeta. Both plugins carry this code; whichever is loaded first registers the types, the other finds them
+ * by name (a second registration under the same name fails). */
+GType gst_mi355_hsv_meta_api_get_type(void) {
+  static GType type = 0;
+  if (g_once_init_enter(&type)) {
+    static const gchar *tags[] = {NULL};
+    GType t = g_type_from_name("GstMi355HsvMetaAPI");
+    if (!t) t = gst_meta_api_type_register("GstMi355HsvMetaAPI", tags);
+    g_once_init_leave(&type, t);
+  }
+  return type;
+}
+
+static gboolean gst_mi355_hsv_meta_init(GstMeta *meta, gpointer params, GstBuffer *buffer) {
+  GstMi355HsvMeta *m = (GstMi355HsvMeta *)meta;
+  memset(&m->settings, 0, sizeof m->settings);
+  return TRUE;
+}
+
+/* the meta describes work still to be done on THESE pixels: it follows a plain copy of the buffer and nothing else */
+static gboolean gst_mi355_hsv_meta_transform(GstBuffer *dest, GstMeta *meta, GstBuffer *buffer, GQuark type, gpointer data) {
+  if (!GST_META_TRANSFORM_IS_COPY(type)) return FALSE;
+  const GstMetaTransformCopy *copy = data;
+  if (copy->region) return FALSE;
+  return gst_buffer_add_mi355_hsv_meta(dest, &((GstMi355HsvMeta *)meta)->settings) != NULL;
+}
+
+const GstMetaInfo *gst_mi355_hsv_meta_get_info(void) {
+  static const GstMetaInfo *info = NULL;
+  if (g_once_init_enter((GstMetaInfo **)&info)) {
+    const GstMetaInfo *mi = gst_meta_get_info("GstMi355HsvMeta");
+    if (!mi)
+      mi = gst_meta_register(GST_MI355_HSV_META_API_TYPE, "GstMi355HsvMeta", sizeof(GstMi355HsvMeta), gst_mi355_hsv_meta_init, NULL,
+                             gst_mi355_hsv_meta_transform);
+    g_once_init_leave((GstMetaInfo **)&info, (GstMetaInfo *)mi);
+  }
+  return info;
+}
+
+GstMi355HsvMeta *gst_buffer_add_mi355_hsv_meta(GstBuffer *b, const mi355_hsv_settings *s) {
+  GstMi355HsvMeta *m = (GstMi355HsvMeta *)gst_buffer_add_meta(b, gst_mi355_hsv_meta_get_info(), NULL);
+  if (m) m->settings = *s;
+  return m;
 }

@@ -99,7 +99,7 @@ typedef enum mi355_flag {
   MI355_FLAG_LUT_STAGGER = 5,  /* colorlut 3D LDS kernel: spread of the per-block start delay in units of 256 clock ticks (0 = off) */
   MI355_FLAG_FUSED_VARIANT = 3, /* fused hsv+colorlut tiling: 0 = hsv inline after the load (default); 1 = software-pipelined kernel */
   MI355_FLAG_BRICK_TILES_PER_RUN = 7, /* brick-cache kernel: tiles (128 pixels x 4 or 8 rows) in a run, the part of a strip one wave owns (0 = default: one run per wave of the chip) */
-  MI355_FLAG_DSSIM_TRANSLUCENT = 11, /* Dssim on RGBA frames with alpha < 255: 0 (default) = mi355_dssim_create_image* returns MI355_ERR_UNSUPPORTED (the caller keeps its CPU path for that frame), 1 = treat such pixels as premultiplied over black */
+  MI355_FLAG_DSSIM_TRANSLUCENT = 11, /* Dssim on RGBA pixels with alpha < 255: 0 (default) = composed over the crate's coloured, position-dependent pattern (mi355_dssim_create_image), 1 = over black (premultiplied values as they are) */
   MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
@@ -323,10 +323,11 @@ double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t f
  *   mi355_dssim_create_image  = Dssim::create_image_rgb / create_image_rgba on the packed frame (host pointer; the
  *                               _device variant takes a device-resident frame). The DssimImage<f32> stays on the device.
  *   mi355_dssim_compare       = Dssim::compare(original, modified).0 as f64 (0.0 for identical images).
- * format: MI355_FMT_RGB or MI355_FMT_RGBA. An RGBA frame with translucent pixels (alpha < 255) is REFUSED with
- * MI355_ERR_UNSUPPORTED - the crate blends such pixels over a position-dependent pattern whose source is not in the
- * reference tree, and a different number would be worse than none: the element keeps its crate path for that frame.
- * MI355_FLAG_DSSIM_TRANSLUCENT = 1 opts in to treating them as premultiplied over black instead. */
+ * format: MI355_FMT_RGB or MI355_FMT_RGBA. Translucent RGBA pixels (alpha < 255) are composed over dssim's coloured,
+ * position-dependent background pattern (hashed_image.rs:54-55 -> create_image_rgba; written from memory of the crate:
+ * parity unpinned like the rest of the engine; round 2 refused such frames); MI355_FLAG_DSSIM_TRANSLUCENT = 1 composes
+ * them over black instead. create / free do not wait for the device; mi355_dssim_compare does (it returns the value). An
+ * image is created, compared and freed through ONE context. */
 typedef struct mi355_dssim_image mi355_dssim_image;
 int mi355_dssim_create_image(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height,
                              int format, mi355_dssim_image **out);

@@ -7,8 +7,10 @@ call sites video/videofx/src/videocompare/hashed_image.rs:41-53,66-70,92-94), wh
 distance <= 0.0. This file restates the crate's published multi-scale SSIM-in-LAB algorithm:
 
   * 8-bit sRGB -> linear light through a 256-entry table (s <= 0.04045 ? s/12.92 : ((s+0.055)/1.055)^2.4);
-    RGBA is premultiplied by a/255 (translucent pixels are treated as composited over black here; the crate blends
-    them over a position-dependent pattern — NOT restated, opaque frames are what videocompare sees).
+    RGBA is premultiplied by a/255; translucent pixels are composed over dssim's coloured background pattern: with
+    n = (x + 11) ^ (y + 11) in the coordinates of the scale being converted, r += 1 - a where n & 16, g += 1 - a where
+    n & 8, b += 1 - a where n & 32 (from memory of dssim-core's to_lab for RGBA, unverified; `pattern=False` composes
+    over black). Opaque frames - what videocompare's tests feed - do not depend on it.
   * 5 scales (weights 0.028, 0.197, 0.322, 0.298, 0.155), each the 2x2 box average ((a+b+c+d)*0.25) of the previous
     one in linear RGB, floor(w/2) x floor(h/2), stopping early below 8 pixels.
   * per scale: linear RGB -> the crate's LAB variant (D65-normalised XYZ, polynomial+2xHalley cube root,
@@ -70,8 +72,15 @@ def cbrt_poly(x):
     return y
 
 
-def to_lab(img):
+def to_lab(img, pattern=True):
     r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    if pattern:
+        h, w = img.shape[:2]
+        n = (np.arange(w)[None, :] + 11) ^ (np.arange(h)[:, None] + 11)
+        t = F(1.0) - img[..., 3]
+        r = np.where(n & 16, r + t, r).astype(F)
+        g = np.where(n & 8, g + t, g).astype(F)
+        b = np.where(n & 32, b + t, b).astype(F)
     def mat(rx, gx, bx, d):
         return (r * (F(rx) / d) + g * (F(gx) / d)) + b * (F(bx) / d)
     fx = mat(0.4124, 0.3576, 0.1805, D65[0]); fy = mat(0.2126, 0.7152, 0.0722, D65[1]); fz = mat(0.0193, 0.1192, 0.9505, D65[2])
@@ -102,12 +111,12 @@ def blur(p):
 
 
 class DssimImage:
-    def __init__(self, frame, width, height, stride, channels):
+    def __init__(self, frame, width, height, stride, channels, pattern=True):
         lin = to_linear(frame, width, height, stride, channels)
         self.scales = []
         cur = lin
         while cur is not None and len(self.scales) < len(WEIGHTS):
-            planes = to_lab(cur)
+            planes = to_lab(cur, pattern and channels == 4)
             chans = []
             for n, p in enumerate(planes):
                 if n > 0:

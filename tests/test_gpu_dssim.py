@@ -77,20 +77,22 @@ def test_dssim_errors(ctx):
         ctx.dssim_free_image(a); ctx.dssim_free_image(b)
 
 
+@pytest.mark.parametrize("pattern", [True, False])
 @pytest.mark.parametrize("w,h,fmt", [(128, 96, "RGBA"), (322, 246, "RGBA"), (100, 50, "RGB"), (37, 19, "RGBA")])
-def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
+def test_dssim_image_planes_bit_identical(ctx, w, h, fmt, pattern):
     """Every plane of every scale (LAB image, mu, img_sq_blur) equals the numpy restatement bit for bit: pins the fused
-    per-scale kernel (tiles, halos, per-pass edge replication) incl. sizes that are not multiples of the tile."""
+    per-scale kernel (tiles, halos, per-pass edge replication) incl. sizes that are not multiples of the tile, and the
+    composition of translucent pixels - over dssim's coloured pattern (default) or over black (MI355_FLAG_DSSIM_TRANSLUCENT)."""
     from oracle import dssim_restate as D
     rng = np.random.default_rng(w * h)
     ch = 4 if fmt == "RGBA" else 3
     f = rng.integers(0, 256, (h, w * ch), dtype=np.uint8)
     if ch == 4:
-        f[:, 3::4] = np.where(rng.random((h, w)) < 0.2, rng.integers(0, 256, (h, w)), 255)   # some translucent pixels (premultiplied)
+        f[:, 3::4] = np.where(rng.random((h, w)) < 0.2, rng.integers(0, 256, (h, w)), 255)   # some translucent pixels
     import mi355fx
-    ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 1)   # opt in to "premultiplied over black" (what the restatement does as well)
+    ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 0 if pattern else 1)
     g = ctx.dssim_create_image(f, w * ch, w, h, fmt)
-    o = D.DssimImage(f, w, h, w * ch, ch)
+    o = D.DssimImage(f, w, h, w * ch, ch, pattern=pattern)
     try:
         for s, chans in enumerate(o.scales):
             for c in range(3):
@@ -104,33 +106,33 @@ def test_dssim_image_planes_bit_identical(ctx, w, h, fmt):
         ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 0)
 
 
-def test_dssim_refuses_translucent_frames_by_default(ctx):
-    """The crate blends translucent RGBA pixels over a position-dependent background; that arithmetic is not in the reference
-    tree, so by default a frame with any alpha < 255 is refused (MI355_ERR_UNSUPPORTED: the element keeps its crate path for
-    that frame) instead of getting a different number. Opaque RGBA, RGB, and the opt-in flag still work; one translucent
-    pixel anywhere - first row, last pixel, inside a tile - is enough."""
-    import mi355fx
+def test_dssim_translucent_frames_are_compared(ctx):
+    """hashed_image.rs:54-55 hands RGBA frames to create_image_rgba whatever their alpha: a frame with translucent pixels gets a
+    value (round 2 refused it), the value agrees with the restatement, a translucent pixel moves it away from the opaque
+    frame's, and an all-opaque RGBA frame equals the RGB one."""
+    from oracle import dssim_restate as D
     w, h = 200, 120
     rng = np.random.default_rng(1)
     base = rng.integers(0, 256, (h, w * 4), dtype=np.uint8)
     base[:, 3::4] = 255
-    g = ctx.dssim_create_image(base, w * 4, w, h, "RGBA")
-    ctx.dssim_free_image(g)
-    for (y, x) in [(0, 0), (h - 1, w - 1), (57, 101)]:
-        f = base.copy()
-        f[y, 4 * x + 3] = 254
-        with pytest.raises(mi355fx.Mi355Error) as e:
-            ctx.dssim_create_image(f, w * 4, w, h, "RGBA")
-        assert e.value.status == mi355fx.ERR_UNSUPPORTED and "translucent" in str(e.value)
-        ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 1)
-        try:
-            g = ctx.dssim_create_image(f, w * 4, w, h, "RGBA")
-            ctx.dssim_free_image(g)
-        finally:
-            ctx.set_flag(mi355fx.FLAG_DSSIM_TRANSLUCENT, 0)
-    rgb = rng.integers(0, 256, (h, w * 3), dtype=np.uint8)   # no alpha channel: nothing to refuse
-    g = ctx.dssim_create_image(rgb, w * 3, w, h, "RGB")
-    ctx.dssim_free_image(g)
+    mod = base.copy()
+    mod[20:70, 4 * 30 + 3:4 * 150 + 3:4] = rng.integers(0, 200, (50, 120), dtype=np.uint8)   # a translucent patch
+    a, b = ctx.dssim_create_image(base, w * 4, w, h, "RGBA"), ctx.dssim_create_image(mod, w * 4, w, h, "RGBA")
+    try:
+        got = ctx.dssim_compare(a, b)
+        same = ctx.dssim_compare(a, a)
+    finally:
+        ctx.dssim_free_image(a)
+        ctx.dssim_free_image(b)
+    exp = D.compare(D.DssimImage(base, w, h, w * 4, 4), D.DssimImage(mod, w, h, w * 4, 4))
+    assert same == 0.0 and got > 1e-3 and got == pytest.approx(exp, rel=1e-9, abs=1e-13)
+    rgb = np.ascontiguousarray(base.reshape(h, w, 4)[..., :3]).reshape(h, w * 3)
+    x, y = ctx.dssim_create_image(base, w * 4, w, h, "RGBA"), ctx.dssim_create_image(rgb, w * 3, w, h, "RGB")
+    try:
+        assert ctx.dssim_compare(x, y) == 0.0
+    finally:
+        ctx.dssim_free_image(x)
+        ctx.dssim_free_image(y)
 
 
 def test_dssim_matches_restatement_at_4k(ctx, synth):
