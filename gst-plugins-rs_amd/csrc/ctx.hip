@@ -142,6 +142,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   lut_release(ctx);
   hsv_table_release(ctx);
   loudnorm_release(ctx);
+  loudnorm_batch_release(ctx);
   dssim_release(ctx);
   ebur128_release(ctx);
   hrtf_release(ctx);
@@ -628,7 +629,23 @@ int mi355_loudnorm_teardown(mi355_ctx *ctx) {
   BIND_DEVICE(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   loudnorm_release(ctx);
+  loudnorm_batch_release(ctx);
   return MI355_OK;
+}
+
+int mi355_loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target, double loudness_range_target,
+                               double max_true_peak, double offset) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  return loudnorm_setup_batch(ctx, n_streams, channels, loudness_target, loudness_range_target, max_true_peak, offset);
+}
+size_t mi355_loudnorm_batch_frame_size(mi355_ctx *ctx) { return ctx ? loudnorm_batch_frame_size(ctx) : 0; }
+int mi355_loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stream_stride,
+                                 size_t out_capacity_frames, size_t *out_frames, int final_frame, int device_data) {
+  REQUIRE_CTX(ctx);
+  if (!out_frames) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: null argument");
+  BIND_DEVICE(ctx);
+  return loudnorm_process_batch(ctx, data, stream_stride, frames, out, out_stream_stride, out_capacity_frames, out_frames, device_data, final_frame);
 }
 
 /* ------------------------------------------------------------------ videocompare */

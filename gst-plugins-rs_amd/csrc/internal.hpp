@@ -92,6 +92,7 @@ struct mi355_ctx {
   void *hrtf = nullptr;        // mi355::HrtfState (hrtf_kernels.hip)
   void *sofa = nullptr;        // mi355::SofaState (sofa_kernels.hip)
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
+  void *loudnorm_batch = nullptr;  // mi355::LoudNormBatch (loudnorm.hip): n streams in lock step
   void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
@@ -162,6 +163,11 @@ int loudnorm_setup(mi355_ctx *ctx, unsigned channels, double loudness_target, do
 int loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, double *out, size_t out_cap_frames, size_t *out_frames);
 int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *out_frames, int *eos);
 void loudnorm_release(mi355_ctx *ctx);
+int loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak, double offset_db);
+size_t loudnorm_batch_frame_size(mi355_ctx *ctx);
+int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride, size_t out_cap_frames,
+                           size_t *out_frames, int device_data, int final_frame);
+void loudnorm_batch_release(mi355_ctx *ctx);
 int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width, int height, int channels, mi355_dssim_image **out);
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);

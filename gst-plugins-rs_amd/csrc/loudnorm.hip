@@ -647,4 +647,538 @@ int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *o
   return rc;
 }
 
+
+// ================================================================== batches of streams (round 3)
+// n_streams instances of the element in LOCK STEP: every stream gets the same number of frames per call, so frame types,
+// ring indices and launch shapes are shared and only values differ per stream. What kept round 2 from batching - the
+// limiter's state machines of different streams take different transitions - is solved by running the state machine ON THE
+// DEVICE: one 1024-lane block per stream executes true_peak_limiter (imp.rs:1374-1430) for the whole frame: every lane
+// carries an identical copy of the state and takes the transitions together (they are scalar f64 expressions, the host
+// code above transcribed once more), detect_peak is the block-wide first-match search of ln_detect_kernel, the envelopes
+// are applied by all lanes, and the output copy with its hard clamp closes the kernel. A 100 ms frame of 256 stereo streams
+// is then: one meter pass over the input, one fill launch, ONE limiter launch, one meter pass over the output, and the gain
+// bookkeeping of update_gain_inner_frame on the host (four meter queries for all streams: two syncs) - instead of 256
+// host-driven state machines with a device round trip per limiter transition.
+// Samples are bit-identical to n separate single-stream contexts (tests/test_gpu_loudnorm.py).
+
+struct LnbLimiter {  // per stream, device
+  int state, have_sustain;
+  unsigned long long env_cnt, sustain_cnt;
+  double gr0, gr1;
+};
+struct LnbGain { double gain, gain_next, offset; };  // per stream and fill launch
+
+struct LoudNormBatch {
+  size_t S = 0, channels = 0;
+  size_t current_samples_per_frame = GAIN_LOOKAHEAD;
+  double target_i = 0, target_lra = 0, target_tp = 0;
+  double weights[21];
+  size_t index = 1;  // shared: every stream advances it once per inner frame
+  std::vector<double> delta, prev_delta, offset;  // [S][30], [S], [S]
+  std::vector<char> above_threshold;              // [S]
+  size_t buf_len = 0, buf_index = 0, prev_buf_index = 0, limiter_len = 0, limiter_buf_index = 0;
+  int frame_type = FT_FIRST;
+  double *d_buf = nullptr, *d_limiter = nullptr, *d_src = nullptr, *d_dst = nullptr;  // [S][...]
+  LnbLimiter *d_lim = nullptr;
+  LnbGain *d_gain = nullptr, *h_gain = nullptr;
+  hipEvent_t gain_ev = nullptr;
+  void *r128_in = nullptr, *r128_out = nullptr;
+};
+
+__global__ __launch_bounds__(256) void lnb_scale_kernel(double *__restrict__ limiter, size_t llen, const double *__restrict__ buf, size_t blen,
+                                                        const LnbGain *__restrict__ g) {
+  const size_t s = blockIdx.y, gs = (size_t)gridDim.x * 256;
+  const double pd = g[s].gain, off = g[s].offset;  // gain = prev_delta here
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < llen; i += gs) limiter[s * llen + i] = buf[s * blen + i] * pd * off;
+}
+
+__global__ __launch_bounds__(256) void lnb_fill_kernel(double *__restrict__ limiter, size_t llen, size_t lidx, double *__restrict__ buf, size_t blen,
+                                                       size_t bidx, size_t pidx, const double *__restrict__ src, size_t src_stride, size_t ch, size_t n0, size_t n1,
+                                                       double denom, const LnbGain *__restrict__ g) {
+  const size_t s = blockIdx.y, total = (n1 - n0) * ch, gs = (size_t)gridDim.x * 256;
+  const double gain = g[s].gain, gain_next = g[s].gain_next, offset = g[s].offset;
+  double *lim = limiter + s * llen, *b = buf + s * blen;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gs) {
+    const size_t n = n0 + i / ch;
+    const double current_gain = (gain + (((double)n / denom) * (gain_next - gain))) * offset;  // ln_fill_kernel's expression
+    size_t r = bidx + i; if (r >= blen) r -= blen;
+    size_t l = lidx + i; if (l >= llen) l -= llen;
+    const double v = b[r];
+    if (src) { size_t w = pidx + i; if (w >= blen) w -= blen; b[w] = src[s * src_stride + i]; }
+    lim[l] = v * current_gain;
+  }
+}
+
+__global__ __launch_bounds__(256) void lnb_linear_kernel(double *__restrict__ dst, size_t dst_stride, const double *__restrict__ src, size_t src_stride, size_t n,
+                                                         const LnbGain *__restrict__ g) {
+  const size_t s = blockIdx.y, gs = (size_t)gridDim.x * 256;
+  const double off = g[s].offset;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) dst[s * dst_stride + i] = src[s * src_stride + i] * off;
+}
+
+// detect_peak for one stream by its block (the search of ln_detect_kernel): n in [1, samples) relative to `base`
+__device__ __forceinline__ bool lnb_detect(const double *lim, size_t llen, size_t base, size_t ch, size_t samples, double target_tp,
+                                           unsigned long long *s_min, double *s_val, size_t *pd, double *pv) {
+  if (samples < 2) return false;
+  if (threadIdx.x == 0) *s_min = ~0ull;
+  __syncthreads();
+  auto at = [&](size_t n, size_t c) -> double { return fabs(lim[(base + n * ch + c) % llen]); };
+  for (size_t n0 = 1; n0 < samples; n0 += 1024) {
+    const size_t n = n0 + threadIdx.x;
+    if (n < samples) {
+      bool hit = false;
+      for (size_t c = 0; c < ch && !hit; c++) {
+        const double th = at(n, c);
+        if (at(n - 1, c) <= th && th >= at(n + 1, c) && th > target_tp) {
+          bool ok = true;
+          for (size_t i = 2; i < 12; i++)
+            if (at(n + i, c) > th) { ok = false; break; }
+          hit = ok;
+        }
+      }
+      if (hit) atomicMin(s_min, (unsigned long long)n);
+    }
+    __syncthreads();
+    if (*s_min != ~0ull) break;
+    __syncthreads();
+  }
+  const unsigned long long m = *s_min;
+  if (m == ~0ull) { __syncthreads(); return false; }
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (size_t c = 0; c < ch; c++) { const double v = at((size_t)m, c); if (c == 0 || v > mx) mx = v; }
+    *s_val = mx;
+  }
+  __syncthreads();
+  *pd = (size_t)m;
+  *pv = *s_val;
+  __syncthreads();
+  return true;
+}
+
+__device__ __forceinline__ void lnb_envelope(double *lim, size_t llen, size_t lidx, size_t ch, size_t smp_cnt, size_t count, int mode, double g0, double g1,
+                                             size_t env_cnt0) {
+  if (count) {
+    size_t start = lidx + smp_cnt * ch;
+    if (start >= llen) start -= llen;
+    const size_t total = count * ch;
+    for (size_t e = threadIdx.x; e < total; e += 1024) {
+      const size_t i = e / ch;
+      double env = g1;  // ln_envelope_kernel's expressions
+      if (mode == ENV_ATTACK) env = g0 - ((double)(env_cnt0 + i) / ((double)LIMITER_ATTACK_WINDOW - 1.0) * (g0 - g1));
+      else if (mode == ENV_RELEASE) env = g0 - ((double)(env_cnt0 + i) / ((double)LIMITER_RELEASE_WINDOW - 1.0) * (g1 - g0));
+      lim[(start + e) % llen] *= env;
+    }
+  }
+  __syncthreads();  // later searches read what the envelope wrote
+}
+
+// true_peak_limiter (imp.rs:1374-1430) of stream blockIdx.x over `nb` frames, then the output copy with the hard clamp.
+// Every lane keeps the same copy of the limiter state; the transitions below are limiter_out / _attack / _sustain /
+// _release of the host path, line for line.
+__global__ __launch_bounds__(1024) void lnb_limiter_kernel(double *__restrict__ limiter, size_t llen, size_t lidx, size_t ch, size_t nb, double target_tp,
+                                                           int first_frame, LnbLimiter *__restrict__ state, double *__restrict__ dst, size_t dst_stride) {
+  __shared__ unsigned long long s_min;
+  __shared__ double s_val;
+  const size_t s = blockIdx.x;
+  double *lim = limiter + s * llen;
+  LnbLimiter L = state[s];
+  if (first_frame) {  // limiter_first_frame: the serial scan with the reference's quirk (`max` keeps the SIGNED sample, imp.rs:1339-1342)
+    if (threadIdx.x == 0) {
+      const size_t n = (LIMITER_LOOKAHEAD + 1) * ch;
+      double mx = 0.0;
+      for (size_t i = 0; i < n; i++)
+        if (fabs(lim[i]) > mx) mx = lim[i];
+      s_val = mx;
+    }
+    __syncthreads();
+    const double mx = s_val;
+    __syncthreads();
+    if (mx > target_tp) { L.state = LS_SUSTAIN; L.have_sustain = 1; L.sustain_cnt = LIMITER_LOOKAHEAD; L.gr1 = target_tp / mx; }
+  }
+  size_t smp_cnt = 0;
+  while (smp_cnt < nb) {
+    size_t pd = 0;
+    double pv = 0.0;
+    size_t base = lidx + (smp_cnt + LIMITER_LOOKAHEAD) * ch;
+    if (base >= llen) base -= llen;
+    const bool peak = lnb_detect(lim, llen, base, ch, nb - smp_cnt, target_tp, &s_min, &s_val, &pd, &pv);
+    if (L.state == LS_OUT) {
+      if (peak) {
+        L.state = LS_ATTACK; L.env_cnt = 0; L.have_sustain = 0; L.gr0 = 1.0; L.gr1 = target_tp / pv;
+        smp_cnt += LIMITER_LOOKAHEAD + pd - LIMITER_ATTACK_WINDOW;
+      } else {
+        smp_cnt = nb;
+      }
+    } else if (L.state == LS_ATTACK) {
+      const size_t new_peak_smp_cnt = smp_cnt + pd;
+      size_t ramp = 0;
+      if (L.env_cnt < LIMITER_ATTACK_WINDOW && smp_cnt < nb) {
+        ramp = LIMITER_ATTACK_WINDOW - (size_t)L.env_cnt;
+        if (ramp > nb - smp_cnt) ramp = nb - smp_cnt;
+        if (peak && new_peak_smp_cnt >= smp_cnt && new_peak_smp_cnt - smp_cnt < ramp) ramp = new_peak_smp_cnt - smp_cnt;
+      }
+      lnb_envelope(lim, llen, lidx, ch, smp_cnt, ramp, ENV_ATTACK, L.gr0, L.gr1, (size_t)L.env_cnt);
+      smp_cnt += ramp;
+      L.env_cnt += ramp;
+      bool done = false;
+      if (peak) {
+        if (smp_cnt < new_peak_smp_cnt) {
+          lnb_envelope(lim, llen, lidx, ch, smp_cnt, new_peak_smp_cnt - smp_cnt, ENV_CONST, 0.0, L.gr1, 0);
+          smp_cnt = new_peak_smp_cnt;
+        }
+        const double gain_reduction = target_tp / pv;
+        if (gain_reduction < L.gr1) {
+          const double current = L.gr0 - ((double)L.env_cnt / ((double)LIMITER_ATTACK_WINDOW - 1.0) * (L.gr0 - L.gr1));
+          const double old_slope = -(L.gr0 - L.gr1);
+          const double new_slope = -(current - gain_reduction);
+          if (new_slope <= old_slope) {
+            L.state = LS_ATTACK; L.gr0 = current; L.gr1 = gain_reduction; L.env_cnt = 0; L.have_sustain = 0;
+          } else {
+            double new_end = (gain_reduction - L.gr0) / old_slope;
+            new_end = fmax(new_end, 1.0);
+            const double new_start = new_end - 1.0;
+            L.gr0 = L.gr0 + new_start * old_slope;
+            L.gr1 = gain_reduction;
+            double cur_pos = (current - L.gr0) / old_slope;
+            if (cur_pos < 0.0) cur_pos = 0.0; else if (cur_pos > 1.0) cur_pos = 1.0;  // f64::clamp
+            const double pos = ((double)LIMITER_ATTACK_WINDOW - 1.0) * cur_pos;
+            L.env_cnt = (pos != pos) ? 0ull : (unsigned long long)pos;                 // `as usize`
+            L.have_sustain = 1;
+            L.sustain_cnt = L.env_cnt;
+          }
+          done = true;
+        } else if (L.env_cnt < LIMITER_ATTACK_WINDOW) {
+          L.have_sustain = 1;
+          L.sustain_cnt = L.env_cnt;
+        }
+      }
+      if (!done && L.env_cnt == LIMITER_ATTACK_WINDOW && smp_cnt < nb) L.state = LS_SUSTAIN;
+    } else if (L.state == LS_SUSTAIN) {
+      if (peak || L.have_sustain) {
+        const size_t sustain_cnt = peak ? pd : (size_t)L.sustain_cnt;
+        size_t k = sustain_cnt;
+        if (k > nb - smp_cnt) k = nb - smp_cnt;
+        lnb_envelope(lim, llen, lidx, ch, smp_cnt, k, ENV_CONST, 0.0, L.gr1, 0);
+        smp_cnt += k;
+        if (peak) {
+          const double gain_reduction = target_tp / pv;
+          if (gain_reduction < L.gr1) { L.state = LS_ATTACK; L.env_cnt = 0; L.have_sustain = 0; L.gr0 = L.gr1; L.gr1 = gain_reduction; }
+          else { L.have_sustain = 1; L.sustain_cnt = LIMITER_LOOKAHEAD; }
+        } else {
+          L.sustain_cnt -= k;
+          if (L.sustain_cnt == 0) L.have_sustain = 0;
+        }
+      } else {
+        L.state = LS_RELEASE; L.gr0 = L.gr1; L.gr1 = 1.0; L.env_cnt = 0;
+      }
+    } else {  // LS_RELEASE
+      if (peak) {
+        const double gain_reduction = target_tp / pv;
+        const double current = L.gr0 - ((double)L.env_cnt / ((double)LIMITER_RELEASE_WINDOW - 1.0) * (L.gr1 - L.gr0));
+        if (gain_reduction < current) {
+          lnb_envelope(lim, llen, lidx, ch, smp_cnt, pd, ENV_CONST, 0.0, L.gr1, 0);  // sic: multiplies by gain_reduction[1] (imp.rs:1252-1263)
+          smp_cnt += pd;
+          L.state = LS_ATTACK; L.env_cnt = 0; L.have_sustain = 0; L.gr0 = current; L.gr1 = gain_reduction;
+        } else {
+          L.gr1 = current;
+          L.state = LS_SUSTAIN;
+        }
+      } else {
+        size_t ramp = 0;
+        if (L.env_cnt < LIMITER_RELEASE_WINDOW && smp_cnt < nb) {
+          ramp = LIMITER_RELEASE_WINDOW - (size_t)L.env_cnt;
+          if (ramp > nb - smp_cnt) ramp = nb - smp_cnt;
+        }
+        lnb_envelope(lim, llen, lidx, ch, smp_cnt, ramp, ENV_RELEASE, L.gr0, L.gr1, (size_t)L.env_cnt);
+        smp_cnt += ramp;
+        L.env_cnt += ramp;
+        if (smp_cnt < nb) L.state = LS_OUT;
+      }
+    }
+  }
+  __syncthreads();
+  const size_t total = nb * ch;
+  for (size_t i = threadIdx.x; i < total; i += 1024) {  // ln_output_kernel
+    size_t l = lidx + i; if (l >= llen) l -= llen;
+    double o = lim[l];
+    if (fabs(o) > target_tp) o = target_tp * (signbit(o) ? -1.0 : 1.0);
+    dst[s * dst_stride + i] = o;
+  }
+  if (threadIdx.x == 0) state[s] = L;
+}
+
+static LoudNormBatch *lnb_of(mi355_ctx *ctx) { return (LoudNormBatch *)ctx->loudnorm_batch; }
+
+void loudnorm_batch_release(mi355_ctx *ctx) {
+  LoudNormBatch *b = lnb_of(ctx);
+  if (!b) return;
+  for (void *m : {b->r128_in, b->r128_out}) {
+    if (!m) continue;
+    MeterSwap sw(ctx, m);
+    ebur128_release(ctx);
+  }
+  for (double **p : {&b->d_buf, &b->d_limiter, &b->d_src, &b->d_dst}) if (*p) (void)hipFree(*p);
+  if (b->d_lim) (void)hipFree(b->d_lim);
+  if (b->d_gain) (void)hipFree(b->d_gain);
+  if (b->h_gain) (void)hipHostFree(b->h_gain);
+  if (b->gain_ev) (void)hipEventDestroy(b->gain_ev);
+  delete b;
+  ctx->loudnorm_batch = nullptr;
+}
+
+static int lnb_make_meter(mi355_ctx *ctx, unsigned S, unsigned channels, void **out) {
+  void *saved = ctx->ebur128;
+  ctx->ebur128 = nullptr;
+  const int rc = ebur128_setup_batch(ctx, S, channels, 192000, 4 | 2 | 8 | 16, nullptr);  // I | S | LRA | SAMPLE_PEAK (imp.rs:131-150)
+  *out = ctx->ebur128;
+  ctx->ebur128 = saved;
+  return rc;
+}
+
+int loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak,
+                         double offset_db) {
+  loudnorm_batch_release(ctx);
+  if (n_streams < 1 || n_streams > 4096) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: 1..4096 streams per batch");
+  if (channels < 1 || channels > 64) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: channels must be 1..64");
+  LoudNormBatch *b = new LoudNormBatch();
+  ctx->loudnorm_batch = b;
+  const size_t S = n_streams;
+  b->S = S; b->channels = channels;
+  int rc;
+  if ((rc = lnb_make_meter(ctx, n_streams, channels, &b->r128_in)) || (rc = lnb_make_meter(ctx, n_streams, channels, &b->r128_out))) { loudnorm_batch_release(ctx); return rc; }
+  b->buf_len = GAIN_LOOKAHEAD * channels;
+  b->limiter_len = (2 * FRAME_SIZE + LIMITER_LOOKAHEAD) * channels;
+  struct { double **p; size_t n; } bufs[] = {{&b->d_buf, S * b->buf_len}, {&b->d_limiter, S * b->limiter_len}, {&b->d_src, S * b->buf_len}, {&b->d_dst, S * b->buf_len}};
+  for (auto &x : bufs)
+    if ((rc = check_hip(ctx, hipMalloc((void **)x.p, x.n * 8), "hipMalloc(loudnorm batch)")) || (rc = check_hip(ctx, hipMemset(*x.p, 0, x.n * 8), "hipMemset(loudnorm batch)"))) {
+      loudnorm_batch_release(ctx);
+      return rc;
+    }
+  if ((rc = check_hip(ctx, hipMalloc((void **)&b->d_lim, S * sizeof(LnbLimiter)), "hipMalloc(loudnorm limiter states)")) ||
+      (rc = check_hip(ctx, hipMalloc((void **)&b->d_gain, S * sizeof(LnbGain)), "hipMalloc(loudnorm gains)")) ||
+      (rc = check_hip(ctx, hipHostMalloc((void **)&b->h_gain, S * sizeof(LnbGain), hipHostMallocDefault), "hipHostMalloc(loudnorm gains)")) ||
+      (rc = check_hip(ctx, hipEventCreateWithFlags(&b->gain_ev, hipEventDisableTiming), "hipEventCreate(loudnorm)"))) { loudnorm_batch_release(ctx); return rc; }
+  std::vector<LnbLimiter> lim(S, LnbLimiter{LS_OUT, 0, 0ull, 0ull, 0.0, 0.0});
+  if ((rc = check_hip(ctx, hipMemcpy(b->d_lim, lim.data(), S * sizeof(LnbLimiter), hipMemcpyHostToDevice), "loudnorm: limiter states"))) { loudnorm_batch_release(ctx); return rc; }
+  b->target_tp = std::pow(10.0, max_true_peak / 20.0);
+  b->target_i = loudness_target;
+  b->target_lra = loudness_range_target;
+  b->offset.assign(S, std::pow(10.0, offset_db / 20.0));
+  b->delta.assign(S * 30, 0.0);
+  b->prev_delta.assign(S, 0.0);
+  b->above_threshold.assign(S, 0);
+  {  // init_gaussian_filter (imp.rs:1893-1914)
+    double total = 0.0;
+    const double sigma = 3.5, c1 = 1.0 / (sigma * std::sqrt(2.0 * M_PI)), c2 = 2.0 * std::pow(sigma, 2.0);
+    for (int i = 0; i < 21; i++) { const double x = (double)i - (double)(21 / 2); b->weights[i] = c1 * std::exp(-(std::pow(x, 2.0) / c2)); total += b->weights[i]; }
+    const double adjust = 1.0 / total;
+    for (int i = 0; i < 21; i++) b->weights[i] *= adjust;
+  }
+  return MI355_OK;
+}
+
+static double lnb_gaussian(const LoudNormBatch *b, size_t s, size_t index) {
+  double result = 0.0;
+  index = index > 10 ? index - 10 : index + 20;
+  for (size_t k = 0; k < 21; k++) {
+    const size_t j = index + k < 30 ? index + k : index + k - 30;
+    result += b->delta[s * 30 + j] * b->weights[k];
+  }
+  return result;
+}
+
+// per-stream {gain, gain_next, offset} of the next fill launch -> device, in stream order
+static int lnb_upload_gains(mi355_ctx *ctx, LoudNormBatch *b, bool scale_first) {
+  int rc = check_hip(ctx, hipEventSynchronize(b->gain_ev), "hipEventSynchronize(loudnorm gains)");  // the previous upload has been consumed
+  if (rc) return rc;
+  for (size_t s = 0; s < b->S; s++) {
+    if (scale_first) b->h_gain[s] = LnbGain{b->prev_delta[s], 0.0, b->offset[s]};
+    else b->h_gain[s] = LnbGain{lnb_gaussian(b, s, b->index + 10 < 30 ? b->index + 10 : b->index + 10 - 30),
+                                lnb_gaussian(b, s, b->index + 11 < 30 ? b->index + 11 : b->index + 11 - 30), b->offset[s]};
+  }
+  if ((rc = check_hip(ctx, hipMemcpyAsync(b->d_gain, b->h_gain, b->S * sizeof(LnbGain), hipMemcpyHostToDevice, ctx->stream), "loudnorm: gains H2D"))) return rc;
+  return check_hip(ctx, hipEventRecord(b->gain_ev, ctx->stream), "hipEventRecord(loudnorm gains)");
+}
+
+static int lnb_meter_add(mi355_ctx *ctx, void *m, const double *d_data, size_t frames) {
+  MeterSwap sw(ctx, m);
+  return ebur128_add_frames_batch(ctx, d_data, frames, 3, 1);
+}
+static int lnb_meter_query(mi355_ctx *ctx, void *m, int what, std::vector<double> &out) {
+  MeterSwap sw(ctx, m);
+  return ebur128_query_batch(ctx, what, out.data());
+}
+
+static int lnb_fill(mi355_ctx *ctx, LoudNormBatch *b, const double *d_src, size_t n0, size_t n1, double denom) {
+  if (n0 >= n1) return MI355_OK;
+  int rc = lnb_upload_gains(ctx, b, false);
+  if (rc) return rc;
+  const size_t ch = b->channels, frames = n1 - n0;
+  hipLaunchKernelGGL(lnb_fill_kernel, dim3(ln_blocks(frames * ch, ctx->n_cu / 4 + 1), (unsigned)b->S), dim3(256), 0, ctx->stream, b->d_limiter, b->limiter_len,
+                     b->limiter_buf_index, b->d_buf, b->buf_len, b->buf_index, b->prev_buf_index, d_src, frames * ch, ch, n0, n1, denom, (const LnbGain *)b->d_gain);
+  advance(&b->limiter_buf_index, frames * ch, b->limiter_len);
+  if (d_src) advance(&b->prev_buf_index, frames * ch, b->buf_len);
+  advance(&b->buf_index, frames * ch, b->buf_len);
+  return MI355_OK;
+}
+
+static int lnb_limit(mi355_ctx *ctx, LoudNormBatch *b, double *d_dst, size_t dst_stride, size_t nb) {
+  hipLaunchKernelGGL(lnb_limiter_kernel, dim3((unsigned)b->S), dim3(1024), 0, ctx->stream, b->d_limiter, b->limiter_len, b->limiter_buf_index, b->channels, nb,
+                     b->target_tp, b->frame_type == FT_FIRST ? 1 : 0, b->d_lim, d_dst, dst_stride);
+  return check_hip(ctx, hipGetLastError(), "loudnorm batch kernel launch");
+}
+
+// process_update_gain_inner_frame (imp.rs:526-608) for every stream
+static int lnb_update_gain(mi355_ctx *ctx, LoudNormBatch *b) {
+  const size_t S = b->S;
+  std::vector<double> global(S), shortterm(S), rel(S), shortterm_out(S);
+  int rc;
+  if ((rc = lnb_meter_query(ctx, b->r128_in, 2, global)) || (rc = lnb_meter_query(ctx, b->r128_in, 1, shortterm)) || (rc = lnb_meter_query(ctx, b->r128_in, 3, rel))) return rc;
+  bool need_out = false;
+  for (size_t s = 0; s < S; s++) need_out |= !b->above_threshold[s];
+  if (need_out && (rc = lnb_meter_query(ctx, b->r128_out, 1, shortterm_out))) return rc;
+  for (size_t s = 0; s < S; s++) {
+    if (!b->above_threshold[s]) {
+      if (shortterm[s] > -70.0) b->prev_delta[s] *= 1.0058;
+      if (shortterm_out[s] >= b->target_i) b->above_threshold[s] = 1;
+    }
+    double &d = b->delta[s * 30 + b->index];
+    if (shortterm[s] < rel[s] || shortterm[s] <= -70.0 || !b->above_threshold[s]) {
+      d = b->prev_delta[s];
+    } else {
+      double env_global;
+      if (std::fabs(shortterm[s] - global[s]) < (b->target_lra / 2.0)) env_global = shortterm[s] - global[s];
+      else if ((b->target_lra / 2.0) * (shortterm[s] - global[s]) < 0.0) env_global = -1.0;
+      else env_global = 1.0;
+      const double env_shortterm = b->target_i - shortterm[s];
+      d = std::pow(10.0, (env_global + env_shortterm) / 20.0);
+    }
+    b->prev_delta[s] = d;
+  }
+  b->index += 1;
+  if (b->index >= 30) b->index -= 30;
+  return MI355_OK;
+}
+
+size_t loudnorm_batch_frame_size(mi355_ctx *ctx) {
+  LoudNormBatch *b = lnb_of(ctx);
+  return b ? b->current_samples_per_frame : 0;
+}
+
+// State::process (imp.rs:800-828) for the batch. `data`: stream s at data + s * stream_stride, `frames` frames each; full frames
+// (frames == current_samples_per_frame) or, with `final_frame`, the shorter tail at drain. Output likewise.
+int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride, size_t out_cap_frames,
+                           size_t *out_frames, int device_data, int final_frame) {
+  LoudNormBatch *b = lnb_of(ctx);
+  if (!b) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "audioloudnorm: not negotiated (setup_batch not called)");
+  *out_frames = 0;
+  const size_t ch = b->channels, S = b->S;
+  if (!final_frame && frames != b->current_samples_per_frame) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: a batch takes whole frames (mi355_loudnorm_batch_frame_size)");
+  if (final_frame && frames >= b->current_samples_per_frame && !(frames == 0)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: the final frame is shorter than a full one");
+  if (frames && (!data || stream_stride < frames * ch)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: bad input / stream stride");
+  if (final_frame) {
+    if (b->current_samples_per_frame == FRAME_SIZE) b->frame_type = FT_FINAL;
+    else if (frames == 0) return MI355_OK;  // nothing at all: the element answers FlowError::Eos (imp.rs:289-293)
+  }
+  int rc;
+  // the frame on the device, packed [S][frames * ch]
+  const double *d_in = b->d_src;
+  if (frames) {
+    if (device_data && stream_stride == frames * ch) d_in = data;
+    else if ((rc = check_hip(ctx, hipMemcpy2DAsync(b->d_src, frames * ch * 8, data, stream_stride * 8, frames * ch * 8, S, device_data ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                                   ctx->stream), "loudnorm: input copy"))) return rc;
+    if ((rc = lnb_meter_add(ctx, b->r128_in, d_in, frames))) return rc;
+  }
+  if (b->frame_type == FT_FIRST && frames < b->current_samples_per_frame) {  // process_first_frame_is_last (imp.rs:334-366)
+    std::vector<double> global(S), peaks(S * ch);
+    if ((rc = lnb_meter_query(ctx, b->r128_in, 2, global))) return rc;
+    { MeterSwap sw(ctx, b->r128_in); if ((rc = ebur128_peak_batch(ctx, 0, peaks.data()))) return rc; }
+    for (size_t s = 0; s < S; s++) {
+      double true_peak = 0.0;
+      for (size_t c = 0; c < ch; c++) if (c == 0 || peaks[s * ch + c] > true_peak) true_peak = peaks[s * ch + c];
+      const double offset = std::pow(10.0, (b->target_i - global[s]) / 20.0);
+      const double offset_tp = true_peak * offset;
+      b->offset[s] = offset_tp < b->target_tp ? offset : b->target_tp / true_peak;
+    }
+    b->frame_type = FT_LINEAR;
+  }
+  const size_t need = b->frame_type == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames)
+                      : (b->frame_type == FT_LINEAR ? frames : (b->frame_type == FT_FIRST ? FRAME_SIZE : b->current_samples_per_frame));
+  if (need > out_cap_frames || (need && (!out || out_stride < need * ch))) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
+  // a sub-frame of `n` frames from d_dst (packed [S][n * ch]) to the caller's buffer at frame offset `at`
+  auto deliver = [&](size_t at, size_t n) -> int {
+    return check_hip(ctx, hipMemcpy2DAsync(out + at * ch, out_stride * 8, b->d_dst, n * ch * 8, n * ch * 8, S, device_data ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream),
+                     "loudnorm: output copy");
+  };
+  switch (b->frame_type) {
+    case FT_FIRST: {
+      if ((rc = check_hip(ctx, hipMemcpyAsync(b->d_buf, d_in, S * b->buf_len * 8, hipMemcpyDeviceToDevice, ctx->stream), "loudnorm: buf fill"))) return rc;
+      std::vector<double> shortterm(S);
+      if ((rc = lnb_meter_query(ctx, b->r128_in, 1, shortterm))) return rc;
+      for (size_t s = 0; s < S; s++) {
+        double env_shortterm;
+        if (shortterm[s] < -70.0) { b->above_threshold[s] = 0; env_shortterm = 0.0; }
+        else { b->above_threshold[s] = 1; env_shortterm = b->target_i - shortterm[s]; }
+        for (int i = 0; i < 30; i++) b->delta[s * 30 + i] = std::pow(10.0, env_shortterm / 20.0);
+        b->prev_delta[s] = b->delta[s * 30 + b->index];
+      }
+      if ((rc = lnb_upload_gains(ctx, b, true))) return rc;
+      hipLaunchKernelGGL(lnb_scale_kernel, dim3(ln_blocks(b->limiter_len, ctx->n_cu / 4 + 1), (unsigned)S), dim3(256), 0, ctx->stream, b->d_limiter, b->limiter_len,
+                         (const double *)b->d_buf, b->buf_len, (const LnbGain *)b->d_gain);
+      b->buf_index = b->limiter_len;
+      b->limiter_buf_index = 0;
+      if ((rc = lnb_limit(ctx, b, b->d_dst, FRAME_SIZE * ch, FRAME_SIZE))) return rc;
+      if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, FRAME_SIZE))) return rc;
+      if ((rc = deliver(0, FRAME_SIZE))) return rc;
+      b->current_samples_per_frame = FRAME_SIZE;
+      b->frame_type = FT_INNER;
+      *out_frames = FRAME_SIZE;
+      break;
+    }
+    case FT_INNER: {
+      if ((rc = lnb_fill(ctx, b, d_in, 0, frames, (double)FRAME_SIZE))) return rc;
+      if ((rc = lnb_limit(ctx, b, b->d_dst, frames * ch, frames))) return rc;
+      if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frames))) return rc;
+      if ((rc = deliver(0, frames))) return rc;
+      if ((rc = lnb_update_gain(ctx, b))) return rc;
+      *out_frames = frames;
+      break;
+    }
+    case FT_FINAL: {
+      const size_t num_samples = frames;
+      if ((rc = lnb_fill(ctx, b, d_in, 0, frames, (double)FRAME_SIZE))) return rc;
+      if (num_samples != FRAME_SIZE && (rc = lnb_fill(ctx, b, nullptr, num_samples, FRAME_SIZE, (double)FRAME_SIZE))) return rc;  // process_fill_final_frame(num_samples, FRAME_SIZE)
+      size_t smp_cnt = 0;
+      while (smp_cnt < need) {
+        const size_t frame_size = need - smp_cnt < FRAME_SIZE ? need - smp_cnt : FRAME_SIZE;
+        if ((rc = lnb_limit(ctx, b, b->d_dst, frame_size * ch, frame_size))) return rc;
+        if ((rc = deliver(smp_cnt, frame_size))) return rc;
+        smp_cnt += frame_size;
+        if (smp_cnt == need) break;
+        if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frame_size))) return rc;
+        if ((rc = lnb_update_gain(ctx, b))) return rc;
+        const size_t next_frame_size = need - smp_cnt < FRAME_SIZE ? need - smp_cnt : FRAME_SIZE;
+        if ((rc = lnb_fill(ctx, b, nullptr, 0, next_frame_size, (double)next_frame_size))) return rc;
+        if (next_frame_size < FRAME_SIZE) advance(&b->limiter_buf_index, FRAME_SIZE - next_frame_size, b->limiter_len);  // sic (imp.rs:763)
+      }
+      *out_frames = need;
+      break;
+    }
+    default: {
+      if (frames) {
+        if ((rc = lnb_upload_gains(ctx, b, true))) return rc;
+        hipLaunchKernelGGL(lnb_linear_kernel, dim3(ln_blocks(frames * ch, ctx->n_cu / 4 + 1), (unsigned)S), dim3(256), 0, ctx->stream, b->d_dst, frames * ch, d_in, frames * ch,
+                           frames * ch, (const LnbGain *)b->d_gain);
+        if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frames))) return rc;
+        if ((rc = deliver(0, frames))) return rc;
+      }
+      *out_frames = frames;
+      break;
+    }
+  }
+  // host buffers are the caller's again when this returns; device callers stay asynchronous
+  return device_data ? check_hip(ctx, hipGetLastError(), "loudnorm batch") : check_hip(ctx, hipStreamSynchronize(ctx->stream), "loudnorm: sync");
+}
+
 }  // namespace mi355

@@ -124,6 +124,9 @@ def load_library():
         "mi355_loudnorm_push": (i, [vp, vp, sz, vp, sz, C.POINTER(sz)]),
         "mi355_loudnorm_drain": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(i)]),
         "mi355_loudnorm_teardown": (i, [vp]),
+        "mi355_loudnorm_setup_batch": (i, [vp, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double]),
+        "mi355_loudnorm_batch_frame_size": (sz, [vp]),
+        "mi355_loudnorm_process_batch": (i, [vp, vp, sz, sz, vp, sz, sz, C.POINTER(sz), i, i]),
         "mi355_host_alloc": (vp, [vp, sz]),
         "mi355_host_free": (i, [vp, vp]),
         "mi355_pipe_create": (vp, [vp, i, sz]),
@@ -341,6 +344,30 @@ class Context:
 
     def loudnorm_teardown(self):
         self._ck(self.L.mi355_loudnorm_teardown(self.h))
+
+    # ---- audioloudnorm, n streams in lock step
+    def loudnorm_setup_batch(self, n_streams, channels, loudness_target=-24.0, loudness_range_target=7.0, max_true_peak=-2.0, offset=0.0):
+        self._ck(self.L.mi355_loudnorm_setup_batch(self.h, n_streams, channels, loudness_target, loudness_range_target, max_true_peak, offset))
+        self._lnb = (n_streams, channels)
+
+    def loudnorm_batch_frame_size(self):
+        return int(self.L.mi355_loudnorm_batch_frame_size(self.h))
+
+    def loudnorm_process_batch(self, data, final=False):
+        """data: (n_streams, frames * channels) float64, one frame (or, final, the shorter rest) per stream. -> (n_streams, out_frames * channels)."""
+        S, ch = self._lnb
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(S, -1)
+        frames = a.shape[1] // ch
+        cap = 31 * 19200 if final else max(frames, 19200)
+        out = np.zeros((S, cap * ch), np.float64)
+        n = C.c_size_t(0)
+        self._ck(self.L.mi355_loudnorm_process_batch(self.h, a.ctypes.data if a.size else None, a.shape[1], frames, out.ctypes.data, cap * ch, cap, C.byref(n), int(final), 0))
+        return out[:, : n.value * ch]
+
+    def loudnorm_process_batch_device(self, d_in, stream_stride, frames, d_out, out_stride, cap_frames, final=False):
+        n = C.c_size_t(0)
+        self._ck(self.L.mi355_loudnorm_process_batch(self.h, d_in, stream_stride, frames, d_out, out_stride, cap_frames, C.byref(n), int(final), 1))
+        return n.value
 
     # ---- pinned host memory + asynchronous host-buffer pipeline
     def host_array(self, nbytes):

@@ -298,6 +298,20 @@ int mi355_loudnorm_push(mi355_ctx *ctx, const double *data, size_t frames, doubl
 int mi355_loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_capacity_frames, size_t *out_frames,
                          int *eos);
 int mi355_loudnorm_teardown(mi355_ctx *ctx);
+/* Batches (round 3): n_streams elements of one configuration in LOCK STEP - State::process (imp.rs:800-828) for all of them
+ * per call, with the true-peak limiter's state machine (:845-1430) running on the device, one block per stream. The element
+ * keeps its adapter: `process_batch` is called the way drain_full_frames (:226-268) calls State::process, with exactly
+ * mi355_loudnorm_batch_frame_size() frames per stream (576,000 for the first call, then 19,200) - or, with final_frame = 1,
+ * with the shorter rest at drain() (:270-310; 0 frames allowed). Stream s reads data + s * stream_stride and writes
+ * out + s * out_stream_stride (interleaved f64, elements); every stream produces *out_frames frames. device_data = 1: both
+ * are device pointers and the call does not wait for the device. Per-stream samples are identical to n separate
+ * mi355_loudnorm_* contexts. mi355_loudnorm_teardown releases a batch as well. */
+int mi355_loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target,
+                               double loudness_range_target, double max_true_peak, double offset);
+size_t mi355_loudnorm_batch_frame_size(mi355_ctx *ctx);
+int mi355_loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_stride, size_t frames,
+                                 double *out, size_t out_stream_stride, size_t out_capacity_frames,
+                                 size_t *out_frames, int final_frame, int device_data);
 
 /* ---------------------------------------------------------------- videocompare
  * Replaces HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79) for

@@ -88,3 +88,70 @@ def test_not_negotiated(ctx):
         ctx._ln_channels = 1
         ctx.loudnorm_push(np.zeros(10))
     assert e.value.status == mi355fx.ERR_NOT_CONFIGURED
+
+
+# ------------------------------------------------------------------ batches of streams (round 3)
+
+def _burst_stream(seed, seconds, ch):
+    """programme material with limiter work in it: a tone at a per-stream level with bursts far above the ceiling"""
+    rng = np.random.default_rng(seed)
+    x = _tone(seconds, ch, amp=0.01 * (1 + seed % 5), f=300.0 + 37 * seed)
+    for _ in range(6):
+        i = int(rng.uniform(0.0, seconds - 0.05) * RATE)
+        x[i:i + int(rng.integers(10, 3000))] *= rng.uniform(20.0, 90.0)
+    return x + 1e-4 * rng.standard_normal(x.shape)
+
+
+def _run_batch(ctx, streams, ch, **kw):
+    """feeds the batch the way drain_full_frames does: whole frames, then the rest at drain"""
+    S = len(streams)
+    ctx.loudnorm_setup_batch(S, ch, **kw)
+    n = len(streams[0])
+    outs, pos = [], 0
+    while True:
+        need = ctx.loudnorm_batch_frame_size()
+        if n - pos < need:
+            break
+        outs.append(ctx.loudnorm_process_batch(np.stack([s[pos:pos + need].reshape(-1) for s in streams])))
+        pos += need
+    outs.append(ctx.loudnorm_process_batch(np.stack([s[pos:].reshape(-1) for s in streams]), final=True))
+    ctx.loudnorm_teardown()
+    return np.concatenate(outs, axis=1)
+
+
+@pytest.mark.parametrize("ch,seconds", [(2, 5.23), (1, 3.0), (6, 3.71)])
+def test_batch_equals_separate_streams_and_oracle(ctx, oracle, ch, seconds):
+    """n streams in lock step, the limiter's state machine on the device: every stream's samples equal those of a separate
+    single-stream context BIT FOR BIT (same expressions, same meters) and the oracle's within the meters' 1e-9."""
+    import mi355fx
+    S = 5
+    streams = [_burst_stream(10 * ch + s, seconds, ch) for s in range(S)]
+    streams[3] = _tone(seconds, ch, amp=1e-6)           # below -70 LUFS throughout: above_threshold never set
+    got = _run_batch(ctx, streams, ch)
+    assert got.shape == (S, int(seconds * RATE) * ch)
+    for s in range(S):
+        with mi355fx.Context(0) as c1:
+            single, exp = _both(c1, oracle, streams[s], 200000)
+        assert (got[s] == single).all(), (s, int((got[s] != single).sum()))
+        assert _close(got[s], exp) <= 1e-9
+        assert np.abs(got[s]).max() <= 10 ** (-2.0 / 20)
+
+
+def test_batch_short_streams_take_the_linear_path(ctx, oracle):
+    """less than 3 s in all: process_first_frame_is_last (imp.rs:334-366), a per-stream linear gain"""
+    streams = [_tone(1.3, 2, amp=0.05 * (s + 1)) for s in range(3)]
+    got = _run_batch(ctx, streams, 2, loudness_target=-20.0)
+    for s in range(3):
+        ln = oracle.LoudNorm(2, loudness_target=-20.0)
+        assert ln.push(streams[s]).size == 0
+        assert _close(got[s], ln.drain()) <= 1e-9
+
+
+def test_batch_argument_checks(ctx):
+    import mi355fx
+    ctx.loudnorm_setup_batch(2, 2)
+    assert ctx.loudnorm_batch_frame_size() == 3 * RATE
+    with pytest.raises(mi355fx.Mi355Error):
+        ctx.loudnorm_process_batch(np.zeros((2, 100 * 2)))   # not a whole frame
+    ctx.loudnorm_teardown()
+    assert ctx.loudnorm_batch_frame_size() == 0
