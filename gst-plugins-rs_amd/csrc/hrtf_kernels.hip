@@ -15,6 +15,12 @@
 //                         the previous block's tail in front (the crate's prev_left/right_samples are both the
 //                         raw input tail)
 //   hrtf_fir_kernel     : per (step, tile, channel) — direct-form FIR from LDS tiles of the input and both ears' taps
+//   hrtf_fft_kernel     : the same convolution as ONE overlap-save FFT per (step, channel) in LDS, the form BASELINE config 4
+//                         names and the crate uses (round 3): window [L-1 history | B samples] zero-padded to N = 2^k,
+//                         X = FFT(x), Z = FFT(h_left + i h_right), y = IFFT(X Z): x is real, so Re y is the left ear and
+//                         Im y the right one - three radix-2 transforms in LDS per step and channel instead of 2 B L MACs.
+//                         Serves whenever N <= 4096 fits the LDS (HRIRs up to ~3.5 k taps at the default block of 512);
+//                         the FIR stays for what does not (and can be pinned with MI355_FLAG_HRTF_METHOD).
 //   hrtf_mix_kernel     : channel-ordered sum into the interleaved stereo output (imp.rs:256-268 order)
 // HBM traffic per block is ~C*(frames+taps)*4 B in and frames*8 B out; the FIR is LDS-bound (1 LDS read per MAC).
 #include "internal.hpp"
@@ -37,6 +43,7 @@ struct HrtfState {
   bool configured = false;
   float *d_x[2] = {nullptr, nullptr};  // ping-pong [C][pad + frames]: history + de-interleaved block
   int cur = 0;
+  int fft_n = 0, fft_log = 0;    // overlap-save transform size (0: the time-domain FIR serves)
   float *d_taps = nullptr;       // [C][S][2][len]
   float *d_last_taps = nullptr;  // [C][2][len] taps of the last successful mesh lookup
   float *d_gain = nullptr;       // [C][S]
@@ -185,6 +192,70 @@ __global__ __launch_bounds__(256) void hrtf_fir_kernel(const float *__restrict__
   }
 }
 
+// ---- overlap-save FFT form. grid (S, C); block 256; dynamic LDS: X[N], Z[N], twiddles[N/2] (float2)
+__device__ __forceinline__ float2 hrtf_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ int hrtf_bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+// in-place radix-2 decimation-in-time transform of buf[0..N) (input stored bit-reversed), all lanes of the block
+template <bool INVERSE>
+__device__ __forceinline__ void hrtf_fft_lds(float2 *buf, const float2 *tw, int N, int logN) {
+  for (int st = 1; st <= logN; st++) {
+    const int half = 1 << (st - 1);
+    __syncthreads();
+    for (int t = threadIdx.x; t < N / 2; t += 256) {
+      const int j = t & (half - 1), base = (t >> (st - 1)) << st;
+      float2 w = tw[j << (logN - st)];
+      if (INVERSE) w.y = -w.y;
+      const float2 a = buf[base + j], b = hrtf_cmul(buf[base + j + half], w);
+      buf[base + j] = make_float2(a.x + b.x, a.y + b.y);
+      buf[base + j + half] = make_float2(a.x - b.x, a.y - b.y);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void hrtf_fft_kernel(const float *__restrict__ x, const float *__restrict__ taps, const float *__restrict__ gain,
+                                                       float *__restrict__ partial, int S, int B, int L, int N, int logN) {
+  extern __shared__ float2 hsm[];
+  float2 *X = hsm, *Z = hsm + N, *tw = hsm + 2 * N;
+  const int s = blockIdx.x, c = blockIdx.y;
+  const int pad = L - 1, frames = S * B, W = pad + B;  // window: x[n0 - pad .. n0 + B), n0 = s * B; row index of frame n is pad + n
+  const float *xrow = x + (size_t)c * (pad + frames) + (size_t)s * B;
+  const float *tp = taps + ((size_t)c * S + s) * 2 * L;
+  for (int i = threadIdx.x; i < N / 2; i += 256) {
+    float sn, cs;
+    sincospif(-2.0f * (float)i / (float)N, &sn, &cs);
+    tw[i] = make_float2(cs, sn);
+  }
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const int r = hrtf_bitrev(i, logN);
+    X[r] = make_float2(i < W ? xrow[i] : 0.0f, 0.0f);
+    Z[r] = i < L ? make_float2(tp[i], tp[L + i]) : make_float2(0.0f, 0.0f);  // left ear in the real part, right ear in the imaginary
+  }
+  hrtf_fft_lds<false>(X, tw, N, logN);
+  hrtf_fft_lds<false>(Z, tw, N, logN);
+  // Y = X Z back into X in bit-reversed order (every lane first reads its products, then all write)
+  float2 y[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < N) y[k] = hrtf_cmul(X[i], Z[i]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < N) X[hrtf_bitrev(i, logN)] = y[k];
+  }
+  hrtf_fft_lds<true>(X, tw, N, logN);
+  const float g = gain[c * S + s] / (float)N;
+  for (int i = threadIdx.x; i < B; i += 256) {  // overlap-save: window position pad + i holds output frame n0 + i
+    const float2 v = X[pad + i];
+    float *o = partial + ((size_t)c * frames + (size_t)s * B + i) * 2;
+    o[0] = v.x * g;
+    o[1] = v.y * g;
+  }
+}
+
 // out[n] = ((0 + ch0) + ch1) + ...   (imp.rs:186 zero fill, :256-268 accumulation order)
 __global__ __launch_bounds__(256) void hrtf_mix_kernel(const float *__restrict__ partial, float *__restrict__ out, int C, int frames) {
   const int i = blockIdx.x * 256 + threadIdx.x;  // index into [frames][2]
@@ -319,7 +390,17 @@ int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps) {
   hrtf_free_processors(H);
   const size_t L = H->len, pad = L - 1, frames = (size_t)block_len * steps, C = (size_t)channels, S = (size_t)steps;
   const size_t T = block_len < 1024 ? (size_t)block_len : 1024;
-  if ((T + pad + 2 * L) * 4 > 160 * 1024) return set_error(ctx, MI355_ERR_UNSUPPORTED, "hrtfrender: HRIR too long for the LDS-tiled FIR");
+  // overlap-save transform size: the next power of two that holds the window [L-1 | block]; X, Z and the twiddles fit the LDS up to 4096
+  int fft_n = 1, fft_log = 0;
+  while ((size_t)fft_n < (size_t)block_len + pad) { fft_n <<= 1; fft_log++; }
+  const bool fft_fits = fft_n <= 4096 && fft_n >= 512;
+  const bool fir_fits = (T + pad + 2 * L) * 4 <= 160 * 1024;
+  if (!fft_fits && !fir_fits) return set_error(ctx, MI355_ERR_UNSUPPORTED, "hrtfrender: HRIR too long for the LDS (block + HRIR length above 4096 and FIR tile above 160 KB)");
+  // method: 1 = FFT, 2 = FIR pinned; 0 = FFT from kHrtfFftMinTaps taps on, FIR below
+  // measured, 64 sources, block 512 x 8 (ms per block, FFT / FIR): 64 taps 0.040 / 0.030, 256: 0.042 / 0.040, 512: 0.047 / 0.056,
+  // 1024: 0.072 / 0.087, 2048: 0.128 / 0.156 (tools/bench_hrtf.py --method 1 / 2, r03)
+  constexpr size_t kHrtfFftMinTaps = 384;
+  const bool use_fft = fft_fits && (ctx->hrtf_method == 1 || !fir_fits || (ctx->hrtf_method == 0 && L >= kHrtfFftMinTaps));
   int rc;
   for (int i = 0; i < 2; i++) {
     if ((rc = check_hip(ctx, hipMalloc(&H->d_x[i], C * (pad + frames) * 4 + 4), "hipMalloc(hrtf input rows)"))) return rc;
@@ -333,6 +414,7 @@ int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps) {
   }
   if ((rc = check_hip(ctx, hipMalloc(&H->d_face, C * S * 4 + 4), "hipMalloc(hrtf faces)"))) return rc;
   H->channels = channels; H->steps = steps; H->block_len = block_len; H->cur = 0;
+  H->fft_n = use_fft ? fft_n : 0; H->fft_log = use_fft ? fft_log : 0;
   H->prev_vec.assign(C * 3, 0.0f); H->prev_gain.assign(C, 0.0f); H->have_prev.assign(C, 0);
   H->configured = true;
   return MI355_OK;
@@ -368,12 +450,19 @@ int hrtf_process_block_device(mi355_ctx *ctx, const float *d_in, float *d_out, c
   hipLaunchKernelGGL(hrtf_prepare_kernel, dim3(C), dim3(256), 0, ctx->stream, d_in, C, S, B, L, (const float *)H->d_pos, (const uint32_t *)H->d_idx,
                      (int)H->n_faces, (const float *)H->d_hrir, vg, (const float *)x_old, x_new, H->d_taps, H->d_last_taps,
                      H->d_gain, H->d_face, H->d_uvw);
-  const int T = B < 1024 ? B : 1024, tiles = (B + T - 1) / T;
-  const size_t lds = (size_t)(T + (L - 1) + 2 * L) * 4;
-  int rc = check_hip(ctx, hipFuncSetAttribute((const void *)hrtf_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(hrtf fir LDS)");
-  if (rc) return rc;
-  hipLaunchKernelGGL(hrtf_fir_kernel, dim3(S * tiles, C), dim3(256), lds, ctx->stream, (const float *)x_new, (const float *)H->d_taps,
-                     (const float *)H->d_gain, H->d_partial, S, B, L, T, tiles);
+  int rc;
+  if (H->fft_n) {
+    const size_t lds = (size_t)(2 * H->fft_n + H->fft_n / 2) * sizeof(float2);
+    if ((rc = check_hip(ctx, hipFuncSetAttribute((const void *)hrtf_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(hrtf fft LDS)"))) return rc;
+    hipLaunchKernelGGL(hrtf_fft_kernel, dim3(S, C), dim3(256), lds, ctx->stream, (const float *)x_new, (const float *)H->d_taps, (const float *)H->d_gain, H->d_partial,
+                       S, B, L, H->fft_n, H->fft_log);
+  } else {
+    const int T = B < 1024 ? B : 1024, tiles = (B + T - 1) / T;
+    const size_t lds = (size_t)(T + (L - 1) + 2 * L) * 4;
+    if ((rc = check_hip(ctx, hipFuncSetAttribute((const void *)hrtf_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(hrtf fir LDS)"))) return rc;
+    hipLaunchKernelGGL(hrtf_fir_kernel, dim3(S * tiles, C), dim3(256), lds, ctx->stream, (const float *)x_new, (const float *)H->d_taps,
+                       (const float *)H->d_gain, H->d_partial, S, B, L, T, tiles);
+  }
   hipLaunchKernelGGL(hrtf_mix_kernel, dim3((2 * frames + 255) / 256), dim3(256), 0, ctx->stream, (const float *)H->d_partial, d_out, C, frames);
   rc = check_hip(ctx, hipGetLastError(), "hrtf kernel launch");
   if (rc) return rc;

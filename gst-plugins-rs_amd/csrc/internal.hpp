@@ -105,6 +105,7 @@ struct mi355_ctx {
   int dssim_translucent = 0;    // MI355_FLAG_DSSIM_TRANSLUCENT: 1 = treat alpha < 255 as premultiplied over black instead of refusing the frame
   int brick_prio = 3;           // MI355_FLAG_BRICK_PRIO: bit 0 progress-based wave priorities, bit 1 tile stealing within a block
   int brick_sets = 0;           // MI355_FLAG_BRICK_SETS: 0 = content watch decides (default); 32 (4x4x2 sets, 16 waves per CU) or 64 (4x4x4 sets, 8 waves per CU) pinned
+  int hrtf_method = 0;         // MI355_FLAG_HRTF_METHOD: 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (takes effect at mi355_hrtf_setup)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

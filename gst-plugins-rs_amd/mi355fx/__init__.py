@@ -33,6 +33,7 @@ FLAG_BRICK_SETS = 8
 FLAG_BRICK_PRIO = 9
 FLAG_BRICK_FOLD_AXIS = 10
 FLAG_DSSIM_TRANSLUCENT = 11
+FLAG_HRTF_METHOD = 12
 
 
 class HsvSettings(C.Structure):
@@ -489,6 +490,11 @@ class Context:
         out = np.zeros((bl, 2), np.float32)
         self._ck(self.L.mi355_sofa_process_block(self.h, x.ctypes.data_as(fp), out.ctypes.data_as(fp), g.ctypes.data_as(fp)))
         return out
+
+    def sofa_process_block_device(self, d_in, d_out, gains):
+        fp = C.POINTER(C.c_float)
+        g = np.ascontiguousarray(gains, np.float32)
+        self._ck(self.L.mi355_sofa_process_block_device(self.h, d_in, d_out, g.ctypes.data_as(fp)))
 
     # ---- hrtfrender
     def hrtf_load_sphere(self, data, rate):

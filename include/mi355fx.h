@@ -102,6 +102,7 @@ typedef enum mi355_flag {
   MI355_FLAG_DSSIM_TRANSLUCENT = 11, /* Dssim on RGBA pixels with alpha < 255: 0 (default) = composed over the crate's coloured, position-dependent pattern (mi355_dssim_create_image), 1 = over black (premultiplied values as they are) */
   MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
+  MI355_FLAG_HRTF_METHOD = 12, /* hrtfrender convolution, read at mi355_hrtf_setup: 0 (default) = overlap-save FFT in LDS from 384-tap HRIRs on (the measured crossover), time-domain FIR below; 1 = FFT, 2 = FIR pinned (each only where it fits the LDS) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);

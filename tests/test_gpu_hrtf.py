@@ -41,11 +41,16 @@ def test_load_errors(ctx):
     assert ctx.hrtf_sphere_info() == (1, 187, 370)
 
 
-def _run(ctx, oracle, synth, length, channels, steps, block, n_blocks, seed, static=False):
+def _run(ctx, oracle, synth, length, channels, steps, block, n_blocks, seed, static=False, method=0):
+    import mi355fx
     data = synth.hrir_sphere_bytes(_mesh(), length)
     sphere = oracle.HrirSphere(data, 44100)
     ctx.hrtf_load_sphere(data, 44100)
-    ctx.hrtf_setup(channels, block, steps)
+    ctx.set_flag(mi355fx.FLAG_HRTF_METHOD, method)   # 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (read at setup)
+    try:
+        ctx.hrtf_setup(channels, block, steps)
+    finally:
+        ctx.set_flag(mi355fx.FLAG_HRTF_METHOD, 0)
     r = oracle.HrtfRender(sphere, channels, steps, block)
     ex = oracle.HrtfExact(sphere, channels, steps, block)
     rng = np.random.default_rng(seed)
@@ -76,16 +81,30 @@ def _run(ctx, oracle, synth, length, channels, steps, block, n_blocks, seed, sta
     return worst_exact, worst_oracle, oracle_exact, max(scale, 1.0)
 
 
+@pytest.mark.parametrize("method", [1, 2])
 @pytest.mark.parametrize("length,channels,steps,block", [(1, 1, 8, 512), (32, 2, 8, 64), (128, 8, 8, 512), (100, 3, 4, 77), (512, 4, 2, 1500)])
-def test_blocks_match_oracle_and_exact(ctx, oracle, synth, length, channels, steps, block):
-    we, wo, oe, scale = _run(ctx, oracle, synth, length, channels, steps, block, 4, 17 * length + block)
+def test_blocks_match_oracle_and_exact(ctx, oracle, synth, length, channels, steps, block, method):
+    """both convolution forms - the overlap-save FFT in LDS (round 3; where block + HRIR fit 4096 points, else the call falls
+    back to the FIR) and the time-domain FIR - against the f64 exact value and the f32 FFT restatement"""
+    we, wo, oe, scale = _run(ctx, oracle, synth, length, channels, steps, block, 4, 17 * length + block, method=method)
     assert we <= TOL_EXACT * scale, (we, scale)
     assert wo <= TOL_ORACLE * scale, (wo, scale)
 
 
-def test_config4_64_sources_default_block(ctx, oracle, synth):
-    """BASELINE config 4: 64 sources, block 512 x 8 steps, 256-tap HRIRs; moving sources over 3 blocks."""
-    we, wo, oe, scale = _run(ctx, oracle, synth, 256, 64, 8, 512, 3, 4242)
+@pytest.mark.parametrize("length,block,steps", [(1024, 512, 4), (2048, 512, 2), (3000, 1024, 2), (1500, 256, 4)])
+def test_long_hrirs_through_the_fft(ctx, oracle, synth, length, block, steps):
+    """HRIRs of 1 k - 3 k taps (hrtf/imp.rs:221-230 convolves whatever length the sphere file holds): O(N log N) per step on
+    the device as well since round 3; default method selection."""
+    we, wo, oe, scale = _run(ctx, oracle, synth, length, 3, steps, block, 3, length + block)
+    assert we <= 2 * TOL_EXACT * scale, (we, scale)
+    assert wo <= 2 * TOL_ORACLE * scale, (wo, scale)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_config4_64_sources_default_block(ctx, oracle, synth, method):
+    """BASELINE config 4: 64 sources, block 512 x 8 steps, 256-tap HRIRs; moving sources over 3 blocks; the default method
+    (FIR at this length: the measured crossover is near 384 taps) and both forms pinned."""
+    we, wo, oe, scale = _run(ctx, oracle, synth, 256, 64, 8, 512, 3, 4242, method=method)
     assert we <= TOL_EXACT * scale, (we, scale)
     assert wo <= TOL_ORACLE * scale, (wo, scale)
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--sources", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--method", type=int, default=0, help="MI355_FLAG_HRTF_METHOD: 0 by HRIR length, 1 overlap-save FFT, 2 time-domain FIR")
     a = ap.parse_args()
     rate, steps, bl = 48000, 8, 512
     frames = steps * bl
@@ -24,6 +25,7 @@ def main():
     data = synth.hrir_sphere_bytes(mesh, a.taps, rate=rate)
     ctx = mi355fx.Context(0)
     ctx.hrtf_load_sphere(data, rate)
+    ctx.set_flag(mi355fx.FLAG_HRTF_METHOD, a.method)
     ctx.hrtf_setup(a.sources, bl, steps)
     rng = np.random.default_rng(0)
     x = rng.uniform(-1, 1, (frames, a.sources)).astype(np.float32)
@@ -42,7 +44,7 @@ def main():
     for i in range(a.blocks // 4):
         ctx.hrtf_process_block(x, pos, gains)
     dth = (time.perf_counter() - t0) / (a.blocks // 4)
-    out = {"config": "hrtfrender %d sources, %d-tap HRIRs, %d Hz f32, block %dx%d" % (a.sources, a.taps, rate, bl, steps),
+    out = {"config": "hrtfrender %d sources, %d-tap HRIRs, %d Hz f32, block %dx%d, method %d" % (a.sources, a.taps, rate, bl, steps, a.method),
            "device_blocks_per_s": a.blocks / dt, "device_ms_per_block": dt / a.blocks * 1e3,
            "realtime_factor": (frames / rate) / (dt / a.blocks),
            "host_buffer_ms_per_block": dth * 1e3, "host_buffer_realtime_factor": (frames / rate) / dth,
