@@ -164,7 +164,8 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 #ifndef BRICK_DUMMY_LDS
 #define BRICK_DUMMY_LDS 0
 #endif
-__device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t px) {
+// the seven lerps: O = clamped (r, g), ob = clamped b (float_to_u8 / float_to_u16's clamp rides on the last adds)
+__device__ __forceinline__ void brick_lerps(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t px, f2_t &O, float &ob) {
   if constexpr (BRICK_DUMMY_VALU > 0) {
     uint32_t sink = px;
 #pragma unroll
@@ -182,12 +183,17 @@ __device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, fl
   // [0, 1] and turns NaN into 0 (DX10_CLAMP is set for HSA kernels) - the inherent clamp lets NaN through and `as u8` then
   // makes it 0: the same byte
   const f2_t OZ = (Y1 - Y0) * TZ;
-  f2_t O;
   asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(O) : "v"(Y0), "v"(OZ));
   // blue: the same clamp as an output modifier of the z-lerp's add (VOP3 clamp: [0, 1], NaN -> 0)
   const float obz = (Yb.y - Yb.x) * tz;
-  float ob;
   asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(ob) : "v"(Yb.x), "v"(obz));
+}
+
+// RGBA8: lerps + float_to_u8 of one pixel from its brick; returns the three output bytes merged into `px`.
+__device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t px) {
+  f2_t O;
+  float ob;
+  brick_lerps(f, tx, ty, tz, px, O, ob);
   const f2_t O255 = O * (f2_t){255.0f, 255.0f};
   uint32_t out = px;
   brick_round_into<0>(out, O255.x);
@@ -195,6 +201,29 @@ __device__ __forceinline__ uint32_t brick_pixel(const f4_t (&f)[6], float tx, fl
   brick_round_into<2>(out, ob * 255.0f);
   return out;
 }
+
+// RGBA64 (transform_rgba64_3d::<LE>, imp.rs:348-397): float_to_u16 = round-half-away(clamp(v) * 65535) (v_cvt_rpi: exact on
+// [0, 65536], tools/sem_probe.hip) into the two colour words of `lo` and the low word of `hi`; the alpha word (high half of
+// hi) is copied raw. SWAP: the samples are big-endian words in memory.
+__device__ __forceinline__ uint32_t brick_swap_words(uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x02030001u); }  // bytes (1,0,3,2)
+template <bool SWAP>
+__device__ __forceinline__ void brick_pixel64(const f4_t (&f)[6], float tx, float ty, float tz, uint32_t &lo, uint32_t &hi) {
+  f2_t O;
+  float ob;
+  brick_lerps(f, tx, ty, tz, lo, O, ob);
+  const f2_t Os = O * (f2_t){65535.0f, 65535.0f};
+  const float bs = ob * 65535.0f;
+  uint32_t w0 = 0, w1 = SWAP ? brick_swap_words(hi) : hi;
+  asm("v_cvt_rpi_i32_f32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w0) : "v"(Os.x));
+  asm("v_cvt_rpi_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w0) : "v"(Os.y));
+  asm("v_cvt_rpi_i32_f32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w1) : "v"(bs));
+  lo = SWAP ? brick_swap_words(w0) : w0;
+  hi = SWAP ? brick_swap_words(w1) : w1;
+}
+
+// coordinate arithmetic of the RGBA64 path (norm_comp_u16 imp.rs:476-480, apply_3d_u16 :451-469, sample_3d :496-506): 65,536
+// input levels do not fit an LDS axis table, so x0 and t are computed - the expressions of colorlut3d_lds64_kernel
+struct BrickK64 { float scale[3], offset[3], sm1; };
 
 // HSV: kBrickNoHsv = plain colorlut; otherwise the fused hsvfilter -> colorlut chain (variant as in hsv_kernels.hip)
 constexpr int kBrickNoHsv = -2;
@@ -223,16 +252,23 @@ __device__ __forceinline__ gl_byte *uniform_ptr(const void *p) {
   return (gl_byte *)(((uint64_t)hi << 32) | lo);
 }
 
-template <int P, int HSV, int ZN, int G>  // P = 16-byte loads per lane and tile (a tile is 128 px x 2P rows), G of them per step
+// P = 16-byte loads per lane and tile (a tile is 32 lanes x 2P rows of 16-byte groups), G of them per step.
+// FMT: 0 = RGBA8 (four pixels per group, coordinates from the LDS axis tables), 1 / 2 = RGBA64 little / big endian (two
+// pixels per group, coordinates computed; everything else - cache, fills, work sharing, lerps - is the same code).
+template <int P, int HSV, int ZN, int G, int FMT = 0>
 __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
                                                                                  unsigned rows, unsigned n_strips, unsigned tiles_per_run, unsigned n_runs_flags,
                                                                                  const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
                                                                                  const uint32_t *__restrict__ cellnum,
-                                                                                 unsigned long long *__restrict__ counters, HsvK hk, unsigned fold_axis, unsigned lut_size) {
+                                                                                 unsigned long long *__restrict__ counters, HsvK hk, unsigned fold_axis, unsigned lut_size,
+                                                                                 BrickK64 k64) {
+  static_assert(FMT == 0 || HSV == kBrickNoHsv, "the fused hsvfilter form is RGBA8 only");
+  static_assert(FMT == 0 || ZN != 3, "RGBA64: 32 hashed sets or the 4 x 4 x 4 box");
   // All LDS of this kernel is the dynamic allocation and there are no static __shared__ objects, so the allocation starts
   // at LDS address 0. LDS is addressed by absolute byte address (address-space-3 pointers made from integers): every table
   // base then folds into the ds_read offset field instead of costing an add of the link-time base symbol per access.
-  constexpr int NP = 4 * G, NT = 64 * brick_waves(ZN);
+  constexpr int NPX = FMT ? 2 : 4;  // pixels in a 16-byte group
+  constexpr int NP = NPX * G, NT = 64 * brick_waves(ZN);
 #ifndef BRICK_PIPE
 #define BRICK_PIPE 1
 #endif
@@ -426,9 +462,13 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #pragma unroll
     for (int j = 0; j < P; j += G) {
       // one STEP = G 16-byte groups per lane = NP pixels per lane (64 NP pixels per wave), checked and filled together
-      uint32_t px[NP];
+      uint32_t px[NP];                // RGBA8: the pixel; RGBA64: its r | g << 16 words
+      uint32_t px_hi[FMT ? NP : 1];   // RGBA64: b | a << 16
 #pragma unroll
-      for (int g2 = 0; g2 < G; g2++) { px[4 * g2 + 0] = cur[j + g2].x; px[4 * g2 + 1] = cur[j + g2].y; px[4 * g2 + 2] = cur[j + g2].z; px[4 * g2 + 3] = cur[j + g2].w; }
+      for (int g2 = 0; g2 < G; g2++) {
+        if constexpr (FMT == 0) { px[4 * g2 + 0] = cur[j + g2].x; px[4 * g2 + 1] = cur[j + g2].y; px[4 * g2 + 2] = cur[j + g2].z; px[4 * g2 + 3] = cur[j + g2].w; }
+        else { px[2 * g2] = cur[j + g2].x; px_hi[2 * g2] = cur[j + g2].y; px[2 * g2 + 1] = cur[j + g2].z; px_hi[2 * g2 + 1] = cur[j + g2].w; }
+      }
       if constexpr (HSV >= 0) {
 #pragma unroll
         for (int i = 0; i < NP; i += 2) hsvfilter_px2_fast<0, 1, 2, 3, HSV & 3, (HSV >> 2) != 0>(px[i], px[i + 1], hk, hsv_sel);
@@ -440,7 +480,28 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
       // round trip for the step, not one per pixel: the compiler keeps the order it is given and waits with lgkmcnt(0))
       float tx[NP], ty[NP], tz[NP];
       uint32_t set[NP], tag[NP], baddr[NP];
-      {
+      if constexpr (FMT != 0) {
+        // RGBA64: x0 / t per axis by arithmetic; the tag is the cell number, the set its hash (32 sets) or residue box (64)
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          const uint32_t lo = FMT == 2 ? brick_swap_words(px[i]) : px[i], hi = FMT == 2 ? brick_swap_words(px_hi[i]) : px_hi[i];
+          const uint32_t c16[3] = {lo & 0xffffu, lo >> 16, hi & 0xffffu};
+          uint32_t idx[3];
+          float t[3];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            float n = div65535_u16((float)c16[a]);
+            n = fminf(fmaxf(n * k64.scale[a] + k64.offset[a], 0.0f), 1.0f);  // finite domain (brick_upload): == the inherent clamp
+            const float x = n * k64.sm1;
+            idx[a] = (uint32_t)x;                     // floor; x <= S - 1, so the min(.., size - 1) never bites
+            t[a] = __builtin_amdgcn_fractf(x);        // x - x0
+          }
+          tx[i] = t[0]; ty[i] = t[1]; tz[i] = t[2];
+          tag[i] = idx[0] + lut_size * (idx[1] + lut_size * idx[2]);
+          if constexpr (brick_hashed(ZN)) set[i] = __umul24((idx[0] + 3u * idx[1] + 9u * idx[2]) & 31u, (uint32_t)kBrickSetBytes) + wave_base;
+          else set[i] = wave_base + (idx[0] & 3u) * kBrickSetBytes + (idx[1] & 3u) * (4u * kBrickSetBytes) + (idx[2] & 3u) * (uint32_t)kBrickZStride;
+        }
+      } else {
         u2_t ex[NP], ey[NP], ez[NP];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -508,7 +569,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
                 const uint32_t cnt = (fw >> 3) == gen ? ((fw >> 1) & 3u) : 0u;
                 if (cnt < 2u) {
                   const uint32_t way = fw & 1u;
-                  const uint32_t cell = cell_of(px[i]);
+                  const uint32_t cell = FMT ? tag[i] : cell_of(px[i]);
                   const u2_t qe = {cell, set[i] + 96u * way};
                   lds_w64(queue + 8u * pos, qe);
                   lds_w32(set[i] + 192u + 4u * way, tag[i]);
@@ -548,7 +609,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
             bool m = tg.x != tag[i] && tg.y != tag[i];
             unsigned long long mb = __ballot(m);
             if (mb) {
-              const uint32_t cell = cell_of(px[i]);
+              const uint32_t cell = FMT ? tag[i] : cell_of(px[i]);
               while (mb && n_ovf < (uint32_t)kBrickScratch) {
                 const int L = __builtin_ctzll(mb);
                 const uint32_t cellL = __builtin_amdgcn_readlane(cell, L);
@@ -577,6 +638,11 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
         }
       }
       uint32_t out[NP];
+      // one pixel from its brick into out[i] (RGBA64: the pixel's two words are rewritten in place in px / px_hi)
+      auto emit = [&](const f4_t (&f)[6], int i) {
+        if constexpr (FMT == 0) out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
+        else { brick_pixel64<FMT == 2>(f, tx[i], ty[i], tz[i], px[i], px_hi[i]); out[i] = px[i]; }
+      };
       if (__builtin_expect(!slow, 1)) {
         // fast path: every lane's four bricks are resident. The next pixel's brick is read while this one's is worked on (two
         // register sets): a brick read left to its own devices waits out a full LDS round trip per pixel with nothing to issue
@@ -594,7 +660,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #pragma unroll
               for (int d = 0; d < BRICK_DUMMY_LDS; d++) { const f4_t x = lds_r128(baddr[i] + 16u * (d % 6)); asm volatile("" ::"v"(x)); }
             }
-            out[i] = brick_pixel(f[i & 1], tx[i], ty[i], tz[i], px[i]);
+            emit(f[i & 1], i);
           }
         } else {
 #pragma unroll
@@ -602,7 +668,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
             f4_t f[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
-            out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
+            emit(f, i);
           }
         }
       } else {
@@ -613,7 +679,7 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
         for (int i = 0; i < NP; i++) {
           f4_t f[6];
           if ((lane_res >> i) & 1u) {
-            const uint32_t cell = cell_of(px[i]);
+            const uint32_t cell = FMT ? tag[i] : cell_of(px[i]);
             const f4_t *gb = bricks + (size_t)cell * 8;
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = gb[k];
@@ -621,14 +687,16 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = lds_r128(baddr[i] + 16u * k);
           }
-          out[i] = brick_pixel(f, tx[i], ty[i], tz[i], px[i]);
+          emit(f, i);
         }
       }
 #pragma unroll
       for (int g2 = 0; g2 < G; g2++) {
         const unsigned ro = 2u * (j + g2) + sub;
         if (col_ok && row0 + ro < rows) {
-          const u4_t o = {out[4 * g2 + 0], out[4 * g2 + 1], out[4 * g2 + 2], out[4 * g2 + 3]};
+          u4_t o;
+          if constexpr (FMT == 0) o = u4_t{out[4 * g2 + 0], out[4 * g2 + 1], out[4 * g2 + 2], out[4 * g2 + 3]};
+          else o = u4_t{out[2 * g2], px_hi[2 * g2], out[2 * g2 + 1], px_hi[2 * g2 + 1]};
           const uint32_t byte_off = (ro * dw4 + col) * 16u;
           __builtin_nontemporal_store(o, (gl_u4 *)(dst_tile + byte_off));
         }
@@ -768,27 +836,29 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
   if ((rc = check_hip(ctx, hipEventCreateWithFlags(&B.ev, hipEventDisableTiming), "hipEventCreate(brick)"))) return rc;
   B.size = S;
   B.fold_axis = fold_axis;
+  for (int c = 0; c < 3; c++) { B.scale[c] = scale[c]; B.offset[c] = offset[c]; }
   B.ok = true;
   return MI355_OK;
 }
 
 bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch,
-                      int dst_stride, int n_frames, int width, int height) {
-  if (!B.ok || width < 4 || width % 4 != 0) return false;
+                      int dst_stride, int n_frames, int width, int height, int bytes_per_pixel) {
+  const int px_per_group = 16 / bytes_per_pixel;  // 4 (RGBA8) or 2 (RGBA64)
+  if (!B.ok || width < px_per_group || width % px_per_group != 0) return false;
   // rows may be padded (strides that are multiples of 16 B - what aligned allocators negotiate); a batch must then be one
   // tall picture: frames `stride * height` apart
-  const size_t row_bytes = (size_t)width * 4;
+  const size_t row_bytes = (size_t)width * (size_t)bytes_per_pixel;
   if ((size_t)src_stride < row_bytes || (size_t)dst_stride < row_bytes || src_stride % 16 != 0 || dst_stride % 16 != 0) return false;
   if (n_frames != 1 && (src_pitch != (size_t)src_stride * (size_t)height || dst_pitch != (size_t)dst_stride * (size_t)height)) return false;
   if ((uintptr_t)d_src % 16 != 0 || (uintptr_t)d_dst % 16 != 0) return false;
   return (size_t)n_frames * (size_t)height < (1u << 30) && (size_t)src_stride * 4 < (1u << 28) && (size_t)dst_stride * 4 < (1u << 28);
 }
 
-template <int HSV, int ZN>
+template <int HSV, int ZN, int FMT = 0>
 static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height, const HsvK &hk) {
   // tile = 128 px x 2P rows, prefetched one tile ahead: with 8 waves per CU a 4-row tile is consumed faster than HBM answers
   constexpr int P = ZN == 4 ? BRICK_P64 : 2;
-  const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
+  const unsigned w4 = (unsigned)width / (FMT ? 2 : 4), rows = (unsigned)((size_t)n_frames * height);
   const unsigned n_strips = (w4 + 31) / 32;
   const unsigned tile_rows = (rows + 2 * P - 1) / (2 * P);
   // Run length: a wave's cache starts cold at the top of its run, so runs are as long as the launch allows while still
@@ -811,10 +881,15 @@ static int brick_launch_t(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_sr
   size_t grid = (n_groups + K - 1) / K;
   const size_t spread = n_groups < (size_t)ctx->n_cu ? n_groups : (size_t)ctx->n_cu;
   if (grid < spread) grid = spread;
-  constexpr int G = ZN == 4 ? BRICK_G64 : 1;
-  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G>), dim3((unsigned)grid), dim3(64 * W), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
+  // RGBA64: two pixels per 16-byte group, so two groups per step keep a step at four pixels per lane
+  constexpr int G = FMT ? 2 : (ZN == 4 ? BRICK_G64 : 1);
+  static_assert(P % G == 0, "a tile is a whole number of steps");
+  BrickK64 k64;
+  for (int c = 0; c < 3; c++) { k64.scale[c] = B.scale[c]; k64.offset[c] = B.offset[c]; }
+  k64.sm1 = (float)B.size - 1.0f;
+  hipLaunchKernelGGL((colorlut3d_brick_kernel<P, HSV, ZN, G, FMT>), dim3((unsigned)grid), dim3(64 * W), brick_lds_bytes(ZN), ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4,
                      (unsigned)src_stride / 16, (unsigned)dst_stride / 16, rows, n_strips, tpr, (unsigned)n_runs | ((unsigned)(ctx->brick_prio & 3) << 30), (const f4_t *)B.d_bricks,
-                     (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768, (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis, (unsigned)B.size);
+                     (const u2_t *)B.d_axis + (size_t)(ZN - 2) * 768, (const uint32_t *)B.d_cellnum, B.d_counters, hk, (unsigned)B.fold_axis, (unsigned)B.size, k64);
 #ifdef BRICK_TIMING
   if (const char *path = getenv("BRICK_TIMING_FILE")) {
     std::vector<unsigned long long> tr(kBrickTimingBytes / 8);
@@ -834,7 +909,14 @@ static int brick_launch_z(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_sr
 }
 
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height,
-                 const mi355_hsv_settings *hs, int sets) {
+                 const mi355_hsv_settings *hs, int sets, int fmt64) {
+  if (fmt64) {  // RGBA64 (1 little endian, 2 big endian): plain colorlut only, 32 hashed sets or the 64-set box
+    if (hs) return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: the fused hsvfilter form is RGBA only");
+    if (sets == 64) return fmt64 == 1 ? brick_launch_t<kBrickNoHsv, 4, 1>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{})
+                                      : brick_launch_t<kBrickNoHsv, 4, 2>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{});
+    return fmt64 == 1 ? brick_launch_t<kBrickNoHsv, 2, 1>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{})
+                      : brick_launch_t<kBrickNoHsv, 2, 2>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{});
+  }
   if (!hs) return brick_launch_z<kBrickNoHsv>(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, HsvK{}, sets);
   const HsvK hk{hs->hue_shift, hs->saturation_mul, hs->saturation_off, hs->value_mul, hs->value_off};
   switch (hsv_variant_for(*hs, false)) {

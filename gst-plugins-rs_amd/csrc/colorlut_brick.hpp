@@ -19,6 +19,7 @@ struct BrickLut {
   uint32_t *d_cellnum = nullptr;           // 3 x 256: per-axis contribution to the cell number x0 + S*y0 + S*S*z0 (miss path)
   unsigned long long *d_counters = nullptr;  // 1024 slots x {256-pixel steps with a cache miss, steps that ended on the slow path}
   int size = 0;
+  float scale[3] = {1, 1, 1}, offset[3] = {0, 0, 0};  // domain (the RGBA64 kernels compute coordinates from it)
   int fold_axis = 2;                       // axis that has 2 residues in the 32-set geometry (2 = z)
   bool ok = false;                         // kernel applicable to this LUT (3D, size <= kBrickMaxSize, finite domain)
   // content watch (brick_choose / brick_after_launch): the miss counters are copied to pinned host memory every few
@@ -44,10 +45,10 @@ int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, i
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);
 void brick_release(BrickLut &B);
 bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch, int src_stride, const uint8_t *d_dst, size_t dst_pitch,
-                      int dst_stride, int n_frames, int width, int height);
+                      int dst_stride, int n_frames, int width, int height, int bytes_per_pixel = 4);
 // hs == nullptr: colorlut alone; otherwise the fused hsvfilter -> colorlut chain. src == dst is allowed.
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height,
-                 const mi355_hsv_settings *hs, int sets);  // sets: 32 or 64
+                 const mi355_hsv_settings *hs, int sets, int fmt64 = 0);  // sets: 32 or 64; fmt64: 0 RGBA8, 1 RGBA64_LE, 2 RGBA64_BE
 // synchronous read (and optional reset) of the miss counters
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);
 

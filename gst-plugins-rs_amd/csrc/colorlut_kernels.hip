@@ -1337,6 +1337,29 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
     }
   }
 
+  // RGBA64 with a 3D LUT: the brick-cache kernel (round 3: coordinates computed instead of tabled) under the same content
+  // watch as RGBA8 - noise-like streams go on to the three-pass 16-bit kernel below
+  if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && L.is3d && !ctx->force_generic && ctx->lut_variant != 3 &&
+      brick_applicable(ctx->lut.brick, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, 8)) {
+    BrickLut &B = ctx->lut.brick;
+    const size_t row_bytes64 = (size_t)width * 8;
+    const bool three_pass64_ok = L.lds_ok && (size_t)src_stride == row_bytes64 && (size_t)dst_stride == row_bytes64 &&
+                                 (n_frames == 1 || (src_pitch == row_bytes64 * (size_t)height && dst_pitch == row_bytes64 * (size_t)height));
+    const bool pinned = ctx->lut_variant == 7 || !three_pass64_ok || ctx->brick_sets != 0;
+    int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : brick_choose(B);
+    if (level == 2 && !three_pass64_ok) level = 1;
+    if (level == 2 || pinned) brick_mark_unwatched(B);
+    if (level < 2) {
+      const int sets = pinned && ctx->brick_sets == 64 ? 64 : (level ? 64 : 32);
+      ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel<RGBA64> (64 sets)" : "colorlut3d_brick_kernel<RGBA64>";
+      int rc = pinned ? MI355_OK : brick_before_launch(ctx, B, level);
+      if (rc) return rc;
+      rc = brick_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, nullptr, sets, format == MI355_FMT_RGBA64_LE ? 1 : 2);
+      if (rc || pinned) return rc;
+      return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
+    }
+  }
+
   if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && L.is3d && L.lds_ok && !ctx->force_generic) {
     const size_t row_bytes = (size_t)width * 8;
     const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
