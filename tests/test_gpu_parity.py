@@ -747,9 +747,71 @@ def test_colorlut_rgba64_lds_kernel(ctx, oracle, synth, le, domain, size):
     src = (px if le else px.byteswap()).reshape(-1).view(np.uint8).copy()
     exp = np.zeros_like(src)
     oracle.colorlut_rgba64(cube, src, w * 8, exp, w * 8, w, h, le=le)
+    import mi355fx
     got = np.zeros_like(src)
-    ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, "RGBA64_LE" if le else "RGBA64_BE")
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 3)   # the three-pass kernel pinned (round 3: RGBA64 goes to the brick kernel first)
+    try:
+        ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, "RGBA64_LE" if le else "RGBA64_BE")
+        assert ctx.colorlut_kernel_name() == "colorlut3d_lds64_kernel"
+    finally:
+        ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
     assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+@pytest.mark.parametrize("le", [True, False])
+@pytest.mark.parametrize("size,domain", [(33, None), (17, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))), (2, None), (65, None)])
+@pytest.mark.parametrize("sets", [32, 64])
+def test_colorlut_rgba64_brick_kernel(ctx, oracle, synth, le, size, domain, sets):
+    """RGBA64 through the brick-cache kernel (round 3: x0 / t computed from the 16-bit sample instead of tabled, two pixels per
+    16-byte group): random 16-bit pixels - every step misses, fills, overflows - every channel value 0..65535 on ramps, and a
+    smooth picture (hits); both endiannesses, both cache geometries, LUT sizes 2..65, a non-unit domain, padded rows."""
+    import mi355fx
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(size, amp=0.06, domain=domain))
+    rng = np.random.default_rng(size + sets)
+    w, h = 1024, 400
+    px = rng.integers(0, 65536, size=(h * w, 4), dtype=np.uint16)
+    ramp = np.arange(65536, dtype=np.uint16)
+    px[:65536, 0] = ramp; px[:65536, 1] = ramp[::-1]; px[:65536, 2] = (ramp * 3) & 0xffff
+    px[65536:131072, :3] = ramp[:, None]
+    sm = synth.smooth_frame(w, 128, seed=3).reshape(128 * w, 4).astype(np.uint16)          # coherent content: cache hits
+    px[131072 * 2:131072 * 2 + 128 * w] = sm * 257 + rng.integers(0, 200, size=sm.shape, dtype=np.uint16)
+    ss, ds = w * 8 + 64, w * 8 + 16
+    src = np.zeros((h, ss), np.uint8)
+    src[:, :w * 8] = (px if le else px.byteswap()).reshape(h, w * 4).view(np.uint8)
+    src = src.reshape(-1)
+    exp = np.full(h * ds, 0xEE, np.uint8)
+    oracle.colorlut_rgba64(cube, src, ss, exp, ds, w, h, le=le)
+    got = np.full(h * ds, 0xEE, np.uint8)
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 7)
+    ctx.set_flag(mi355fx.FLAG_BRICK_SETS, sets)
+    try:
+        ctx.colorlut_frame(src, ss, got, ds, w, h, "RGBA64_LE" if le else "RGBA64_BE")
+        assert ctx.colorlut_kernel_name().startswith("colorlut3d_brick_kernel<RGBA64>")
+    finally:
+        ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
+        ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)
+    assert (got == exp).all(), _mismatch_report(got, exp)
+
+
+def test_colorlut_rgba64_content_watch(ctx, oracle, synth):
+    """default flags on RGBA64: coherent frames stay on the brick kernel, noise climbs to the three-pass 16-bit kernel, every
+    output exact on the way"""
+    cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
+    w, h = 1920, 270
+    rng = np.random.default_rng(4)
+    smooth = (synth.smooth_frame(w, h, seed=5).reshape(h * w, 4).astype(np.uint16) * 257).reshape(-1).view(np.uint8).copy()
+    noise = rng.integers(0, 65536, size=h * w * 4, dtype=np.uint16).view(np.uint8).copy()
+    seen = set()
+    for name, src, reps in (("smooth", smooth, 6), ("noise", noise, 40), ("smooth", smooth, 6)):
+        exp = np.zeros_like(src)
+        oracle.colorlut_rgba64(cube, src, w * 8, exp, w * 8, w, h, le=True)
+        for _ in range(reps):
+            got = np.zeros_like(src)
+            ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, "RGBA64_LE")
+            assert (got == exp).all(), (name, ctx.colorlut_kernel_name())
+            seen.add((name, ctx.colorlut_kernel_name()))
+    assert ("smooth", "colorlut3d_brick_kernel<RGBA64>") in seen
+    assert ("noise", "colorlut3d_lds64_kernel") in seen
 
 
 # ------------------------------------------------------------------ hsvfilter ! colorlut, one pass

@@ -24,6 +24,11 @@ for content in ("smooth", "noise"):
         ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
         mi355fx.warm_clocks(lambda: ctx.colorlut_frames_device(d_s, W * H * 8, W * 8, d_o, W * H * 8, W * 8, N, W, H, "RGBA64_LE"), ctx.synchronize)
         ms = min(ctx.time_colorlut_device(d_s, W * H * 8, W * 8, d_o, W * H * 8, W * 8, N, W, H, "RGBA64_LE", 30) for _ in range(3))
-        print("%-7s RGBA64_LE %-8s %.4f ms  %.0f GB/s (%.1f %% of 8 TB/s)" % (content, name, ms, 2 * nb / ms / 1e6, 2 * nb / ms / 8e7), flush=True)
+        print("%-7s RGBA64_LE %-8s %.4f ms  %.0f GB/s (%.1f %% of 8 TB/s)  [%s]" % (content, name, ms, 2 * nb / ms / 1e6, 2 * nb / ms / 8e7, ctx.colorlut_kernel_name()), flush=True)
+        if lut.is3d:  # the three-pass 16-bit kernel pinned, for comparison
+            ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 3)
+            ms = min(ctx.time_colorlut_device(d_s, W * H * 8, W * 8, d_o, W * H * 8, W * 8, N, W, H, "RGBA64_LE", 30) for _ in range(2))
+            print("%-7s RGBA64_LE %-8s %.4f ms  (%.1f %%)  [%s pinned]" % (content, name, ms, 2 * nb / ms / 8e7, ctx.colorlut_kernel_name()), flush=True)
+            ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
     ctx.free(d_s); ctx.free(d_o)
 ctx.close()
