@@ -69,6 +69,8 @@ def parse_args():
                     help="0 = the headline chain (default). 5 = BASELINE config 5: `--streams` concurrent 4K streams per GPU through the\n"
                          "videocompare SSIM (dssim) engine, one comparison per stream and step; prints its own JSON line (comparisons/s)")
     ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
+    ap.add_argument("--shared-reference", action="store_true",
+                    help="config 5: the streams are the non-reference pads of --workers videocompare elements (reference frame hashed once per aggregate)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST SCAFFOLDING, no GPU: tiny CPU frames and a fake context that sleeps instead of launching kernels, so that\n"
                          "the N>1 control flow (gloo group, barriers, MAX over ranks, aggregation, rank-0 JSON) can be exercised by the CPU\n"
@@ -275,9 +277,21 @@ def run_config5(args, rank, local_rank, world):
         frames.append((da, db))
     results = [0.0] * n_streams
 
+    shared_ref = bool(getattr(args, "shared_reference", False))
+
     def serve(w, steps):
         c = ctxs[w]
         for _ in range(steps):
+            if shared_ref:
+                # one videocompare element per worker: its reference pad's frame is hashed ONCE per aggregate, every other pad's
+                # frame is hashed and compared with it (videocompare/imp.rs:316-345) - the worker's streams are those pads
+                x = c.dssim_create_image_device(frames[w][0], W * 4, W, H)
+                for s in range(w, n_streams, n_workers):
+                    y = c.dssim_create_image_device(frames[s][1], W * 4, W, H)
+                    results[s] = c.dssim_compare(x, y)
+                    c.dssim_free_image(y)
+                c.dssim_free_image(x)
+                continue
             for s in range(w, n_streams, n_workers):
                 da, db = frames[s]
                 x = c.dssim_create_image_device(da, W * 4, W, H)
@@ -307,13 +321,16 @@ def run_config5(args, rank, local_rank, world):
         return {"comparisons_per_s": comps, "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "steps": args.steps,
                 "seconds": dt, "real_time_need": 30 * n_streams, "frac_of_hbm_peak": comps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_comparison": 2 * FRAME_BYTES, "dssim_of_stream_0": results[0],
-                "what": "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, hash both frames + compare per stream and step"}
+                "what": ("BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA; %d aggregators, each hashing its reference pad's frame once per "
+                         "step and hashing + comparing the frames of its %d other pads (videocompare/imp.rs:316-345)" % (n_workers, n_streams // n_workers)) if shared_ref else
+                        "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, one two-pad element per stream: hash both frames + compare per stream and step"}
     if rank == 0:
         algo = 2 * FRAME_BYTES  # two 4K RGBA frames read per comparison
         out = {"metric": "videocompare SSIM comparisons/sec, 32 concurrent 4K streams per GPU (BASELINE config 5)", "value": comps, "unit": "comparisons/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "videocompare hash-algorithm=dssim, 3840x2160 RGBA, hash both frames + compare per stream and step",
+               "config": {"workload": "videocompare hash-algorithm=dssim, 3840x2160 RGBA, " + ("streams = non-reference pads of %d aggregators: reference hashed once per step, every pad hashed + compared" % n_workers
+                                                                                                 if shared_ref else "hash both frames + compare per stream and step"),
                           "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "frames": "natural-like frame vs the same + N(0, 2) noise, resident",
                           "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process",
                           "real_time_need": "%d streams x 30 frames/s = %d comparisons/s per GPU" % (n_streams, 30 * n_streams)},
@@ -641,6 +658,11 @@ def main():
         leg_args = argparse.Namespace(**vars(args))
         leg_args.as_leg, leg_args.streams, leg_args.workers, leg_args.steps, leg_args.warmup = True, 32, 8, 48, 4
         config5 = run_config5(leg_args, rank, local_rank, 1)
+        # the same 32 streams as the non-reference pads of 4 videocompare elements (8 pads + one reference pad each): the element
+        # hashes its reference frame once per aggregate, so a comparison costs one hash + one compare (+ 1/8 of a hash)
+        leg_args = argparse.Namespace(**vars(leg_args))
+        leg_args.shared_reference, leg_args.workers = True, 4
+        config5["as_pads_of_four_aggregators"] = run_config5(leg_args, rank, local_rank, 1)
 
     if rank == 0:
         # dominant kernel = the longer of the two launches
