@@ -325,6 +325,11 @@ static GstFlowReturn gst_color_lut_transform_frame(GstVideoFilter *filter, GstVi
   }
   const int fmt = gst_mi355_format(GST_VIDEO_FRAME_FORMAT(in));
   if (fmt != MI355_FMT_RGBA && fmt != MI355_FMT_RGBA64_LE && fmt != MI355_FMT_RGBA64_BE) return GST_FLOW_NOT_NEGOTIATED;
+  if (gst_buffer_get_mi355_hsv_meta(in->buffer)) {
+    /* cannot happen: the fusion query is only answered while the pipeline exists, and this path only runs without one */
+    GST_ERROR_OBJECT(self, "buffer carries a deferred hsvfilter but the fused path is not available");
+    return GST_FLOW_ERROR;
+  }
   const int rc = mi355_colorlut_frame(self->ctx, GST_VIDEO_FRAME_PLANE_DATA(in, 0), GST_VIDEO_FRAME_PLANE_STRIDE(in, 0),
                                       GST_VIDEO_FRAME_PLANE_DATA(out, 0), GST_VIDEO_FRAME_PLANE_STRIDE(out, 0), GST_VIDEO_FRAME_WIDTH(in),
                                       GST_VIDEO_FRAME_HEIGHT(in), fmt);
