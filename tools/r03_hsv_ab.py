@@ -42,11 +42,14 @@ for tab in (1,):
         refill()
         ms = min(t(bufs[i % 4], st, fmt) for i in range(2))
         print("%-12s %s  %.4f ms  %.3f" % ("hue90", fmt, ms, 2 * fr.nbytes / ms / 1e6 / 8000), flush=True)
-# 3-byte formats: 8 x 4K RGB = 8 x 24.9 MB
+# 3-byte formats: 8 x 4K RGB = 8 x 24.9 MB, the natural-like frame without its alpha byte (not the RGBA bytes reinterpreted:
+# that would make every fourth "channel" random)
 n3 = W * H * 3
-refill()
+rgb = np.ascontiguousarray(np.stack([one.reshape(H, W, 4)[..., :3]] * B)).reshape(-1)
 for fmt in ("RGB", "BGR"):
-    ms = min(t(bufs[0], st, fmt, pitch=n3, stride=W * 3) for i in range(2))
+    ctx.h2d(bufs[0], rgb)
+    for _ in range(6): ctx.time_hsvfilter_device(bufs[3], B, W*H*4, W, H, W*4, "xBGR", st, 40)
+    ms = min(t(bufs[0], st, fmt, pitch=n3, stride=W * 3) for i in range(3))
     print("hue90 %s 8x4K  %.4f ms  %.3f" % (fmt, ms, 2 * 8 * n3 / ms / 1e6 / 8000), flush=True)
 # padded rows: 4K RGBA with stride 15,424 (64 B of padding per row), 8 frames
 stride = W * 4 + 64
