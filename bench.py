@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
     ap.add_argument("--shared-reference", action="store_true",
                     help="config 5: the streams are the non-reference pads of --workers videocompare elements (reference frame hashed once per aggregate)")
+    ap.add_argument("--dssim-two-step", action="store_true",
+                    help="config 5: hash every frame with mi355_dssim_create_image and compare the two images (the round-2 form) instead of\n"
+                         "hashing + comparing the non-reference frames in one pass (mi355_dssim_compare_frames)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST SCAFFOLDING, no GPU: tiny CPU frames and a fake context that sleeps instead of launching kernels, so that\n"
                          "the N>1 control flow (gloo group, barriers, MAX over ranks, aggregation, rank-0 JSON) can be exercised by the CPU\n"
@@ -278,6 +281,7 @@ def run_config5(args, rank, local_rank, world):
     results = [0.0] * n_streams
 
     shared_ref = bool(getattr(args, "shared_reference", False))
+    two_step = bool(getattr(args, "dssim_two_step", False))   # round-2 form: create_image for every frame, then compare
 
     def serve(w, steps):
         c = ctxs[w]
@@ -286,18 +290,27 @@ def run_config5(args, rank, local_rank, world):
                 # one videocompare element per worker: its reference pad's frame is hashed ONCE per aggregate, every other pad's
                 # frame is hashed and compared with it (videocompare/imp.rs:316-345) - the worker's streams are those pads
                 x = c.dssim_create_image_device(frames[w][0], W * 4, W, H)
-                for s in range(w, n_streams, n_workers):
-                    y = c.dssim_create_image_device(frames[s][1], W * 4, W, H)
-                    results[s] = c.dssim_compare(x, y)
-                    c.dssim_free_image(y)
+                pads = list(range(w, n_streams, n_workers))
+                if two_step:
+                    for s in pads:
+                        y = c.dssim_create_image_device(frames[s][1], W * 4, W, H)
+                        results[s] = c.dssim_compare(x, y)
+                        c.dssim_free_image(y)
+                else:   # the pads' frames are hashed and compared in one pass each, one synchronisation per aggregate
+                    for s, v in zip(pads, c.dssim_compare_frames_device(x, [frames[s][1] for s in pads], W * 4, W, H)):
+                        results[s] = v
                 c.dssim_free_image(x)
                 continue
             for s in range(w, n_streams, n_workers):
                 da, db = frames[s]
                 x = c.dssim_create_image_device(da, W * 4, W, H)
-                y = c.dssim_create_image_device(db, W * 4, W, H)
-                results[s] = c.dssim_compare(x, y)
-                c.dssim_free_image(x); c.dssim_free_image(y)
+                if two_step:
+                    y = c.dssim_create_image_device(db, W * 4, W, H)
+                    results[s] = c.dssim_compare(x, y)
+                    c.dssim_free_image(y)
+                else:
+                    results[s] = c.dssim_compare_frames_device(x, [db], W * 4, W, H)[0]
+                c.dssim_free_image(x)
 
     def run(steps):
         ts = [threading.Thread(target=serve, args=(w, steps)) for w in range(n_workers)]
@@ -330,11 +343,11 @@ def run_config5(args, rank, local_rank, world):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "videocompare hash-algorithm=dssim, 3840x2160 RGBA, " + ("streams = non-reference pads of %d aggregators: reference hashed once per step, every pad hashed + compared" % n_workers
-                                                                                                 if shared_ref else "hash both frames + compare per stream and step"),
+                                                                                                 if shared_ref else "hash the reference frame, hash + compare the other per stream and step"),
                           "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "frames": "natural-like frame vs the same + N(0, 2) noise, resident",
                           "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process",
                           "real_time_need": "%d streams x 30 frames/s = %d comparisons/s per GPU" % (n_streams, 30 * n_streams)},
-               "roofline": {"bound": "hbm", "kernel": "dssim_* (create_image x2 + compare)", "achieved": comps / world * algo / 1e9, "peak": HBM_PEAK_GBS,
+               "roofline": {"bound": "hbm", "kernel": "dssim_* (create_image + compare_frames)", "achieved": comps / world * algo / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": comps / world * algo / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "algorithmic_bytes_per_comparison": algo},
                "dssim_of_stream_0": results[0]}

@@ -148,6 +148,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   hrtf_release(ctx);
   sofa_release(ctx);
   echo_release(ctx);
+  if (ctx->host_copy_ev) (void)hipEventDestroy(ctx->host_copy_ev);
   for (int i = 0; i < 2; i++)
     if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -739,6 +740,12 @@ int mi355_dssim_create_image(mi355_ctx *ctx, const uint8_t *data, int stride, in
   if (rc) return rc;
   rc = check_hip(ctx, hipMemcpy2DAsync(ctx->d_stage[0], row, data, (size_t)stride, row, (size_t)height, hipMemcpyHostToDevice, ctx->stream), "dssim H2D");
   if (rc) return rc;
+  // The caller may reuse `data` as soon as this returns, and an "async" copy from pageable memory is not always finished with
+  // the host buffer when the call returns (seen with 2D copies of rows that are no multiple of 4 bytes): wait for the COPY -
+  // the kernels queued behind it stay asynchronous.
+  if (!ctx->host_copy_ev && (rc = check_hip(ctx, hipEventCreateWithFlags(&ctx->host_copy_ev, hipEventDisableTiming), "hipEventCreate"))) return rc;
+  if ((rc = check_hip(ctx, hipEventRecord(ctx->host_copy_ev, ctx->stream), "hipEventRecord"))) return rc;
+  if ((rc = check_hip(ctx, hipEventSynchronize(ctx->host_copy_ev), "dssim: wait for the frame upload"))) return rc;
   return dssim_create_image(ctx, (const uint8_t *)ctx->d_stage[0], (int)row, width, height, channels, out);
 }
 
@@ -753,6 +760,46 @@ int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original, const
   if (!original || !modified || !dssim) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null argument");
   BIND_DEVICE(ctx);
   return dssim_compare(ctx, original, modified, dssim);
+}
+
+int mi355_dssim_compare_frames_device(mi355_ctx *ctx, const mi355_dssim_image *original, const uint8_t *const *d_frames, int n_frames, int stride,
+                                      int width, int height, int format, double *dssim) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = dssim_channels(ctx, format, &channels);
+  if (rc) return rc;
+  if (!original || !d_frames || !dssim || n_frames < 0 || width <= 0 || height <= 0 || (size_t)stride < (size_t)width * channels)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: bad frames");
+  for (int f = 0; f < n_frames; f++)
+    if (!d_frames[f]) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null frame");
+  if (n_frames == 0) return MI355_OK;
+  BIND_DEVICE(ctx);
+  return dssim_compare_frames(ctx, original, d_frames, n_frames, stride, width, height, channels, dssim);
+}
+
+int mi355_dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *original, const uint8_t *const *frames, int n_frames, int stride, int width,
+                               int height, int format, double *dssim) {
+  REQUIRE_CTX(ctx);
+  int channels = 0;
+  int rc = dssim_channels(ctx, format, &channels);
+  if (rc) return rc;
+  if (!original || !frames || !dssim || n_frames < 0 || n_frames > 64 || width <= 0 || height <= 0 || (size_t)stride < (size_t)width * channels)
+    return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: bad frames");
+  for (int f = 0; f < n_frames; f++)
+    if (!frames[f]) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null frame");
+  if (n_frames == 0) return MI355_OK;
+  BIND_DEVICE(ctx);
+  const size_t row = (size_t)width * channels, frame_bytes = (row * (size_t)height + 255) & ~(size_t)255;
+  rc = ensure_stage(ctx, 0, frame_bytes * (size_t)n_frames);
+  if (rc) return rc;
+  const uint8_t *d_frames[64];
+  for (int f = 0; f < n_frames; f++) {
+    uint8_t *d = (uint8_t *)ctx->d_stage[0] + frame_bytes * (size_t)f;
+    rc = check_hip(ctx, hipMemcpy2DAsync(d, row, frames[f], (size_t)stride, row, (size_t)height, hipMemcpyHostToDevice, ctx->stream), "dssim H2D");
+    if (rc) return rc;
+    d_frames[f] = d;
+  }
+  return dssim_compare_frames(ctx, original, d_frames, n_frames, (int)row, width, height, channels, dssim);
 }
 
 int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind, float *out, int *width, int *height) {

@@ -219,10 +219,10 @@ __device__ __forceinline__ void dssim_blur_2x2(const float (&v)[4][4], float (&o
 // of 36), each output accumulated over its nine taps in the usual order. DUAL also produces the blur of the squares from
 // the same window (the squares are formed once per cell: the same values as squaring per tap).
 template <int M, bool DUAL>
-__device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, float *dst_sq) {
+__device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, float *dst_sq, int first_cell) {
   constexpr int cw = (kRw - 2 * M) / 2, ch = (kRh - 2 * M) / 2;
   static_assert((kRw - 2 * M) % 2 == 0 && (kRh - 2 * M) % 2 == 0, "even pass extents");
-  for (int e = threadIdx.x; e < cw * ch; e += 256) {
+  for (int e = first_cell; e < cw * ch; e += 256) {
     const int cy = e / cw, cx = e - cy * cw;
     const int ly = M + 2 * cy, lx = M + 2 * cx;
     const float *p = src + (ly - 1) * kRw + (lx - 1);
@@ -253,10 +253,9 @@ __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, flo
 
 struct DssimPlanes { float *img[3], *mu[3], *sq[3]; };
 
+// step 1 of a scale: LAB of every in-image cell of the region
 template <bool INTERIOR>
-__device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h, const DssimPlanes &O, float (*s_lab)[kRw * kRh], float *s_a,
-                                                 float *s_b, const float *s_lut, int x0, int y0) {
-  // 1. LAB of every in-image region cell
+__device__ __forceinline__ void dssim_lab_region(const DssimSrc &S, int w, int h, float (*s_lab)[kRw * kRh], const float *s_lut, int x0, int y0) {
   for (int e = threadIdx.x; e < kRw * kRh; e += 256) {
     const int ly = e / kRw, lx = e - ly * kRw;
     const int gx = x0 + lx, gy = y0 + ly;
@@ -279,20 +278,58 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
     }
     s_lab[0][e] = L; s_lab[1][e] = A; s_lab[2][e] = B;
   }
-  __syncthreads();
-  // 2. chroma pre-blur (two passes): valid on the region minus a margin of 2
+}
+
+// step 2: chroma pre-blur (two passes through s_a): the a / b planes are valid on the region minus a margin of 2 afterwards
+template <bool INTERIOR>
+__device__ __forceinline__ void dssim_chroma_preblur(float (*s_lab)[kRw * kRh], float *s_a, int x0, int y0, int w, int h) {
   for (int c = 1; c < 3; c++) {
-    if (INTERIOR) dssim_pass_2x2<1, false>(s_lab[c], s_a, nullptr);
+    if (INTERIOR) dssim_pass_2x2<1, false>(s_lab[c], s_a, nullptr, threadIdx.x);
     else dssim_region_pass<false, 1, INTERIOR>(s_lab[c], s_a, x0, y0, w, h);
     __syncthreads();
-    if (INTERIOR) dssim_pass_2x2<2, false>(s_a, s_lab[c], nullptr);
+    if (INTERIOR) dssim_pass_2x2<2, false>(s_a, s_lab[c], nullptr, threadIdx.x);
     else dssim_region_pass<false, 2, INTERIOR>(s_a, s_lab[c], x0, y0, w, h);
     __syncthreads();
   }
+}
+
+// the second blur pass for a lane's 2 x 2 block of TILE outputs (cell cx, cy of the 16 x 8 grid), from the first pass in LDS
+__device__ __forceinline__ void dssim_tile_pass2_2x2(const float *src, int cx, int cy, float (&o)[2][2]) {
+  const int j0 = (kHalo + 2 * cy - 1) * kRw + (kHalo + 2 * cx - 1);
+  float v[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[r][q] = src[j0 + r * kRw + q];
+  dssim_blur_2x2(v, o);
+}
+
+// the same for ONE tile pixel with per-pass edge replication in image coordinates (tiles that touch the image border)
+__device__ __forceinline__ float dssim_tile_pass2_px(const float *src, int gx, int gy, int x0, int y0, int w, int h) {
+  const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
+  float acc = 0.0f;
+#pragma unroll
+  for (int dyy = 0; dyy < 3; dyy++) {
+    int yy = gy + dyy - 1; yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+#pragma unroll
+    for (int dxx = 0; dxx < 3; dxx++) {
+      int xx = gx + dxx - 1; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      acc = acc + src[(yy - y0) * kRw + (xx - x0)] * K[dyy * 3 + dxx];
+    }
+  }
+  return acc;
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h, const DssimPlanes &O, float (*s_lab)[kRw * kRh], float *s_a,
+                                                 float *s_b, const float *s_lut, int x0, int y0) {
+  dssim_lab_region<INTERIOR>(S, w, h, s_lab, s_lut, x0, y0);
+  __syncthreads();
+  dssim_chroma_preblur<INTERIOR>(s_lab, s_a, x0, y0, w, h);
   // 3. per plane: img = plane (tile), mu = blur(plane), sq = blur(plane^2); margins 3 and 4
   for (int c = 0; c < 3; c++) {
     if (INTERIOR) {
-      dssim_pass_2x2<3, true>(s_lab[c], s_a, s_b);
+      dssim_pass_2x2<3, true>(s_lab[c], s_a, s_b, threadIdx.x);
     } else {
       dssim_region_pass<false, 3, INTERIOR>(s_lab[c], s_a, x0, y0, w, h);
       dssim_region_pass<true, 3, INTERIOR>(s_lab[c], s_b, x0, y0, w, h);
@@ -390,6 +427,18 @@ __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
 constexpr int kCh = 2, kCw = kTw + 2 * kCh, kChh = kTh + 2 * kCh;  // 36 x 20
 struct DssimCmp { const float *img1[3], *img2[3], *mu1[3], *mu2[3], *sq1[3], *sq2[3]; };
 
+// SSIM of one pixel from the channel-averaged moments (1 = original, 2 = modified)
+__device__ __forceinline__ float dssim_ssim_px(const float (&m1)[3], const float (&m2)[3], const float (&q1)[3], const float (&q2)[3], const float (&x12)[3]) {
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
+  const float mu1mu1 = ((m1[0] * m1[0] + m1[1] * m1[1]) + m1[2] * m1[2]) * third;
+  const float mu2mu2 = ((m2[0] * m2[0] + m2[1] * m2[1]) + m2[2] * m2[2]) * third;
+  const float mu1mu2 = ((m1[0] * m2[0] + m1[1] * m2[1]) + m1[2] * m2[2]) * third;
+  const float sig1 = (((q1[0] - m1[0] * m1[0]) + (q1[1] - m1[1] * m1[1])) + (q1[2] - m1[2] * m1[2])) * third;
+  const float sig2 = (((q2[0] - m2[0] * m2[0]) + (q2[1] - m2[1] * m2[1])) + (q2[2] - m2[2] * m2[2])) * third;
+  const float sig12 = (((x12[0] - m1[0] * m2[0]) + (x12[1] - m1[1] * m2[1])) + (x12[2] - m1[2] * m2[2])) * third;
+  return ((2.0f * mu1mu2 + c1) * (2.0f * sig12 + c2)) / (((mu1mu1 + mu2mu2) + c1) * ((sig1 + sig2) + c2));
+}
+
 template <bool INTERIOR>
 __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, int h, float *__restrict__ ssim_map, float (*s_p)[kCw * kChh],
                                                      float (*s_q)[kCw * kChh], int x0, int y0) {
@@ -450,7 +499,6 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
     }
   }
   __syncthreads();
-  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
   double dsum = 0.0;
   for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
     const int ly = kCh + e / kTw, lx = kCh + e - (e / kTw) * kTw;
@@ -474,13 +522,7 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
       float m1[3], m2[3], q1[3], q2[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) { m1[c] = P.mu1[c][i]; m2[c] = P.mu2[c][i]; q1[c] = P.sq1[c][i]; q2[c] = P.sq2[c][i]; }
-      const float mu1mu1 = ((m1[0] * m1[0] + m1[1] * m1[1]) + m1[2] * m1[2]) * third;
-      const float mu2mu2 = ((m2[0] * m2[0] + m2[1] * m2[1]) + m2[2] * m2[2]) * third;
-      const float mu1mu2 = ((m1[0] * m2[0] + m1[1] * m2[1]) + m1[2] * m2[2]) * third;
-      const float sig1 = (((q1[0] - m1[0] * m1[0]) + (q1[1] - m1[1] * m1[1])) + (q1[2] - m1[2] * m1[2])) * third;
-      const float sig2 = (((q2[0] - m2[0] * m2[0]) + (q2[1] - m2[1] * m2[1])) + (q2[2] - m2[2] * m2[2])) * third;
-      const float sig12 = (((x12[0] - m1[0] * m2[0]) + (x12[1] - m1[1] * m2[1])) + (x12[2] - m1[2] * m2[2])) * third;
-      const float ssim = ((2.0f * mu1mu2 + c1) * (2.0f * sig12 + c2)) / (((mu1mu1 + mu2mu2) + c1) * ((sig1 + sig2) + c2));
+      const float ssim = dssim_ssim_px(m1, m2, q1, q2, x12);
       ssim_map[i] = ssim;
       dsum += (double)ssim;
     }
@@ -499,6 +541,138 @@ __global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, in
                                                                              : dssim_compare_body<false>(P, w, h, ssim_map, s_p, s_q, x0, y0);
   const double t = dssim_block_sum(dsum, s_w);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ---- hash-and-compare in one pass (videocompare's per-aggregate loop, imp.rs:316-345: every non-reference pad's frame is
+// hashed, compared against the reference pad's image, and its hash is dropped). The MODIFIED frame's scale is converted and
+// blurred exactly as dssim_scale_fused_kernel does, but its img / mu / sq planes never leave the CU: the products with the
+// original's img plane, their two blur passes and the SSIM map of dssim_compare_fused_kernel follow in the same block. Per
+// scale that is 4 + 9 * 4 B/pixel read (bytes or float4, the original's nine planes, its img plane with a halo of 2) and
+// 4 B/pixel written (the SSIM map) instead of 36 written + 72 + 4 read and written again by the two-kernel form, under the
+// arithmetic of the scale kernel, which bounds it. Every value is produced by the operations of the two-kernel form in the
+// same order; the block partials are summed in the comparison kernel's pixel order, so the f64 scores are the same bits.
+struct DssimFusedJob { DssimSrc S; int w, h; const float *img1[3], *mu1[3], *sq1[3]; float *map; double *partial; };
+struct DssimFusedJobs { DssimFusedJob job[3]; unsigned first[4]; };
+
+template <bool INTERIOR>
+__device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float (*s_lab)[kRw * kRh], float *s_a, float *s_b, float *s_p,
+                                                   const float *s_lut, int x0, int y0) {
+  const int w = J.w, h = J.h;
+  dssim_lab_region<INTERIOR>(J.S, w, h, s_lab, s_lut, x0, y0);
+  __syncthreads();
+  dssim_chroma_preblur<INTERIOR>(s_lab, s_a, x0, y0, w, h);
+  constexpr int pw = kRw - 4, ph = kRh - 4;   // the products' region: the tile plus a halo of 2 (36 x 20)
+  double dsum = 0.0;
+  if (INTERIOR) {
+    // lanes 0..127 own a 2 x 2 block of tile outputs each (their moments stay in registers over the channel loop); while they
+    // run the second passes of mu / sq, lanes 128..255 run the first pass of the products
+    const bool owner = threadIdx.x < (kTw / 2) * (kTh / 2);
+    const int cy = (int)threadIdx.x / (kTw / 2), cx = (int)threadIdx.x - cy * (kTw / 2);
+    float mu2[3][2][2], sq2[3][2][2], x12[3][2][2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      // first pass of plane and squares; the products of the region (modified: s_lab, post pre-blur; original: from memory)
+      dssim_pass_2x2<3, true>(s_lab[c], s_a, s_b, threadIdx.x);
+      for (int e = threadIdx.x; e < pw * ph; e += 256) {
+        const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
+        s_p[ly * kRw + lx] = J.img1[c][(size_t)(y0 + ly) * w + (x0 + lx)] * s_lab[c][ly * kRw + lx];
+      }
+      if (c > 0 && owner) dssim_tile_pass2_2x2(s_lab[c - 1], cx, cy, x12[c - 1]);   // the previous channel's products, second pass
+      __syncthreads();
+      if (owner) {
+        dssim_tile_pass2_2x2(s_a, cx, cy, mu2[c]);
+        dssim_tile_pass2_2x2(s_b, cx, cy, sq2[c]);
+      }
+      // first pass of the products into s_lab[c] (the plane itself is not needed any more)
+      dssim_pass_2x2<3, false>(s_p, s_lab[c], nullptr, (threadIdx.x + 128) & 255);
+      __syncthreads();
+    }
+    if (owner) {
+      dssim_tile_pass2_2x2(s_lab[2], cx, cy, x12[2]);
+#pragma unroll
+      for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+        for (int ox = 0; ox < 2; ox++) {
+          const int ty = 2 * cy + oy, tx = 2 * cx + ox;
+          const size_t i = (size_t)(y0 + kHalo + ty) * w + (x0 + kHalo + tx);
+          float m1[3], q1[3], m2[3], q2[3], xx[3];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { m1[c] = J.mu1[c][i]; q1[c] = J.sq1[c][i]; m2[c] = mu2[c][oy][ox]; q2[c] = sq2[c][oy][ox]; xx[c] = x12[c][oy][ox]; }
+          const float ssim = dssim_ssim_px(m1, m2, q1, q2, xx);
+          J.map[i] = ssim;
+          s_p[ty * kTw + tx] = ssim;
+        }
+    }
+    __syncthreads();
+    // the block partial in the comparison kernel's order: lane t adds pixel t, then pixel t + 256 of the tile
+    for (int e = threadIdx.x; e < kTw * kTh; e += 256) dsum += (double)s_p[e];
+  } else {
+    // tiles that touch the image border: lane t owns tile pixels t and t + 256, every pass replicates edges in image coordinates
+    float mu2[3][2], sq2[3][2], x12[3][2];
+    int gx[2], gy[2];
+    bool in[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int e = (int)threadIdx.x + 256 * k;
+      gx[k] = x0 + kHalo + e % kTw; gy[k] = y0 + kHalo + e / kTw;
+      in[k] = gx[k] < w && gy[k] < h;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      dssim_region_pass<false, 3, false>(s_lab[c], s_a, x0, y0, w, h);
+      dssim_region_pass<true, 3, false>(s_lab[c], s_b, x0, y0, w, h);
+      for (int e = threadIdx.x; e < pw * ph; e += 256) {
+        const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
+        const int px = x0 + lx, py = y0 + ly;
+        const bool inside = px >= 0 && px < w && py >= 0 && py < h;
+        s_p[ly * kRw + lx] = inside ? J.img1[c][(size_t)py * w + px] * s_lab[c][ly * kRw + lx] : 0.0f;
+      }
+      if (c > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) x12[c - 1][k] = in[k] ? dssim_tile_pass2_px(s_lab[c - 1], gx[k], gy[k], x0, y0, w, h) : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        mu2[c][k] = in[k] ? dssim_tile_pass2_px(s_a, gx[k], gy[k], x0, y0, w, h) : 0.0f;
+        sq2[c][k] = in[k] ? dssim_tile_pass2_px(s_b, gx[k], gy[k], x0, y0, w, h) : 0.0f;
+      }
+      dssim_region_pass<false, 3, false>(s_p, s_lab[c], x0, y0, w, h);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (!in[k]) continue;
+      x12[2][k] = dssim_tile_pass2_px(s_lab[2], gx[k], gy[k], x0, y0, w, h);
+      const size_t i = (size_t)gy[k] * w + gx[k];
+      float m1[3], q1[3], m2[3], q2[3], xx[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { m1[c] = J.mu1[c][i]; q1[c] = J.sq1[c][i]; m2[c] = mu2[c][k]; q2[c] = sq2[c][k]; xx[c] = x12[c][k]; }
+      const float ssim = dssim_ssim_px(m1, m2, q1, q2, xx);
+      J.map[i] = ssim;
+      dsum += (double)ssim;
+    }
+  }
+  return dsum;
+}
+
+__global__ __launch_bounds__(256) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
+  __shared__ float s_lab[3][kRw * kRh];
+  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh], s_p[kRw * kRh];
+  __shared__ float s_lut[256];
+  __shared__ double s_w[4];
+  const int j = blockIdx.x >= JJ.first[2] ? 2 : (blockIdx.x >= JJ.first[1] ? 1 : 0);
+  const DssimFusedJob &J = JJ.job[j];
+  const unsigned tile = blockIdx.x - JJ.first[j];
+  if (J.S.u8) s_lut[threadIdx.x] = J.S.lut[threadIdx.x];
+  const int tiles_x = (J.w + kTw - 1) / kTw;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;
+  __syncthreads();
+  const double dsum = (x0 >= 0 && y0 >= 0 && x0 + kRw <= J.w && y0 + kRh <= J.h) ? dssim_fused_body<true>(J, s_lab, s_a, s_b, s_p, s_lut, x0, y0)
+                                                                               : dssim_fused_body<false>(J, s_lab, s_a, s_b, s_p, s_lut, x0, y0);
+  const double t = dssim_block_sum(dsum, s_w);
+  if (threadIdx.x == 0) J.partial[tile] = t;
 }
 
 // The reductions of all scales of a comparison run in three launches (one block per scale, or a block range per scale):
@@ -606,6 +780,36 @@ static int dssim_scratch(mi355_ctx *ctx, int slot, size_t bytes, void **out) {
   return MI355_OK;
 }
 
+// the sRGB -> linear table (uploaded once per context)
+static int dssim_gamma_table(mi355_ctx *ctx, DssimCache *cache) {
+  if (cache->d_lut) return MI355_OK;
+  float lut[256];
+  for (int i = 0; i < 256; i++) {
+    const double s = (double)i / 255.0;
+    lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
+  }
+  int rc = check_hip(ctx, hipMalloc((void **)&cache->d_lut, sizeof lut), "hipMalloc(dssim gamma table)");
+  if (rc) return rc;
+  if ((rc = check_hip(ctx, hipMemcpy(cache->d_lut, lut, sizeof lut, hipMemcpyHostToDevice), "dssim: gamma table"))) {
+    (void)hipFree(cache->d_lut);
+    cache->d_lut = nullptr;
+  }
+  return rc;
+}
+
+// the dssim value from the per-scale [sum, avg, dev] slots
+static double dssim_value_of(const mi355_dssim_image *a, const double *slots) {
+  double ssim_sum = 0.0, weight_sum = 0.0;
+  for (int k = 0; k < a->n_scales; k++) {
+    const double len = (double)a->s[k].w * (double)a->s[k].h;
+    const double score = 1.0 - slots[3 * k + 2] / len;
+    ssim_sum += score * kDssimWeights[k];
+    weight_sum += kDssimWeights[k];
+  }
+  const double total = ssim_sum / weight_sum;
+  return 1.0 / std::fmax(total, 2.220446049250313e-16) - 1.0;
+}
+
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img) {
   if (!img) return;
   // no host wait: the pool goes back to THIS context's free list and is handed out again by a later create_image on the same
@@ -659,15 +863,7 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     for (int k = 1; k < ns; k++) { lin[k] = q; q += (size_t)ws[k] * hs[k]; }
   }
   DssimCache *cache = dssim_cache(ctx);
-  if (!cache->d_lut) {
-    float lut[256];
-    for (int i = 0; i < 256; i++) {
-      const double s = (double)i / 255.0;
-      lut[i] = (float)(s <= 0.04045 ? s / 12.92 : std::pow((s + 0.055) / 1.055, 2.4));
-    }
-    if ((rc = check_hip(ctx, hipMalloc((void **)&cache->d_lut, sizeof lut), "hipMalloc(dssim gamma table)"))) { dssim_free_image(ctx, img); return rc; }
-    if ((rc = check_hip(ctx, hipMemcpy(cache->d_lut, lut, sizeof lut, hipMemcpyHostToDevice), "dssim: gamma table"))) { dssim_free_image(ctx, img); return rc; }
-  }
+  if ((rc = dssim_gamma_table(ctx, cache))) { dssim_free_image(ctx, img); return rc; }
   float *d_lut = cache->d_lut;
   // the downsampling chain first (scale 1 straight from the bytes), then the per-scale kernels: scales 0 and 1 on their
   // own, the small ones in one launch
@@ -778,15 +974,105 @@ int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_
   double slots[3 * kDssimScales];
   if ((rc = check_hip(ctx, hipMemcpyAsync(slots, d_slots, sizeof(double) * 3 * a->n_scales, hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
   if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
-  double ssim_sum = 0.0, weight_sum = 0.0;
-  for (int k = 0; k < a->n_scales; k++) {
-    const double len = (double)a->s[k].w * (double)a->s[k].h;
-    const double score = 1.0 - slots[3 * k + 2] / len;
-    ssim_sum += score * kDssimWeights[k];
-    weight_sum += kDssimWeights[k];
+  *out = dssim_value_of(a, slots);
+  return MI355_OK;
+}
+
+// videocompare's loop over the non-reference pads of one aggregate (imp.rs:316-345): frames[i] is hashed and compared against
+// `a` (the reference pad's image) in one pass per scale, nothing of frames[i] is kept. All frames are queued before the single
+// synchronisation that returns the values; the scratch (linear images, SSIM maps, partials) is shared in stream order.
+int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
+                         int channels, double *out) {
+  if (a->s[0].w != width || a->s[0].h != height) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: frame and image differ in size");
+  const int ns = a->n_scales;
+  if (n_frames > 64) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: at most 64 frames per call");
+  DssimRed R;
+  R.n_scales = ns;
+  size_t map_px = 0, n_pa = 0, lin_px = 0;
+  unsigned n_pb = 0;
+  unsigned tiles[kDssimScales];
+  for (int k = 0; k < ns; k++) {
+    const size_t n = (size_t)a->s[k].w * a->s[k].h;
+    tiles[k] = (unsigned)(((a->s[k].w + kTw - 1) / kTw) * ((a->s[k].h + kTh - 1) / kTh));
+    R.n[k] = n;
+    R.n_a[k] = tiles[k];
+    R.first_b[k] = n_pb;
+    R.len[k] = (double)n;
+    R.exponent[k] = std::pow(0.5, (double)k);
+    map_px += n + (n & 1);
+    n_pa += tiles[k];
+    n_pb += dssim_grid(ctx, n);
+    if (k > 0) lin_px += n;
   }
-  const double total = ssim_sum / weight_sum;
-  *out = 1.0 / std::fmax(total, 2.220446049250313e-16) - 1.0;
+  R.first_b[ns] = n_pb;
+  for (int k = ns; k < kDssimScales; k++) { R.n[k] = 0; R.n_a[k] = 0; R.first_b[k + 1] = n_pb; R.len[k] = 1.0; R.exponent[k] = 1.0; R.map[k] = nullptr; R.part_a[k] = nullptr; R.part_b[k] = nullptr; }
+  void *scr = nullptr;
+  const size_t lin_bytes = (lin_px + 16) * 16;
+  int rc = dssim_scratch(ctx, 1, lin_bytes + map_px * 4 + (n_pa + n_pb) * 8 + (size_t)n_frames * 3 * kDssimScales * 8 + 1024, &scr);
+  if (rc) return rc;
+  float4 *lin[kDssimScales] = {nullptr};
+  {
+    float4 *q = (float4 *)scr;
+    for (int k = 1; k < ns; k++) { lin[k] = q; q += (size_t)a->s[k].w * a->s[k].h; }
+  }
+  float *map = (float *)((char *)scr + lin_bytes);
+  double *d_pa = (double *)(map + map_px), *d_pb = d_pa + n_pa;
+  double *d_slots = d_pb + n_pb;  // per frame, per scale: [sum, avg, dev]
+  {
+    float *m = map;
+    double *pa = d_pa;
+    for (int k = 0; k < ns; k++) {
+      R.map[k] = m; m += R.n[k] + (R.n[k] & 1);
+      R.part_a[k] = pa; pa += tiles[k];
+      R.part_b[k] = d_pb + R.first_b[k];
+    }
+  }
+  DssimCache *cache = dssim_cache(ctx);
+  if ((rc = dssim_gamma_table(ctx, cache))) return rc;
+  float *d_lut = cache->d_lut;
+  for (int f = 0; f < n_frames; f++) {
+    const uint8_t *d_frame = d_frames[f];
+    for (int k = 1; k < ns; k++) {
+      const unsigned g = dssim_grid(ctx, R.n[k]);
+      if (k == 1) hipLaunchKernelGGL(dssim_downsample_u8_kernel, dim3(g), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin[1]);
+      else hipLaunchKernelGGL(dssim_downsample_kernel, dim3(g), dim3(256), 0, ctx->stream, (const float4 *)lin[k - 1], a->s[k - 1].w, a->s[k - 1].h, lin[k]);
+    }
+    auto job_of = [&](int k) {
+      DssimFusedJob j;
+      const DssimScale &s = a->s[k];
+      if (k == 0) { j.S.u8 = d_frame; j.S.stride = stride; j.S.channels = channels; j.S.lut = d_lut; j.S.lin = nullptr; }
+      else { j.S.u8 = nullptr; j.S.stride = 0; j.S.channels = 0; j.S.lut = nullptr; j.S.lin = lin[k]; }
+      j.S.pattern = (channels == 4 && !ctx->dssim_translucent) ? 1 : 0;
+      j.w = s.w; j.h = s.h;
+      for (int c = 0; c < 3; c++) { j.img1[c] = s.img[c]; j.mu1[c] = s.mu[c]; j.sq1[c] = s.sq[c]; }
+      j.map = (float *)R.map[k];
+      j.partial = (double *)R.part_a[k];
+      return j;
+    };
+    for (int k = 0; k < ns; ) {
+      DssimFusedJobs J;
+      const int count = k < 2 ? 1 : (ns - k < 3 ? ns - k : 3);
+      unsigned total = 0;
+      for (int j = 0; j < 3; j++) {
+        J.first[j] = total;
+        if (j < count) { J.job[j] = job_of(k + j); total += tiles[k + j]; }
+        else J.job[j] = J.job[0];
+      }
+      J.first[3] = total;
+      for (int j = count; j < 3; j++) J.first[j] = total;
+      hipLaunchKernelGGL(dssim_hash_compare_kernel, dim3(total), dim3(256), 0, ctx->stream, J);
+      k += count;
+    }
+    R.slots = d_slots + (size_t)f * 3 * kDssimScales;
+    hipLaunchKernelGGL(dssim_avg_kernel, dim3(ns), dim3(256), 0, ctx->stream, R);
+    hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb), dim3(256), 0, ctx->stream, R);
+    hipLaunchKernelGGL(dssim_sum_kernel, dim3(ns), dim3(256), 0, ctx->stream, R);
+  }
+  if ((rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch"))) return rc;
+  std::vector<double> slots((size_t)n_frames * 3 * kDssimScales);
+  if ((rc = check_hip(ctx, hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
+  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
+  for (int f = 0; f < n_frames; f++) out[f] = dssim_value_of(a, slots.data() + (size_t)f * 3 * kDssimScales);
   return MI355_OK;
 }
 

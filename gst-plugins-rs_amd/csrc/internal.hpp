@@ -102,7 +102,8 @@ struct mi355_ctx {
   int lut_stagger = 0;    // MI355_FLAG_LUT_STAGGER (x256 clock ticks)
   int brick_tiles_per_run = 0;  // MI355_FLAG_BRICK_TILES_PER_RUN (tuning; 0 = default)
   int brick_fold_axis = 2;      // MI355_FLAG_BRICK_FOLD_AXIS (accepted, ignored)
-  int dssim_translucent = 0;    // MI355_FLAG_DSSIM_TRANSLUCENT: 1 = treat alpha < 255 as premultiplied over black instead of refusing the frame
+  hipEvent_t host_copy_ev = nullptr;  // marks "the caller's host buffer has been read" for entry points that return before their kernels end
+  int dssim_translucent = 0;    // MI355_FLAG_DSSIM_TRANSLUCENT: 1 = alpha < 255 composed over black instead of over the crate's pattern
   int brick_prio = 3;           // MI355_FLAG_BRICK_PRIO: bit 0 progress-based wave priorities, bit 1 tile stealing within a block
   int brick_sets = 0;           // MI355_FLAG_BRICK_SETS: 0 = content watch decides (default); 32 (4x4x2 sets, 16 waves per CU) or 64 (4x4x4 sets, 8 waves per CU) pinned
   int hrtf_method = 0;         // MI355_FLAG_HRTF_METHOD: 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (takes effect at mi355_hrtf_setup)
@@ -172,6 +173,8 @@ void loudnorm_batch_release(mi355_ctx *ctx);
 int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int width, int height, int channels, mi355_dssim_image **out);
 void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);
+int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
+                         int channels, double *out);
 void dssim_release(mi355_ctx *ctx);
 int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, int channel, int kind, float *out, int *w, int *h);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);

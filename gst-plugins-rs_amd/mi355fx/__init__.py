@@ -144,6 +144,8 @@ def load_library():
         "mi355_dssim_create_image_device": (i, [vp, u8p, i, i, i, i, C.POINTER(vp)]),
         "mi355_dssim_free_image": (None, [vp, vp]),
         "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
+        "mi355_dssim_compare_frames": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
+        "mi355_dssim_compare_frames_device": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_sofa_setup": (i, [vp, i, i, i, i]),
         "mi355_sofa_set_filter": (i, [vp, i, f32p, f32p, i, i]),
@@ -456,6 +458,21 @@ class Context:
         out = np.zeros((h.value, w.value), np.float32)
         self._ck(self.L.mi355_dssim_image_plane(self.h, img, scale, channel, k, out.ctypes.data_as(C.POINTER(C.c_float)), None, None))
         return out
+
+    def dssim_compare_frames(self, original, frames, stride, width, height, fmt="RGBA"):
+        """videocompare's loop over the non-reference pads: hash + compare each host frame against `original` in one pass."""
+        n = len(frames)
+        ptrs = (C.c_void_p * max(n, 1))(*[f.ctypes.data for f in frames])
+        out = (C.c_double * max(n, 1))()
+        self._ck(self.L.mi355_dssim_compare_frames(self.h, original, ptrs, n, stride, width, height, FMT[fmt], out))
+        return [out[k] for k in range(n)]
+
+    def dssim_compare_frames_device(self, original, d_frames, stride, width, height, fmt="RGBA"):
+        n = len(d_frames)
+        ptrs = (C.c_void_p * max(n, 1))(*[int(d) for d in d_frames])
+        out = (C.c_double * max(n, 1))()
+        self._ck(self.L.mi355_dssim_compare_frames_device(self.h, original, ptrs, n, stride, width, height, FMT[fmt], out))
+        return [out[k] for k in range(n)]
 
     def dssim_compare(self, a, b):
         v = C.c_double(0)

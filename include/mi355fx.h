@@ -341,7 +341,8 @@ double mi355_videocompare_distance(int algo, uint64_t reference_hash, uint64_t f
  * format: MI355_FMT_RGB or MI355_FMT_RGBA. Translucent RGBA pixels (alpha < 255) are composed over dssim's coloured,
  * position-dependent background pattern (hashed_image.rs:54-55 -> create_image_rgba; written from memory of the crate:
  * parity unpinned like the rest of the engine; round 2 refused such frames); MI355_FLAG_DSSIM_TRANSLUCENT = 1 composes
- * them over black instead. create / free do not wait for the device; mi355_dssim_compare does (it returns the value). An
+ * them over black instead. create / free do not wait for the kernels (the host variant of create returns once `data` has
+ * been uploaded and may be reused); mi355_dssim_compare does (it returns the value). An
  * image is created, compared and freed through ONE context. */
 typedef struct mi355_dssim_image mi355_dssim_image;
 int mi355_dssim_create_image(mi355_ctx *ctx, const uint8_t *data, int stride, int width, int height,
@@ -351,6 +352,17 @@ int mi355_dssim_create_image_device(mi355_ctx *ctx, const uint8_t *d_frame, int 
 void mi355_dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *image);
 int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original,
                         const mi355_dssim_image *modified, double *dssim);
+/* videocompare's loop over the non-reference pads of one aggregate (videocompare/imp.rs:316-345: each pad's frame goes
+ * through HashedImage::new and HashedImage::compare against the reference pad's image, and its hash is dropped):
+ * `n_frames` (<= 64) frames of the original's size are hashed AND compared against `original` in one pass per scale - their
+ * DssimImages never reach memory - and dssim[i] receives what mi355_dssim_create_image + mi355_dssim_compare(original, .)
+ * return for frames[i], bit for bit. One synchronisation per call. `frames` is a host array of host pointers (of device
+ * pointers for the _device variant). */
+int mi355_dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *original, const uint8_t *const *frames,
+                               int n_frames, int stride, int width, int height, int format, double *dssim);
+int mi355_dssim_compare_frames_device(mi355_ctx *ctx, const mi355_dssim_image *original,
+                                      const uint8_t *const *d_frames, int n_frames, int stride, int width,
+                                      int height, int format, double *dssim);
 /* Diagnostics: one f32 plane of the image (kind 0 = LAB plane, 1 = mu, 2 = img_sq_blur) copied to `out` (may be NULL
  * to query the scale's size only). */
 int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind,

@@ -171,3 +171,84 @@ def test_config5_bench_leg_runs(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["unit"] == "comparisons/s" and d["value"] > 0 and d["config"]["streams_per_gpu"] == 32 and d["config"]["worker_contexts_per_gpu"] == 8
     assert d["roofline"]["bound"] == "hbm" and 0 < d["dssim_of_stream_0"] < 0.1
+
+
+@pytest.mark.parametrize("w,h,fmt", [(128, 96, "RGBA"), (322, 246, "RGBA"), (35, 20, "RGB"), (7, 50, "RGBA"), (1920, 1080, "RGBA"), (641, 363, "RGB"),
+                                     (3840, 2160, "RGBA")])
+def test_dssim_compare_frames_is_create_plus_compare_bit_for_bit(ctx, w, h, fmt):
+    """mi355_dssim_compare_frames (hash and compare in one pass, videocompare/imp.rs:316-345) returns the f64 bits of
+    mi355_dssim_create_image + mi355_dssim_compare for every frame of the call - interior tiles, border tiles, sizes below one
+    tile, fewer than five scales, RGB and RGBA, padded rows."""
+    ch = 4 if fmt == "RGBA" else 3
+    rng = np.random.default_rng(w * 7 + h)
+    smooth = np.kron(rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8, ch), dtype=np.uint8), np.ones((8, 8, 1), np.uint8))[:h, :w].reshape(h, w * ch)
+    stride = w * ch + 12
+    def padded(a):
+        p = np.zeros((h, stride), np.uint8); p[:, : w * ch] = a
+        return p
+    base = smooth.copy()
+    if ch == 4:
+        base[:, 3::4] = 255
+    frames = []
+    for amp in (0, 2, 25, 120):
+        f = np.clip(base.astype(int) + rng.integers(-amp, amp + 1, base.shape), 0, 255).astype(np.uint8)
+        if ch == 4:
+            f[:, 3::4] = 255 if amp != 25 else rng.integers(0, 256, (h, w), dtype=np.uint8)   # one translucent frame
+        frames.append(padded(f))
+    ref = ctx.dssim_create_image(padded(base), stride, w, h, fmt)
+    try:
+        two_step = []
+        for f in frames:
+            g = ctx.dssim_create_image(f, stride, w, h, fmt)
+            two_step.append(ctx.dssim_compare(ref, g))
+            ctx.dssim_free_image(g)
+        fused = ctx.dssim_compare_frames(ref, frames, stride, w, h, fmt)
+        assert fused == two_step, (fused, two_step)
+        assert fused[0] == 0.0
+        # one frame per call, and the reference's planes are untouched by the fused passes
+        assert ctx.dssim_compare_frames(ref, frames[2:3], stride, w, h, fmt) == two_step[2:3]
+        assert ctx.dssim_compare(ref, ref) == 0.0
+        assert ctx.dssim_compare_frames(ref, [], stride, w, h, fmt) == []
+    finally:
+        ctx.dssim_free_image(ref)
+
+
+def test_dssim_compare_frames_device_and_errors(ctx):
+    import mi355fx
+    w, h = 256, 144
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (h, w * 4), dtype=np.uint8); a[:, 3::4] = 255
+    b = rng.integers(0, 256, (h, w * 4), dtype=np.uint8); b[:, 3::4] = 255
+    ref = ctx.dssim_create_image(a, w * 4, w, h)
+    d = ctx.alloc(2 * a.nbytes)
+    try:
+        ctx.h2d(d, np.concatenate([a.reshape(-1), b.reshape(-1)]))
+        got = ctx.dssim_compare_frames_device(ref, [d, d + a.nbytes], w * 4, w, h)
+        assert got == ctx.dssim_compare_frames(ref, [a, b], w * 4, w, h)
+        assert got[0] == 0.0 and got[1] > 0.1
+        with pytest.raises(mi355fx.Mi355Error):
+            ctx.dssim_compare_frames(ref, [a[:, : 128 * 4].copy()], 128 * 4, 128, h)      # size differs from the original's
+        with pytest.raises(mi355fx.Mi355Error):
+            ctx.dssim_compare_frames(ref, [a], w * 4, w, h, "BGRx")
+    finally:
+        ctx.free(d); ctx.dssim_free_image(ref)
+
+
+@pytest.mark.parametrize("w,h,fmt", [(35, 20, "RGB"), (35, 20, "RGBA"), (641, 363, "RGB"), (1920, 1080, "RGBA")])
+def test_dssim_create_image_is_done_with_the_host_frame_when_it_returns(ctx, w, h, fmt):
+    """The element unmaps its buffer right after HashedImage::new: the host variant of create_image may not read `data` after
+    it has returned (round-3 regression: without the final wait the upload of a 105-byte-row frame was still in flight)."""
+    ch = 4 if fmt == "RGBA" else 3
+    rng = np.random.default_rng(w + h)
+    stride = w * ch + 4
+    frame = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    if ch == 4:
+        frame[:, 3: w * 4: 4] = 255
+    keep = frame.copy()
+    a = ctx.dssim_create_image(frame, stride, w, h, fmt)
+    frame[:] = 0                                            # the caller's buffer is recycled at once
+    b = ctx.dssim_create_image(keep, stride, w, h, fmt)
+    try:
+        assert ctx.dssim_compare(a, b) == 0.0
+    finally:
+        ctx.dssim_free_image(a); ctx.dssim_free_image(b)

@@ -29,10 +29,23 @@ def main():
     for _ in range(n):
         d = ctx.dssim_compare(x, y)
     t_cmp = (time.perf_counter() - t0) / n
+    for _ in range(10):
+        ctx.dssim_compare_frames_device(x, [db], w * 4, w, h)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        d1 = ctx.dssim_compare_frames_device(x, [db], w * 4, w, h)[0]
+    t_fused = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n // 8):
+        d8 = ctx.dssim_compare_frames_device(x, [db] * 8, w * 4, w, h)
+    t_fused8 = (time.perf_counter() - t0) / (n // 8) / 8
+    assert d1 == d and d8 == [d] * 8, (d, d1, d8)
     ctx.dssim_free_image(x); ctx.dssim_free_image(y)
     out = {"config": "videocompare hash-algo=dssim, 3840x2160 RGBA, device-resident frames", "dssim": d,
            "create_image_ms": t_create * 1e3, "compare_ms": t_cmp * 1e3,
-           "comparisons_per_s_per_stream_pair": 1.0 / (2 * t_create + t_cmp)}
+           "comparisons_per_s_per_stream_pair": 1.0 / (2 * t_create + t_cmp),
+           "hash_and_compare_ms": t_fused * 1e3, "hash_and_compare_ms_in_calls_of_8": t_fused8 * 1e3,
+           "comparisons_per_s_pair_fused": 1.0 / (t_create + t_fused), "comparisons_per_s_pads_of_one_reference": 1.0 / (t_create / 8 + t_fused8)}
     from oracle import dssim_restate as D
     ws, hs = 1920, 1080
     sa, sb = a[:hs, : ws * 4].copy(), b[:hs, : ws * 4].copy()
