@@ -802,6 +802,13 @@ int mi355_dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *original
   return dssim_compare_frames(ctx, original, d_frames, n_frames, (int)row, width, height, channels, dssim);
 }
 
+int mi355_selftest_dssim_cbrt(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches) {
+  REQUIRE_CTX(ctx);
+  if (!mismatches) return set_error(ctx, MI355_ERR_INVALID_ARG, "selftest: null argument");
+  BIND_DEVICE(ctx);
+  return dssim_cbrt_selftest(ctx, lo_bits, hi_bits, mismatches);
+}
+
 int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind, float *out, int *width, int *height) {
   REQUIRE_CTX(ctx);
   if (!image) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: null image");

@@ -97,19 +97,38 @@ __global__ __launch_bounds__(256) void dssim_downsample_u8_kernel(const uint8_t 
   }
 }
 
+// n / d, correctly rounded, for operands that need no range scaling. The compiler's IEEE division is this very sequence
+// (reciprocal, one Newton step on it, quotient, two residual corrections) bracketed by v_div_scale (which returns its
+// operand unchanged unless an exponent is near the ends of the range) and v_div_fixup (which passes the quotient through
+// unless an operand is zero, infinite, NaN or the result denormal): for the Halley steps below - numerator and denominator
+// in [2^-8, 2^3] - those three instructions do nothing, and leaving them out saves 3 of 11 VALU slots per division, six
+// divisions per LAB cell. mi355_selftest_dssim_cbrt replays every f32 in (216/24389, 2] through both forms.
+__device__ __forceinline__ float dssim_div_unscaled(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = n * r;
+  const float e2 = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e2, r, q);
+  const float e3 = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e3, r, q);
+}
+
+template <bool LITERAL = false>
 __device__ __forceinline__ float dssim_cbrt_poly(float x) {
   float y = (-0.5f * x + 1.51f) * x + 0.2f;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const float y3 = y * y * y;
-    y = y * (y3 + 2.0f * x) / (2.0f * y3 + x);
+    const float num = y * (y3 + 2.0f * x), den = 2.0f * y3 + x;
+    y = LITERAL ? num / den : dssim_div_unscaled(num, den);
   }
   return y;
 }
 
 __device__ __forceinline__ float dssim_f(float t) {
   const float eps = 216.0f / 24389.0f, kk = 24389.0f / (27.0f * 116.0f);
-  return t > eps ? dssim_cbrt_poly(t) - 16.0f / 116.0f : kk * t;
+  return t > eps ? dssim_cbrt_poly<>(t) - 16.0f / 116.0f : kk * t;
 }
 
 // ---- fused per-scale kernel: LAB conversion, chroma pre-blur and the mu / sq blurs of all three planes in one pass
@@ -118,7 +137,16 @@ __device__ __forceinline__ float dssim_f(float t) {
 // applied PER PASS as in the unfused form: an out-of-image neighbour of pass k reads pass k-1's value at the clamped
 // coordinate (always inside the tile's region because the region contains the border pixel), never a value computed
 // at a virtual position. Arithmetic and tap order are those of dssim_blur_kernel, so the planes are bit-identical.
-constexpr int kTw = 32, kTh = 16, kHalo = 4;
+#ifndef DSSIM_TW
+#define DSSIM_TW 32
+#define DSSIM_TH 16
+#define DSSIM_NT 256
+#endif
+constexpr int kTw = DSSIM_TW, kTh = DSSIM_TH, kHalo = 4;
+constexpr int kNt = DSSIM_NT;                      // lanes of a tile block
+constexpr int kOwners = (kTw / 2) * (kTh / 2);     // lanes that own a 2 x 2 block of tile outputs in the register-tiled passes
+constexpr int kPpl = (kTw * kTh) / kNt;            // tile pixels per lane in the per-pixel passes
+static_assert((kTw * kTh) % kNt == 0 && kOwners <= kNt && kNt % 64 == 0 && kNt >= 256, "tile geometry");
 constexpr int kRw = kTw + 2 * kHalo, kRh = kTh + 2 * kHalo;  // 40 x 24 region
 
 struct DssimSrc {          // source of the scale's linear RGB
@@ -159,7 +187,7 @@ template <bool SQ, int M, bool INTERIOR>
 __device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, int x0, int y0, int w, int h) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
   constexpr int rw = kRw - 2 * M, rh = kRh - 2 * M;
-  for (int e = threadIdx.x; e < rw * rh; e += 256) {
+  for (int e = threadIdx.x; e < rw * rh; e += kNt) {
     const int ly = M + e / rw, lx = M + e - (e / rw) * rw;
     float acc = 0.0f;
     if (INTERIOR) {
@@ -222,7 +250,7 @@ template <int M, bool DUAL>
 __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, float *dst_sq, int first_cell) {
   constexpr int cw = (kRw - 2 * M) / 2, ch = (kRh - 2 * M) / 2;
   static_assert((kRw - 2 * M) % 2 == 0 && (kRh - 2 * M) % 2 == 0, "even pass extents");
-  for (int e = first_cell; e < cw * ch; e += 256) {
+  for (int e = first_cell; e < cw * ch; e += kNt) {
     const int cy = e / cw, cx = e - cy * cw;
     const int ly = M + 2 * cy, lx = M + 2 * cx;
     const float *p = src + (ly - 1) * kRw + (lx - 1);
@@ -256,7 +284,7 @@ struct DssimPlanes { float *img[3], *mu[3], *sq[3]; };
 // step 1 of a scale: LAB of every in-image cell of the region
 template <bool INTERIOR>
 __device__ __forceinline__ void dssim_lab_region(const DssimSrc &S, int w, int h, float (*s_lab)[kRw * kRh], const float *s_lut, int x0, int y0) {
-  for (int e = threadIdx.x; e < kRw * kRh; e += 256) {
+  for (int e = threadIdx.x; e < kRw * kRh; e += kNt) {
     const int ly = e / kRw, lx = e - ly * kRw;
     const int gx = x0 + lx, gy = y0 + ly;
     float L = 0, A = 0, B = 0;
@@ -265,7 +293,7 @@ __device__ __forceinline__ void dssim_lab_region(const DssimSrc &S, int w, int h
       if (S.u8) {
         const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
         if (S.channels == 4) {
-          const float a = (float)p[3] / 255.0f; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
+          const float a = s_lut[256 + p[3]]; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
           if (S.pattern) dssim_pattern(r, g, b, a, gx, gy);
         }
         else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
@@ -338,7 +366,7 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
     // second passes straight to global for the tile cells
     const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
     if (INTERIOR) {
-      for (int e = threadIdx.x; e < (kTw / 2) * (kTh / 2); e += 256) {
+      for (int e = threadIdx.x; e < (kTw / 2) * (kTh / 2); e += kNt) {
         const int cy = e / (kTw / 2), cx = e - cy * (kTw / 2);
         const int ly = kHalo + 2 * cy, lx = kHalo + 2 * cx;
         const int j0 = (ly - 1) * kRw + (lx - 1);
@@ -361,7 +389,7 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
           }
       }
     } else
-    for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
+    for (int e = threadIdx.x; e < kTw * kTh; e += kNt) {
       const int ly = kHalo + e / kTw, lx = kHalo + e - (e / kTw) * kTw;
       const int gx = x0 + lx, gy = y0 + ly;
       if (INTERIOR || (gx < w && gy < h)) {
@@ -394,16 +422,16 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
 struct DssimScaleJob { DssimSrc S; int w, h; DssimPlanes O; };
 struct DssimScaleJobs { DssimScaleJob job[3]; unsigned first[4]; };
 
-__global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimScaleJobs J) {
+__global__ __launch_bounds__(kNt) void dssim_scale_fused_kernel(DssimScaleJobs J) {
   __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
   __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
-  __shared__ float s_lut[256];
+  __shared__ float s_lut[512];   // [0, 256): sRGB -> linear; [256, 512): alpha byte / 255 (the IEEE quotient, once per block instead of per cell)
   const int j = blockIdx.x >= J.first[2] ? 2 : (blockIdx.x >= J.first[1] ? 1 : 0);
   const DssimSrc &S = J.job[j].S;
   const DssimPlanes &O = J.job[j].O;
   const int w = J.job[j].w, h = J.job[j].h;
   const unsigned tile = blockIdx.x - J.first[j];
-  if (S.u8) s_lut[threadIdx.x] = S.lut[threadIdx.x];
+  if (S.u8 && threadIdx.x < 256) { s_lut[threadIdx.x] = S.lut[threadIdx.x]; s_lut[256 + threadIdx.x] = (float)threadIdx.x / 255.0f; }
   const int tiles_x = (w + kTw - 1) / kTw;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;  // image coords of region cell (0,0)
@@ -412,12 +440,17 @@ __global__ __launch_bounds__(256) void dssim_scale_fused_kernel(DssimScaleJobs J
   else dssim_scale_body<false>(S, w, h, O, s_lab, s_a, s_b, s_lut, x0, y0);
 }
 
+template <int NW = 4>
 __device__ __forceinline__ double dssim_block_sum(double v, double *s_w) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = 0.0;
-  if (threadIdx.x == 0) t = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+  if (threadIdx.x == 0) {
+    t = s_w[0];
+#pragma unroll
+    for (int k = 1; k < NW; k++) t = t + s_w[k];   // wave order, left to right
+  }
   __syncthreads();
   return t;
 }
@@ -443,7 +476,7 @@ template <bool INTERIOR>
 __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, int h, float *__restrict__ ssim_map, float (*s_p)[kCw * kChh],
                                                      float (*s_q)[kCw * kChh], int x0, int y0) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
-  for (int e = threadIdx.x; e < kCw * kChh; e += 256) {
+  for (int e = threadIdx.x; e < kCw * kChh; e += kNt) {
     const int ly = e / kCw, lx = e - ly * kCw;
     const int gx = x0 + lx, gy = y0 + ly;
     const bool in = INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h);
@@ -456,7 +489,7 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
   if (INTERIOR) {
     constexpr int cw = (kCw - 2) / 2, ch = (kChh - 2) / 2;
     static_assert((kCw - 2) % 2 == 0 && (kChh - 2) % 2 == 0, "even pass extents");
-    for (int e = threadIdx.x; e < cw * ch; e += 256) {
+    for (int e = threadIdx.x; e < cw * ch; e += kNt) {
       const int cy = e / cw, cx = e - cy * cw;
       const int ly = 1 + 2 * cy, lx = 1 + 2 * cx;
       const int j0 = (ly - 1) * kCw + (lx - 1);
@@ -476,7 +509,7 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
       }
     }
   } else
-  for (int e = threadIdx.x; e < (kCw - 2) * (kChh - 2); e += 256) {
+  for (int e = threadIdx.x; e < (kCw - 2) * (kChh - 2); e += kNt) {
     const int ly = 1 + e / (kCw - 2), lx = 1 + e - (e / (kCw - 2)) * (kCw - 2);
     const int gx = x0 + lx, gy = y0 + ly;
     if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
@@ -500,7 +533,7 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
   }
   __syncthreads();
   double dsum = 0.0;
-  for (int e = threadIdx.x; e < kTw * kTh; e += 256) {
+  for (int e = threadIdx.x; e < kTw * kTh; e += kNt) {
     const int ly = kCh + e / kTw, lx = kCh + e - (e / kTw) * kTw;
     const int gx = x0 + lx, gy = y0 + ly;
     if (INTERIOR || (gx < w && gy < h)) {
@@ -530,16 +563,16 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
   return dsum;
 }
 
-__global__ __launch_bounds__(256) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
+__global__ __launch_bounds__(kNt) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
   __shared__ float s_p[3][kCw * kChh];   // products img1*img2 of the region
   __shared__ float s_q[3][kCw * kChh];   // first blur pass
-  __shared__ double s_w[4];
+  __shared__ double s_w[kNt / 64];
   const int tiles_x = (w + kTw - 1) / kTw;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int x0 = tx * kTw - kCh, y0 = ty * kTh - kCh;
   const double dsum = (x0 >= 0 && y0 >= 0 && x0 + kCw <= w && y0 + kChh <= h) ? dssim_compare_body<true>(P, w, h, ssim_map, s_p, s_q, x0, y0)
                                                                              : dssim_compare_body<false>(P, w, h, ssim_map, s_p, s_q, x0, y0);
-  const double t = dssim_block_sum(dsum, s_w);
+  const double t = dssim_block_sum<kNt / 64>(dsum, s_w);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
@@ -565,15 +598,15 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
   double dsum = 0.0;
   if (INTERIOR) {
     // lanes 0..127 own a 2 x 2 block of tile outputs each (their moments stay in registers over the channel loop); while they
-    // run the second passes of mu / sq, lanes 128..255 run the first pass of the products
-    const bool owner = threadIdx.x < (kTw / 2) * (kTh / 2);
+    // run the second passes of mu / sq, the other lanes (if the block has any) start the first pass of the products
+    const bool owner = threadIdx.x < kOwners;
     const int cy = (int)threadIdx.x / (kTw / 2), cx = (int)threadIdx.x - cy * (kTw / 2);
     float mu2[3][2][2], sq2[3][2][2], x12[3][2][2];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       // first pass of plane and squares; the products of the region (modified: s_lab, post pre-blur; original: from memory)
       dssim_pass_2x2<3, true>(s_lab[c], s_a, s_b, threadIdx.x);
-      for (int e = threadIdx.x; e < pw * ph; e += 256) {
+      for (int e = threadIdx.x; e < pw * ph; e += kNt) {
         const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
         s_p[ly * kRw + lx] = J.img1[c][(size_t)(y0 + ly) * w + (x0 + lx)] * s_lab[c][ly * kRw + lx];
       }
@@ -584,7 +617,7 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
         dssim_tile_pass2_2x2(s_b, cx, cy, sq2[c]);
       }
       // first pass of the products into s_lab[c] (the plane itself is not needed any more)
-      dssim_pass_2x2<3, false>(s_p, s_lab[c], nullptr, (threadIdx.x + 128) & 255);
+      dssim_pass_2x2<3, false>(s_p, s_lab[c], nullptr, kOwners < kNt ? (int)(threadIdx.x + kNt - kOwners) % kNt : (int)threadIdx.x);
       __syncthreads();
     }
     if (owner) {
@@ -604,16 +637,16 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
         }
     }
     __syncthreads();
-    // the block partial in the comparison kernel's order: lane t adds pixel t, then pixel t + 256 of the tile
-    for (int e = threadIdx.x; e < kTw * kTh; e += 256) dsum += (double)s_p[e];
+    // the block partial in the comparison kernel's order: lane t adds pixels t, t + kNt, ... of the tile
+    for (int e = threadIdx.x; e < kTw * kTh; e += kNt) dsum += (double)s_p[e];
   } else {
-    // tiles that touch the image border: lane t owns tile pixels t and t + 256, every pass replicates edges in image coordinates
-    float mu2[3][2], sq2[3][2], x12[3][2];
-    int gx[2], gy[2];
-    bool in[2];
+    // tiles that touch the image border: lane t owns tile pixels t, t + kNt, ..., every pass replicates edges in image coordinates
+    float mu2[3][kPpl], sq2[3][kPpl], x12[3][kPpl];
+    int gx[kPpl], gy[kPpl];
+    bool in[kPpl];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const int e = (int)threadIdx.x + 256 * k;
+    for (int k = 0; k < kPpl; k++) {
+      const int e = (int)threadIdx.x + kNt * k;
       gx[k] = x0 + kHalo + e % kTw; gy[k] = y0 + kHalo + e / kTw;
       in[k] = gx[k] < w && gy[k] < h;
     }
@@ -621,7 +654,7 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
     for (int c = 0; c < 3; c++) {
       dssim_region_pass<false, 3, false>(s_lab[c], s_a, x0, y0, w, h);
       dssim_region_pass<true, 3, false>(s_lab[c], s_b, x0, y0, w, h);
-      for (int e = threadIdx.x; e < pw * ph; e += 256) {
+      for (int e = threadIdx.x; e < pw * ph; e += kNt) {
         const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
         const int px = x0 + lx, py = y0 + ly;
         const bool inside = px >= 0 && px < w && py >= 0 && py < h;
@@ -629,11 +662,11 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
       }
       if (c > 0) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) x12[c - 1][k] = in[k] ? dssim_tile_pass2_px(s_lab[c - 1], gx[k], gy[k], x0, y0, w, h) : 0.0f;
+        for (int k = 0; k < kPpl; k++) x12[c - 1][k] = in[k] ? dssim_tile_pass2_px(s_lab[c - 1], gx[k], gy[k], x0, y0, w, h) : 0.0f;
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
+      for (int k = 0; k < kPpl; k++) {
         mu2[c][k] = in[k] ? dssim_tile_pass2_px(s_a, gx[k], gy[k], x0, y0, w, h) : 0.0f;
         sq2[c][k] = in[k] ? dssim_tile_pass2_px(s_b, gx[k], gy[k], x0, y0, w, h) : 0.0f;
       }
@@ -641,7 +674,7 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
       __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kPpl; k++) {
       if (!in[k]) continue;
       x12[2][k] = dssim_tile_pass2_px(s_lab[2], gx[k], gy[k], x0, y0, w, h);
       const size_t i = (size_t)gy[k] * w + gx[k];
@@ -656,22 +689,22 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
   return dsum;
 }
 
-__global__ __launch_bounds__(256) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
+__global__ __launch_bounds__(kNt) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
   __shared__ float s_lab[3][kRw * kRh];
   __shared__ float s_a[kRw * kRh], s_b[kRw * kRh], s_p[kRw * kRh];
-  __shared__ float s_lut[256];
-  __shared__ double s_w[4];
+  __shared__ float s_lut[512];
+  __shared__ double s_w[kNt / 64];
   const int j = blockIdx.x >= JJ.first[2] ? 2 : (blockIdx.x >= JJ.first[1] ? 1 : 0);
   const DssimFusedJob &J = JJ.job[j];
   const unsigned tile = blockIdx.x - JJ.first[j];
-  if (J.S.u8) s_lut[threadIdx.x] = J.S.lut[threadIdx.x];
+  if (J.S.u8 && threadIdx.x < 256) { s_lut[threadIdx.x] = J.S.lut[threadIdx.x]; s_lut[256 + threadIdx.x] = (float)threadIdx.x / 255.0f; }
   const int tiles_x = (J.w + kTw - 1) / kTw;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * kTw - kHalo, y0 = ty * kTh - kHalo;
   __syncthreads();
   const double dsum = (x0 >= 0 && y0 >= 0 && x0 + kRw <= J.w && y0 + kRh <= J.h) ? dssim_fused_body<true>(J, s_lab, s_a, s_b, s_p, s_lut, x0, y0)
                                                                                : dssim_fused_body<false>(J, s_lab, s_a, s_b, s_p, s_lut, x0, y0);
-  const double t = dssim_block_sum(dsum, s_w);
+  const double t = dssim_block_sum<kNt / 64>(dsum, s_w);
   if (threadIdx.x == 0) J.partial[tile] = t;
 }
 
@@ -894,7 +927,7 @@ int dssim_create_image(mi355_ctx *ctx, const uint8_t *d_frame, int stride, int w
     }
     J.first[3] = total;
     for (int j = count; j < 3; j++) J.first[j] = total;  // empty ranges
-    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(total), dim3(256), 0, ctx->stream, J);
+    hipLaunchKernelGGL(dssim_scale_fused_kernel, dim3(total), dim3(kNt), 0, ctx->stream, J);
     k += count;
   }
   rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch");
@@ -965,7 +998,7 @@ int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_
     for (int c = 0; c < 3; c++) {
       P.img1[c] = s1.img[c]; P.img2[c] = s2.img[c]; P.mu1[c] = s1.mu[c]; P.mu2[c] = s2.mu[c]; P.sq1[c] = s1.sq[c]; P.sq2[c] = s2.sq[c];
     }
-    hipLaunchKernelGGL(dssim_compare_fused_kernel, dim3(tiles[k]), dim3(256), 0, ctx->stream, P, s1.w, s1.h, (float *)R.map[k], (double *)R.part_a[k]);
+    hipLaunchKernelGGL(dssim_compare_fused_kernel, dim3(tiles[k]), dim3(kNt), 0, ctx->stream, P, s1.w, s1.h, (float *)R.map[k], (double *)R.part_a[k]);
   }
   hipLaunchKernelGGL(dssim_avg_kernel, dim3(a->n_scales), dim3(256), 0, ctx->stream, R);
   hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb), dim3(256), 0, ctx->stream, R);
@@ -1060,7 +1093,7 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
       }
       J.first[3] = total;
       for (int j = count; j < 3; j++) J.first[j] = total;
-      hipLaunchKernelGGL(dssim_hash_compare_kernel, dim3(total), dim3(256), 0, ctx->stream, J);
+      hipLaunchKernelGGL(dssim_hash_compare_kernel, dim3(total), dim3(kNt), 0, ctx->stream, J);
       k += count;
     }
     R.slots = d_slots + (size_t)f * 3 * kDssimScales;
@@ -1074,6 +1107,31 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
   if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
   for (int f = 0; f < n_frames; f++) out[f] = dssim_value_of(a, slots.data() + (size_t)f * 3 * kDssimScales);
   return MI355_OK;
+}
+
+// every f32 with bits in [lo_bits, hi_bits]: the cube root with the trimmed division against the one with the compiler's
+__global__ __launch_bounds__(256) void dssim_cbrt_selftest_kernel(uint32_t lo_bits, uint64_t count, unsigned long long *mismatches) {
+  unsigned long long bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+    const float x = __uint_as_float(lo_bits + (uint32_t)i);
+    bad += __float_as_uint(dssim_cbrt_poly<false>(x)) != __float_as_uint(dssim_cbrt_poly<true>(x));
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+int dssim_cbrt_selftest(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches) {
+  if (hi_bits < lo_bits) return set_error(ctx, MI355_ERR_INVALID_ARG, "selftest: empty range");
+  unsigned long long *d = nullptr;
+  int rc = check_hip(ctx, hipMalloc((void **)&d, 8), "hipMalloc(selftest)");
+  if (rc) return rc;
+  (void)hipMemsetAsync(d, 0, 8, ctx->stream);
+  hipLaunchKernelGGL(dssim_cbrt_selftest_kernel, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, lo_bits, (uint64_t)(hi_bits - lo_bits) + 1, d);
+  unsigned long long h = 0;
+  rc = check_hip(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream), "selftest D2H");
+  if (!rc) rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "selftest sync");
+  (void)hipFree(d);
+  *mismatches = h;
+  return rc;
 }
 
 }  // namespace mi355

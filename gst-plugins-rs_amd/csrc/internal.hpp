@@ -175,6 +175,7 @@ void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);
 int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
                          int channels, double *out);
+int dssim_cbrt_selftest(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 void dssim_release(mi355_ctx *ctx);
 int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, int channel, int kind, float *out, int *w, int *h);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);

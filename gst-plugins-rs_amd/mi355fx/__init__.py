@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "libmi355fx.so")
+LIB_PATH = os.environ.get("MI355FX_LIB") or os.path.join(PKG_ROOT, "libmi355fx.so")   # MI355FX_LIB: an experimental build (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "mi355fx.h")
 
 # mi355_video_format
@@ -146,6 +146,7 @@ def load_library():
         "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
         "mi355_dssim_compare_frames": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
         "mi355_dssim_compare_frames_device": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
+        "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_sofa_setup": (i, [vp, i, i, i, i]),
         "mi355_sofa_set_filter": (i, [vp, i, f32p, f32p, i, i]),
@@ -473,6 +474,13 @@ class Context:
         out = (C.c_double * max(n, 1))()
         self._ck(self.L.mi355_dssim_compare_frames_device(self.h, original, ptrs, n, stride, width, height, FMT[fmt], out))
         return [out[k] for k in range(n)]
+
+    def selftest_dssim_cbrt(self, lo, hi):
+        """Mismatches between the kernels' cube root and the literal one over every f32 in [lo, hi] (both > 0)."""
+        n = C.c_uint64(0)
+        lo_bits, hi_bits = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
+        self._ck(self.L.mi355_selftest_dssim_cbrt(self.h, lo_bits, hi_bits, C.byref(n)))
+        return n.value
 
     def dssim_compare(self, a, b):
         v = C.c_double(0)

@@ -363,6 +363,10 @@ int mi355_dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *original
 int mi355_dssim_compare_frames_device(mi355_ctx *ctx, const mi355_dssim_image *original,
                                       const uint8_t *const *d_frames, int n_frames, int stride, int width,
                                       int height, int format, double *dssim);
+/* Device self test of the LAB conversion's cube root: for every f32 whose bit pattern lies in [lo_bits, hi_bits], the
+ * Halley iteration with the range-restricted division the kernels use against the same iteration with the compiler's IEEE
+ * division; *mismatches = how many differ in any bit (0 over (216/24389, 2], the whole domain of the conversion). */
+int mi355_selftest_dssim_cbrt(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 /* Diagnostics: one f32 plane of the image (kind 0 = LAB plane, 1 = mu, 2 = img_sq_blur) copied to `out` (may be NULL
  * to query the scale's size only). */
 int mi355_dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *image, int scale, int channel, int kind,

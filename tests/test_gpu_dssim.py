@@ -252,3 +252,11 @@ def test_dssim_create_image_is_done_with_the_host_frame_when_it_returns(ctx, w, 
         assert ctx.dssim_compare(a, b) == 0.0
     finally:
         ctx.dssim_free_image(a); ctx.dssim_free_image(b)
+
+
+def test_dssim_cube_root_with_trimmed_division_over_its_whole_domain(ctx):
+    """The LAB conversion divides without v_div_scale / v_div_fixup (csrc/dssim_kernels.hip: dssim_div_unscaled). Every f32 the
+    conversion can feed the cube root - (216/24389, 1.0x] - and an octave beyond goes through both forms: no bit differs."""
+    eps = np.nextafter(np.float32(216.0 / 24389.0), np.float32(1))
+    assert ctx.selftest_dssim_cbrt(eps, 2.0) == 0
+    assert ctx.selftest_dssim_cbrt(2.0, 64.0) == 0          # far beyond what an image can produce
