@@ -247,7 +247,7 @@ def source_fingerprint():
 def run_config5(args, rank, local_rank, world):
     """BASELINE config 5: 256 concurrent 4K streams through videocompare's SSIM engine = 32 streams per GPU. Every stream is a
     pair of resident 4K RGBA frames (the natural-like frame and the same frame + noise of sigma 2, SURVEY.md 8d synthetic (8));
-    a step = one comparison per stream the way HasherEngine does it (hash_image of both frames, then compare:
+    a step = one comparison per stream the way the element does it (hash_image of the reference frame; the other frame hashed and compared,
     video/videofx/src/videocompare/hashed_image.rs:24-79). The streams are independent and sharded over the ranks; `--workers`
     host threads per rank, each with its own context and HIP stream, take the rank's streams in turn (the calls release the
     GIL and return a double, so a context is busy until its comparison is done). Timing: gloo barrier + MAX over ranks."""
@@ -336,7 +336,7 @@ def run_config5(args, rank, local_rank, world):
                 "algorithmic_bytes_per_comparison": 2 * FRAME_BYTES, "dssim_of_stream_0": results[0],
                 "what": ("BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA; %d aggregators, each hashing its reference pad's frame once per "
                          "step and hashing + comparing the frames of its %d other pads (videocompare/imp.rs:316-345)" % (n_workers, n_streams // n_workers)) if shared_ref else
-                        "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, one two-pad element per stream: hash both frames + compare per stream and step"}
+                        "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, one two-pad element per stream: hash the reference frame, hash + compare the other in one pass per stream and step"}
     if rank == 0:
         algo = 2 * FRAME_BYTES  # two 4K RGBA frames read per comparison
         out = {"metric": "videocompare SSIM comparisons/sec, 32 concurrent 4K streams per GPU (BASELINE config 5)", "value": comps, "unit": "comparisons/s",

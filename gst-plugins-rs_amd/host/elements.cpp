@@ -1143,6 +1143,9 @@ FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames,
     mi355_dssim_image *ref_img = nullptr;
     int rc = mi355_dssim_create_image(ctx_, ref.data, ref.stride, ref.width, ref.height, ref.format, &ref_img);
     if (rc != MI355_OK) return flow_from_status(rc);
+    // every other pad's frame is hashed and compared in one pass (mi355_dssim_compare_frames): one call for the whole
+    // aggregate when the pads share stride and format, one call per pad otherwise
+    bool uniform = true;
     for (size_t k = 1; k < frames.size(); k++) {
       const VideoFrame &f = frames[k];
       if (!f.data) { mi355_dssim_free_image(ctx_, ref_img); return FlowReturn::Ok; }
@@ -1151,13 +1154,23 @@ FlowReturn VideoCompare::aggregate_frames(const std::vector<VideoFrame> &frames,
         last_error_ = "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)";
         return FlowReturn::NotNegotiated;
       }
-      mi355_dssim_image *img = nullptr;
-      rc = mi355_dssim_create_image(ctx_, f.data, f.stride, f.width, f.height, f.format, &img);
+      uniform = uniform && f.stride == frames[1].stride && f.format == frames[1].format;
+    }
+    const size_t n_other = frames.size() - 1;
+    std::vector<const uint8_t *> ptrs(n_other);
+    std::vector<double> dist(n_other, 0.0);
+    for (size_t k = 0; k < n_other; k++) ptrs[k] = frames[k + 1].data;
+    if (uniform && n_other > 0 && n_other <= 64) {
+      rc = mi355_dssim_compare_frames(ctx_, ref_img, ptrs.data(), (int)n_other, frames[1].stride, ref.width, ref.height, frames[1].format, dist.data());
+    } else {
+      for (size_t k = 0; k < n_other && rc == MI355_OK; k++)
+        rc = mi355_dssim_compare_frames(ctx_, ref_img, &ptrs[k], 1, frames[k + 1].stride, ref.width, ref.height, frames[k + 1].format, &dist[k]);
+    }
+    if (rc != MI355_OK) { mi355_dssim_free_image(ctx_, ref_img); return flow_from_status(rc); }
+    for (size_t k = 0; k < n_other; k++) {
       VideoCompareMessage::PadDistance pd;
-      pd.pad = "sink_" + std::to_string(k);
-      if (rc == MI355_OK) rc = mi355_dssim_compare(ctx_, ref_img, img, &pd.distance);
-      mi355_dssim_free_image(ctx_, img);
-      if (rc != MI355_OK) { mi355_dssim_free_image(ctx_, ref_img); return flow_from_status(rc); }
+      pd.pad = "sink_" + std::to_string(k + 1);
+      pd.distance = dist[k];
       m.pad_distances.push_back(pd);
     }
     mi355_dssim_free_image(ctx_, ref_img);
