@@ -97,6 +97,8 @@ __global__ __launch_bounds__(256) void dssim_downsample_u8_kernel(const uint8_t 
   }
 }
 
+typedef float dssim_f2 __attribute__((ext_vector_type(2)));   // a pair of f32 in an even-aligned register pair: v_pk_* = two IEEE operations
+
 // n / d, correctly rounded, for operands that need no range scaling. The compiler's IEEE division is this very sequence
 // (reciprocal, one Newton step on it, quotient, two residual corrections) bracketed by v_div_scale (which returns its
 // operand unchanged unless an exponent is near the ends of the range) and v_div_fixup (which passes the quotient through
@@ -129,6 +131,41 @@ __device__ __forceinline__ float dssim_cbrt_poly(float x) {
 __device__ __forceinline__ float dssim_f(float t) {
   const float eps = 216.0f / 24389.0f, kk = 24389.0f / (27.0f * 116.0f);
   return t > eps ? dssim_cbrt_poly<>(t) - 16.0f / 116.0f : kk * t;
+}
+
+// The same for two values at once (the same channel of two neighbouring cells): every operation of dssim_cbrt_poly /
+// dssim_div_unscaled as its packed-f32 twin (v_pk_mul / v_pk_add / v_pk_fma: one IEEE operation per element, nothing fused
+// that the scalar form does not fuse), the two reciprocals scalar. Half the VALU slots per cube root.
+__device__ __forceinline__ dssim_f2 dssim_pk_fma(dssim_f2 a, dssim_f2 b, dssim_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ dssim_f2 dssim_div_unscaled2(dssim_f2 n, dssim_f2 d) {
+  dssim_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const dssim_f2 one = {1.0f, 1.0f};
+  const dssim_f2 e = dssim_pk_fma(-d, r, one);
+  r = dssim_pk_fma(e, r, r);
+  dssim_f2 q = n * r;
+  const dssim_f2 e2 = dssim_pk_fma(-d, q, n);
+  q = dssim_pk_fma(e2, r, q);
+  const dssim_f2 e3 = dssim_pk_fma(-d, q, n);
+  return dssim_pk_fma(e3, r, q);
+}
+__device__ __forceinline__ dssim_f2 dssim_cbrt_poly2(dssim_f2 x) {
+  dssim_f2 y = (-0.5f * x + 1.51f) * x + 0.2f;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const dssim_f2 y3 = y * y * y;
+    const dssim_f2 num = y * (y3 + 2.0f * x), den = 2.0f * y3 + x;
+    y = dssim_div_unscaled2(num, den);
+  }
+  return y;
+}
+// both branches for both elements (the cube-root branch is finite for every t >= 0), then a per-element select
+__device__ __forceinline__ dssim_f2 dssim_f_pair(dssim_f2 t) {
+  const float eps = 216.0f / 24389.0f, kk = 24389.0f / (27.0f * 116.0f);
+  const dssim_f2 cb = dssim_cbrt_poly2(t) - 16.0f / 116.0f, lin = kk * t;
+  dssim_f2 o;
+  o.x = t.x > eps ? cb.x : lin.x;
+  o.y = t.y > eps ? cb.y : lin.y;
+  return o;
 }
 
 // ---- fused per-scale kernel: LAB conversion, chroma pre-blur and the mu / sq blurs of all three planes in one pass
@@ -179,6 +216,18 @@ __device__ __forceinline__ void dssim_lab_px(float r, float g, float b, float &L
   B = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
 }
 
+// two cells at once: element k of every pair belongs to cell k; the operations per element are those of dssim_lab_px
+__device__ __forceinline__ void dssim_lab_px2(dssim_f2 r, dssim_f2 g, dssim_f2 b, dssim_f2 &L, dssim_f2 &A, dssim_f2 &B) {
+  const float dx = 0.9505f, dy = 1.0f, dz = 1.089f;
+  const dssim_f2 fx = (r * (0.4124f / dx) + g * (0.3576f / dx)) + b * (0.1805f / dx);
+  const dssim_f2 fy = (r * (0.2126f / dy) + g * (0.7152f / dy)) + b * (0.0722f / dy);
+  const dssim_f2 fz = (r * (0.0193f / dz) + g * (0.1192f / dz)) + b * (0.9505f / dz);
+  const dssim_f2 X = dssim_f_pair(fx), Y = dssim_f_pair(fy), Z = dssim_f_pair(fz);
+  L = Y * 1.05f;
+  A = (500.0f / 220.0f) * (X - Y) + 86.2f / 220.0f;
+  B = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
+}
+
 // one 3x3 pass inside the LDS region: dst(lx,ly) for region coords in [M, kRw-M) x [M, kRh-M), reading src with
 // per-pass edge replication in IMAGE coordinates. SQ: square the input on the fly. INTERIOR (block-uniform: the whole
 // region lies inside the image) drops the clamps and the in-image test - the per-tap coordinate arithmetic was ~80 % of
@@ -224,7 +273,6 @@ __device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, 
 // The 3 x 3 blur of a 2 x 2 block of outputs from its 4 x 4 window, the two outputs of a row as one packed-f32 pair:
 // v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations per instruction (never fused: -ffp-contract=off), so every output is
 // accumulated over its nine taps in the same order, with the same roundings, as the scalar loop - in half the instructions.
-typedef float dssim_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dssim_blur_2x2(const float (&v)[4][4], float (&o)[2][2]) {
   const float K[9] = {0.095332f, 0.118095f, 0.095332f, 0.118095f, 0.146293f, 0.118095f, 0.095332f, 0.118095f, 0.095332f};
 #pragma unroll
@@ -282,26 +330,46 @@ __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, flo
 struct DssimPlanes { float *img[3], *mu[3], *sq[3]; };
 
 // step 1 of a scale: LAB of every in-image cell of the region
+// linear r, g, b of one in-image cell (gamma table, premultiplication, background pattern)
+__device__ __forceinline__ void dssim_linear_px(const DssimSrc &S, int w, const float *s_lut, int gx, int gy, float &r, float &g, float &b) {
+  if (S.u8) {
+    const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
+    if (S.channels == 4) {
+      const float a = s_lut[256 + p[3]]; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
+      if (S.pattern && a != 1.0f) dssim_pattern(r, g, b, a, gx, gy);   // a == 1 adds + 0.0f to values >= + 0: skipped, same bits
+    }
+    else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
+  } else {
+    const float4 v = S.lin[(size_t)gy * w + gx];
+    r = v.x; g = v.y; b = v.z;
+    if (S.pattern && v.w != 1.0f) dssim_pattern(r, g, b, v.w, gx, gy);
+  }
+}
+
 template <bool INTERIOR>
 __device__ __forceinline__ void dssim_lab_region(const DssimSrc &S, int w, int h, float (*s_lab)[kRw * kRh], const float *s_lut, int x0, int y0) {
+  if (INTERIOR) {
+    // two horizontally adjacent cells per step, their cube roots as packed pairs; the region's rows are even, so a pair never
+    // straddles two rows and the three results go to LDS as 8-byte words
+    static_assert(kRw % 2 == 0, "pairs of cells per row");
+    for (int e = threadIdx.x; e < kRw * kRh / 2; e += kNt) {
+      const int ly = e / (kRw / 2), lx = 2 * (e - ly * (kRw / 2));
+      float r0, g0, b0, r1, g1, b1;
+      dssim_linear_px(S, w, s_lut, x0 + lx, y0 + ly, r0, g0, b0);
+      dssim_linear_px(S, w, s_lut, x0 + lx + 1, y0 + ly, r1, g1, b1);
+      dssim_f2 L, A, B;
+      dssim_lab_px2(dssim_f2{r0, r1}, dssim_f2{g0, g1}, dssim_f2{b0, b1}, L, A, B);
+      *(dssim_f2 *)&s_lab[0][2 * e] = L; *(dssim_f2 *)&s_lab[1][2 * e] = A; *(dssim_f2 *)&s_lab[2][2 * e] = B;
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < kRw * kRh; e += kNt) {
     const int ly = e / kRw, lx = e - ly * kRw;
     const int gx = x0 + lx, gy = y0 + ly;
     float L = 0, A = 0, B = 0;
     if (INTERIOR || (gx >= 0 && gx < w && gy >= 0 && gy < h)) {
       float r, g, b;
-      if (S.u8) {
-        const uint8_t *p = S.u8 + (size_t)gy * S.stride + (size_t)gx * S.channels;
-        if (S.channels == 4) {
-          const float a = s_lut[256 + p[3]]; r = s_lut[p[0]] * a; g = s_lut[p[1]] * a; b = s_lut[p[2]] * a;
-          if (S.pattern) dssim_pattern(r, g, b, a, gx, gy);
-        }
-        else { r = s_lut[p[0]]; g = s_lut[p[1]]; b = s_lut[p[2]]; }
-      } else {
-        const float4 v = S.lin[(size_t)gy * w + gx];
-        r = v.x; g = v.y; b = v.z;
-        if (S.pattern) dssim_pattern(r, g, b, v.w, gx, gy);
-      }
+      dssim_linear_px(S, w, s_lut, gx, gy, r, g, b);
       dssim_lab_px(r, g, b, L, A, B);
     }
     s_lab[0][e] = L; s_lab[1][e] = A; s_lab[2][e] = B;
@@ -1109,12 +1177,16 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
   return MI355_OK;
 }
 
-// every f32 with bits in [lo_bits, hi_bits]: the cube root with the trimmed division against the one with the compiler's
+// every f32 with bits in [lo_bits, hi_bits]: the cube root with the trimmed division, scalar and packed, against the one with the compiler's
 __global__ __launch_bounds__(256) void dssim_cbrt_selftest_kernel(uint32_t lo_bits, uint64_t count, unsigned long long *mismatches) {
   unsigned long long bad = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
     const float x = __uint_as_float(lo_bits + (uint32_t)i);
-    bad += __float_as_uint(dssim_cbrt_poly<false>(x)) != __float_as_uint(dssim_cbrt_poly<true>(x));
+    const uint32_t lit = __float_as_uint(dssim_cbrt_poly<true>(x));
+    bad += __float_as_uint(dssim_cbrt_poly<false>(x)) != lit;
+    // the packed form: x in either element, an unrelated value in the other
+    const dssim_f2 p0 = dssim_cbrt_poly2(dssim_f2{x, 0.731f}), p1 = dssim_cbrt_poly2(dssim_f2{0.0123f, x});
+    bad += __float_as_uint(p0.x) != lit || __float_as_uint(p1.y) != lit;
   }
   if (bad) atomicAdd(mismatches, bad);
 }
