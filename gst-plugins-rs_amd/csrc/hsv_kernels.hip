@@ -348,10 +348,19 @@ __global__ __launch_bounds__(256) void hsvdetect_rows_kernel(const uint8_t *__re
   }
 }
 
-// FAST detector kernel: 4-byte input formats on contiguous storage, 4 pixels per lane. Valid for
-// hue_ref in [-180,180] (finite): shifted = hue + (180 - hue_ref) lies in [0,720), so the reference's
-// `if shifted < 0` never fires and `% 360` is one conditional exact subtraction.
-template <int IN_FIRST, bool IN_BGR>
+// FAST detector kernel: 4-byte input formats on contiguous storage, 4 pixels per lane. Two classes of the offset
+// off = 180 - hue_ref (hsvdetector/imp.rs:140-144: shifted = hue + off; if shifted < 0 { shifted += 360 }; shifted %= 360):
+//   NEG = false, off in [0, 360] (hue_ref in [-180, 180]): shifted lies in [0, 720), the `< 0` test never fires and `% 360`
+//         is one conditional exact subtraction;
+//   NEG = true, off in [-360, 0) (hue_ref in (180, 540], i.e. every hue on the usual 0..360 dial): shifted lies in
+//         [-360, 360); negative values get + 360 (one rounding, as in the reference) and land in [0, 360], where `% 360` only
+//         turns an exact 360 into 0; non-negative values are below 360 and `% 360` keeps them.
+__device__ __forceinline__ f2 hsvdetect_shifted(f2 h, float off, bool neg) {
+  const f2 t = h + splat2(off);
+  return sub360_if_reached2(neg ? add360_if_negative2(t) : t);
+}
+
+template <int IN_FIRST, bool IN_BGR, bool NEG = false>
 __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_vec,
                                                              HsvDetK k, uint32_t out_sel) {
   constexpr int RPOS = IN_FIRST + (IN_BGR ? 2 : 0), GPOS = IN_FIRST + 1, BPOS = IN_FIRST + (IN_BGR ? 0 : 2);
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__rest
     for (int j = 0; j < 4; j += 2) {
       f2 h, s, v;
       hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS, 1>(in[j], in[j + 1], h, s, v, &lds);
-      const f2 sh = sub360_if_reached2(h + splat2(off));
+      const f2 sh = hsvdetect_shifted(h, off, NEG);
       const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = v - splat2(k.val_ref);
       const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
       const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(256) void hsvdetect_flat_kernel(const uint4 *__rest
 
 // Same for the 3-byte input formats (RGB / BGR): one lane reads 12 B = 4 pixels as three dwords, splits them into four
 // pixel words (byte 3 = scratch) and writes 16 B.
-template <bool IN_BGR>
+template <bool IN_BGR, bool NEG = false>
 __global__ __launch_bounds__(256) void hsvdetect_rgb24_kernel(const Rgb24x4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_grp, HsvDetK k,
                                                               uint32_t out_sel) {
   constexpr int RPOS = IN_BGR ? 2 : 0, GPOS = 1, BPOS = IN_BGR ? 0 : 2;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(256) void hsvdetect_rgb24_kernel(const Rgb24x4 *__r
     for (int j = 0; j < 4; j += 2) {
       f2 h, s, vv;
       hsv_from_rgb_pair_fast<RPOS, GPOS, BPOS, 1>(in[j], in[j + 1], h, s, vv, &lds);
-      const f2 sh = sub360_if_reached2(h + splat2(off));
+      const f2 sh = hsvdetect_shifted(h, off, NEG);
       const f2 dh = sh - splat2(180.0f), dsat = s - splat2(k.sat_ref), dv = vv - splat2(k.val_ref);
       const bool hit0 = fabsf(dh.x) <= k.hue_var && fabsf(dsat.x) <= k.sat_var && fabsf(dv.x) <= k.val_var;
       const bool hit1 = fabsf(dh.y) <= k.hue_var && fabsf(dsat.y) <= k.sat_var && fabsf(dv.y) <= k.val_var;
@@ -421,7 +430,9 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
   const size_t row_bytes = (size_t)width * 4;
   const bool contiguous = sfmt.pixel_stride == 4 && (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
                           (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
-  const bool fast = !ctx->force_generic && s.hue_ref >= -180.0f && s.hue_ref <= 180.0f;
+  const float off = 180.0f - s.hue_ref;   // as the kernels (and the reference) compute it
+  const bool fast = !ctx->force_generic && off >= -360.0f && off <= 360.0f;
+  const bool neg = off < 0.0f;
   if (fast && contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && ((total * 4) % 16 == 0)) {
     // output byte j: colour channel c sits at input byte in_pos(c); alpha comes from operand 1 byte 0
     const int in_pos[3] = {sfmt.first + (sfmt.bgr ? 2 : 0), sfmt.first + 1, sfmt.first + (sfmt.bgr ? 0 : 2)};  // R,G,B
@@ -436,10 +447,16 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
     dim3 g(fgrid), b(256);
     const uint4 *sp = (const uint4 *)d_src;
     uint4 *dp = (uint4 *)d_dst;
-    if (sfmt.first == 0 && !sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<0, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
-    else if (sfmt.first == 0 && sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<0, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
-    else if (sfmt.first == 1 && !sfmt.bgr) hipLaunchKernelGGL((hsvdetect_flat_kernel<1, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
-    else hipLaunchKernelGGL((hsvdetect_flat_kernel<1, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);
+#define MI355_DET_LAUNCH(F, B)                                                                                              \
+    do {                                                                                                                    \
+      if (neg) hipLaunchKernelGGL((hsvdetect_flat_kernel<F, B, true>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);       \
+      else hipLaunchKernelGGL((hsvdetect_flat_kernel<F, B, false>), g, b, 0, ctx->stream, sp, dp, n_vec, k, sel);          \
+    } while (0)
+    if (sfmt.first == 0 && !sfmt.bgr) MI355_DET_LAUNCH(0, false);
+    else if (sfmt.first == 0 && sfmt.bgr) MI355_DET_LAUNCH(0, true);
+    else if (sfmt.first == 1 && !sfmt.bgr) MI355_DET_LAUNCH(1, false);
+    else MI355_DET_LAUNCH(1, true);
+#undef MI355_DET_LAUNCH
     return check_hip(ctx, hipGetLastError(), "hsvdetect flat kernel launch");
   }
   const size_t row3 = (size_t)width * 3;
@@ -455,8 +472,10 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
     }
     const size_t n_grp = total / 4;
     const int fgrid = grid_for(ctx, n_grp, 256, 64);
-    if (sfmt.bgr) hipLaunchKernelGGL((hsvdetect_rgb24_kernel<true>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
-    else hipLaunchKernelGGL((hsvdetect_rgb24_kernel<false>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    if (sfmt.bgr && neg) hipLaunchKernelGGL((hsvdetect_rgb24_kernel<true, true>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    else if (sfmt.bgr) hipLaunchKernelGGL((hsvdetect_rgb24_kernel<true, false>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    else if (neg) hipLaunchKernelGGL((hsvdetect_rgb24_kernel<false, true>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
+    else hipLaunchKernelGGL((hsvdetect_rgb24_kernel<false, false>), dim3(fgrid), dim3(256), 0, ctx->stream, (const Rgb24x4 *)d_src, (uint4 *)d_dst, n_grp, k, sel);
     return check_hip(ctx, hipGetLastError(), "hsvdetect rgb24 kernel launch");
   }
   const int grid = grid_for(ctx, total, 256, 32);

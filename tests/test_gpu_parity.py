@@ -636,11 +636,13 @@ def test_echo_not_negotiated(ctx):
     (0.0, 10.0, 0.0, 0.15, 0.0, 0.3),            # defaults (hsvdetector/imp.rs:25-30)
     (120.0, 40.0, 0.8, 0.5, 0.7, 0.6),
     (-180.0, 180.0, 0.5, 0.5, 0.5, 0.5), (180.0, 1.0, 1.0, 0.25, 1.0, 0.25), (-0.0, 0.0, 0.0, 1.0, 0.0, 1.0),
-    (359.0, 15.0, 0.5, 0.4, 0.5, 0.4), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5),   # outside [-180,180]: literal kernel
+    (359.0, 15.0, 0.5, 0.4, 0.5, 0.4), (240.0, 25.0, 0.6, 0.4, 0.5, 0.5), (180.00002, 90.0, 0.5, 0.5, 0.5, 0.5),   # (180, 540]: FAST, negative offset
+    (360.0, 0.0, 0.0, 1.0, 0.5, 0.5), (540.0, 180.0, 0.5, 0.5, 0.5, 0.5),
+    (540.00006, 30.0, 0.5, 0.5, 0.5, 0.5), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5),   # outside [-180, 540]: literal kernel
 ])
 @pytest.mark.parametrize("in_fmt,out_fmt", [("RGBx", "RGBA"), ("xBGR", "ARGB"), ("BGRx", "ABGR"), ("xRGB", "BGRA")])
 def test_hsvdetect_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
-    """hsvdetector on every colour (vectorised FAST kernel for hue-ref in [-180,180], literal otherwise)."""
+    """hsvdetector on every colour (vectorised FAST kernel for hue-ref in [-180, 540] in its two offset classes, literal otherwise)."""
     from mi355fx import FMT_LAYOUT
     ps, first, bgr = FMT_LAYOUT[in_fmt]
     af, obgr = {"RGBA": (0, 0), "ARGB": (1, 0), "BGRA": (0, 1), "ABGR": (1, 1)}[out_fmt]
@@ -1098,7 +1100,8 @@ def test_colorlut_auto_switches_with_content(ctx, oracle, synth):
             ctx.free(d)
 
 
-@pytest.mark.parametrize("st", [(0.0, 10.0, 0.0, 0.15, 0.0, 0.3), (120.0, 40.0, 0.8, 0.5, 0.7, 0.6), (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5)])
+@pytest.mark.parametrize("st", [(0.0, 10.0, 0.0, 0.15, 0.0, 0.3), (120.0, 40.0, 0.8, 0.5, 0.7, 0.6), (300.0, 45.0, 0.5, 0.5, 0.5, 0.5),
+                                (-725.0, 30.0, 0.5, 0.5, 0.5, 0.5)])
 @pytest.mark.parametrize("in_fmt,out_fmt", [("RGB", "RGBA"), ("BGR", "ARGB"), ("RGB", "ABGR"), ("BGR", "BGRA")])
 def test_hsvdetect_rgb24_allcolors(ctx, oracle, synth, st, in_fmt, out_fmt):
     """3-byte input formats on every colour: the 12-byte vector kernel (and the literal kernel for hue-ref outside
