@@ -270,6 +270,26 @@ __device__ __forceinline__ void dssim_region_pass(const float *src, float *dst, 
   }
 }
 
+// The 4 x 4 window of a 2 x 2 output block, first cell at plane index j (row stride `stride`, even), as 8-byte LDS reads: lanes
+// that are neighbours in x are 8 bytes apart, so 4-byte reads use every second bank (two passes per instruction) where 8-byte
+// reads are conflict-free. ALIGNED: j is even - two reads per row; otherwise the row's four cells straddle three aligned
+// pairs and the outer halves are dropped (the cells j - 1 and j + 4 exist in every caller: a window never starts in column 0
+// or ends in the last column of a misaligned pass).
+template <bool ALIGNED>
+__device__ __forceinline__ void dssim_window_load(const float *plane, int j, int stride, float (&v)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (ALIGNED) {
+      const dssim_f2 a = *(const dssim_f2 *)&plane[j + r * stride], b = *(const dssim_f2 *)&plane[j + r * stride + 2];
+      v[r][0] = a.x; v[r][1] = a.y; v[r][2] = b.x; v[r][3] = b.y;
+    } else {
+      const dssim_f2 a = *(const dssim_f2 *)&plane[j + r * stride - 1], b = *(const dssim_f2 *)&plane[j + r * stride + 1],
+                     c = *(const dssim_f2 *)&plane[j + r * stride + 3];
+      v[r][0] = a.y; v[r][1] = b.x; v[r][2] = b.y; v[r][3] = c.x;
+    }
+  }
+}
+
 // The 3 x 3 blur of a 2 x 2 block of outputs from its 4 x 4 window, the two outputs of a row as one packed-f32 pair:
 // v_pk_mul_f32 / v_pk_add_f32 are two IEEE operations per instruction (never fused: -ffp-contract=off), so every output is
 // accumulated over its nine taps in the same order, with the same roundings, as the scalar loop - in half the instructions.
@@ -301,12 +321,8 @@ __device__ __forceinline__ void dssim_pass_2x2(const float *src, float *dst, flo
   for (int e = first_cell; e < cw * ch; e += kNt) {
     const int cy = e / cw, cx = e - cy * cw;
     const int ly = M + 2 * cy, lx = M + 2 * cx;
-    const float *p = src + (ly - 1) * kRw + (lx - 1);
     float v[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int c = 0; c < 4; c++) v[r][c] = p[r * kRw + c];
+    dssim_window_load<(M - 1) % 2 == 0>(src, (ly - 1) * kRw + (lx - 1), kRw, v);
     float o[2][2];
     dssim_blur_2x2(v, o);
 #pragma unroll
@@ -393,10 +409,7 @@ __device__ __forceinline__ void dssim_chroma_preblur(float (*s_lab)[kRw * kRh], 
 __device__ __forceinline__ void dssim_tile_pass2_2x2(const float *src, int cx, int cy, float (&o)[2][2]) {
   const int j0 = (kHalo + 2 * cy - 1) * kRw + (kHalo + 2 * cx - 1);
   float v[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) v[r][q] = src[j0 + r * kRw + q];
+  dssim_window_load<(kHalo - 1) % 2 == 0>(src, j0, kRw, v);
   dssim_blur_2x2(v, o);
 }
 
@@ -439,10 +452,8 @@ __device__ __forceinline__ void dssim_scale_body(const DssimSrc &S, int w, int h
         const int ly = kHalo + 2 * cy, lx = kHalo + 2 * cx;
         const int j0 = (ly - 1) * kRw + (lx - 1);
         float va[4][4], vb[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) { va[r][q] = s_a[j0 + r * kRw + q]; vb[r][q] = s_b[j0 + r * kRw + q]; }
+        dssim_window_load<(kHalo - 1) % 2 == 0>(s_a, j0, kRw, va);
+        dssim_window_load<(kHalo - 1) % 2 == 0>(s_b, j0, kRw, vb);
         float om[2][2], os[2][2];
         dssim_blur_2x2(va, om);
         dssim_blur_2x2(vb, os);
@@ -491,8 +502,8 @@ struct DssimScaleJob { DssimSrc S; int w, h; DssimPlanes O; };
 struct DssimScaleJobs { DssimScaleJob job[3]; unsigned first[4]; };
 
 __global__ __launch_bounds__(kNt) void dssim_scale_fused_kernel(DssimScaleJobs J) {
-  __shared__ float s_lab[3][kRw * kRh];   // LAB planes of the region
-  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh];
+  __shared__ __attribute__((aligned(16))) float s_lab[3][kRw * kRh];   // LAB planes of the region
+  __shared__ __attribute__((aligned(16))) float s_a[kRw * kRh], s_b[kRw * kRh];
   __shared__ float s_lut[512];   // [0, 256): sRGB -> linear; [256, 512): alpha byte / 255 (the IEEE quotient, once per block instead of per cell)
   const int j = blockIdx.x >= J.first[2] ? 2 : (blockIdx.x >= J.first[1] ? 1 : 0);
   const DssimSrc &S = J.job[j].S;
@@ -564,10 +575,7 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         float v[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) v[r][q] = s_p[c][j0 + r * kCw + q];
+        dssim_window_load<true>(s_p[c], j0, kCw, v);   // lx - 1 = 2 cx: even
         float o[2][2];
         dssim_blur_2x2(v, o);
 #pragma unroll
@@ -632,8 +640,8 @@ __device__ __forceinline__ double dssim_compare_body(const DssimCmp &P, int w, i
 }
 
 __global__ __launch_bounds__(kNt) void dssim_compare_fused_kernel(DssimCmp P, int w, int h, float *__restrict__ ssim_map, double *__restrict__ partial) {
-  __shared__ float s_p[3][kCw * kChh];   // products img1*img2 of the region
-  __shared__ float s_q[3][kCw * kChh];   // first blur pass
+  __shared__ __attribute__((aligned(16))) float s_p[3][kCw * kChh];   // products img1*img2 of the region
+  __shared__ __attribute__((aligned(16))) float s_q[3][kCw * kChh];   // first blur pass
   __shared__ double s_w[kNt / 64];
   const int tiles_x = (w + kTw - 1) / kTw;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -655,38 +663,60 @@ __global__ __launch_bounds__(kNt) void dssim_compare_fused_kernel(DssimCmp P, in
 struct DssimFusedJob { DssimSrc S; int w, h; const float *img1[3], *mu1[3], *sq1[3]; float *map; double *partial; };
 struct DssimFusedJobs { DssimFusedJob job[3]; unsigned first[4]; };
 
+#ifdef DSSIM_EXPERIMENT_NO_BARRIERS   /* timing experiment only (wrong results): what do the phase barriers cost? */
+#define DSSIM_PHASE_SYNC() ((void)0)
+#else
+#define DSSIM_PHASE_SYNC() __syncthreads()
+#endif
 template <bool INTERIOR>
 __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float (*s_lab)[kRw * kRh], float *s_a, float *s_b, float *s_p,
                                                    const float *s_lut, int x0, int y0) {
   const int w = J.w, h = J.h;
-  dssim_lab_region<INTERIOR>(J.S, w, h, s_lab, s_lut, x0, y0);
-  __syncthreads();
-  dssim_chroma_preblur<INTERIOR>(s_lab, s_a, x0, y0, w, h);
   constexpr int pw = kRw - 4, ph = kRh - 4;   // the products' region: the tile plus a halo of 2 (36 x 20)
+  float pimg[(pw * ph + kNt - 1) / kNt];      // interior tiles: the original's img values of this lane's product cells, one channel ahead
+  if (INTERIOR) {
+#pragma unroll
+    for (int k = 0; k < (pw * ph + kNt - 1) / kNt; k++) {
+      const int e = (int)threadIdx.x + k * kNt;
+      pimg[k] = e < pw * ph ? J.img1[0][(size_t)(y0 + 2 + e / pw) * w + (x0 + 2 + e - (e / pw) * pw)] : 0.0f;
+    }
+  }
+  dssim_lab_region<INTERIOR>(J.S, w, h, s_lab, s_lut, x0, y0);
+  DSSIM_PHASE_SYNC();
+  dssim_chroma_preblur<INTERIOR>(s_lab, s_a, x0, y0, w, h);
   double dsum = 0.0;
   if (INTERIOR) {
     // lanes 0..127 own a 2 x 2 block of tile outputs each (their moments stay in registers over the channel loop); while they
-    // run the second passes of mu / sq, the other lanes (if the block has any) start the first pass of the products
+    // run the second passes of mu / sq, the other lanes (if the block has any) start the first pass of the products. The
+    // original's img values for the products are requested one channel ahead (`pimg`: before the LAB conversion for channel 0),
+    // so the product phase does not wait on memory
     const bool owner = threadIdx.x < kOwners;
+    constexpr int kPimg = (pw * ph + kNt - 1) / kNt;
     const int cy = (int)threadIdx.x / (kTw / 2), cx = (int)threadIdx.x - cy * (kTw / 2);
     float mu2[3][2][2], sq2[3][2][2], x12[3][2][2];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       // first pass of plane and squares; the products of the region (modified: s_lab, post pre-blur; original: from memory)
       dssim_pass_2x2<3, true>(s_lab[c], s_a, s_b, threadIdx.x);
-      for (int e = threadIdx.x; e < pw * ph; e += kNt) {
-        const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
-        s_p[ly * kRw + lx] = J.img1[c][(size_t)(y0 + ly) * w + (x0 + lx)] * s_lab[c][ly * kRw + lx];
+#pragma unroll
+      for (int k = 0; k < kPimg; k++) {
+        const int e = (int)threadIdx.x + k * kNt;
+        if (e < pw * ph) {
+          const int ly = 2 + e / pw, lx = 2 + e - (e / pw) * pw;
+          s_p[ly * kRw + lx] = pimg[k] * s_lab[c][ly * kRw + lx];
+          // the next channel's values of the same cells: requested now, multiplied a channel later
+          if (c < 2) pimg[k] = J.img1[c + 1][(size_t)(y0 + ly) * w + (x0 + lx)];
+        }
       }
       if (c > 0 && owner) dssim_tile_pass2_2x2(s_lab[c - 1], cx, cy, x12[c - 1]);   // the previous channel's products, second pass
-      __syncthreads();
+      DSSIM_PHASE_SYNC();
       if (owner) {
         dssim_tile_pass2_2x2(s_a, cx, cy, mu2[c]);
         dssim_tile_pass2_2x2(s_b, cx, cy, sq2[c]);
       }
       // first pass of the products into s_lab[c] (the plane itself is not needed any more)
       dssim_pass_2x2<3, false>(s_p, s_lab[c], nullptr, kOwners < kNt ? (int)(threadIdx.x + kNt - kOwners) % kNt : (int)threadIdx.x);
-      __syncthreads();
+      DSSIM_PHASE_SYNC();
     }
     if (owner) {
       dssim_tile_pass2_2x2(s_lab[2], cx, cy, x12[2]);
@@ -704,7 +734,7 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
           s_p[ty * kTw + tx] = ssim;
         }
     }
-    __syncthreads();
+    DSSIM_PHASE_SYNC();
     // the block partial in the comparison kernel's order: lane t adds pixels t, t + kNt, ... of the tile
     for (int e = threadIdx.x; e < kTw * kTh; e += kNt) dsum += (double)s_p[e];
   } else {
@@ -732,14 +762,14 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
 #pragma unroll
         for (int k = 0; k < kPpl; k++) x12[c - 1][k] = in[k] ? dssim_tile_pass2_px(s_lab[c - 1], gx[k], gy[k], x0, y0, w, h) : 0.0f;
       }
-      __syncthreads();
+      DSSIM_PHASE_SYNC();
 #pragma unroll
       for (int k = 0; k < kPpl; k++) {
         mu2[c][k] = in[k] ? dssim_tile_pass2_px(s_a, gx[k], gy[k], x0, y0, w, h) : 0.0f;
         sq2[c][k] = in[k] ? dssim_tile_pass2_px(s_b, gx[k], gy[k], x0, y0, w, h) : 0.0f;
       }
       dssim_region_pass<false, 3, false>(s_p, s_lab[c], x0, y0, w, h);
-      __syncthreads();
+      DSSIM_PHASE_SYNC();
     }
 #pragma unroll
     for (int k = 0; k < kPpl; k++) {
@@ -758,8 +788,8 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
 }
 
 __global__ __launch_bounds__(kNt) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
-  __shared__ float s_lab[3][kRw * kRh];
-  __shared__ float s_a[kRw * kRh], s_b[kRw * kRh], s_p[kRw * kRh];
+  __shared__ __attribute__((aligned(16))) float s_lab[3][kRw * kRh];
+  __shared__ __attribute__((aligned(16))) float s_a[kRw * kRh], s_b[kRw * kRh], s_p[kRw * kRh];
   __shared__ float s_lut[512];
   __shared__ double s_w[kNt / 64];
   const int j = blockIdx.x >= JJ.first[2] ? 2 : (blockIdx.x >= JJ.first[1] ? 1 : 0);
