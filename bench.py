@@ -676,6 +676,10 @@ def main():
         leg_args = argparse.Namespace(**vars(leg_args))
         leg_args.shared_reference, leg_args.workers = True, 4
         config5["as_pads_of_four_aggregators"] = run_config5(leg_args, rank, local_rank, 1)
+        # ... and of 2 elements with 16 pads each (fewer reference hashes, one synchronisation per 16 comparisons)
+        leg_args = argparse.Namespace(**vars(leg_args))
+        leg_args.workers, leg_args.steps = 2, 32
+        config5["as_pads_of_two_aggregators"] = run_config5(leg_args, rank, local_rank, 1)
 
     if rank == 0:
         # dominant kernel = the longer of the two launches

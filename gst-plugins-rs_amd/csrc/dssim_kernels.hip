@@ -819,6 +819,9 @@ struct DssimRed {
   size_t n[kDssimScales];
   double *slots;                         // per scale: [sum, avg, dev]
   int n_scales;
+  // blockIdx.y = frame of a call that reduces several comparisons at once: its maps / partials / slots lie these strides
+  // behind frame 0's (all 0 for one comparison per launch)
+  size_t frame_map = 0, frame_pa = 0, frame_pb = 0, frame_slots = 0;
 };
 
 // block k: sum the block partials of scale k (256 lanes, strided, then the fixed-order block reduction: deterministic);
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256) void dssim_avg_kernel(DssimRed R) {
   double acc = 0.0;
   // eight loads in flight; the additions stay in index order
   const unsigned n_a = R.n_a[k];
-  const double *pa = R.part_a[k];
+  const double *pa = R.part_a[k] + blockIdx.y * R.frame_pa;
   unsigned i = threadIdx.x;
   for (; i + 7 * 256 < n_a; i += 8 * 256) {
     double v[8];
@@ -841,8 +844,9 @@ __global__ __launch_bounds__(256) void dssim_avg_kernel(DssimRed R) {
   for (; i < n_a; i += 256) acc += pa[i];
   const double sum = dssim_block_sum(acc, s_w);
   if (threadIdx.x == 0) {
-    R.slots[3 * k] = sum;
-    R.slots[3 * k + 1] = pow(fmax(sum / R.len[k], 0.0), R.exponent[k]);
+    double *slots = R.slots + blockIdx.y * R.frame_slots;
+    slots[3 * k] = sum;
+    slots[3 * k + 1] = pow(fmax(sum / R.len[k], 0.0), R.exponent[k]);
   }
 }
 
@@ -851,13 +855,13 @@ __global__ __launch_bounds__(256) void dssim_absdev2_kernel(DssimRed R) {
   int k = 0;
   while (k + 1 < R.n_scales && blockIdx.x >= R.first_b[k + 1]) k++;
   const unsigned j = blockIdx.x - R.first_b[k], g = R.first_b[k + 1] - R.first_b[k];
-  const double avg = R.slots[3 * k + 1];
+  const double avg = R.slots[blockIdx.y * R.frame_slots + 3 * k + 1];
   const size_t gs = (size_t)g * 256, n = R.n[k];
-  const float *map = R.map[k];
+  const float *map = R.map[k] + blockIdx.y * R.frame_map;
   double acc = 0.0;
   for (size_t i = (size_t)j * 256 + threadIdx.x; i < n; i += gs) acc += fabs(avg - (double)map[i]);
   const double t = dssim_block_sum(acc, s_w);
-  if (threadIdx.x == 0) R.part_b[k][j] = t;
+  if (threadIdx.x == 0) R.part_b[k][blockIdx.y * R.frame_pb + j] = t;
 }
 
 __global__ __launch_bounds__(256) void dssim_sum_kernel(DssimRed R) {
@@ -865,9 +869,10 @@ __global__ __launch_bounds__(256) void dssim_sum_kernel(DssimRed R) {
   const int k = blockIdx.x;
   const unsigned g = R.first_b[k + 1] - R.first_b[k];
   double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < g; i += 256) acc += R.part_b[k][i];
+  const double *pb = R.part_b[k] + blockIdx.y * R.frame_pb;
+  for (unsigned i = threadIdx.x; i < g; i += 256) acc += pb[i];
   const double sum = dssim_block_sum(acc, s_w);
-  if (threadIdx.x == 0) R.slots[3 * k + 2] = sum;
+  if (threadIdx.x == 0) R.slots[blockIdx.y * R.frame_slots + 3 * k + 2] = sum;
 }
 
 // ------------------------------------------------------------------ host side
@@ -1139,7 +1144,9 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
   for (int k = ns; k < kDssimScales; k++) { R.n[k] = 0; R.n_a[k] = 0; R.first_b[k + 1] = n_pb; R.len[k] = 1.0; R.exponent[k] = 1.0; R.map[k] = nullptr; R.part_a[k] = nullptr; R.part_b[k] = nullptr; }
   void *scr = nullptr;
   const size_t lin_bytes = (lin_px + 16) * 16;
-  int rc = dssim_scratch(ctx, 1, lin_bytes + map_px * 4 + (n_pa + n_pb) * 8 + (size_t)n_frames * 3 * kDssimScales * 8 + 1024, &scr);
+  // per frame: SSIM maps and both families of partials (the reductions of all frames run after the last frame's kernels)
+  const size_t F = (size_t)n_frames;
+  int rc = dssim_scratch(ctx, 1, lin_bytes + F * (map_px * 4 + (n_pa + n_pb) * 8 + 3 * kDssimScales * 8) + 1024, &scr);
   if (rc) return rc;
   float4 *lin[kDssimScales] = {nullptr};
   {
@@ -1147,8 +1154,10 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
     for (int k = 1; k < ns; k++) { lin[k] = q; q += (size_t)a->s[k].w * a->s[k].h; }
   }
   float *map = (float *)((char *)scr + lin_bytes);
-  double *d_pa = (double *)(map + map_px), *d_pb = d_pa + n_pa;
-  double *d_slots = d_pb + n_pb;  // per frame, per scale: [sum, avg, dev]
+  double *d_pa = (double *)(map + F * map_px), *d_pb = d_pa + F * n_pa;
+  double *d_slots = d_pb + F * n_pb;  // per frame, per scale: [sum, avg, dev]
+  R.frame_map = map_px; R.frame_pa = n_pa; R.frame_pb = n_pb; R.frame_slots = 3 * kDssimScales;
+  R.slots = d_slots;
   {
     float *m = map;
     double *pa = d_pa;
@@ -1176,8 +1185,8 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
       j.S.pattern = (channels == 4 && !ctx->dssim_translucent) ? 1 : 0;
       j.w = s.w; j.h = s.h;
       for (int c = 0; c < 3; c++) { j.img1[c] = s.img[c]; j.mu1[c] = s.mu[c]; j.sq1[c] = s.sq[c]; }
-      j.map = (float *)R.map[k];
-      j.partial = (double *)R.part_a[k];
+      j.map = (float *)R.map[k] + (size_t)f * map_px;
+      j.partial = (double *)R.part_a[k] + (size_t)f * n_pa;
       return j;
     };
     for (int k = 0; k < ns; ) {
@@ -1194,11 +1203,10 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
       hipLaunchKernelGGL(dssim_hash_compare_kernel, dim3(total), dim3(kNt), 0, ctx->stream, J);
       k += count;
     }
-    R.slots = d_slots + (size_t)f * 3 * kDssimScales;
-    hipLaunchKernelGGL(dssim_avg_kernel, dim3(ns), dim3(256), 0, ctx->stream, R);
-    hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb), dim3(256), 0, ctx->stream, R);
-    hipLaunchKernelGGL(dssim_sum_kernel, dim3(ns), dim3(256), 0, ctx->stream, R);
   }
+  hipLaunchKernelGGL(dssim_avg_kernel, dim3(ns, n_frames), dim3(256), 0, ctx->stream, R);
+  hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb, n_frames), dim3(256), 0, ctx->stream, R);
+  hipLaunchKernelGGL(dssim_sum_kernel, dim3(ns, n_frames), dim3(256), 0, ctx->stream, R);
   if ((rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch"))) return rc;
   std::vector<double> slots((size_t)n_frames * 3 * kDssimScales);
   if ((rc = check_hip(ctx, hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
