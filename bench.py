@@ -472,7 +472,7 @@ def main():
                 done += n
             return fills
 
-        def measure(content, steps, warmup, record, fused=False, streams=None):
+        def measure(content, steps, warmup, record, fused=False, streams=None, native_round=None):
             """One leg: ramp on scratch batches, W warm-up steps and K timed steps, each on its own pristine batch.
             streams: list of per-stream contexts - frame i of every batch then belongs to stream i and is processed by
             that stream's own context with one-frame launches (what N independent pipelines issue)."""
@@ -490,6 +490,11 @@ def main():
                 if streams:
                     for k in range(n):
                         s_, d_ = srcs_[k % len(srcs_)], dsts[k % len(dsts)]
+                        if native_round is not None:
+                            # the 2 x n launches of a round from one native loop (what n streaming threads written in C cost),
+                            # not from n x 2 interpreter calls
+                            native_round.issue([s_[i].data_ptr() for i in range(nb)], [d_[i].data_ptr() for i in range(nb)])
+                            continue
                         for i, c in enumerate(streams):
                             p_ = s_[i].data_ptr()
                             c.hsvfilter_frames_device(p_, 1, pitch, W, H, W * 4, "RGBA", settings)
@@ -639,8 +644,14 @@ def main():
                 sctx.append(c)
             torch.cuda.synchronize()
             n_s = max(8, args.steps // 4)
-            leg = measure(args.content, n_s, 24, False, streams=sctx)
+            leg_py = measure(args.content, n_s, 24, False, streams=sctx)
+            if args.stub:
+                leg = leg_py
+            else:
+                leg = measure(args.content, n_s, 24, False, streams=sctx, native_round=mi355fx.StreamsRound(sctx, W, H, W * 4, "RGBA", settings))
             streams_leg = {"streams_per_gpu": args.streams, "frames_per_s": leg["frames"] / leg["dt"], "launches": "one 4K frame per launch and stream",
+                           "issued_by": "one native loop per round of 2 x %d launches (mi355_issue_streams_round)" % args.streams,
+                           "frames_per_s_issued_from_python": leg_py["frames"] / leg_py["dt"],
                            "colorlut_kernel": sctx[0].colorlut_kernel_name(),
                            "memoised_tables_alive": mi355fx.load_library().mi355_shared_table_count() if not args.stub else 0}
             for c in sctx:

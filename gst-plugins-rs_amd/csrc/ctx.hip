@@ -762,6 +762,19 @@ int mi355_dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *original, const
   return dssim_compare(ctx, original, modified, dssim);
 }
 
+int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src, uint8_t *const *d_dst, int width, int height, int stride,
+                              int format, const mi355_hsv_settings *settings) {
+  if (!ctxs || !d_src || !d_dst || !settings || n_streams < 0) return MI355_ERR_INVALID_ARG;
+  const size_t pitch = (size_t)stride * (size_t)(height > 0 ? height : 0);
+  for (int i = 0; i < n_streams; i++) {
+    int rc = mi355_hsvfilter_frames_device(ctxs[i], d_src[i], 1, pitch, width, height, stride, format, settings);
+    if (rc) return rc;
+    rc = mi355_colorlut_frames_device(ctxs[i], d_src[i], pitch, stride, d_dst[i], pitch, stride, 1, width, height, format);
+    if (rc) return rc;
+  }
+  return MI355_OK;
+}
+
 int mi355_dssim_compare_frames_device(mi355_ctx *ctx, const mi355_dssim_image *original, const uint8_t *const *d_frames, int n_frames, int stride,
                                       int width, int height, int format, double *dssim) {
   REQUIRE_CTX(ctx);

@@ -146,6 +146,7 @@ def load_library():
         "mi355_dssim_compare": (i, [vp, vp, vp, C.POINTER(C.c_double)]),
         "mi355_dssim_compare_frames": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
         "mi355_dssim_compare_frames_device": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
+        "mi355_issue_streams_round": (i, [C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_sofa_setup": (i, [vp, i, i, i, i]),
@@ -184,6 +185,28 @@ def _ptr(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data
     return a  # raw device pointer (int)
+
+
+class StreamsRound:
+    """n independent streams (one Context each) issued from one native loop per round: mi355_issue_streams_round. The pointer
+    arrays are built once per (sources, destinations) pair so that a round costs one foreign call."""
+
+    def __init__(self, contexts, width, height, stride, fmt, settings):
+        self.L = load_library()
+        self.n = len(contexts)
+        self.ctxs = (C.c_void_p * self.n)(*[c.h for c in contexts])
+        self.geom = (width, height, stride, FMT[fmt])
+        self.settings = HsvSettings(*[float(v) for v in settings])
+        self._arrays = {}
+
+    def issue(self, src_ptrs, dst_ptrs):
+        key = (tuple(src_ptrs), tuple(dst_ptrs))
+        arr = self._arrays.get(key)
+        if arr is None:
+            arr = self._arrays[key] = ((C.c_void_p * self.n)(*src_ptrs), (C.c_void_p * self.n)(*dst_ptrs))
+        rc = self.L.mi355_issue_streams_round(self.ctxs, self.n, arr[0], arr[1], *self.geom, C.byref(self.settings))
+        if rc != 0:
+            raise Mi355Error(rc, "mi355_issue_streams_round")
 
 
 class Context:

@@ -198,6 +198,14 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
                                  int src_stride, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                                  int n_frames, int width, int height, int format);
 
+/* Measurement plumbing, no reference counterpart: one round of n independent streams issued from ONE native loop - for
+ * stream i, hsvfilter in place on the frame at d_src[i] and colorlut from it into d_dst[i], each through its own context
+ * ctxs[i] (own HIP stream, LUT loaded) exactly as mi355_hsvfilter_frames_device + mi355_colorlut_frames_device would be
+ * called by that stream's thread. Lets a benchmark written in an interpreter measure the device instead of its own call
+ * overhead. Returns the first error; asynchronous like the calls it makes. */
+int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src, uint8_t *const *d_dst,
+                              int width, int height, int stride, int format, const mi355_hsv_settings *settings);
+
 /* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
  * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and
  * colorlut/imp.rs:125-137) as ONE pass: every pixel goes through hsv_filter's body (hsvfilter/imp.rs:96-118) and

@@ -1173,3 +1173,35 @@ def test_memoised_tables_are_shared_between_contexts(oracle, synth, mi355lib):
         for c in ctxs[:4]:
             c.close()
     assert mi355lib.mi355_shared_table_count() == base
+
+
+def test_issue_streams_round_is_the_two_calls_per_stream(ctx, oracle, synth):
+    """mi355_issue_streams_round (bench plumbing: one native loop instead of 2 x n interpreter calls) gives every stream exactly
+    what mi355_hsvfilter_frames_device + mi355_colorlut_frames_device give it."""
+    import mi355fx
+    w, h, n = 256, 64, 3
+    st = synth.HSV_SETTINGS["hue90"]
+    ctxs = [mi355fx.Context(0) for _ in range(n)]
+    cube = None
+    for c in ctxs:
+        cube = _load_cube(c, oracle, synth.cube_text_3d(9))
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (h, w * 4), dtype=np.uint8) for _ in range(n)]
+    d_src = [c.alloc(f.nbytes) for c, f in zip(ctxs, frames)]
+    d_dst = [c.alloc(f.nbytes) for c, f in zip(ctxs, frames)]
+    try:
+        for c, d, f in zip(ctxs, d_src, frames):
+            c.h2d(d, f.reshape(-1))
+        mi355fx.StreamsRound(ctxs, w, h, w * 4, "RGBA", st).issue(d_src, d_dst)
+        for c, f, ds, dd in zip(ctxs, frames, d_src, d_dst):
+            c.synchronize()
+            filt = f.copy()
+            oracle.hsvfilter(filt, w, w * 4, 4, 0, False, st)
+            exp = np.zeros_like(f)
+            oracle.colorlut_rgba8(cube, filt, w * 4, exp, w * 4, w, h)
+            got_f, got = np.zeros_like(f), np.zeros_like(f)
+            c.d2h(got_f, ds); c.d2h(got, dd)
+            assert (got_f == filt).all() and (got == exp).all()
+    finally:
+        for c, a, b in zip(ctxs, d_src, d_dst):
+            c.free(a); c.free(b); c.close()
