@@ -131,3 +131,48 @@ def test_fused_chain_random_sweep(ctx, oracle, variant):
         if not (got == exp).all():
             bad.append((st, int((got != exp).sum())))
     assert not bad, bad[:5]
+
+
+def test_dssim_fused_against_two_step_random_geometry(ctx):
+    """Random frame sizes (below a tile, ragged right / bottom tiles, odd sizes whose down-sampled scales drop a column, sizes
+    with fewer than five scales), formats, strides and contents: mi355_dssim_compare_frames == create_image + compare, to the
+    last bit, and the detector of the restatement agrees on a few of them."""
+    from oracle import dssim_restate as D
+    rng = np.random.default_rng(20261002)
+    for trial in range(24):
+        w = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 31, 32, 33, 40, 63, 64, 65, 100, 129, 257, int(rng.integers(34, 700))]))
+        h = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 24, 33, 47, 48, 49, 80, 130, int(rng.integers(18, 400))]))
+        fmt = "RGBA" if rng.integers(0, 2) else "RGB"
+        ch = 4 if fmt == "RGBA" else 3
+        stride = w * ch + int(rng.choice([0, 0, 1, 5, 16]))
+        def frame(kind):
+            f = np.zeros((h, stride), np.uint8)
+            if kind == 0:
+                v = rng.integers(0, 256, (h, w * ch), dtype=np.uint8)
+            elif kind == 1:
+                v = np.full((h, w * ch), int(rng.integers(0, 256)), np.uint8)
+            else:
+                g = np.linspace(0, 255, w * ch)[None, :] * np.linspace(0.3, 1.0, h)[:, None]
+                v = np.clip(g + rng.normal(0, 3, (h, w * ch)), 0, 255).astype(np.uint8)
+            f[:, : w * ch] = v
+            if ch == 4 and rng.integers(0, 3):
+                f[:, 3: w * 4: 4] = 255
+            return f
+        ref = frame(int(rng.integers(0, 3)))
+        others = [frame(int(rng.integers(0, 3))) for _ in range(3)] + [ref.copy()]
+        a = ctx.dssim_create_image(ref, stride, w, h, fmt)
+        try:
+            two_step = []
+            for f in others:
+                b = ctx.dssim_create_image(f, stride, w, h, fmt)
+                two_step.append(ctx.dssim_compare(a, b))
+                ctx.dssim_free_image(b)
+            fused = ctx.dssim_compare_frames(a, others, stride, w, h, fmt)
+            assert fused == two_step, (trial, w, h, fmt, stride, fused, two_step)
+            assert fused[-1] == 0.0
+            if trial % 6 == 0 and w * h < 40000:
+                oa = D.DssimImage(np.ascontiguousarray(ref[:, : w * ch]), w, h, w * ch, ch)
+                ob = D.DssimImage(np.ascontiguousarray(others[0][:, : w * ch]), w, h, w * ch, ch)
+                assert fused[0] == pytest.approx(D.compare(oa, ob), rel=1e-9, abs=1e-13)
+        finally:
+            ctx.dssim_free_image(a)
