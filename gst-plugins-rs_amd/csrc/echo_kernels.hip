@@ -26,11 +26,20 @@ namespace mi355 {
 // streams of a batch are independent AudioEcho instances advanced by the same number of samples per call.
 struct EchoPar { unsigned long long D; double intensity, feedback; };
 
+// Where a launch finds the per-stream parameters: up to kEchoInline streams travel in the kernel arguments (no copy, no
+// event: the single-stream element path), larger batches through the device array refreshed in stream order.
+constexpr int kEchoInline = 4;
+struct EchoParSrc {
+  const EchoPar *dev;
+  EchoPar inl[kEchoInline];
+  __device__ __forceinline__ EchoPar at(unsigned s) const { return dev ? dev[s] : inl[s]; }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void echo_widen_kernel(const T *__restrict__ data, double *__restrict__ w, size_t n, size_t stream_stride,
-                                                         const EchoPar *__restrict__ par) {
+                                                         EchoParSrc par) {
   const unsigned s = blockIdx.y;
-  if (par[s].feedback != 0.0) return;  // the chain kernel widens as it goes
+  if (par.at(s).feedback != 0.0) return;  // the chain kernel widens as it goes
   data += (size_t)s * stream_stride;
   w += (size_t)s * n;
   const size_t gs = (size_t)gridDim.x * blockDim.x;
@@ -41,9 +50,9 @@ __global__ __launch_bounds__(256) void echo_widen_kernel(const T *__restrict__ d
 // feedback != 0: one lane per residue class mod D.
 template <typename T>
 __global__ __launch_bounds__(256) void echo_main_kernel(T *__restrict__ data, double *__restrict__ w, const double *__restrict__ ring, size_t n,
-                                                        size_t size, size_t pos, size_t stream_stride, const EchoPar *__restrict__ par) {
+                                                        size_t size, size_t pos, size_t stream_stride, EchoParSrc par) {
   const unsigned s = blockIdx.y;
-  const EchoPar P = par[s];
+  const EchoPar P = par.at(s);
   const size_t D = (size_t)P.D;
   data += (size_t)s * stream_stride;
   w += (size_t)s * n;
@@ -113,12 +122,22 @@ static int echo_run(mi355_ctx *ctx, T *d_data, size_t n, size_t stream_stride, c
   if (rc) return rc;
   double *w = (double *)ctx->d_stage[1];
   // parameters: pinned host copy -> device, in stream order (a call may change delay / intensity / feedback)
-  std::memcpy(E.h_par, par_host, S * sizeof(EchoPar));
-  if ((rc = check_hip(ctx, hipMemcpyAsync(E.d_par, E.h_par, S * sizeof(EchoPar), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(echo parameters)"))) return rc;
-  // the pinned parameter block may be rewritten by the next call once THIS COPY has been consumed: the event sits right
-  // behind the copy, not behind the kernels (behind them, the next call's hipEventSynchronize would wait for the whole
-  // previous buffer and serialise host and device)
-  if ((rc = check_hip(ctx, hipEventRecord(E.par_ev, ctx->stream), "hipEventRecord(echo)"))) return rc;
+  EchoParSrc par;
+  par.dev = nullptr;
+  if (S <= (unsigned)kEchoInline) {
+    for (unsigned s = 0; s < (unsigned)kEchoInline; s++) par.inl[s] = par_host[s < S ? s : 0];
+  } else {
+    // the previous call's parameter copy must have left the pinned block (long done in practice)
+    if ((rc = check_hip(ctx, hipEventSynchronize(E.par_ev), "hipEventSynchronize(echo)"))) return rc;
+    std::memcpy(E.h_par, par_host, S * sizeof(EchoPar));
+    if ((rc = check_hip(ctx, hipMemcpyAsync(E.d_par, E.h_par, S * sizeof(EchoPar), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(echo parameters)"))) return rc;
+    // the pinned parameter block may be rewritten by the next call once THIS COPY has been consumed: the event sits right
+    // behind the copy, not behind the kernels (behind them, the next call's hipEventSynchronize would wait for the whole
+    // previous buffer and serialise host and device)
+    if ((rc = check_hip(ctx, hipEventRecord(E.par_ev, ctx->stream), "hipEventRecord(echo)"))) return rc;
+    par.dev = (const EchoPar *)E.d_par;
+    for (int s = 0; s < kEchoInline; s++) par.inl[s] = par_host[0];
+  }
   bool any_nofb = false;
   size_t most = 1;  // widest parallel extent of the main kernel over the streams
   for (unsigned s = 0; s < S; s++) {
@@ -126,7 +145,6 @@ static int echo_run(mi355_ctx *ctx, T *d_data, size_t n, size_t stream_stride, c
     else { const size_t chains = par_host[s].D < n ? (size_t)par_host[s].D : n; most = chains > most ? chains : most; }
   }
   const unsigned gb = blocks_for(n, ctx->n_cu), mb = blocks_for(most, ctx->n_cu);
-  const EchoPar *par = (const EchoPar *)E.d_par;
   if (any_nofb) hipLaunchKernelGGL((echo_widen_kernel<T>), dim3(gb, S), dim3(256), 0, ctx->stream, (const T *)d_data, w, n, stream_stride, par);
   hipLaunchKernelGGL((echo_main_kernel<T>), dim3(mb, S), dim3(256), 0, ctx->stream, d_data, w, (const double *)E.d_ring, n, size, E.pos, stream_stride, par);
   hipLaunchKernelGGL(echo_commit_kernel, dim3(gb, S), dim3(256), 0, ctx->stream, E.d_ring, (const double *)w, n, size, E.pos);
@@ -174,8 +192,6 @@ int launch_echo_batch(mi355_ctx *ctx, void *d_data, size_t stream_stride, size_t
     if (delay[s] > E.ring_len) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: delay exceeds ring buffer size");
   if (n == 0) return MI355_OK;
   if (E.n_streams > 1 && stream_stride < n) return set_error(ctx, MI355_ERR_INVALID_ARG, "rsaudioecho: stream stride shorter than the buffer");
-  int rc = check_hip(ctx, hipEventSynchronize(E.par_ev), "hipEventSynchronize(echo)");  // previous call's parameter copy (long done in practice)
-  if (rc) return rc;
   std::vector<EchoPar> par((size_t)E.n_streams);
   for (int s = 0; s < E.n_streams; s++) par[s] = EchoPar{(unsigned long long)(delay[s] == 0 ? E.ring_len : delay[s]), intensity[s], feedback[s]};
   return is_f64 ? echo_run<double>(ctx, (double *)d_data, n, stream_stride, par.data()) : echo_run<float>(ctx, (float *)d_data, n, stream_stride, par.data());

@@ -14,4 +14,9 @@ for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_loudnorm
 done
 python3 "$R/tools/bench_hrtf.py" --taps 512 --no-cpu 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench_hrtf_512taps", /' >> "$OUT"
 python3 "$R/bench.py" --config 5 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 --shared-reference --workers 2 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --shared-reference --workers 2", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 --shared-reference --workers 4 --dssim-two-step 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --shared-reference --workers 4 --dssim-two-step", /' >> "$OUT"
+python3 "$R/tools/bench_rgba64.py" 2>/dev/null >> "$R/gpurun_out/configs_${TAG}_elements.txt"
+python3 "$R/tools/bench_loudnorm_batch.py" 2>/dev/null >> "$R/gpurun_out/configs_${TAG}_elements.txt"
+python3 "$R/tools/bench_sofa.py" 2>/dev/null | grep '^{' | sed 's/^{/{"tool": "bench_sofa", /' >> "$OUT"
 wc -l "$OUT" >&2

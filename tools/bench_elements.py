@@ -45,10 +45,23 @@ mi355fx_flag = mi355fx.FLAG_FORCE_GENERIC
 ctx.set_flag(mi355fx_flag, 1)
 report("hsvfilter 1080p BGRx GENERIC (literal) kernel, batch 32", timeit(lambda: ctx.hsvfilter_frames_device(d, B, W * H * 4, W, H, W * 4, "BGRx", st), n=5), 2 * fr.nbytes, B)
 ctx.set_flag(mi355fx_flag, 0)
-# 3-byte format row kernel
-fr3 = np.stack([synth.noise_frame(W * 3, H, channels=1)] * 8)
+# wide hue shifts (360 < |shift| <= 2^22: FAST since round 3) and a non-finite shift (memoised table)
+report("hsvfilter 1080p BGRx hue-shift=725.5 (wide), batch 32", timeit(lambda: ctx.hsvfilter_frames_device(d, B, W * H * 4, W, H, W * 4, "BGRx", (725.5, 1.0, 0.0, 1.0, 0.0))), 2 * fr.nbytes, B)
+ctx.free(d)
+# 3-byte formats: natural-like RGB frames (the RGBA frame without its alpha byte), 8 x 4K
+W3, H3 = 3840, 2160
+one = synth.smooth_frame(W3, H3).reshape(H3, W3, 4)
+fr3 = np.ascontiguousarray(np.stack([one[..., :3]] * 8))
 d3 = ctx.alloc(fr3.nbytes); ctx.h2d(d3, fr3)
-report("hsvfilter 1080p RGB (3 B/px row kernel), batch 8", timeit(lambda: ctx.hsvfilter_frames_device(d3, 8, W * H * 3, W, H, W * 3, "RGB", st), n=10), 2 * fr3.nbytes, 8)
+for f3 in ("RGB", "BGR"):
+    report("hsvfilter 4K %s (3 B/px, 16-pixel chunks), batch 8" % f3, timeit(lambda: ctx.hsvfilter_frames_device(d3, 8, W3 * H3 * 3, W3, H3, W3 * 3, f3, st), n=50), 2 * fr3.nbytes, 8)
+ctx.free(d3)
+# padded rows (stride = row + 64 bytes): the strided kernel
+pad = W3 * 4 + 64
+frp = np.zeros((8, H3, pad), np.uint8); frp[:, :, : W3 * 4] = one.reshape(H3, W3 * 4)
+dp = ctx.alloc(frp.nbytes); ctx.h2d(dp, frp)
+report("hsvfilter 4K RGBA padded rows (stride + 64 B), batch 8", timeit(lambda: ctx.hsvfilter_frames_device(dp, 8, pad * H3, W3, H3, pad, "RGBA", st), n=50), 2 * 8 * H3 * W3 * 4, 8)
+ctx.free(dp)
 
 # hsvdetector 4K RGBx -> RGBA
 W, H, B = 3840, 2160, 8
@@ -56,6 +69,8 @@ fr = np.stack([synth.smooth_frame(W, H)] * B)
 ds, dd = ctx.alloc(fr.nbytes), ctx.alloc(fr.nbytes); ctx.h2d(ds, fr)
 s = HsvDetectSettings(120.0, 40.0, 0.8, 0.5, 0.7, 0.6)
 L = ctx.L
+s240 = HsvDetectSettings(240.0, 40.0, 0.8, 0.5, 0.7, 0.6)
+report("hsvdetector 4K RGBx->RGBA hue-ref=240 (negative offset class), batch 8", timeit(lambda: L.mi355_hsvdetect_frames_device(ctx.h, ds, W * H * 4, W * 4, FMT["RGBx"], dd, W * H * 4, W * 4, FMT["RGBA"], B, W, H, C.byref(s240))), 2 * fr.nbytes, B)
 report("hsvdetector 4K RGBx->RGBA, batch 8", timeit(lambda: L.mi355_hsvdetect_frames_device(ctx.h, ds, W * H * 4, W * 4, FMT["RGBx"], dd, W * H * 4, W * 4, FMT["RGBA"], B, W, H, C.byref(s))), 2 * fr.nbytes, B)
 
 # colorlut variants on 4K RGBA batch 8
