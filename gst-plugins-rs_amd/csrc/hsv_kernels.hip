@@ -273,12 +273,14 @@ int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size
   const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
   if (fmt.pixel_stride == 4 && packed_rows && ((uintptr_t)d_data % 16 == 0) && (total_bytes % 16 == 0)) {
     const size_t n_vec = total_bytes / 16;
-    const int grid = grid_for(ctx, n_vec, 256, ctx->hsv_blocks_per_cu);
+    // at least two 16-byte groups per lane: a block pays its LDS tables and its ramp once, and launches of one or two frames
+    // (one stream's buffer) are 10-15 % faster than with one group per lane (tools/r03_single_frame_launch.py)
+    const int grid = grid_for(ctx, (n_vec + 1) / 2, 256, ctx->hsv_blocks_per_cu);
     uint4 *d = (uint4 *)d_data;
     MI355_HSV_VARIANT_SWITCH(variant, launch_flat, ctx, d, n_vec, k, fmt.first, fmt.bgr, grid)
   } else if (fmt.pixel_stride == 4 && ((uintptr_t)d_data % 16 == 0) && stride % 16 == 0 && (n_frames == 1 || frame_pitch % 16 == 0)) {
     const size_t n_grp = (size_t)((width + 3) / 4) * (size_t)height * (size_t)n_frames;
-    const int grid = grid_for(ctx, n_grp, 256, ctx->hsv_blocks_per_cu);
+    const int grid = grid_for(ctx, (n_grp + 1) / 2, 256, ctx->hsv_blocks_per_cu);
     MI355_HSV_VARIANT_SWITCH(variant, launch_strided, ctx, d_data, n_frames, frame_pitch, width, height, stride, k, fmt.first, fmt.bgr, grid)
   } else if (fmt.pixel_stride == 3 && fmt.first == 0 && packed_rows && ((uintptr_t)d_data % 4 == 0) && (total_bytes % 12 == 0)) {
     // whole 3 KB chunks (1024 pixels) through the coalescing kernel when the base is 16-byte aligned, the rest 12 bytes per lane
