@@ -787,10 +787,13 @@ __device__ __forceinline__ double dssim_fused_body(const DssimFusedJob &J, float
   return dsum;
 }
 
-__global__ __launch_bounds__(kNt) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
+__global__ __launch_bounds__(kNt, kNt == 256 ? 7 : 1) void dssim_hash_compare_kernel(DssimFusedJobs JJ) {
+  // 6 planes + the block-sum words = 23,072 B and <= 72 VGPRs: seven blocks per CU (the gamma / alpha tables are only read by
+  // the LAB conversion and live in the products' plane, which is first written after it)
   __shared__ __attribute__((aligned(16))) float s_lab[3][kRw * kRh];
   __shared__ __attribute__((aligned(16))) float s_a[kRw * kRh], s_b[kRw * kRh], s_p[kRw * kRh];
-  __shared__ float s_lut[512];
+  float *const s_lut = s_p;
+  static_assert(kRw * kRh >= 512, "the tables fit the products' plane");
   __shared__ double s_w[kNt / 64];
   const int j = blockIdx.x >= JJ.first[2] ? 2 : (blockIdx.x >= JJ.first[1] ? 1 : 0);
   const DssimFusedJob &J = JJ.job[j];
