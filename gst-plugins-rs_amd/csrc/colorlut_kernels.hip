@@ -788,6 +788,48 @@ __global__ __launch_bounds__(NT) void colorlut1d_lds_kernel(const uint4 *__restr
   }
 }
 
+// ---------------------------------------------------------------- 1D LUT, RGBA64, tables in LDS
+//
+// transform_rgba64_1d::<LE> / apply_1d_u16 / sample_1d (imp.rs:296-346,416-430,482-490) from the LDS image of the RGBA8
+// kernel (its three channel tables with the zero pad; the byte-indexed axis tables are not used: 65,536 input levels are
+// computed with the expressions of colorlut3d_lds64_kernel - div65535_u16, scale / offset, clamp, * (size - 1), integer part
+// and fraction). One lane = 2 pixels per 16-byte group; 16 B/pixel of HBM traffic, two 4-byte LDS reads per channel.
+struct Lut1d64K { float scale[3], offset[3]; float sm1; uint32_t table_bytes; };   // table_bytes = (size + 1) * 4
+
+template <int NT, bool LE>
+__global__ __launch_bounds__(NT) void colorlut1d_lds64_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n_groups,
+                                                              const uint32_t *__restrict__ lds_image, uint32_t image_dwords, Lut1d64K k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  for (uint32_t i = threadIdx.x; i < image_dwords; i += NT) ((uint32_t *)lds)[i] = lds_image[i];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * NT;
+  for (size_t g = (size_t)blockIdx.x * NT + threadIdx.x; g < n_groups; g += stride) {
+    const uint4 v = src[g];
+    uint32_t lo[2] = {v.x, v.z}, hi[2] = {v.y, v.w};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint32_t c16[3] = {lo[i] & 0xffffu, lo[i] >> 16, hi[i] & 0xffffu};
+      uint32_t o16[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const uint32_t in = LE ? c16[a] : swap16(c16[a]);
+        float n = div65535_u16((float)in);
+        n = fminf(fmaxf(n * k.scale[a] + k.offset[a], 0.0f), 1.0f);   // finite domain: == the inherent clamp
+        const float x = n * k.sm1;
+        const uint32_t idx = (uint32_t)x;
+        const float t = __builtin_amdgcn_fractf(x);
+        const float *L = (const float *)(lds + kAxisTableBytes + (uint32_t)a * k.table_bytes + 4u * idx);
+        const float o = lerp1(L[0], L[1], t);   // idx == size - 1: t == 0 and the pad is never weighted
+        const uint32_t v16 = round_half_away_nonneg(fminf(fmaxf(o, 0.0f), 1.0f) * 65535.0f);
+        o16[a] = LE ? v16 : swap16(v16);
+      }
+      lo[i] = o16[0] | (o16[1] << 16);
+      hi[i] = (hi[i] & 0xffff0000u) | o16[2];
+    }
+    dst[g] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+  }
+}
+
 // ---------------------------------------------------------------- host side: LUT upload + dispatch
 
 static constexpr size_t kLdsBytes = 160 * 1024;
@@ -1389,6 +1431,39 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       else hipLaunchKernelGGL(kbe, dim3((unsigned)grid), dim3(NT), lds, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_groups,
                               (const float *)L.d_planar, (const uint32_t *)L.d_axis, (uint32_t)L.planar_plane_floats, k64);
       return check_hip(ctx, hipGetLastError(), "colorlut3d_lds64 kernel launch");
+    }
+  }
+
+  if ((format == MI355_FMT_RGBA64_LE || format == MI355_FMT_RGBA64_BE) && !L.is3d && L.lds_ok && !ctx->force_generic) {
+    const size_t row_bytes = (size_t)width * 8;
+    const bool contiguous = (size_t)src_stride == row_bytes && (size_t)dst_stride == row_bytes &&
+                            (n_frames == 1 || (src_pitch == row_bytes * (size_t)height && dst_pitch == row_bytes * (size_t)height));
+    const size_t total_bytes = row_bytes * (size_t)height * (size_t)n_frames;
+    if (contiguous && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0) && (total_bytes % 16 == 0)) {
+      constexpr int NT = 512;
+      ctx->lut.last_kernel = "colorlut1d_lds64_kernel";
+      Lut1d64K k1;
+      for (int c = 0; c < 3; c++) { k1.scale[c] = L.scale[c]; k1.offset[c] = L.offset[c]; }
+      k1.sm1 = (float)L.size - 1.0f;
+      k1.table_bytes = ((uint32_t)L.size + 1u) * 4u;
+      const bool le = format == MI355_FMT_RGBA64_LE;
+      auto kle = colorlut1d_lds64_kernel<NT, true>;
+      auto kbe = colorlut1d_lds64_kernel<NT, false>;
+      int rc = check_hip(ctx, hipFuncSetAttribute(le ? (const void *)kle : (const void *)kbe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes),
+                         "hipFuncSetAttribute(max dynamic LDS)");
+      if (rc) return rc;
+      const size_t n_groups = total_bytes / 16;
+      size_t per_cu = kLdsBytes / (L.lds_bytes ? L.lds_bytes : 1);
+      if (per_cu < 1) per_cu = 1;
+      if (per_cu > 4) per_cu = 4;
+      size_t grid = (size_t)ctx->n_cu * per_cu;
+      const size_t max_blocks = (n_groups + NT - 1) / NT;
+      if (grid > max_blocks) grid = max_blocks;
+      if (le) hipLaunchKernelGGL(kle, dim3((unsigned)grid), dim3(NT), L.lds_bytes, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_groups,
+                                 (const uint32_t *)L.d_axis, (uint32_t)(L.lds_bytes / 4), k1);
+      else hipLaunchKernelGGL(kbe, dim3((unsigned)grid), dim3(NT), L.lds_bytes, ctx->stream, (const uint4 *)d_src, (uint4 *)d_dst, n_groups,
+                              (const uint32_t *)L.d_axis, (uint32_t)(L.lds_bytes / 4), k1);
+      return check_hip(ctx, hipGetLastError(), "colorlut1d_lds64 kernel launch");
     }
   }
 

@@ -1205,3 +1205,36 @@ def test_issue_streams_round_is_the_two_calls_per_stream(ctx, oracle, synth):
     finally:
         for c, a, b in zip(ctxs, d_src, d_dst):
             c.free(a); c.free(b); c.close()
+
+
+@pytest.mark.parametrize("le", [True, False])
+@pytest.mark.parametrize("size,domain", [(2, None), (64, None), (1024, None), (4096, ((-0.1, 0.0, 0.2), (1.2, 1.0, 0.7))), (12000, None)])
+def test_colorlut_rgba64_1d_lds_kernel(ctx, oracle, synth, le, size, domain):
+    """RGBA64 + a 1D LUT whose three tables fit LDS, on contiguous frames (round 3: colorlut1d_lds64_kernel instead of the
+    one-pixel-per-lane literal kernel): random 16-bit pixels plus every channel value 0..65535 on ramps, both byte orders, LUT
+    sizes 2..12000, a non-unit domain; a host frame with padded rows agrees too (padding untouched)."""
+    text = synth.cube_text_1d(size, gamma=0.6)
+    if domain:
+        text = text.replace("LUT_1D_SIZE", "DOMAIN_MIN %g %g %g\nDOMAIN_MAX %g %g %g\nLUT_1D_SIZE" % (domain[0] + domain[1]), 1)
+    cube = _load_cube(ctx, oracle, text)
+    rng = np.random.default_rng(size)
+    w, h = 1024, 160
+    px = rng.integers(0, 65536, size=(h * w, 4), dtype=np.uint16)
+    ramp = np.arange(65536, dtype=np.uint16)
+    px[:65536, 0] = ramp; px[:65536, 1] = ramp[::-1]; px[:65536, 2] = (ramp * 3) & 0xffff
+    px[65536:131072, :3] = ramp[:, None]
+    src = (px if le else px.byteswap()).reshape(-1).view(np.uint8).copy()
+    fmt = "RGBA64_LE" if le else "RGBA64_BE"
+    exp = np.zeros_like(src)
+    oracle.colorlut_rgba64(cube, src, w * 8, exp, w * 8, w, h, le=le)
+    got = np.zeros_like(src)
+    ctx.colorlut_frame(src, w * 8, got, w * 8, w, h, fmt)
+    assert ctx.colorlut_kernel_name() == "colorlut1d_lds64_kernel"
+    assert (got == exp).all(), _mismatch_report(got, exp)
+    # a host frame with padded rows
+    ss = w * 8 + 24
+    srcp = np.zeros((h, ss), np.uint8); srcp[:, : w * 8] = src.reshape(h, w * 8)
+    expp, gotp = np.full(h * ss, 0xAB, np.uint8), np.full(h * ss, 0xAB, np.uint8)
+    oracle.colorlut_rgba64(cube, srcp.reshape(-1), ss, expp, ss, w, h, le=le)
+    ctx.colorlut_frame(srcp.reshape(-1), ss, gotp, ss, w, h, fmt)
+    assert (gotp == expp).all()
