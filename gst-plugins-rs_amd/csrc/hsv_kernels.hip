@@ -445,7 +445,7 @@ int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int
       sel |= (uint32_t)(4 + in_pos[c]) << (8 * out_byte);
     }
     const size_t n_vec = total / 4;
-    const int fgrid = grid_for(ctx, n_vec, 256, 64);
+    const int fgrid = grid_for(ctx, (n_vec + 1) / 2, 256, 64);   // two groups per lane, as the hsvfilter kernels (one-frame launches)
     dim3 g(fgrid), b(256);
     const uint4 *sp = (const uint4 *)d_src;
     uint4 *dp = (uint4 *)d_dst;
