@@ -88,3 +88,44 @@ def test_round3_data_path_surface():
     for text in src.values():
         for fn in set(re.findall(r"\b(mi355h?_[a-z0-9_]+)\(", text)):
             assert re.search(r"\b%s\(" % fn, abi), fn
+
+
+def test_shim_calls_match_the_header_argument_counts():
+    """The shim cannot be compiled in this image (no GStreamer headers): at least every mi355_* call in gst/*.c passes as many
+    arguments as the prototype in include/mi355fx.h declares."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "mi355fx.h")).read(), flags=re.S)
+
+    def count(arglist):
+        depth, n, seen = 0, 0, False
+        for ch in arglist:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 0:
+                n += 1
+            if not ch.isspace():
+                seen = True
+        return n + 1 if seen and arglist.strip() != "void" else 0
+
+    protos = {m.group(1): count(m.group(2)) for m in re.finditer(r"\b(mi355_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+    checked = 0
+    for path in glob.glob(os.path.join(root, "gst", "*.c")):
+        src = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        for m in re.finditer(r"\b(mi355_[a-z0-9_]+)\s*\(", src):
+            name = m.group(1)
+            if name not in protos:
+                continue            # shim-local helpers (gst_mi355_* are not matched; mi355_* statics would be)
+            i, depth = m.end(), 1
+            while depth and i < len(src):
+                depth += src[i] in "([{"
+                depth -= src[i] in ")]}"
+                i += 1
+            args = src[m.end(): i - 1]
+            assert count(args) == protos[name], (os.path.basename(path), name, count(args), protos[name])
+            checked += 1
+    assert checked >= 20
