@@ -62,3 +62,34 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|#include\s+\"[^\"]*oracle", txt, flags=re.M):
                     offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_ctypes_signatures_match_the_header_argument_counts(mi355lib):
+    """The bindings the tests and the bench go through declare as many arguments as the C prototypes (a drifted argtypes list
+    would silently pass garbage)."""
+    import mi355fx
+    text = re.sub(r"/\*.*?\*/", "", open(mi355fx.HEADER_PATH).read(), flags=re.S)
+
+    def count(arglist):
+        depth, n, seen = 0, 0, False
+        for ch in arglist:
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            elif ch == "," and depth == 0:
+                n += 1
+            if not ch.isspace():
+                seen = True
+        return n + 1 if seen and arglist.strip() != "void" else 0
+
+    protos = {m.group(1): count(m.group(2)) for m in re.finditer(r"\b(mi355_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)}
+    checked, wrong = 0, {}
+    for name, n in protos.items():
+        fn = getattr(mi355lib, name)
+        if fn.argtypes is None:
+            continue
+        checked += 1
+        if len(fn.argtypes) != n:
+            wrong[name] = (len(fn.argtypes), n)
+    assert checked >= 80 and not wrong, (checked, wrong)
