@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
     ap.add_argument("--shared-reference", action="store_true",
                     help="config 5: the streams are the non-reference pads of --workers videocompare elements (reference frame hashed once per aggregate)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child runs at the end (then it is quoted from\n"
+                         "profiles/pmc_latest.json when that profile carries this code's fingerprint, else null)")
     ap.add_argument("--dssim-two-step", action="store_true",
                     help="config 5: hash every frame with mi355_dssim_create_image and compare the two images (the round-2 form) instead of\n"
                          "hashing + comparing the non-reference frames in one pass (mi355_dssim_compare_frames)")
@@ -229,6 +232,55 @@ def _install_stub(torch, mi355fx, rank):
         def close(self): pass
 
     mi355fx.Context = Ctx
+
+
+def live_pmc_traffic(args, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel, measured on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - they
+    do not fit one pass) over a short run of this file's main leg, as child processes after the timed work is done. gfx950
+    corrections as in tools/summarize_profiles.py (MI355X_MICROARCH.md, HBM section): the counters are in KiB and FETCH_SIZE
+    reports half the bytes of wide coalesced streaming reads. Returns (bytes, provenance) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself being profiled"
+    out = tempfile.mkdtemp(prefix="mi355fx_pmc_", dir="/tmp")
+    child = ["python3", os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--no-live-pmc",
+             "--batch", str(args.batch), "--content", args.content, "--lut-variant", str(args.lut_variant), "--pairs-per-step", str(args.pairs_per_step)]
+    for f in args.ctx_flag:
+        child += ["--ctx-flag", f]
+    if args.hsv_blocks_per_cu:
+        child += ["--hsv-blocks-per-cu", str(args.hsv_blocks_per_cu)]
+    avg = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row.get("Counter_Name") == counter and "mi355::" in row["Kernel_Name"] and \
+                            row["Kernel_Name"].split("mi355::")[1].startswith(kernel_prefix):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for %s" % (counter, kernel_prefix)
+            avg[counter] = (sum(vals) / len(vals), len(vals))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    traffic = avg["FETCH_SIZE"][0] * 1024 * 2 + avg["WRITE_SIZE"][0] * 1024
+    return traffic, ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (child processes of this run, after the timed legs) over "
+                     "`bench.py --steps 10 --warmup 2 --no-extra`: %d / %d launches averaged; FETCH_SIZE(KiB) * 1024 * 2 + WRITE_SIZE(KiB) * 1024"
+                     % (avg["FETCH_SIZE"][1], avg["WRITE_SIZE"][1]))
 
 
 def source_fingerprint():
@@ -701,12 +753,18 @@ def main():
         else:
             dom, dom_ms = ("colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel"), hsv_ms
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch cannot be read from inside the process. `traffic` is the per-launch figure of the committed
-        # rocprofv3 --pmc passes of THIS command (tools/collect_profiles.sh -> profiles/pmc_latest.json) when that profile was
-        # taken with the same batch size, content and kernel; otherwise null. Its provenance is spelled out next to it.
-        traffic, traffic_src = None, None
+        # HBM bytes per launch cannot be read from inside the process: `traffic` comes from rocprofv3 --pmc passes run as child
+        # processes at the end of this run (live_pmc_traffic); if that is not possible (no rocprofv3, N > 1, --no-extra), it is the
+        # per-launch figure of the committed passes of THIS command (tools/collect_profiles.sh -> profiles/pmc_latest.json) when that
+        # profile was taken with the same batch size, content, kernel and code; otherwise null. The provenance is spelled out next to it.
+        traffic, traffic_src, live_note = None, None, None
+        if world == 1 and not args.stub and not args.no_extra and not args.no_live_pmc:
+            # measured on this box, by this run (a committed file is not a measurement of the driver's run)
+            traffic, traffic_src = live_pmc_traffic(args, dom.split(" ")[0].split("<")[0])
+            if traffic is None:
+                live_note, traffic_src = traffic_src, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))) if traffic is None else {}
             if (pmc.get("frames_per_launch", pmc.get("frames_per_step")) == args.batch and pmc.get("content", "smooth") == args.content
                     and pmc.get("pristine_sources") and pmc.get("lut_variant", 0) == args.lut_variant
                     and pmc.get("source_fingerprint") == source_fingerprint()):   # taken from THIS code, or null
@@ -715,7 +773,7 @@ def main():
                         traffic = rec["hbm_bytes"]
                         traffic_src = "profiles/pmc_latest.json: separate rocprofv3 --pmc passes of this command (%s)" % pmc.get("collected", "?")
         except (OSError, ValueError, KeyError):
-            traffic = None
+            pass
         chain_gbs = 2 * per_launch_bytes / ((hsv_ms + lut_ms) * 1e-3) / 1e9
         out = {
             "metric": "4K RGBA frames/sec through hsvfilter+colorlut at 1 GPU; % HBM roofline",
@@ -732,7 +790,8 @@ def main():
                        "source_stats": main_leg["source_stats"], "dst_ring_batches": args.ring,
                        "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "source_fingerprint": source_fingerprint(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_live_note": live_note,
+                         "source_fingerprint": source_fingerprint(),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms,
                          "avg_launch_ms_raw_bracket": main_leg["raw_ms"][1] if lut_ms >= hsv_ms else main_leg["raw_ms"][0],
                          "launch_samples": main_leg["samples"]},

@@ -14,7 +14,7 @@ BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra $E
 # kernel traces: (1) the bench line's own command (all legs: the table kernel's average then mixes the two-launch leg,
 # whose input is on-die, with the fused leg, whose input comes from HBM); (2) the same K / W with only the main leg, whose
 # per-kernel averages are the ones roofline.avg_launch_ms must agree with
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_full" -o t -- python3 $R/bench.py $EXTRA > "$OUT/trace_full.log" 2>&1; echo "trace_full rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_full" -o t -- python3 $R/bench.py --no-live-pmc $EXTRA > "$OUT/trace_full.log" 2>&1; echo "trace_full rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --no-cpu-baseline --no-extra $EXTRA > "$OUT/trace.log" 2>&1; echo "trace rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > "$OUT/pmc_fetch.log" 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > "$OUT/pmc_write.log" 2>&1; echo "write rc=$?"
