@@ -238,7 +238,8 @@ def live_pmc_traffic(args, kernel_prefix):
     """HBM bytes per launch of the dominant kernel, measured on THIS box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - they
     do not fit one pass) over a short run of this file's main leg, as child processes after the timed work is done. gfx950
     corrections as in tools/summarize_profiles.py (MI355X_MICROARCH.md, HBM section): the counters are in KiB and FETCH_SIZE
-    reports half the bytes of wide coalesced streaming reads. Returns (bytes, provenance) or (None, reason)."""
+    reports half the bytes of wide coalesced streaming reads. A third child run (--kernel-trace --stats) gives the kernel's average
+    duration as the profiler sees it. Returns (bytes, rocprof_avg_ms, provenance) or (None, rocprof_avg_ms or None, reason)."""
     import csv
     import glob
     import shutil
@@ -246,9 +247,9 @@ def live_pmc_traffic(args, kernel_prefix):
     import tempfile
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not rocprof:
-        return None, "rocprofv3 not found"
+        return None, None, "rocprofv3 not found"
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
-        return None, "this run is itself being profiled"
+        return None, None, "this run is itself being profiled"
     out = tempfile.mkdtemp(prefix="mi355fx_pmc_", dir="/tmp")
     child = ["python3", os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--no-live-pmc",
              "--batch", str(args.batch), "--content", args.content, "--lut-variant", str(args.lut_variant), "--pairs-per-step", str(args.pairs_per_step)]
@@ -257,13 +258,23 @@ def live_pmc_traffic(args, kernel_prefix):
     if args.hsv_blocks_per_cu:
         child += ["--hsv-blocks-per-cu", str(args.hsv_blocks_per_cu)]
     avg = {}
+    rocprof_ms = None
     try:
+        # the kernel's average duration as rocprofv3 --kernel-trace --stats sees it on this box (must agree with avg_launch_ms)
+        d = os.path.join(out, "trace")
+        r = subprocess.run([rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+        if r.returncode == 0:
+            for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if "mi355::" in row["Name"] and row["Name"].split("mi355::")[1].startswith(kernel_prefix) and int(row["Calls"]) >= 20:
+                        rocprof_ms = float(row["AverageNs"]) * 1e-6
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
             r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
                                env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+                return None, rocprof_ms, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
             vals = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(path)):
@@ -271,14 +282,14 @@ def live_pmc_traffic(args, kernel_prefix):
                             row["Kernel_Name"].split("mi355::")[1].startswith(kernel_prefix):
                         vals.append(float(row["Counter_Value"]))
             if not vals:
-                return None, "no %s rows for %s" % (counter, kernel_prefix)
+                return None, rocprof_ms, "no %s rows for %s" % (counter, kernel_prefix)
             avg[counter] = (sum(vals) / len(vals), len(vals))
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
-        return None, "live PMC pass failed: %r" % (e,)
+        return None, rocprof_ms, "live PMC pass failed: %r" % (e,)
     finally:
         shutil.rmtree(out, ignore_errors=True)
     traffic = avg["FETCH_SIZE"][0] * 1024 * 2 + avg["WRITE_SIZE"][0] * 1024
-    return traffic, ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (child processes of this run, after the timed legs) over "
+    return traffic, rocprof_ms, ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (child processes of this run, after the timed legs) over "
                      "`bench.py --steps 10 --warmup 2 --no-extra`: %d / %d launches averaged; FETCH_SIZE(KiB) * 1024 * 2 + WRITE_SIZE(KiB) * 1024"
                      % (avg["FETCH_SIZE"][1], avg["WRITE_SIZE"][1]))
 
@@ -757,10 +768,10 @@ def main():
         # processes at the end of this run (live_pmc_traffic); if that is not possible (no rocprofv3, N > 1, --no-extra), it is the
         # per-launch figure of the committed passes of THIS command (tools/collect_profiles.sh -> profiles/pmc_latest.json) when that
         # profile was taken with the same batch size, content, kernel and code; otherwise null. The provenance is spelled out next to it.
-        traffic, traffic_src, live_note = None, None, None
+        traffic, traffic_src, live_note, rocprof_ms = None, None, None, None
         if world == 1 and not args.stub and not args.no_extra and not args.no_live_pmc:
             # measured on this box, by this run (a committed file is not a measurement of the driver's run)
-            traffic, traffic_src = live_pmc_traffic(args, dom.split(" ")[0].split("<")[0])
+            traffic, rocprof_ms, traffic_src = live_pmc_traffic(args, dom.split(" ")[0].split("<")[0])
             if traffic is None:
                 live_note, traffic_src = traffic_src, None
         try:
@@ -793,6 +804,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_live_note": live_note,
                          "source_fingerprint": source_fingerprint(),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms,
+                         "rocprof_avg_launch_ms": rocprof_ms,   # the same kernel in a rocprofv3 --kernel-trace --stats child run on this box
                          "avg_launch_ms_raw_bracket": main_leg["raw_ms"][1] if lut_ms >= hsv_ms else main_leg["raw_ms"][0],
                          "launch_samples": main_leg["samples"]},
             "kernels": {"hsvfilter_ms_per_launch": hsv_ms, "colorlut_ms_per_launch": lut_ms,
