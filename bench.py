@@ -672,7 +672,8 @@ def main():
             fused_ms = leg["ms"][0]
             f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
             fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
-                     "kernel": "colorlut_table_tiled_kernel (composed hsv+lut table)" if f_tab else "fused compute kernel",
+                     "kernel": (max(leg["colorlut_kernels_served"], key=leg["colorlut_kernels_served"].get) + " (composed hsv+lut table)") if f_tab and leg.get("colorlut_kernels_served") else ("memoised table kernel (composed hsv+lut table)" if f_tab else "fused compute kernel"),
+                     "kernels_served": leg.get("colorlut_kernels_served"),
                      "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
                      "algorithmic_bytes_per_launch": lb, "GBps": lb / (fused_ms * 1e-3) / 1e9,
                      # two different quantities: the kernel inside its event bracket, and the leg's wall-clock throughput
@@ -758,7 +759,9 @@ def main():
     if rank == 0:
         # dominant kernel = the longer of the two launches
         per_launch_bytes = lb
-        lut_name = "colorlut_table_tiled_kernel" if lut_tab else main_kernel_name
+        # the kernel that served most of the main leg's colorlut launches (auto may sample the other kinds in between)
+        served = main_leg.get("colorlut_kernels_served") or {}
+        lut_name = max(served, key=served.get) if served else main_kernel_name
         if lut_ms >= hsv_ms:
             dom, dom_ms = lut_name, lut_ms
         else:

@@ -1009,6 +1009,8 @@ void lut_release(mi355_ctx *ctx) {
     ctx->lut.table_ref[i].reset();  // the shared table goes when its last user does
     if (ctx->lut.pick[i].ev0) (void)hipEventDestroy(ctx->lut.pick[i].ev0);
     if (ctx->lut.pick[i].ev1) (void)hipEventDestroy(ctx->lut.pick[i].ev1);
+    if (ctx->lut.pick_sub[i].ev0) (void)hipEventDestroy(ctx->lut.pick_sub[i].ev0);
+    if (ctx->lut.pick_sub[i].ev1) (void)hipEventDestroy(ctx->lut.pick_sub[i].ev1);
   }
   if (ctx->lut.d_cells) (void)hipFree(ctx->lut.d_cells);
   if (ctx->lut.d_planar) (void)hipFree(ctx->lut.d_planar);
@@ -1624,15 +1626,39 @@ static int table_ensure(mi355_ctx *ctx, int which, int morton, const mi355_hsv_s
   return MI355_OK;
 }
 
-static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton);
+// `sub`: which kernel reads a Morton table - the gather kernels or the LDS-cached one (colorlut_window.hip)
+enum TableKernel { kTableGather = 0, kTableWindow = 1, kTableEither = 2 };
+template <class Compute, class Ensure, class Table>
+static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&compute, Ensure &&ensure, Table &&table);
+static int launch_table_gather(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton);
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
+                            TableKernel sub = kTableGather, AutoPick *pick = nullptr);
 static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
-                        const mi355_hsv_settings *hs) {
+                        const mi355_hsv_settings *hs, TableKernel sub = kTableGather) {
   int rc = table_ensure(ctx, which, morton, hs);
   if (rc) return rc;
-  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, geo, width, rows, morton);
+  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, geo, width, rows, morton, sub, &ctx->lut.pick_sub[which]);
 }
 
-static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton) {
+// Both kernels read the same table and give the same bytes; which is faster depends on where the pixels come from and on
+// the content: the gather kernel wins when its input was just written by the previous element (Infinity Cache) and the
+// colours are few, the LDS-cached kernel when the frames come from HBM or the colours outgrow L1. With
+// kTableEither the choice is the same measured one as between the interpolating and the table kernels (autopick.hpp), with
+// its own state per entry point: role "compute" = gather kernel, role "table" = LDS-cached kernel.
+static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
+                            TableKernel sub, AutoPick *pick) {
+  const bool window_ok = morton && sub != kTableGather && width % 4 == 0 && window_applicable(ctx, (unsigned)width / 4, geo.dw4, rows);
+  auto gather = [&]() { return launch_table_gather(ctx, t, d_src, d_dst, geo, width, rows, morton); };
+  auto window = [&]() {
+    ctx->lut.last_kernel = "colorlut_window_kernel";
+    return launch_window_table(ctx, t, d_src, d_dst, (unsigned)width / 4, geo.sw4, geo.dw4, rows);
+  };
+  if (!window_ok) return gather();
+  if (sub == kTableWindow || !pick) return window();
+  return auto_launch(ctx, *pick, geo.n_vec, gather, []() { return (int)MI355_OK; }, window);
+}
+
+static int launch_table_gather(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton) {
   const size_t n_vec = geo.n_vec;
   ctx->lut.last_kernel = "colorlut_table_tiled_kernel";
   if (width % 4 == 0 && width >= 128 && rows < (1u << 30)) {
@@ -1721,6 +1747,11 @@ static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&comp
 
 // below 64 K pixels a launch is all fixed cost and a 64 MiB table is not worth building
 constexpr size_t kAutoMinVec = 16384;
+// MI355_FLAG_LUT_VARIANT values that pin a table kernel: 4 linear index, 5 Morton index (gather kernels), 8 Morton index
+// through the LDS-cached kernel (colorlut_window.hip) where the launch is large enough for it
+// 9 = Morton table, the kernel that reads it chosen by measurement as in auto
+static bool table_variant(int v) { return v == 4 || v == 5 || v == 8 || v == 9; }
+static TableKernel table_variant_kernel(int v) { return v == 8 ? kTableWindow : (v == 9 ? kTableEither : kTableGather); }
 
 int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
                     size_t dst_pitch, int dst_stride, int n_frames, int width, int height, int format) {
@@ -1733,10 +1764,11 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   const size_t n_vec = geo.n_vec;
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 5 ? 1 : 0, nullptr);
+  if (table_ok && table_variant(v))
+    return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 4 ? 0 : 1, nullptr, table_variant_kernel(v));
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
-                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr); });
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr, kTableEither); });
 }
 
 // The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
@@ -1754,7 +1786,8 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   const size_t n_vec = geo.n_vec;
   const int v = ctx->lut_variant;
   auto compute = [&]() { return launch_hsv_colorlut_compute(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, hs, false); };
-  if (table_ok && (v == 4 || v == 5)) return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 5 ? 1 : 0, &hs);
+  if (table_ok && table_variant(v))
+    return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 4 ? 0 : 1, &hs, table_variant_kernel(v));
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
   else { L.seen_hs = hs; L.seen_stable = 0; }
@@ -1765,7 +1798,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
     L.pick[1].learn = 2;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
-                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs); });
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, kTableEither); });
 }
 
 // hsvfilter alone is a function of the colour too, and MI355_FLAG_HSV_TABLE = 1 / 2 runs it through the same machinery
@@ -1783,6 +1816,8 @@ void hsv_table_release(mi355_ctx *ctx) {
   T.table_ref.reset();
   if (T.pick.ev0) (void)hipEventDestroy(T.pick.ev0);
   if (T.pick.ev1) (void)hipEventDestroy(T.pick.ev1);
+  if (T.pick_sub.ev0) (void)hipEventDestroy(T.pick_sub.ev0);
+  if (T.pick_sub.ev1) (void)hipEventDestroy(T.pick_sub.ev1);
   T = HsvTable{};
 }
 
@@ -1822,7 +1857,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   if (ctx->hsv_table_mode == 2) {
     int rc = hsv_table_ensure(ctx, fmt, hs);
     T.last_table = true;
-    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1);
+    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, &T.pick_sub);
   }
   if (n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, T.seen_hs) && fmt.bgr == T.seen_bgr) { if (T.seen_stable < kStableCalls) T.seen_stable++; }
@@ -1834,7 +1869,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
     T.pick.learn = 2;
   }
   return auto_launch(ctx, T.pick, n_vec, compute, [&]() { return hsv_table_ensure(ctx, fmt, hs); },
-                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1); });
+                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, &T.pick_sub); });
 }
 
 }  // namespace mi355

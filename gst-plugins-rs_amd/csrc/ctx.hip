@@ -141,6 +141,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   lut_release(ctx);
   hsv_table_release(ctx);
+  window_release(ctx);
   loudnorm_release(ctx);
   loudnorm_batch_release(ctx);
   dssim_release(ctx);
@@ -181,7 +182,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   REQUIRE_CTX(ctx);
   if (flag == MI355_FLAG_FORCE_GENERIC) { ctx->force_generic = value != 0; return MI355_OK; }
   if (flag == MI355_FLAG_LUT_STAGGER && value >= 0 && value <= 4096) { ctx->lut_stagger = value; return MI355_OK; }
-  if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 7) { ctx->lut_variant = value; return MI355_OK; }
+  if (flag == MI355_FLAG_LUT_VARIANT && value >= 0 && value <= 9) { ctx->lut_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_TILES_PER_RUN && value >= 0 && value <= 4096) { ctx->brick_tiles_per_run = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_FOLD_AXIS && value >= 0 && value <= 2) { ctx->brick_fold_axis = value; return MI355_OK; }
   if (flag == MI355_FLAG_DSSIM_TRANSLUCENT && (value == 0 || value == 1)) { ctx->dssim_translucent = value; return MI355_OK; }
@@ -191,6 +192,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
   if (flag == MI355_FLAG_HRTF_METHOD && value >= 0 && value <= 2) { ctx->hrtf_method = value; return MI355_OK; }
+  if (flag == MI355_FLAG_WINDOW_MIN_STEPS && value >= 0 && value <= 4096) { ctx->window_min_steps = value; return MI355_OK; }
   return set_error(ctx, MI355_ERR_INVALID_ARG, "unknown flag");
 }
 
@@ -371,7 +373,7 @@ int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, d
   // times are kept per 16-byte group = 4 pixels
   if (table_in_use)
     *table_in_use = fused == 2 ? (ctx->hsv_table.last_table ? 1 : 0)
-                               : (ctx->lut_variant == 4 || ctx->lut_variant == 5 || (ctx->lut_variant == 0 && A.t_table > 0.0 && A.table));
+                               : (ctx->lut_variant == 4 || ctx->lut_variant == 5 || ctx->lut_variant == 8 || ctx->lut_variant == 9 || (ctx->lut_variant == 0 && A.t_table > 0.0 && A.table));
   if (ms_per_mpx_compute) *ms_per_mpx_compute = A.t_compute * 250000.0;
   if (ms_per_mpx_table) *ms_per_mpx_table = A.t_table * 250000.0;
   return MI355_OK;
@@ -391,6 +393,17 @@ int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *las
   if (counters) { counters[0] = c[0]; counters[1] = c[1]; }
   if (last_miss_fraction) *last_miss_fraction = ctx->lut.brick.watch.last_miss;
   if (hostile) *hostile = ctx->lut.brick.watch.home;
+  return MI355_OK;
+}
+
+int mi355_colorlut_window_stats(mi355_ctx *ctx, uint64_t counters[3], int reset) {
+  REQUIRE_CTX(ctx);
+  BIND_DEVICE(ctx);
+  if (!counters) return set_error(ctx, MI355_ERR_INVALID_ARG, "null counters");
+  unsigned long long c[3] = {0, 0, 0};
+  int rc = window_read_counters(ctx, c, reset != 0);
+  if (rc) return rc;
+  for (int i = 0; i < 3; i++) counters[i] = c[i];
   return MI355_OK;
 }
 

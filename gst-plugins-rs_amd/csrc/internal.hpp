@@ -9,6 +9,7 @@
 
 #include "autopick.hpp"
 #include "colorlut_brick.hpp"
+#include "colorlut_window.hpp"
 
 namespace mi355 {
 
@@ -43,6 +44,7 @@ struct LutDevice {
   mi355_hsv_settings seen_hs{};    // settings of the previous fused call and for how many calls they have not changed
   unsigned seen_stable = 0;
   AutoPick pick[2];                // compute-kernel / table-kernel choice for the two entry points
+  AutoPick pick_sub[2];            // ... and, for the table, gather kernel / LDS-cached kernel (colorlut_window.hip)
   BrickLut brick;                  // brick form of a 3D LUT for the brick-cache interpolating kernel (colorlut_brick.hip)
   bool building_table = false;     // launch_*_compute is being run over the all-colours frame by table_ensure
   const char *last_kernel = "";    // name of the kernel that served the last mi355_colorlut_* / mi355_hsv_colorlut_* launch
@@ -62,6 +64,7 @@ struct HsvTable {
   unsigned seen_stable = 0;
   bool last_table = false;       // the last launch_hsvfilter call ran the table kernel
   AutoPick pick;
+  AutoPick pick_sub;             // gather kernel / LDS-cached kernel for the table
 };
 
 struct EchoDevice {
@@ -107,6 +110,8 @@ struct mi355_ctx {
   int brick_prio = 3;           // MI355_FLAG_BRICK_PRIO: bit 0 progress-based wave priorities, bit 1 tile stealing within a block
   int brick_sets = 0;           // MI355_FLAG_BRICK_SETS: 0 = content watch decides (default); 32 (4x4x2 sets, 16 waves per CU) or 64 (4x4x4 sets, 8 waves per CU) pinned
   int hrtf_method = 0;         // MI355_FLAG_HRTF_METHOD: 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (takes effect at mi355_hrtf_setup)
+  int window_min_steps = mi355::kWindowMinStepsPerBlock;  // MI355_FLAG_WINDOW_MIN_STEPS
+  unsigned long long *d_window_counters = nullptr;  // colorlut_window.hip: {pixels, pixels past the LDS cache, bricks installed} x 1024 slots
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

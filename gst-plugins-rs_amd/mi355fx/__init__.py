@@ -34,6 +34,7 @@ FLAG_BRICK_PRIO = 9
 FLAG_BRICK_FOLD_AXIS = 10
 FLAG_DSSIM_TRANSLUCENT = 11
 FLAG_HRTF_METHOD = 12
+FLAG_WINDOW_MIN_STEPS = 13
 
 
 class HsvSettings(C.Structure):
@@ -91,6 +92,7 @@ def load_library():
         "mi355_shared_table_count": (i, []),
         "mi355_colorlut_last_kernel": (C.c_char_p, [vp]),
         "mi355_colorlut_brick_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_int), i]),
+        "mi355_colorlut_window_stats": (i, [vp, C.POINTER(C.c_uint64), i]),
         "mi355_selftest_brickwatch": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i, C.POINTER(C.c_int)]),
         "mi355_colorlut_frame": (i, [vp, u8p, i, u8p, i, i, i, i]),
         "mi355_colorlut_frames_device": (i, [vp, u8p, sz, i, u8p, sz, i, i, i, i, i]),
@@ -324,6 +326,12 @@ class Context:
         f, h = C.c_double(0), C.c_int(0)
         self._ck(self.L.mi355_colorlut_brick_stats(self.h, c, C.byref(f), C.byref(h), int(reset)))
         return int(c[0]), int(c[1]), f.value, int(h.value)
+
+    def colorlut_window_stats(self, reset=False):
+        """LDS-cached table kernel: (pixels looked up, pixels served past the LDS cache, bricks installed) since the last reset."""
+        c = (C.c_uint64 * 3)()
+        self._ck(self.L.mi355_colorlut_window_stats(self.h, c, int(reset)))
+        return int(c[0]), int(c[1]), int(c[2])
 
     def colorlut_frame(self, src, src_stride, dst, dst_stride, width, height, fmt="RGBA"):
         self._ck(self.L.mi355_colorlut_frame(self.h, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, FMT[fmt]))

@@ -89,8 +89,10 @@ typedef enum mi355_flag {
    * with a table of the composed function. 6 = interpolating kernels only: the brick-cache kernel (colorlut_brick.hip),
    * with noise-like streams handed to the three-pass whole-plane kernel by a miss-counter watch that never blocks;
    * 7 = brick-cache kernel only; 3 = three-pass kernel only; 1 / 2 = the three-pass kernel's late-prefetch / lean-state
-   * forms (tuning experiments); 4 / 5 = table kernel only, linear / Morton table index. Auto records and queries events
-   * on the context's stream: pin a variant (7, 3 or 5) before capturing that stream into a hipGraph. */
+   * forms (tuning experiments); 4 / 5 = table through the gather kernels only, linear / Morton table index; 8 = Morton table
+   * read through a block-shared LDS cache of table bricks (colorlut_window.hip) where the launch is large enough; 9 =
+   * Morton table, 5's or 8's kernel by measurement. Auto builds the Morton table and picks as 9 does. Auto records and queries events on
+   * the context's stream: pin a variant (7, 3, 5 or 8) before capturing that stream into a hipGraph. */
   MI355_FLAG_LUT_VARIANT = 4,
   /* hsvfilter on packed colour-first 4-byte frames through a memoised table: 0 (default) = auto choice as for colorlut,
    * but only for settings that need the literal GENERIC arithmetic (|hue-shift| > 360 or non-finite); 1 = auto choice
@@ -103,6 +105,7 @@ typedef enum mi355_flag {
   MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
   MI355_FLAG_HRTF_METHOD = 12, /* hrtfrender convolution, read at mi355_hrtf_setup: 0 (default) = overlap-save FFT in LDS from 384-tap HRIRs on (the measured crossover), time-domain FIR below; 1 = FFT, 2 = FIR pinned (each only where it fits the LDS) */
+  MI355_FLAG_WINDOW_MIN_STEPS = 13, /* LDS-cached table kernel (LUT variants 0 / 8): smallest launch it serves, in 256 x 32 pixel steps per CU (default 3; 0 = any size - its first step per block runs on a cold cache, so small launches are faster through the gather kernels) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
@@ -179,6 +182,10 @@ const char *mi355_colorlut_last_kernel(mi355_ctx *ctx);
  * *last_miss_fraction = miss fraction of the content watch's last snapshot, *level = the level it has settled on (0 brick
  * kernel with 32 sets, 1 with 64 sets, 2 three-pass kernel). reset != 0 clears the device counters. No reference counterpart. */
 int mi355_colorlut_brick_stats(mi355_ctx *ctx, uint64_t counters[2], double *last_miss_fraction, int *level, int reset);
+/* Diagnostics of the LDS-cached memoised-table kernel (csrc/colorlut_window.hip; synchronous): counters[0] = pixels it
+ * has looked up on this context since the last reset, counters[1] = pixels whose table brick was not in the block's
+ * LDS cache (served from the table in global memory), counters[2] = bricks installed. No reference counterpart. */
+int mi355_colorlut_window_stats(mi355_ctx *ctx, uint64_t counters[3], int reset);
 /* Host-logic self test of the content-watch policy (csrc/brickwatch.hpp) against a scripted stream, no GPU needed: call i
  * would show miss / slow step fractions miss0[i], slow0[i] on the 32-set brick kernel and miss1[i], slow1[i] on the 64-set
  * one; snapshots become readable `lag` calls late. level_out[i] = 0 / 1 / 2 as above. */

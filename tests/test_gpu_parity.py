@@ -927,7 +927,7 @@ def test_fused_chain_4k_batch_equals_two_element_launches(ctx, oracle, synth):
     assert (fused[: exp0.size] == exp0).all()
 
 
-@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("variant", [4, 5, 8])
 @pytest.mark.parametrize("setting,kind,size", [("hue90", "3d", 33), ("mixed", "3d", 65), ("nonfinite", "3d", 17), ("mixed", "1d", 128)])
 def test_fused_chain_table_kernel_allcolors(ctx, oracle, synth, variant, setting, kind, size):
     """The memoised table of the COMPOSED function (hsvfilter then colorlut) on every colour, for LUTs the fused
@@ -994,11 +994,12 @@ def test_colorlut_kernel_variants_allcolors(ctx, oracle, synth, variant, size):
     assert (got == exp).all(), _mismatch_report(got, exp)
 
 
-@pytest.mark.parametrize("variant", [4, 5, 0])
+@pytest.mark.parametrize("variant", [4, 5, 8, 0])
 @pytest.mark.parametrize("kind,size", [("3d", 2), ("3d", 33), ("3d", 65), ("1d", 256)])
 def test_colorlut_table_kernel_allcolors(ctx, oracle, synth, variant, kind, size):
-    """The 2^24-entry memoised-table kernel (MI355_FLAG_LUT_VARIANT 4 linear / 5 Morton index, and whatever 0 = auto
-    picks on the second and later launches) on every colour, with a varying alpha that must pass through."""
+    """The 2^24-entry memoised-table kernels (MI355_FLAG_LUT_VARIANT 4 linear / 5 Morton index through the gather kernels,
+    8 Morton index through the LDS-cached kernel, and whatever 0 = auto picks on the second and later launches) on every
+    colour, with a varying alpha that must pass through."""
     import mi355fx
     text = synth.cube_text_3d(size) if kind == "3d" else synth.cube_text_1d(size)
     cube = _load_cube(ctx, oracle, text)
@@ -1030,8 +1031,8 @@ def test_colorlut_table_follows_lut_reload(ctx, oracle, synth):
         assert (got == exp).all()
 
 
-@pytest.mark.parametrize("variant", [4, 5])
-@pytest.mark.parametrize("w,h", [(4, 1), (100, 37), (128, 4), (516, 3), (1920, 1081), (3840, 7), (1000, 9), (256, 8), (260, 17)])
+@pytest.mark.parametrize("variant", [4, 5, 8])
+@pytest.mark.parametrize("w,h", [(4, 1), (100, 37), (128, 4), (516, 3), (1920, 1081), (3840, 7), (1000, 9), (256, 8), (260, 17), (1924, 1083), (132, 4000)])
 def test_colorlut_table_kernel_chunk_tails(ctx, oracle, synth, variant, w, h):
     """Frame sizes around the table kernels' 512-pixel wave patches: flat kernel (width < 128 or not a multiple of 4) and the
     tiled kernel with 128- and 256-pixel-wide patches, masked last columns and rows."""
