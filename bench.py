@@ -251,7 +251,9 @@ def live_pmc_traffic(args, kernel_prefix):
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
         return None, None, "this run is itself being profiled"
     out = tempfile.mkdtemp(prefix="mi355fx_pmc_", dir="/tmp")
-    child = ["python3", os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--no-live-pmc",
+    # THIS interpreter, resolved to the binary: a `python3` from PATH may be a wrapper script (pyenv, conda) = one more exec
+    # under the profiler's preloaded, GPU-initialised library, which this pool forbids
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--no-live-pmc",
              "--batch", str(args.batch), "--content", args.content, "--lut-variant", str(args.lut_variant), "--pairs-per-step", str(args.pairs_per_step)]
     for f in args.ctx_flag:
         child += ["--ctx-flag", f]
@@ -259,11 +261,26 @@ def live_pmc_traffic(args, kernel_prefix):
         child += ["--hsv-blocks-per-cu", str(args.hsv_blocks_per_cu)]
     avg = {}
     rocprof_ms = None
+
+    def run_child(cmd):
+        """Own session, so that a timeout ends rocprofv3 AND the GPU process under it (subprocess.run would only kill rocprofv3)."""
+        import signal
+        p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            p.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)   # exactly the group this call started
+            except OSError:
+                pass
+            p.wait()
+            raise
+        return p
+
     try:
         # the kernel's average duration as rocprofv3 --kernel-trace --stats sees it on this box (must agree with avg_launch_ms)
         d = os.path.join(out, "trace")
-        r = subprocess.run([rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child, cwd="/tmp",
-                           env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+        r = run_child([rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child)
         if r.returncode == 0:
             for path in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
                 for row in csv.DictReader(open(path)):
@@ -271,8 +288,7 @@ def live_pmc_traffic(args, kernel_prefix):
                         rocprof_ms = float(row["AverageNs"]) * 1e-6
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
-            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
-                               env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            r = run_child([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child)
             if r.returncode != 0:
                 return None, rocprof_ms, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
             vals = []
@@ -535,8 +551,9 @@ def main():
                 done += n
             return fills
 
-        def measure(content, steps, warmup, record, fused=False, streams=None, native_round=None):
+        def measure(content, steps, warmup, record, fused=False, streams=None, native_round=None, solo=False):
             """One leg: ramp on scratch batches, W warm-up steps and K timed steps, each on its own pristine batch.
+            solo: this rank alone (no barrier, no MAX over ranks) - a secondary leg of rank 0 in an N > 1 run.
             streams: list of per-stream contexts - frame i of every batch then belongs to stream i and is processed by
             that stream's own context with one-frame launches (what N independent pipelines issue)."""
             nb = len(streams) if streams else args.batch
@@ -573,6 +590,9 @@ def main():
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                     ctx.hsv_colorlut_frames_device(s_.data_ptr(), pitch, W * 4, d_.data_ptr(), pitch, W * 4, args.batch, W, H, settings)
+                    if in_timed[0]:
+                        name = ctx.colorlut_kernel_name()
+                        served[name] = served.get(name, 0) + 1
                     if sample:
                         e1.record()
                         evs_.append((e0, e1))
@@ -614,7 +634,7 @@ def main():
                     in_timed[0] = True
                     evs.extend(region(sl, n, record and steps >= 64))
                     in_timed[0] = False
-                dts.append(sharding.timed_region(body, dist=dist, device_sync=torch.cuda.synchronize, keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
+                dts.append(sharding.timed_region(body, dist=None if solo else dist, device_sync=torch.cuda.synchronize, keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
 
             consume(pool, srcs, warmup, 0, warm)
             chunks = consume(pool, srcs, steps, warmup, timed)
@@ -681,6 +701,17 @@ def main():
                      "kernel_frac_of_hbm_peak": lb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "throughput_frac_of_hbm_peak": fused_fps * BYTES_PER_FRAME_PER_KERNEL / 1e9 / HBM_PEAK_GBS,
                      "note": "one launch per batch, 8 B/px algorithmic (SURVEY 8d fused accounting); bit-identical to the two-kernel chain"}
+        nt_ab = None
+        if not args.no_extra and world == 1 and not args.stub:
+            # A/B: the same two launches with hsvfilter's output written past the Infinity Cache (non-temporal stores). What the
+            # colorlut launch loses is what it gets from reading the batch hsvfilter has just written on-die instead of from HBM:
+            # the 16 B/pixel of the headline are algorithmic bytes, and 4 of them need not touch HBM (roofline.on_die_bytes_per_launch).
+            ctx.set_flag(mi355fx.FLAG_HSV_NT, 1)
+            leg = measure(args.content, max(10, args.steps // 2), 4, True)
+            ctx.set_flag(mi355fx.FLAG_HSV_NT, 0)
+            nt_ab = {"frames_per_s": leg["frames"] / leg["dt"], "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
+                     "colorlut_kernels_served": leg["colorlut_kernels_served"],
+                     "what": "the headline's two launches with MI355_FLAG_HSV_NT = 1: hsvfilter stores non-temporally, colorlut reads its input from HBM"}
         extra = None
         if not args.no_extra and world == 1:
             other = "noise" if args.content == "smooth" else "smooth"
@@ -737,6 +768,15 @@ def main():
                 row["distinct_colours_frame0"] = leg["source_stats"]["first"]["distinct_colours_frame0"]
                 sweep[label] = row
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
+        elif not args.no_extra and world > 1 and rank == 0:
+            # N > 1: the secondary legs are dropped, but the scaling record should show more than the amp-0 number - rank 0 alone
+            # (the other ranks wait at the final barrier, their GPUs idle) measures the chain on the natural-like frame + uniform
+            # noise of +-4 per channel with the default flags. One GPU's figure, not the job's.
+            leg = measure("smooth+4", max(8, args.steps // 5), 18, True, solo=True)
+            sweep = {"amp4": {"auto": {"frames_per_s": leg["frames"] / leg["dt"], "hsvfilter_ms_per_launch": leg["ms"][0], "colorlut_ms_per_launch": leg["ms"][1],
+                                       "colorlut_frac_of_hbm_peak": lb / (leg["ms"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "colorlut_kernels_served": leg["colorlut_kernels_served"]},
+                              "distinct_colours_frame0": leg["source_stats"]["first"]["distinct_colours_frame0"],
+                              "measured_on": "rank 0 alone after the timed region (one GPU's frames/s; the other ranks idle at the barrier)"}}
 
     fps = sharding.aggregate_throughput(main_leg["frames"], world, dt)
     ms_per_step = dt / args.steps * 1e3
@@ -807,6 +847,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_live_note": live_note,
                          "source_fingerprint": source_fingerprint(),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": dom_ms,
+                         # of the algorithmic bytes of a colorlut launch, its input (half) was written by the hsvfilter launch just
+                         # before it and can be served by the 256 MiB Infinity Cache instead of HBM: an upper bound, not a counter
+                         # (FETCH_SIZE counts Infinity-Cache hits too); the measured effect is the hsvfilter_nontemporal_ab leg
+                         "on_die_bytes_per_launch": (min(per_launch_bytes // 2, 256 << 20) if lut_ms >= hsv_ms else 0),
+                         "on_die_note": "upper bound: the part of this launch's input that the preceding hsvfilter launch left in the Infinity Cache (256 MiB); "
+                                        "with hsvfilter's stores made non-temporal the same launch reads it from HBM - see hsvfilter_nontemporal_ab",
                          "rocprof_avg_launch_ms": rocprof_ms,   # the same kernel in a rocprofv3 --kernel-trace --stats child run on this box
                          "avg_launch_ms_raw_bracket": main_leg["raw_ms"][1] if lut_ms >= hsv_ms else main_leg["raw_ms"][0],
                          "launch_samples": main_leg["samples"]},
@@ -826,6 +872,8 @@ def main():
             out["interpolating_kernel_only"] = interp
         if fused:
             out["fused_chain"] = fused
+        if nt_ab:
+            out["hsvfilter_nontemporal_ab"] = nt_ab
         if extra:
             out["other_content"] = extra
         if streams_leg:

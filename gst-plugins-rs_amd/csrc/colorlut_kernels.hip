@@ -1004,9 +1004,10 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   if (ok1) __builtin_nontemporal_store(r1v, d4 + o1);
 }
 
+void shared_table_release(mi355_ctx *ctx, std::shared_ptr<void> *ref);
 void lut_release(mi355_ctx *ctx) {
   for (int i = 0; i < 2; i++) {
-    ctx->lut.table_ref[i].reset();  // the shared table goes when its last user does
+    shared_table_release(ctx, &ctx->lut.table_ref[i]);  // the shared table goes when its last user does
     if (ctx->lut.pick[i].ev0) (void)hipEventDestroy(ctx->lut.pick[i].ev0);
     if (ctx->lut.pick[i].ev1) (void)hipEventDestroy(ctx->lut.pick[i].ev1);
     if (ctx->lut.pick_sub[i].ev0) (void)hipEventDestroy(ctx->lut.pick_sub[i].ev0);
@@ -1536,18 +1537,49 @@ static bool same_hs(const mi355_hsv_settings &a, const mi355_hsv_settings &b) { 
 struct SharedTable {
   uint32_t *d = nullptr;
   hipEvent_t ready = nullptr;
+  // "the last launch that reads this table on my stream has been enqueued": one event per context that let go of the table
+  // while others kept it (shared_table_release). Whoever later rebuilds the buffer in place makes its stream wait for them.
+  std::vector<hipEvent_t> released;
   int device = 0;
   ~SharedTable() {
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
     if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
-    if (d) (void)hipFree(d);
+    for (hipEvent_t e : released) (void)hipEventDestroy(e);
+    if (d) (void)hipFree(d);  // (a device-wide synchronisation: nothing reads the buffer any more when it returns)
     (void)hipSetDevice(cur);
   }
 };
 static std::mutex g_tables_mu;
 static std::map<std::string, std::weak_ptr<SharedTable>> g_tables;
+
+// Lets go of *ref. If other contexts keep the table, this context's reads of it - all enqueued on ctx->stream before this
+// call - are marked with an event the table remembers: a later sole owner may rebuild the buffer in place, on ITS stream,
+// and must not overtake them. Call with g_tables_mu held.
+static void shared_table_release_locked(mi355_ctx *ctx, std::shared_ptr<void> *ref) {
+  if (!*ref) return;
+  if (ref->use_count() > 1) {
+    SharedTable *sp = static_cast<SharedTable *>(ref->get());
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(e, ctx->stream) == hipSuccess) sp->released.push_back(e);
+      else { (void)hipEventDestroy(e); (void)hipStreamSynchronize(ctx->stream); }
+    } else {
+      (void)hipStreamSynchronize(ctx->stream);  // no event to be had: make the statement true the slow way
+    }
+    (void)hipGetLastError();
+  }
+  ref->reset();
+}
+void shared_table_release(mi355_ctx *ctx, std::shared_ptr<void> *ref) {
+  std::shared_ptr<void> last;  // if this was the last reference, the table is destroyed (device-wide wait) outside the lock
+  {
+    std::lock_guard<std::mutex> g(g_tables_mu);
+    if (*ref && ref->use_count() == 1) last = std::move(*ref);
+    else shared_table_release_locked(ctx, ref);
+  }
+}
 
 // `build(table)` enqueues the kernels that fill a table on ctx->stream. On return *out is usable on ctx->stream.
 // *ref may hold the table this context used under ANOTHER key (new hsv settings, a reloaded LUT). If nobody else has that
@@ -1562,17 +1594,26 @@ static int shared_table_acquire(mi355_ctx *ctx, const std::string &key, std::sha
   if (auto sp = g_tables[full].lock()) {
     int rc = check_hip(ctx, hipStreamWaitEvent(ctx->stream, sp->ready, 0), "hipStreamWaitEvent(shared table)");
     if (rc) return rc;
+    if (ref->get() != sp.get()) shared_table_release_locked(ctx, ref);  // the table used under the old key may live on in other contexts
     *out = sp->d;
     *ref = sp;
     return MI355_OK;
   }
   std::shared_ptr<SharedTable> sp;
   if (*ref && ref->use_count() == 1) {
-    // sole user (strong references are only ever taken under this lock): keep the buffer, give it the new key
+    // sole user (strong references are only ever taken under this lock): keep the buffer, give it the new key. Contexts
+    // that shared it earlier may still have launches in flight on THEIR streams that read the old contents: wait for the
+    // events they left behind (in stream order, no host wait) before the build overwrites it.
     sp = std::static_pointer_cast<SharedTable>(*ref);
+    for (hipEvent_t e : sp->released) {
+      int rc = check_hip(ctx, hipStreamWaitEvent(ctx->stream, e, 0), "hipStreamWaitEvent(released table)");
+      if (rc) return rc;
+    }
+    for (hipEvent_t e : sp->released) (void)hipEventDestroy(e);  // (the waits are enqueued; the runtime keeps what they need)
+    sp->released.clear();
     for (auto it = g_tables.begin(); it != g_tables.end();) it = it->second.lock() == sp ? g_tables.erase(it) : std::next(it);
   } else {
-    ref->reset();
+    shared_table_release_locked(ctx, ref);
     sp = std::make_shared<SharedTable>();
     sp->device = ctx->device;
     int rc = check_hip(ctx, hipMalloc((void **)&sp->d, (size_t)kTableEntries * 4), "hipMalloc(memoised table)");
@@ -1813,7 +1854,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
 // 26.3-27.4 k to 24.6 k frames/s with both tables live.
 void hsv_table_release(mi355_ctx *ctx) {
   HsvTable &T = ctx->hsv_table;
-  T.table_ref.reset();
+  shared_table_release(ctx, &T.table_ref);
   if (T.pick.ev0) (void)hipEventDestroy(T.pick.ev0);
   if (T.pick.ev1) (void)hipEventDestroy(T.pick.ev1);
   if (T.pick_sub.ev0) (void)hipEventDestroy(T.pick_sub.ev0);

@@ -173,11 +173,15 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
 #pragma unroll
         for (int j = 7; j >= 0; j--)
           if (!hit[j]) mb = s[j] >> 6;
+        // (each wave starts its search at another lane: the waves of a block miss the same new bricks at the same time,
+        // and sixteen waves asking for the same eight leave the rest to the gather path)
         unsigned long long want = __builtin_amdgcn_ballot_w64(mb != 0xffffffffu), leaders = 0ull;
+        const unsigned rot = (wave * 4u + 1u) & 63u;
 #pragma unroll
         for (int f = 0; f < kWinFills; f++)
           if (want != 0ull) {
-            const int l = __builtin_ctzll(want);
+            const unsigned long long turned = (want >> rot) | (want << (64u - rot));
+            const int l = (int)((__builtin_ctzll(turned) + rot) & 63u);
             leaders |= 1ull << l;
             want &= ~__builtin_amdgcn_ballot_w64(mb == (uint32_t)__builtin_amdgcn_readlane((int)mb, l));
           }

@@ -192,6 +192,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
   if (flag == MI355_FLAG_HRTF_METHOD && value >= 0 && value <= 2) { ctx->hrtf_method = value; return MI355_OK; }
+  if (flag == MI355_FLAG_HSV_NT && (value == 0 || value == 1)) { ctx->hsv_nt = value; return MI355_OK; }
   if (flag == MI355_FLAG_WINDOW_MIN_STEPS && value >= 0 && value <= 4096) { ctx->window_min_steps = value; return MI355_OK; }
   return set_error(ctx, MI355_ERR_INVALID_ARG, "unknown flag");
 }

@@ -48,13 +48,25 @@ __device__ __forceinline__ void hsvfilter_quad(uint32_t &a, uint32_t &b, uint32_
 // shrunk (63 VGPRs, 8 waves per SIMD cover the latency).
 template <int VARIANT, int FIRST, bool BGR>
 __global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__ data, size_t n_vec,
-                                                             HsvK k) {
+                                                             HsvK k, int nt) {
   constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
   constexpr int NPOS = FIRST == 0 ? 3 : 0;
   __shared__ HsvLds lds;
   hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (nt) {  // MI355_FLAG_HSV_NT (the A/B of bench.py: what the chain costs when this launch's output bypasses the Infinity Cache)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t *d4 = (u32x4_t *)data;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+      const u32x4_t v = __builtin_nontemporal_load(d4 + i);
+      uint4 p = {v.x, v.y, v.z, v.w};
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
+      const u32x4_t o = {p.x, p.y, p.z, p.w};
+      __builtin_nontemporal_store(o, d4 + i);
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     uint4 p = data[i];
     hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
@@ -231,10 +243,11 @@ static int grid_for(mi355_ctx *ctx, size_t work_items, int block, int blocks_per
 template <int VARIANT>
 static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, int first, int bgr, int grid) {
   dim3 g(grid), b(256);
-  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, false>), g, b, 0, ctx->stream, d, n_vec, k);
-  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, true>), g, b, 0, ctx->stream, d, n_vec, k);
-  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, false>), g, b, 0, ctx->stream, d, n_vec, k);
-  else hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_vec, k);
+  const int nt = ctx->hsv_nt;
+  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, false>), g, b, 0, ctx->stream, d, n_vec, k, nt);
+  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 0, true>), g, b, 0, ctx->stream, d, n_vec, k, nt);
+  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, false>), g, b, 0, ctx->stream, d, n_vec, k, nt);
+  else hipLaunchKernelGGL((hsvfilter_flat_kernel<VARIANT, 1, true>), g, b, 0, ctx->stream, d, n_vec, k, nt);
 }
 
 template <int VARIANT>

@@ -1077,10 +1077,18 @@ int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_str
   if (!final_frame && frames != b->current_samples_per_frame) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: a batch takes whole frames (mi355_loudnorm_batch_frame_size)");
   if (final_frame && frames >= b->current_samples_per_frame && !(frames == 0)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: the final frame is shorter than a full one");
   if (frames && (!data || stream_stride < frames * ch)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: bad input / stream stride");
-  if (final_frame) {
-    if (b->current_samples_per_frame == FRAME_SIZE) b->frame_type = FT_FINAL;
-    else if (frames == 0) return MI355_OK;  // nothing at all: the element answers FlowError::Eos (imp.rs:289-293)
+  if (final_frame && b->current_samples_per_frame != FRAME_SIZE && frames == 0) return MI355_OK;  // nothing at all: the element answers FlowError::Eos (imp.rs:289-293)
+  {
+    // The output capacity is checked BEFORE anything changes: the meter has not seen the frame, frame_type has not moved. A
+    // caller told "output buffer too small" can come back with a larger one and gets what State::process gives.
+    int ft = b->frame_type;
+    if (final_frame && b->current_samples_per_frame == FRAME_SIZE) ft = FT_FINAL;
+    if (ft == FT_FIRST && frames < b->current_samples_per_frame) ft = FT_LINEAR;  // process_first_frame_is_last
+    const size_t need = ft == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames)
+                        : (ft == FT_LINEAR ? frames : (ft == FT_FIRST ? FRAME_SIZE : b->current_samples_per_frame));
+    if (need > out_cap_frames || (need && (!out || out_stride < need * ch))) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
   }
+  if (final_frame && b->current_samples_per_frame == FRAME_SIZE) b->frame_type = FT_FINAL;
   int rc;
   // the frame on the device, packed [S][frames * ch]
   const double *d_in = b->d_src;
@@ -1105,7 +1113,6 @@ int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_str
   }
   const size_t need = b->frame_type == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames)
                       : (b->frame_type == FT_LINEAR ? frames : (b->frame_type == FT_FIRST ? FRAME_SIZE : b->current_samples_per_frame));
-  if (need > out_cap_frames || (need && (!out || out_stride < need * ch))) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
   // a sub-frame of `n` frames from d_dst (packed [S][n * ch]) to the caller's buffer at frame offset `at`
   auto deliver = [&](size_t at, size_t n) -> int {
     return check_hip(ctx, hipMemcpy2DAsync(out + at * ch, out_stride * 8, b->d_dst, n * ch * 8, n * ch * 8, S, device_data ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream),

@@ -4,6 +4,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
 
@@ -1003,10 +1004,14 @@ bool RoundedCorners::set_caps(int width, int height, int out_format) {
   return true;
 }
 
-// generate_alpha_mask + draw_rounded_corners (imp.rs:57-180) with the C API of the same library the cairo crate binds
-bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
-  if (radius == 0) { std::fill(alpha_mem_.begin(), alpha_mem_.end(), 0xff); return true; }
-  std::fill(alpha_mem_.begin(), alpha_mem_.end(), 0);
+// generate_alpha_mask + draw_rounded_corners (imp.rs:57-180) with the C API of the same library the cairo crate binds.
+// `alpha`: the A8 plane (stride x round_up_2(height) bytes). One implementation for the C++ element and for the C entry
+// point the GStreamer shim calls (mi355host_rounded_corners_mask).
+static bool draw_rounded_mask(void **cairo_handle, uint8_t *alpha, size_t alpha_bytes, int width_, int height_, int alpha_stride_, uint32_t radius,
+                              std::string &last_error_) {
+  if (radius == 0) { std::fill(alpha, alpha + alpha_bytes, 0xff); return true; }
+  std::fill(alpha, alpha + alpha_bytes, 0);
+  void *&cairo_ = *cairo_handle;
   if (!cairo_) cairo_ = dlopen("libcairo.so.2", RTLD_NOW | RTLD_LOCAL);
   if (!cairo_) { last_error_ = "Failed to create cairo image surface: libcairo.so.2 not found"; return false; }
   typedef void *(*surf_create_t)(unsigned char *, int, int, int, int);
@@ -1029,7 +1034,7 @@ bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
   auto surf_status = (status_t)sym("cairo_surface_status"), cr_status = (status_t)sym("cairo_status");
   if (!surf_create || !create || !new_sub_path || !close_path || !fill_preserve || !stroke || !destroy || !surf_flush || !surf_destroy || !arc || !set_rgb ||
       !set_rgba || !set_lw || !surf_status || !cr_status) { last_error_ = "Failed to create cairo image surface: symbols missing"; return false; }
-  void *surface = surf_create(alpha_mem_.data(), 2 /* CAIRO_FORMAT_A8 */, width_, height_, alpha_stride_);
+  void *surface = surf_create(alpha, 2 /* CAIRO_FORMAT_A8 */, width_, height_, alpha_stride_);
   if (!surface || surf_status(surface) != 0) { last_error_ = "Failed to create cairo image surface"; if (surface) surf_destroy(surface); return false; }
   void *cr = create(surface);
   const double r = (double)radius, w = (double)width_, h = (double)height_, deg = 3.14159265358979323846 / 180.0;
@@ -1050,6 +1055,19 @@ bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
   surf_destroy(surface);
   if (!ok) last_error_ = "Failed to draw rounded corners";
   return ok;
+}
+
+bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
+  return draw_rounded_mask(&cairo_, alpha_mem_.data(), alpha_mem_.size(), width_, height_, alpha_stride_, radius, last_error_);
+}
+
+extern "C" int mi355host_rounded_corners_mask(uint8_t *alpha, int width, int height, int stride, unsigned radius, char *err, size_t errlen) {
+  static void *cairo = nullptr;  // (dlopen is reference counted and thread safe; a duplicate handle is harmless)
+  std::string e;
+  if (!alpha || width <= 0 || height <= 0 || stride < width) e = "bad argument";
+  else if (draw_rounded_mask(&cairo, alpha, (size_t)stride * (((size_t)height + 1) & ~(size_t)1), width, height, stride, radius, e)) return 0;
+  if (err && errlen) { std::snprintf(err, errlen, "%s", e.c_str()); }
+  return -1;
 }
 
 FlowReturn RoundedCorners::prepare_output_buffer(const uint8_t **alpha, size_t *size, int *stride) {

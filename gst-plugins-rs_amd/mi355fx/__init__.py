@@ -35,6 +35,7 @@ FLAG_BRICK_FOLD_AXIS = 10
 FLAG_DSSIM_TRANSLUCENT = 11
 FLAG_HRTF_METHOD = 12
 FLAG_WINDOW_MIN_STEPS = 13
+FLAG_HSV_NT = 14
 
 
 class HsvSettings(C.Structure):

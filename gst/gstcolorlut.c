@@ -243,8 +243,13 @@ static gboolean gst_color_lut_query(GstBaseTransform *trans, GstPadDirection dir
   GstVideoFilter *filter = GST_VIDEO_FILTER(trans);
   if (direction == GST_PAD_SINK && GST_QUERY_TYPE(query) == GST_QUERY_CUSTOM) {
     const GstStructure *s = gst_query_get_structure(query);
-    if (s && gst_structure_has_name(s, GST_MI355_FUSE_QUERY_NAME))
-      return self->pipe != NULL && filter->negotiated && GST_VIDEO_INFO_FORMAT(&filter->in_info) == GST_VIDEO_FORMAT_RGBA;
+    if (s && gst_structure_has_name(s, GST_MI355_FUSE_QUERY_NAME)) {
+      if (!(self->pipe != NULL && filter->negotiated && GST_VIDEO_INFO_FORMAT(&filter->in_info) == GST_VIDEO_FORMAT_RGBA)) return FALSE;
+      /* say WHO answers: the asking hsvfilter only believes the element that owns its peer pad (the query may have been
+       * forwarded to us through elements in between) */
+      gst_structure_set(gst_query_writable_structure(query), GST_MI355_FUSE_QUERY_WHO, G_TYPE_POINTER, (gpointer)self, NULL);
+      return TRUE;
+    }
   }
   if (direction == GST_PAD_SRC && GST_QUERY_TYPE(query) == GST_QUERY_LATENCY && self->pipe) {
     GstQuery *upstream = gst_query_new_latency();
@@ -269,6 +274,9 @@ static gboolean gst_color_lut_query(GstBaseTransform *trans, GstPadDirection dir
 /* caps are known: size the pipeline's device slots for this frame size */
 static gboolean gst_color_lut_set_info(GstVideoFilter *filter, GstCaps *incaps, GstVideoInfo *in_info, GstCaps *outcaps, GstVideoInfo *out_info) {
   GstColorLut *self = GST_COLOR_LUT(filter);
+  /* A caps event has drained already (sink_event); a downstream RECONFIGURE gets here from the streaming thread with a
+   * frame still queued, and its ticket belongs to the pipe that is about to go: finish and push it first. */
+  if (color_lut_drain(self, TRUE) != GST_FLOW_OK) GST_WARNING_OBJECT(self, "frames in flight could not be pushed before the renegotiation");
   if (self->pipe) { (void)mi355_pipe_wait_all(self->pipe); mi355_pipe_destroy(self->pipe); self->pipe = NULL; }
   if (self->ctx) {
     const size_t bytes = MAX(GST_VIDEO_INFO_SIZE(in_info), GST_VIDEO_INFO_SIZE(out_info));

@@ -20,7 +20,7 @@ struct _GstHsvFilter {
   GMutex lock;                /* settings: set from application threads, snapshotted once per frame (imp.rs:85) */
   mi355_hsv_settings settings;
   mi355_ctx *ctx;             /* created in start(), destroyed in stop() */
-  gboolean fuse_checked;      /* the peer has been asked since the last (re)negotiation */
+  gint fuse_checked;          /* the peer has been asked since the last (re)negotiation / relink / reconfigure (atomic) */
   gboolean fuse;              /* downstream is our colorlut: defer the filter to its fused kernel */
 };
 
@@ -90,17 +90,42 @@ static gboolean gst_hsv_filter_propose_allocation(GstBaseTransform *trans, GstQu
 /* (re)negotiation: ask the peer again on the next frame */
 static gboolean gst_hsv_filter_set_info(GstVideoFilter *filter, GstCaps *incaps, GstVideoInfo *in_info, GstCaps *outcaps, GstVideoInfo *out_info) {
   GstHsvFilter *self = GST_HSV_FILTER(filter);
-  self->fuse_checked = FALSE;
-  self->fuse = FALSE;
+  g_atomic_int_set(&self->fuse_checked, FALSE);
   return TRUE;
 }
 
+/* the source pad was linked to something else / unlinked, or downstream asked for a reconfigure: whoever answered before
+ * may not be the neighbour any more */
+static void gst_hsv_filter_src_relinked(GstPad *pad, GstPad *peer, gpointer user_data) {
+  g_atomic_int_set(&GST_HSV_FILTER(user_data)->fuse_checked, FALSE);
+}
+static gboolean gst_hsv_filter_src_event(GstBaseTransform *trans, GstEvent *event) {
+  if (GST_EVENT_TYPE(event) == GST_EVENT_RECONFIGURE) g_atomic_int_set(&GST_HSV_FILTER(trans)->fuse_checked, FALSE);
+  return GST_BASE_TRANSFORM_CLASS(gst_hsv_filter_parent_class)->src_event(trans, event);
+}
+
+/* Is the element that OWNS the pad linked to our source pad a colorlut of this shim that will fuse? A custom query travels:
+ * gst_pad_query_default and GstBaseTransform forward queries they do not know, tee answers TRUE when any branch does - so
+ * "somebody answered" proves nothing about the neighbour (hsvfilter ! tee, hsvfilter ! videoscale ! colorlut would then pass
+ * unfiltered frames to elements that are not colorlut). The question therefore carries no trust in reachability: the
+ * answering element writes its own address into the query, and it must be the parent of our peer pad. A ghost pad's
+ * parent is its bin: no fusion across bin boundaries. */
 static gboolean gst_hsv_filter_peer_fuses(GstHsvFilter *self) {
   if (g_getenv("MI355_GST_NO_FUSE")) return FALSE;
-  GstQuery *q = gst_query_new_custom(GST_QUERY_CUSTOM, gst_structure_new_empty(GST_MI355_FUSE_QUERY_NAME));
-  /* gst_pad_peer_query goes to the pad linked to our source pad, nobody further: only a direct colorlut neighbour answers */
-  const gboolean ok = gst_pad_peer_query(GST_BASE_TRANSFORM_SRC_PAD(self), q);
-  gst_query_unref(q);
+  GstPad *peer = gst_pad_get_peer(GST_BASE_TRANSFORM_SRC_PAD(self));
+  if (!peer) return FALSE;
+  GstObject *owner = gst_pad_get_parent(peer);
+  gboolean ok = FALSE;
+  if (owner && GST_IS_ELEMENT(owner)) {
+    GstQuery *q = gst_query_new_custom(GST_QUERY_CUSTOM, gst_structure_new(GST_MI355_FUSE_QUERY_NAME, GST_MI355_FUSE_QUERY_WHO, G_TYPE_POINTER, NULL, NULL));
+    if (gst_pad_query(peer, q)) {
+      gpointer who = NULL;
+      if (gst_structure_get(gst_query_get_structure(q), GST_MI355_FUSE_QUERY_WHO, G_TYPE_POINTER, &who, NULL)) ok = who != NULL && who == (gpointer)owner;
+    }
+    gst_query_unref(q);
+  }
+  if (owner) gst_object_unref(owner);
+  gst_object_unref(peer);
   return ok;
 }
 
@@ -113,9 +138,9 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
   g_mutex_unlock(&self->lock);
   const int fmt = gst_mi355_format(GST_VIDEO_FRAME_FORMAT(frame));
   if (fmt < 0) return GST_FLOW_NOT_NEGOTIATED; /* the reference's match ends in unreachable!() (imp.rs:374) */
-  if (!self->fuse_checked) {
+  if (!g_atomic_int_get(&self->fuse_checked)) {
+    g_atomic_int_set(&self->fuse_checked, TRUE);  /* (set first: a relink while we ask clears it again) */
     self->fuse = fmt == MI355_FMT_RGBA && gst_hsv_filter_peer_fuses(self);
-    self->fuse_checked = TRUE;
     GST_INFO_OBJECT(self, "hsvfilter %s", self->fuse ? "deferred to the downstream colorlut (fused kernel)" : "runs its own kernel");
   }
   if (self->fuse) {
@@ -169,6 +194,7 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass) {
   trans->start = gst_hsv_filter_start;
   trans->stop = gst_hsv_filter_stop;
   trans->propose_allocation = gst_hsv_filter_propose_allocation;
+  trans->src_event = gst_hsv_filter_src_event;
   trans->passthrough_on_same_caps = FALSE;     /* imp.rs:318 */
   trans->transform_ip_on_passthrough = FALSE;  /* imp.rs:319 */
   vfilter->set_info = gst_hsv_filter_set_info;
@@ -183,6 +209,8 @@ static void gst_hsv_filter_init(GstHsvFilter *self) {
   self->settings.saturation_off = 0.0f;
   self->settings.value_mul = 1.0f;
   self->settings.value_off = 0.0f;
+  g_signal_connect(GST_BASE_TRANSFORM_SRC_PAD(self), "linked", G_CALLBACK(gst_hsv_filter_src_relinked), self);
+  g_signal_connect(GST_BASE_TRANSFORM_SRC_PAD(self), "unlinked", G_CALLBACK(gst_hsv_filter_src_relinked), self);
 }
 
 gboolean gst_hsv_filter_register(GstPlugin *plugin) {

@@ -36,9 +36,13 @@ GstBufferPool *gst_mi355_pinned_pool_new(GstCaps *caps, const GstVideoInfo *info
  * hsvfilter asks its downstream peer `mi355-fuse-hsv` (a custom query); this shim's colorlut answers it when it runs on
  * RGBA frames. From then on hsvfilter does NOT touch the pixels: it attaches a GstMi355HsvMeta with the settings snapshot
  * of that frame to the buffer it passes through, and colorlut runs mi355_pipe_submit_hsv_colorlut (the fused kernel, bit-
- * identical to the two launches: tests/test_gpu_parity.py) when it finds the meta. The query goes to the DIRECT peer of the
- * source pad, so nothing else ever sees an unfiltered frame carrying the meta. */
+ * identical to the two launches: tests/test_gpu_parity.py) when it finds the meta. Queries travel (queue, tee, capsfilter,
+ * every GstBaseTransform forward what they do not know), so an answer alone says nothing about the neighbour: the answering
+ * colorlut writes its own address into the query's "who" field and hsvfilter defers only if that is the element owning the
+ * pad linked to its source pad; it asks again after every relink, RECONFIGURE and renegotiation. Nothing but that colorlut
+ * ever sees an unfiltered frame carrying the meta. */
 #define GST_MI355_FUSE_QUERY_NAME "mi355-fuse-hsv"
+#define GST_MI355_FUSE_QUERY_WHO "who"
 typedef struct {
   GstMeta meta;
   mi355_hsv_settings settings;

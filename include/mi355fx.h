@@ -105,6 +105,7 @@ typedef enum mi355_flag {
   MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
   MI355_FLAG_HRTF_METHOD = 12, /* hrtfrender convolution, read at mi355_hrtf_setup: 0 (default) = overlap-save FFT in LDS from 384-tap HRIRs on (the measured crossover), time-domain FIR below; 1 = FFT, 2 = FIR pinned (each only where it fits the LDS) */
+  MI355_FLAG_HSV_NT = 14, /* hsvfilter on packed 4-byte frames: 1 = loads and stores carry the non-temporal hint. The kernel alone is ~5 % faster, but its output then bypasses the Infinity Cache and the element behind it reads from HBM (bench.py's `hsvfilter_nontemporal_ab` leg measures exactly that); default 0 */
   MI355_FLAG_WINDOW_MIN_STEPS = 13, /* LDS-cached table kernel (LUT variants 0 / 8): smallest launch it serves, in 256 x 32 pixel steps per CU (default 3; 0 = any size - its first step per block runs on a cold cache, so small launches are faster through the gather kernels) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
 } mi355_flag;
@@ -320,8 +321,10 @@ int mi355_loudnorm_teardown(mi355_ctx *ctx);
  * mi355_loudnorm_batch_frame_size() frames per stream (576,000 for the first call, then 19,200) - or, with final_frame = 1,
  * with the shorter rest at drain() (:270-310; 0 frames allowed). Stream s reads data + s * stream_stride and writes
  * out + s * out_stream_stride (interleaved f64, elements); every stream produces *out_frames frames. device_data = 1: both
- * are device pointers and the call does not wait for the device. Per-stream samples are identical to n separate
- * mi355_loudnorm_* contexts. mi355_loudnorm_teardown releases a batch as well. */
+ * are device pointers (no sample crosses PCIe); the call still waits for the device wherever State::process reads a meter
+ * (the short-term / global loudness of every frame decides the gain on the host, as in the reference). The output capacity
+ * is checked before anything changes: after "output buffer too small" the same call can be repeated with a larger buffer.
+ * Per-stream samples are identical to n separate mi355_loudnorm_* contexts. mi355_loudnorm_teardown releases a batch as well. */
 int mi355_loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target,
                                double loudness_range_target, double max_true_peak, double offset);
 size_t mi355_loudnorm_batch_frame_size(mi355_ctx *ctx);

@@ -41,6 +41,9 @@ def test_two_ranks_aggregate_over_the_slowest_rank():
     assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    # N > 1 keeps one secondary leg: rank 0 alone on the +-4-noise content (the scaling record then shows more than amp 0)
+    amp4 = d["content_sweep"]["amp4"]
+    assert amp4["auto"]["frames_per_s"] > 0 and "rank 0 alone" in amp4["measured_on"]
 
 
 def test_single_process_stub_has_all_legs():

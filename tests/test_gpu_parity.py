@@ -1063,9 +1063,9 @@ def test_colorlut_table_geometry_fallback(ctx, oracle, synth):
     assert (rows(got) == rows(exp)).all()
 
 
-def test_colorlut_auto_switches_with_content(ctx, oracle, synth):
-    """Auto mode: natural-like frames end up on the table kernel, uniform noise flips it back to the interpolating
-    kernel within the sampling interval; output stays exact throughout."""
+def test_colorlut_auto_stays_exact_when_the_content_changes(ctx, oracle, synth):
+    """Auto mode across a change of content (natural-like frames, then uniform noise): whatever kernels the policy picks on
+    the way, the output is the oracle's. (What it picks, and when, is a matter of in-stream timings: tests/test_gpu_zz_timing.py.)"""
     import mi355fx
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
     ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
@@ -1078,24 +1078,19 @@ def test_colorlut_auto_switches_with_content(ctx, oracle, synth):
         ctx.h2d(d_s, smooth)
         ctx.h2d(d_n, noise)
         run = lambda d: ctx.colorlut_frames_device(d, H4K * W4K * 4, W4K * 4, d_o, H4K * W4K * 4, W4K * 4, n, W4K, H4K, "RGBA")
-        for _ in range(40):
-            run(d_s)
-            ctx.synchronize()
-        on_table, t_c, t_t = ctx.colorlut_kernel_choice()
-        assert on_table and 0.0 < t_t < t_c, (on_table, t_c, t_t)
-        out = np.zeros_like(smooth)
-        ctx.d2h(out, d_o)
         exp = np.zeros(W4K * H4K * 4, np.uint8)
-        oracle.colorlut_rgba8(cube, smooth[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
-        assert (out[: exp.size] == exp).all()
-        for _ in range(40):
-            run(d_n)
-            ctx.synchronize()
-        on_table, t_c, t_t = ctx.colorlut_kernel_choice()
-        assert not on_table and t_t > t_c, (on_table, t_c, t_t)
-        ctx.d2h(out, d_o)
-        oracle.colorlut_rgba8(cube, noise[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
-        assert (out[: exp.size] == exp).all()
+        out = np.zeros_like(smooth)
+        seen = set()
+        for src_host, d in ((smooth, d_s), (noise, d_n), (smooth, d_s)):
+            oracle.colorlut_rgba8(cube, src_host[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
+            for k in range(40):
+                run(d)
+                ctx.synchronize()
+                seen.add(ctx.colorlut_kernel_name())
+                if k % 8 == 7 or k < 6:   # the learning launches and a sample of the rest
+                    ctx.d2h(out, d_o)
+                    assert (out[: exp.size] == exp).all(), (k, ctx.colorlut_kernel_name())
+        assert len(seen) >= 2, seen   # more than one kernel kind did serve (learning alone runs two)
     finally:
         for d in (d_s, d_n, d_o):
             ctx.free(d)
@@ -1173,6 +1168,53 @@ def test_memoised_tables_are_shared_between_contexts(oracle, synth, mi355lib):
     finally:
         for c in ctxs[:4]:
             c.close()
+    assert mi355lib.mi355_shared_table_count() == base
+
+
+def test_a_table_rebuilt_in_place_waits_for_the_streams_that_used_to_share_it(oracle, synth, mi355lib):
+    """Two contexts share the table of hsvfilter -> colorlut under the same settings. B queues a long run of launches on it
+    and moves to other settings WITHOUT waiting (its reference goes); A, now the sole owner, changes its settings too and
+    rebuilds the 64 MiB buffer in place on ITS stream. B's queued launches must still read the old contents: the table
+    remembers an event on B's stream and A's build waits for it in stream order (no host wait anywhere)."""
+    import mi355fx
+    cube = oracle.Cube.parse(synth.cube_text_3d(33))
+    sc, of = cube.domain
+    st_old, st_b, st_a = synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"], (45.0, 0.9, 0.01, 1.1, -0.02)
+    n = 4
+    frames = np.stack([synth.smooth_frame(W4K, H4K, seed=300 + i) for i in range(n)]).reshape(-1)
+    fb = W4K * H4K * 4
+    exp_old = _oracle_chain(oracle, cube, frames[:fb], W4K, H4K, st_old)
+    exp_a = _oracle_chain(oracle, cube, frames[:fb], W4K, H4K, st_a)
+    base = mi355lib.mi355_shared_table_count()
+    a, b = mi355fx.Context(0), mi355fx.Context(0)
+    bufs = []
+    try:
+        for c in (a, b):
+            c.colorlut_load(cube.is3d, cube.size, cube.table, sc, of)
+            c.set_flag(mi355fx.FLAG_LUT_VARIANT, 5)
+        d_src, d_a, d_b, d_b2 = (a.alloc(frames.nbytes) for _ in range(4))
+        bufs = [d_src, d_a, d_b, d_b2]
+        a.h2d(d_src, frames)
+        a.synchronize()
+        run = lambda c, dst, st: c.hsv_colorlut_frames_device(d_src, fb, W4K * 4, dst, fb, W4K * 4, n, W4K, H4K, st)
+        run(a, d_a, st_old)
+        run(b, d_b, st_old)
+        a.synchronize(); b.synchronize()
+        assert mi355lib.mi355_shared_table_count() == base + 1          # one table, two users
+        for _ in range(40):                                              # B: ~10 ms of queued work on the shared table
+            run(b, d_b, st_old)
+        run(b, d_b2, st_b)                                               # B lets go of it (builds its own), nothing waited for
+        run(a, d_a, st_a)                                                # A: sole owner now -> rebuilds the buffer in place
+        a.synchronize(); b.synchronize()
+        got_b, got_a = np.zeros(fb, np.uint8), np.zeros(fb, np.uint8)
+        b.d2h(got_b, d_b)
+        a.d2h(got_a, d_a)
+        assert (got_b == exp_old).all(), _mismatch_report(got_b, exp_old)
+        assert (got_a == exp_a).all(), _mismatch_report(got_a, exp_a)
+    finally:
+        for d in bufs:
+            a.free(d)
+        a.close(); b.close()
     assert mi355lib.mi355_shared_table_count() == base
 
 
