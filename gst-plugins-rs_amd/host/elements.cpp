@@ -712,6 +712,15 @@ static bool object_from_position(int pos, SpatialObject *o) {
   return false;  // FlowError::NotSupported -> "Unsupported channel position"
 }
 
+// the table above for the GStreamer shim: 0 and the left-handed position of a GstAudioChannelPosition, -1 if the reference
+// answers FlowError::NotSupported for it
+extern "C" int mi355host_hrtf_object_from_channel_position(int gst_audio_channel_position, float xyz_left_handed[3]) {
+  SpatialObject o;
+  if (!xyz_left_handed || !object_from_position(gst_audio_channel_position, &o)) return -1;
+  xyz_left_handed[0] = o.x; xyz_left_handed[1] = o.y; xyz_left_handed[2] = o.z;
+  return 0;
+}
+
 // Position::{to_cartesian, to_left_handed, to_right_handed}().to_vec3() (audio/hrtf/src/spatial.rs:40-70); systems numbered as
 // GstHrtfCoordinateSystem: 0 Cartesian, 1 LeftHanded, 2 RightHanded. The known answers of spatial.rs:235-287 are replayed
 // against this function in tests/test_oracle_hrtf.py.

@@ -28,6 +28,11 @@ void mi355h_cube_domain(const mi355h_cube *c, float scale[3], float offset[3]);
  * GstHrtfCoordinateSystem: 0 Cartesian, 1 LeftHanded, 2 RightHanded. Returns 0, or -1 on a bad argument. */
 int mi355host_position_convert(int from, int to, const float in[3], float out[3]);
 
+/* TryFrom<AudioChannelPosition> for SpatialObject (audio/hrtf/src/spatial.rs:177-222): where hrtfrender puts a positioned input
+ * channel when no spatial-objects were set (left-handed coordinates, distance gain 1). `position` is a GstAudioChannelPosition
+ * value. Returns 0, or -1 for a position the reference does not support. */
+int mi355host_hrtf_object_from_channel_position(int position, float xyz_left_handed[3]);
+
 /* roundedcorners: generate_alpha_mask + draw_rounded_corners (video/videofx/src/border/imp.rs:57-180) into an A8 plane of
  * `stride` x round_up_2(height) bytes: 0xff everywhere for radius 0, otherwise the filled + stroked rounded rectangle drawn by
  * libcairo (dlopen'ed: the library the reference's cairo crate binds). Returns 0, or -1 with the reference's error text. */

@@ -58,10 +58,10 @@ GstMi355HsvMeta *gst_buffer_add_mi355_hsv_meta(GstBuffer *b, const mi355_hsv_set
 /* GstVideoFormat -> mi355_video_format, -1 when the format is not one of the reference's */
 static inline int gst_mi355_format(GstVideoFormat f) {
   switch (f) {
-    case GST_VIDEO_FORMAT_RGBx: return MI355_FMT_RGBx;
-    case GST_VIDEO_FORMAT_xRGB: return MI355_FMT_xRGB;
-    case GST_VIDEO_FORMAT_BGRx: return MI355_FMT_BGRx;
-    case GST_VIDEO_FORMAT_xBGR: return MI355_FMT_xBGR;
+    case GST_VIDEO_FORMAT_RGBx: return MI355_FMT_RGBX;
+    case GST_VIDEO_FORMAT_xRGB: return MI355_FMT_XRGB;
+    case GST_VIDEO_FORMAT_BGRx: return MI355_FMT_BGRX;
+    case GST_VIDEO_FORMAT_xBGR: return MI355_FMT_XBGR;
     case GST_VIDEO_FORMAT_RGBA: return MI355_FMT_RGBA;
     case GST_VIDEO_FORMAT_ARGB: return MI355_FMT_ARGB;
     case GST_VIDEO_FORMAT_BGRA: return MI355_FMT_BGRA;

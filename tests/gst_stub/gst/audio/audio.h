@@ -1,0 +1,2 @@
+/* TEST SCAFFOLDING (see ../mi355_gst_stub.h): stands in for <gst/audio/audio.h> under `make -C gst syntax`. */
+#include "../../mi355_gst_stub.h"

@@ -1,0 +1,2 @@
+/* TEST SCAFFOLDING (see ../mi355_gst_stub.h): stands in for <gst/base/gstbasetransform.h> under `make -C gst syntax`. */
+#include "../../mi355_gst_stub.h"

@@ -12,14 +12,15 @@ GST = os.path.join(ROOT, "gst")
 
 def _have_gst_dev():
     return shutil.which("pkg-config") is not None and subprocess.call(
-        ["pkg-config", "--exists", "gstreamer-1.0", "gstreamer-base-1.0", "gstreamer-video-1.0"]) == 0
+        ["pkg-config", "--exists", "gstreamer-1.0", "gstreamer-base-1.0", "gstreamer-video-1.0", "gstreamer-audio-1.0"]) == 0
 
 
 def test_make_builds_or_explains():
     r = subprocess.run(["make", "-C", GST, "all"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     if _have_gst_dev():
-        assert os.path.exists(os.path.join(GST, "libgsthsv.so")) and os.path.exists(os.path.join(GST, "libgstcolorlut.so"))
+        for lib in ("libgsthsv.so", "libgstcolorlut.so", "libgstrsaudiofx.so", "libgstrsvideofx.so", "libgsthrtf.so"):
+            assert os.path.exists(os.path.join(GST, lib)), lib
     else:
         assert "gst shim not built" in r.stdout
 
@@ -129,3 +130,55 @@ def test_shim_calls_match_the_header_argument_counts():
             assert count(args) == protos[name], (os.path.basename(path), name, count(args), protos[name])
             checked += 1
     assert checked >= 20
+
+
+def test_every_shim_source_passes_a_compiler():
+    """`make -C gst syntax`: gcc -fsyntax-only -Werror over every shim file against the hand-written GLib / GStreamer
+    declarations of tests/gst_stub/ (scaffolding) and the REAL include/mi355fx.h + host header: valid C, the right mi355_*
+    prototypes, vfuncs of the shape of the class members they are assigned to. (Round 3 shipped `MI355_FMT_RGBx` - an
+    enumerator that does not exist - in gstmi355common.h; nothing could notice.)"""
+    r = subprocess.run(["make", "-C", GST, "syntax"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n = len([f for f in os.listdir(GST) if f.endswith(".c")])
+    assert "syntax ok: %d files" % n in r.stdout and n >= 13
+    stub = open(os.path.join(ROOT, "tests", "gst_stub", "mi355_gst_stub.h")).read()
+    assert "TEST SCAFFOLDING" in stub and "not GStreamer" in stub   # labelled for what it is
+
+
+def test_round4_factories_carry_the_reference_surface():
+    """The six remaining factory names of the hot path (audio/audiofx/src/lib.rs:23-46, video/videofx/src/lib.rs:25-48,
+    audio/hrtf/src/lib.rs:49-70): GType and factory names, every property of the reference with its default, the plugin each
+    one registers under, the vfunc slots that define how it runs, and the ABI entry points behind it."""
+    import json
+    src = {f: open(os.path.join(GST, f)).read() for f in os.listdir(GST) if f.endswith((".c", ".h"))}
+    surface = json.load(open(os.path.join(ROOT, "tests", "golden", "element_surface.json")))
+    elements = {
+        "rsaudioecho": ("gstrsaudioecho.c", "plugin_rsaudiofx.c", "rsaudiofx", ["trans->transform_ip =", "afilter->setup =", "mi355_echo_setup(", "mi355_echo_process_f32(", "mi355_echo_process_f64("]),
+        "ebur128level": ("gstebur128level.c", "plugin_rsaudiofx.c", "rsaudiofx", ["trans->transform_ip =", "afilter->setup =", "mi355_ebur128_setup(", "mi355_ebur128_add_frames(", "mi355_ebur128_add_frames_planar(", '"ebur128-level"', '"reset"', "mi355_ebur128_true_peak("]),
+        "audioloudnorm": ("gstaudioloudnorm.c", "plugin_rsaudiofx.c", "rsaudiofx", ["gst_pad_set_chain_function(", "element->change_state =", "mi355_loudnorm_setup(", "mi355_loudnorm_push(", "mi355_loudnorm_drain(", "3 * GST_SECOND", "rate = (int) 192000"]),
+        "roundedcorners": ("gstroundedcorners.c", "plugin_rsvideofx.c", "rsvideofx", ["trans->prepare_output_buffer =", "trans->transform_ip =", "trans->transform_caps =", "mi355host_rounded_corners_mask(", "gst_buffer_append_memory(", "A420"]),
+        "videocompare": ("gstvideocompare.c", "plugin_rsvideofx.c", "rsvideofx", ["vagg->aggregate_frames =", "agg->create_new_pad =", "agg->update_src_caps =", "element->release_pad =", "mi355_videocompare_hash_frame(", "mi355_videocompare_distance(", "mi355_dssim_compare_frames(", '"pad-distances"', '"sink_%u"']),
+        "hrtfrender": ("gsthrtfrender.c", "plugin_hrtf.c", "hrtf", ["trans->transform =", "trans->transform_size =", "trans->set_caps =", "trans->sink_event =", "mi355_hrtf_load_sphere(", "mi355_hrtf_setup(", "mi355_hrtf_process_block(", "mi355_hrtf_reset(", '"application/spatial-object"']),
+    }
+    for factory, (fname, plugin_file, plugin, needles) in elements.items():
+        text, spec = src[fname], surface[factory]
+        assert re.search(r'gst_element_register\(plugin, "%s", GST_RANK_NONE' % factory, text), factory
+        assert "G_DEFINE_TYPE(%s," % spec["type_name"] in text, factory
+        assert re.search(r"GST_PLUGIN_DEFINE\(GST_VERSION_MAJOR, GST_VERSION_MINOR, %s," % plugin, src[plugin_file]), plugin
+        for name, prop in spec["properties"].items():
+            assert '"%s"' % name in text, (factory, name)
+            flag = "GST_PARAM_MUTABLE_PLAYING" if prop["mutable"] == "playing" else "GST_PARAM_MUTABLE_READY"
+            assert flag in text, (factory, name, flag)
+        assert '"%s"' % spec["klass"] in text, factory
+        for needle in needles:
+            assert needle in text, (factory, needle)
+    # numeric defaults, spot-checked against the reference's property table
+    assert re.search(r'g_param_spec_double\("loudness-target",[^;]*-70\.0, -5\.0, -24\.0, f\)', src["gstaudioloudnorm.c"])
+    assert re.search(r'g_param_spec_uint64\("interpolation-steps",[^;]*0, G_MAXUINT64 - 1, 8, ready\)', src["gsthrtfrender.c"])
+    assert re.search(r'g_param_spec_uint64\("block-length",[^;]*0, G_MAXUINT64 - 1, 512, ready\)', src["gsthrtfrender.c"])
+    assert re.search(r'g_param_spec_uint64\("delay",[^;]*500 \* GST_SECOND, f\)', src["gstrsaudioecho.c"])
+    assert re.search(r'g_param_spec_enum\("hash-algo",[^;]*MI355_HASH_BLOCKHASH, f\)', src["gstvideocompare.c"])
+    assert re.search(r'g_param_spec_uint\("border-radius-px",[^;]*0, G_MAXUINT, 0,', src["gstroundedcorners.c"])
+    # the three plugin units register their elements in the reference's order
+    assert src["plugin_rsaudiofx.c"].index("gst_rs_audio_echo_register(plugin)") < src["plugin_rsaudiofx.c"].index("gst_audio_loud_norm_register(plugin)") < src["plugin_rsaudiofx.c"].index("gst_ebur128_level_register(plugin)")
+    assert src["plugin_rsvideofx.c"].index("gst_rounded_corners_register(plugin)") < src["plugin_rsvideofx.c"].index("gst_video_compare_register(plugin)")
