@@ -749,6 +749,27 @@ def main():
                            "frames_per_s_issued_from_python": leg_py["frames"] / leg_py["dt"],
                            "colorlut_kernel": sctx[0].colorlut_kernel_name(),
                            "memoised_tables_alive": mi355fx.load_library().mi355_shared_table_count() if not args.stub else 0}
+            if not args.stub:
+                # the same streams, each still handing over ONE 4K frame per call, through the multi-stream dispatcher
+                # (mi355_group_*, csrc/group.hip): frames that agree in geometry, settings and LUT share a launch pair of up to
+                # eight frames; bit-identical per stream (tests/test_gpu_group.py). This is the figure for many streams; the
+                # one above is what they get when every element launches for itself.
+                group = mi355fx.Group(local_rank)
+
+                class GroupRound:
+                    def issue(self, src_ptrs, dst_ptrs):
+                        group.submit_round(sctx, src_ptrs, dst_ptrs, W, H, W * 4, "RGBA", settings)
+
+                leg_g = measure(args.content, n_s, 24, False, streams=sctx, native_round=GroupRound())
+                group.wait_all()
+                g_frames, g_pairs, g_single = group.stats()
+                streams_leg["frames_per_s_separate_launches"] = streams_leg["frames_per_s"]
+                streams_leg["frames_per_s"] = leg_g["frames"] / leg_g["dt"]
+                streams_leg["launches"] = "one 4K frame per CALL and stream; launches: up to 8 frames of different streams each (mi355_group_*)"
+                streams_leg["issued_by"] = "one native loop per round: %d x mi355_group_submit_chain + flush (mi355_group_submit_round)" % args.streams
+                streams_leg["group"] = {"frames": g_frames, "batched_launch_pairs": g_pairs, "frames_through_own_context": g_single,
+                                        "frames_per_launch_pair": g_frames / max(g_pairs, 1)}
+                group.close()
             for c in sctx:
                 c.close()
 

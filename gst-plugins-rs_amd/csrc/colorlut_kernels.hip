@@ -1004,6 +1004,51 @@ __global__ __launch_bounds__(256) void colorlut_table_tiled_kernel(const uint4 *
   if (ok1) __builtin_nontemporal_store(r1v, d4 + o1);
 }
 
+// The tiled kernel over up to kMultiFrames SEPARATE packed frames of one size: tile t belongs to frame t / tiles_per_frame. The
+// frames of different streams batched into one launch by the group dispatcher (group.hip). Morton table only.
+template <int TW4>
+__global__ __launch_bounds__(256) void colorlut_table_tiled_multi_kernel(MultiFramePtrs srcs, MultiFramePtrs dsts, unsigned w4, unsigned rows, unsigned n_cols,
+                                                                         unsigned tiles_per_frame, const uint32_t *__restrict__ table) {
+  __shared__ uint32_t s_spread[256];
+  __shared__ uint32_t s_strip[4][512];
+  s_spread[threadIdx.x] = spread3(threadIdx.x);
+  __syncthreads();
+  auto index = [&](uint32_t p) -> uint32_t { return s_spread[p & 0xffu] | (s_spread[(p >> 8) & 0xffu] << 1) | (s_spread[(p >> 16) & 0xffu] << 2); };
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t *x = s_strip[wave];
+  const unsigned frame = blockIdx.x / tiles_per_frame, t = blockIdx.x - frame * tiles_per_frame;
+  const u32x4_t *s4 = (const u32x4_t *)srcs.p[frame];
+  u32x4_t *d4 = (u32x4_t *)dsts.p[frame];
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  constexpr unsigned RPL = 64 / TW4;
+  const unsigned sub = lane / TW4, g = lane % TW4;
+  const unsigned tx = t % n_cols, ty = t / n_cols;
+  const unsigned col = tx * TW4 + g;
+  const unsigned r0 = ty * (8 * RPL) + wave * (2 * RPL) + sub, r1 = r0 + RPL;
+  const bool ok0 = col < w4 && r0 < rows, ok1 = col < w4 && r1 < rows;
+  const size_t i0 = (size_t)r0 * w4 + col, i1 = (size_t)r1 * w4 + col;
+  u32x4_t p = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  if (ok0) p = __builtin_nontemporal_load(s4 + i0);
+  if (ok1) q = __builtin_nontemporal_load(s4 + i1);
+  *(u32x4_t *)(x + lane * 4) = p;
+  *(u32x4_t *)(x + 256 + lane * 4) = q;
+  wave_sync();
+  uint32_t px[8], o[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) px[j] = x[j * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = table[index(px[j])];
+#pragma unroll
+  for (int j = 0; j < 8; j++) x[j * 64 + lane] = (o[j] & 0x00ffffffu) | (px[j] & 0xff000000u);
+  wave_sync();
+  const u32x4_t r0v = *(u32x4_t *)(x + lane * 4), r1v = *(u32x4_t *)(x + 256 + lane * 4);
+  if (ok0) __builtin_nontemporal_store(r0v, d4 + i0);
+  if (ok1) __builtin_nontemporal_store(r1v, d4 + i1);
+}
+
 void shared_table_release(mi355_ctx *ctx, std::shared_ptr<void> *ref);
 void lut_release(mi355_ctx *ctx) {
   for (int i = 0; i < 2; i++) {
@@ -1840,6 +1885,37 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
                      [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, kTableEither); });
+}
+
+// ---- frames of several streams in one launch (group.hip)
+int colorlut_multi_table(mi355_ctx *ctx, const uint32_t **table_out) {
+  LutDevice &L = ctx->lut;
+  if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  int rc = table_ensure(ctx, 0, 1, nullptr);
+  if (rc) return rc;
+  *table_out = L.d_table[0];
+  return MI355_OK;
+}
+
+int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
+                          int height) {
+  if (n_frames < 1 || n_frames > kMultiFrames || width % 4 != 0 || width < 128 || height <= 0) return MI355_ERR_UNSUPPORTED;
+  MultiFramePtrs s{}, d{};
+  for (int f = 0; f < n_frames; f++) {
+    if (!srcs[f] || !dsts[f] || (uintptr_t)srcs[f] % 16 != 0 || (uintptr_t)dsts[f] % 16 != 0) return MI355_ERR_UNSUPPORTED;
+    s.p[f] = srcs[f];
+    d.p[f] = dsts[f];
+  }
+  const unsigned w4 = (unsigned)width / 4;
+  const unsigned pad64 = (w4 + 63) / 64 * 64 - w4, pad32 = (w4 + 31) / 32 * 32 - w4;
+  const unsigned tw4 = pad64 <= pad32 ? 64 : 32;
+  const unsigned n_cols = (w4 + tw4 - 1) / tw4, rpb = 8 * (64 / tw4);
+  const size_t tiles_per_frame = (size_t)n_cols * (((size_t)height + rpb - 1) / rpb);
+  const size_t grid = tiles_per_frame * (size_t)n_frames;
+  if (grid >= (1u << 31)) return MI355_ERR_UNSUPPORTED;
+  if (tw4 == 64) hipLaunchKernelGGL((colorlut_table_tiled_multi_kernel<64>), dim3((unsigned)grid), dim3(256), 0, stream, s, d, w4, (unsigned)height, n_cols, (unsigned)tiles_per_frame, table);
+  else hipLaunchKernelGGL((colorlut_table_tiled_multi_kernel<32>), dim3((unsigned)grid), dim3(256), 0, stream, s, d, w4, (unsigned)height, n_cols, (unsigned)tiles_per_frame, table);
+  return check_hip(ctx, hipGetLastError(), "colorlut multi-frame table kernel launch");
 }
 
 // hsvfilter alone is a function of the colour too, and MI355_FLAG_HSV_TABLE = 1 / 2 runs it through the same machinery

@@ -74,6 +74,25 @@ __global__ __launch_bounds__(256) void hsvfilter_flat_kernel(uint4 *__restrict__
   }
 }
 
+// The flat kernel over up to kMultiFrames SEPARATE frames of one size (blockIdx.y = frame): the frames of different streams
+// batched into one launch by the group dispatcher (group.hip), so that a frame does not pay the ramp and the tail of a launch
+// of its own. Same arithmetic, same per-lane work.
+template <int VARIANT, int FIRST, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_flat_multi_kernel(MultiFramePtrs frames, size_t n_vec, HsvK k) {
+  constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
+  constexpr int NPOS = FIRST == 0 ? 3 : 0;
+  __shared__ HsvLds lds;
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
+  __syncthreads();
+  uint4 *__restrict__ data = (uint4 *)frames.p[blockIdx.y];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    uint4 p = data[i];
+    hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
+    data[i] = p;
+  }
+}
+
 // 4-byte formats with padded rows and / or frame pitches (what real caps negotiate when upstream aligns strides):
 // the same 16 B per lane, addressed as (frame, row, 4-pixel group). Needs base, stride and pitch to be multiples of 16;
 // the last group of a row may hold 1-3 pixels: its padding bytes are read, filtered as pixels and NOT written back
@@ -251,6 +270,15 @@ static void launch_flat(mi355_ctx *ctx, uint4 *d, size_t n_vec, const HsvK &k, i
 }
 
 template <int VARIANT>
+static void launch_flat_multi(hipStream_t stream, const MultiFramePtrs &frames, int n_frames, size_t n_vec, const HsvK &k, int first, int bgr, int grid_x) {
+  dim3 g(grid_x, n_frames), b(256);
+  if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_multi_kernel<VARIANT, 0, false>), g, b, 0, stream, frames, n_vec, k);
+  else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_flat_multi_kernel<VARIANT, 0, true>), g, b, 0, stream, frames, n_vec, k);
+  else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_flat_multi_kernel<VARIANT, 1, false>), g, b, 0, stream, frames, n_vec, k);
+  else hipLaunchKernelGGL((hsvfilter_flat_multi_kernel<VARIANT, 1, true>), g, b, 0, stream, frames, n_vec, k);
+}
+
+template <int VARIANT>
 static void launch_strided(mi355_ctx *ctx, uint8_t *d, int n_frames, size_t frame_pitch, int width, int height, int stride, const HsvK &k,
                            int first, int bgr, int grid) {
   dim3 g(grid), b(256);
@@ -320,6 +348,29 @@ int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size
                          frame_pitch, width, height, stride, fmt.pixel_stride, fmt.first, fmt.bgr, k);
   }
   return check_hip(ctx, hipGetLastError(), "hsvfilter kernel launch");
+}
+
+// hsvfilter in place on n separate packed frames of one size and format with one set of settings, ONE launch on `stream`
+// (group.hip). false if the geometry is not the flat kernel's (the caller then goes frame by frame through launch_hsvfilter).
+bool hsvfilter_multi_applicable(const uint8_t *const *frames, int n_frames, int width, int height, int stride, const PixFmt &fmt) {
+  if (n_frames < 1 || n_frames > kMultiFrames || width <= 0 || height <= 0 || fmt.pixel_stride != 4 || (size_t)stride != (size_t)width * 4) return false;
+  if (((size_t)width * 4 * (size_t)height) % 16 != 0) return false;
+  for (int f = 0; f < n_frames; f++)
+    if (!frames[f] || (uintptr_t)frames[f] % 16 != 0) return false;
+  return true;
+}
+int launch_hsvfilter_multi(mi355_ctx *ctx, hipStream_t stream, uint8_t *const *frames, int n_frames, int width, int height, const PixFmt &fmt,
+                           const mi355_hsv_settings &s) {
+  const HsvK k{s.hue_shift, s.saturation_mul, s.saturation_off, s.value_mul, s.value_off};
+  const int variant = hsv_variant_for(s, ctx->force_generic, true);
+  const size_t n_vec = (size_t)width * 4 * (size_t)height / 16;
+  MultiFramePtrs ptrs{};
+  for (int f = 0; f < n_frames; f++) ptrs.p[f] = frames[f];
+  // the same total grid as one launch over n contiguous frames would get, split evenly over the frames
+  int gx = grid_for(ctx, ((size_t)n_frames * n_vec + 1) / 2, 256, ctx->hsv_blocks_per_cu) / n_frames;
+  if (gx < 1) gx = 1;
+  MI355_HSV_VARIANT_SWITCH(variant, launch_flat_multi, stream, ptrs, n_frames, n_vec, k, fmt.first, fmt.bgr, gx)
+  return check_hip(ctx, hipGetLastError(), "hsvfilter multi-frame kernel launch");
 }
 
 // ---------------------------------------------------------------- hsvdetector

@@ -119,6 +119,10 @@ struct mi355_ctx {
 
 namespace mi355 {
 
+// frames of several streams handed to ONE launch (group.hip): base pointers by value in the kernel arguments
+constexpr int kMultiFrames = 16;
+struct MultiFramePtrs { uint8_t *p[kMultiFrames]; };
+
 // pixel layout of a packed-RGB format
 struct PixFmt {
   int pixel_stride;  // bytes per pixel: 3, 4 (8 for RGBA64)
@@ -137,6 +141,14 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
 int launch_hsvfilter_compute(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame_pitch, int width,
                      int height, int stride, const PixFmt &fmt, const mi355_hsv_settings &s);
 void hsv_table_release(mi355_ctx *ctx);
+bool hsvfilter_multi_applicable(const uint8_t *const *frames, int n_frames, int width, int height, int stride, const PixFmt &fmt);
+int launch_hsvfilter_multi(mi355_ctx *ctx, hipStream_t stream, uint8_t *const *frames, int n_frames, int width, int height, const PixFmt &fmt,
+                           const mi355_hsv_settings &s);
+// colorlut of n separate packed RGBA frames of one size through ctx's memoised (Morton) table, ONE launch on `stream`; the table
+// is built on ctx->stream first if need be (*table_out = what the launch reads). MI355_ERR_UNSUPPORTED: not this path's geometry.
+int colorlut_multi_table(mi355_ctx *ctx, const uint32_t **table_out);
+int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
+                          int height);
 int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                      const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                      int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,

@@ -150,6 +150,16 @@ def load_library():
         "mi355_dssim_compare_frames": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
         "mi355_dssim_compare_frames_device": (i, [vp, vp, C.POINTER(vp), i, i, i, i, i, C.POINTER(C.c_double)]),
         "mi355_issue_streams_round": (i, [C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
+        "mi355_group_create": (vp, [i, i, C.POINTER(C.c_int)]),
+        "mi355_group_destroy": (None, [vp]),
+        "mi355_group_last_error": (C.c_char_p, [vp]),
+        "mi355_group_submit_chain": (i, [vp, vp, u8p, u8p, i, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
+        "mi355_group_flush": (i, [vp]),
+        "mi355_group_wait": (i, [vp, C.c_uint64]),
+        "mi355_group_order_after": (i, [vp, vp, C.c_uint64]),
+        "mi355_group_wait_all": (i, [vp]),
+        "mi355_group_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "mi355_group_submit_round": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_sofa_setup": (i, [vp, i, i, i, i]),
@@ -210,6 +220,62 @@ class StreamsRound:
         rc = self.L.mi355_issue_streams_round(self.ctxs, self.n, arr[0], arr[1], *self.geom, C.byref(self.settings))
         if rc != 0:
             raise Mi355Error(rc, "mi355_issue_streams_round")
+
+
+class Group:
+    """Frames of many streams in few launches (mi355_group_*): submit_chain never blocks, wait(ticket) flushes if need be."""
+
+    def __init__(self, device=0, max_batch=0):
+        self.L = load_library()
+        st = C.c_int(0)
+        self.h = self.L.mi355_group_create(device, max_batch, C.byref(st))
+        if not self.h:
+            raise Mi355Error(st.value, "mi355_group_create")
+        self._rounds = {}
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise Mi355Error(rc, (self.L.mi355_group_last_error(self.h) or b"").decode())
+
+    def submit_chain(self, ctx, d_src, d_dst, width, height, stride, fmt, settings):
+        s = HsvSettings(*[float(v) for v in settings])
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_group_submit_chain(self.h, ctx.h, d_src, d_dst, width, height, stride, FMT[fmt], C.byref(s), C.byref(t)))
+        return t.value
+
+    def submit_round(self, contexts, src_ptrs, dst_ptrs, width, height, stride, fmt, settings):
+        """One frame of every stream from one native loop, then a flush (measurement plumbing)."""
+        key = (tuple(c.h for c in contexts), tuple(src_ptrs), tuple(dst_ptrs))
+        arr = self._rounds.get(key)
+        if arr is None:
+            n = len(contexts)
+            arr = self._rounds[key] = ((C.c_void_p * n)(*[c.h for c in contexts]), (C.c_void_p * n)(*src_ptrs), (C.c_void_p * n)(*dst_ptrs),
+                                       HsvSettings(*[float(v) for v in settings]))
+        self._ck(self.L.mi355_group_submit_round(self.h, arr[0], len(contexts), arr[1], arr[2], width, height, stride, FMT[fmt], C.byref(arr[3])))
+
+    def flush(self):
+        self._ck(self.L.mi355_group_flush(self.h))
+
+    def wait(self, ticket):
+        self._ck(self.L.mi355_group_wait(self.h, ticket))
+
+    def order_after(self, ctx, ticket):
+        """ctx's own stream waits (on the device) for that frame."""
+        self._ck(self.L.mi355_group_order_after(self.h, ctx.h, ticket))
+
+    def wait_all(self):
+        self._ck(self.L.mi355_group_wait_all(self.h))
+
+    def stats(self):
+        """(frames, batched launch pairs, frames through their context's own path)."""
+        c = (C.c_uint64 * 3)()
+        self._ck(self.L.mi355_group_stats(self.h, c))
+        return int(c[0]), int(c[1]), int(c[2])
+
+    def close(self):
+        if self.h:
+            self.L.mi355_group_destroy(self.h)
+            self.h = None
 
 
 class Context:

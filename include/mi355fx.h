@@ -214,6 +214,42 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
 int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src, uint8_t *const *d_dst,
                               int width, int height, int stride, int format, const mi355_hsv_settings *settings);
 
+/* ---------------------------------------------------------------- many streams, few launches (csrc/group.hip)
+ * GstBaseTransform hands an element ONE buffer per call (hsvfilter/imp.rs:323-376, colorlut/imp.rs:203-223): N streams through
+ * `hsvfilter ! colorlut` are 2 N short launches per frame period, each paying its own ramp and tail. A group collects what the
+ * streams submit and issues the frames of up to max_batch streams that agree in size, format, hsv settings and LUT as ONE
+ * hsvfilter launch and ONE colorlut launch (the frame's base pointer is looked up per block); everything else goes through
+ * its context's own path, in order. Results are those of mi355_hsvfilter_frames_device + mi355_colorlut_frames_device on that
+ * frame, bit for bit. No reference counterpart (the reference has no device to batch for).
+ *   create : max_batch 0 = default (8 frames per launch), at most 16.
+ *   submit_chain : hsvfilter in place on the packed frame at d_src (stride bytes per row), then colorlut from it into d_dst,
+ *           for stream `ctx` (its LUT, loaded with mi355_colorlut_load; the frame starts after what ctx's HIP stream held at
+ *           this call). Never blocks; launches only when max_batch frames are pending. One frame per stream and launch:
+ *           frames of one stream run in submission order. *ticket identifies the frame.
+ *   flush  : launch what is pending now.
+ *   order_after : makes ctx's HIP stream wait (on the device, no host wait) for the frame `ticket`: what ctx enqueues on its
+ *           own stream afterwards - a download - sees the result. Not implied by submit.
+ *   wait   : host wait until the frame `ticket` is in d_dst; flushes first if the frame has not been launched - an element
+ *           that works one frame deep (submit n, wait n-1) thereby batches with whatever the other streams submitted in
+ *           between. The group's lock is not held while waiting.
+ *   stats  : {frames, batched launch pairs, frames that went through their context's own path}. */
+typedef struct mi355_group mi355_group;
+mi355_group *mi355_group_create(int device, int max_batch, int *status);
+void mi355_group_destroy(mi355_group *group);
+const char *mi355_group_last_error(mi355_group *group);
+int mi355_group_submit_chain(mi355_group *group, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height,
+                             int stride, int format, const mi355_hsv_settings *settings, uint64_t *ticket);
+int mi355_group_flush(mi355_group *group);
+int mi355_group_order_after(mi355_group *group, mi355_ctx *ctx, uint64_t ticket);
+int mi355_group_wait(mi355_group *group, uint64_t ticket);
+int mi355_group_wait_all(mi355_group *group);
+int mi355_group_stats(mi355_group *group, uint64_t stats[3]);
+/* Measurement plumbing like mi355_issue_streams_round: one frame of each of n streams submitted from one native loop, then
+ * flushed - what n streaming threads that submit within one frame period amount to. */
+int mi355_group_submit_round(mi355_group *group, mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src,
+                             uint8_t *const *d_dst, int width, int height, int stride, int format,
+                             const mi355_hsv_settings *settings);
+
 /* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
  * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and
  * colorlut/imp.rs:125-137) as ONE pass: every pixel goes through hsv_filter's body (hsvfilter/imp.rs:96-118) and

@@ -1,0 +1,179 @@
+"""GPU parity of the multi-stream dispatcher (csrc/group.hip, mi355_group_*): frames of many streams batched into multi-frame
+launches give every stream exactly what its own two element launches give it (hsvfilter in place,
+video/hsv/src/hsvfilter/imp.rs:323-376, then colorlut, video/colorlut/src/colorlut/imp.rs:203-223) - bit for bit, in order,
+whatever mix of sizes, settings, LUTs and formats the streams submit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctxs(mi355fx, oracle, synth, n, texts=None):
+    out = []
+    for i in range(n):
+        c = mi355fx.Context(0)
+        cube = oracle.Cube.parse((texts[i] if texts else synth.cube_text_3d(33)))
+        sc, of = cube.domain
+        c.colorlut_load(cube.is3d, cube.size, cube.table, sc, of)
+        out.append((c, cube))
+    return out
+
+
+def _expect(oracle, cube, frame, w, h, st, stride=None, ps=4, fmt_first=0, bgr=False):
+    stride = stride or w * ps
+    mid = frame.copy()
+    oracle.hsvfilter(mid, w, stride, ps, fmt_first, bgr, st, nthreads=8)
+    out = np.zeros_like(mid)
+    oracle.colorlut_rgba8(cube, mid, stride, out, stride, w, h, nthreads=8)
+    return mid, out
+
+
+def test_round_of_streams_equals_the_two_calls_per_stream(oracle, synth, mi355lib):
+    """12 streams, one 1080p frame each per round, three rounds: the group's batched launches == mi355_issue_streams_round ==
+    the oracle chain; the source frames end up hsv-filtered in place exactly as the element leaves them."""
+    import mi355fx
+    w, h, n = 1920, 1080, 12
+    st = synth.HSV_SETTINGS["hue90"]
+    pairs = _ctxs(mi355fx, oracle, synth, n)
+    ctxs = [p[0] for p in pairs]
+    g = mi355fx.Group(0)
+    fb = w * h * 4
+    d_src, d_dst, d_src2, d_dst2 = [], [], [], []
+    try:
+        frames = [synth.smooth_frame(w, h, seed=500 + i).reshape(-1) if i % 3 else synth.noise_frame(w, h, seed=500 + i).reshape(-1) for i in range(n)]
+        for i, c in enumerate(ctxs):
+            for lst in (d_src, d_dst, d_src2, d_dst2):
+                lst.append(c.alloc(fb))
+        for rnd in range(3):
+            for i, c in enumerate(ctxs):
+                c.h2d(d_src[i], frames[i])
+                c.h2d(d_src2[i], frames[i])
+                c.synchronize()
+            g.submit_round(ctxs, d_src, d_dst, w, h, w * 4, "RGBA", st)
+            g.wait_all()
+            mi355fx.StreamsRound(ctxs, w, h, w * 4, "RGBA", st).issue(d_src2, d_dst2)
+            for i, c in enumerate(ctxs):
+                c.synchronize()
+                a, b, s_a, s_b = (np.zeros(fb, np.uint8) for _ in range(4))
+                c.d2h(a, d_dst[i]); c.d2h(b, d_dst2[i]); c.d2h(s_a, d_src[i]); c.d2h(s_b, d_src2[i])
+                assert (a == b).all() and (s_a == s_b).all(), (rnd, i)
+                if rnd == 0 and i < 3:
+                    mid, exp = _expect(oracle, pairs[i][1], frames[i], w, h, st)
+                    assert (a == exp).all() and (s_a == mid).all(), i
+        frames_n, batched, single = g.stats()
+        assert frames_n == 3 * n and single == 0 and batched == 3 * 2   # 12 frames = one launch pair of 8 + one of 4, per round
+    finally:
+        g.close()
+        for i, c in enumerate(ctxs):
+            for lst in (d_src, d_dst, d_src2, d_dst2):
+                if i < len(lst):
+                    c.free(lst[i])
+            c.close()
+
+
+def test_mixed_streams_stay_exact_and_in_order(oracle, synth, mi355lib):
+    """Streams that do not agree: two sizes, two hsv settings, two LUTs, a BGRx stream and a padded-rows stream (neither is the
+    batched kernels' business), and one stream that submits three dependent frames in a row (frame k+1 reads what frame k
+    wrote: order within a stream). Every result is the oracle's."""
+    import mi355fx
+    texts = [synth.cube_text_3d(33), synth.cube_text_3d(33), synth.cube_text_3d(17, amp=0.08), synth.cube_text_3d(33), synth.cube_text_3d(33), synth.cube_text_3d(33)]
+    pairs = _ctxs(mi355fx, oracle, synth, 6, texts)
+    ctxs = [p[0] for p in pairs]
+    g = mi355fx.Group(0, max_batch=4)
+    st_a, st_b = synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"]
+    bufs, jobs = [], []   # jobs: (ctx index, d_src, d_dst, host frame, w, h, stride, fmt, settings, ticket)
+    try:
+        def job(i, frame, w, h, stride, fmt, st):
+            c = ctxs[i]
+            ds, dd = c.alloc(frame.nbytes), c.alloc(frame.nbytes)
+            bufs.extend([(c, ds), (c, dd)])
+            c.h2d(ds, frame)
+            c.h2d(dd, np.full(frame.nbytes, 0xEE, np.uint8))
+            t = g.submit_chain(c, ds, dd, w, h, stride, fmt, st)
+            jobs.append([i, ds, dd, frame, w, h, stride, fmt, st, t])
+        job(0, synth.smooth_frame(1920, 1080, seed=1).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)
+        job(1, synth.smooth_frame(1920, 1080, seed=2).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)
+        job(2, synth.smooth_frame(1920, 1080, seed=3).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)      # another LUT: its own launch
+        job(3, synth.smooth_frame(1280, 720, seed=4).reshape(-1), 1280, 720, 1280 * 4, "RGBA", st_a)        # another size
+        job(1, synth.noise_frame(1920, 1080, seed=5).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_b)        # same stream, other settings: after its first frame
+        job(0, synth.noise_frame(1920, 1080, seed=6).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)
+        rng = np.random.default_rng(9)
+        pad = rng.integers(0, 256, size=(360, 640 * 4 + 64), dtype=np.uint8)
+        pad[:, :640 * 4] = synth.smooth_frame(640, 360, seed=7).reshape(360, 640 * 4)
+        job(4, pad.reshape(-1).copy(), 640, 360, 640 * 4 + 64, "RGBA", st_a)                                 # padded rows: context's own path
+        job(5, synth.smooth_frame(1920, 1080, seed=8).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)
+        # a stream whose frames depend on each other: dst of frame k is src of frame k + 1
+        c = ctxs[5]
+        f0 = synth.smooth_frame(1280, 720, seed=9).reshape(-1)
+        chain_bufs = [c.alloc(f0.nbytes) for _ in range(4)]
+        bufs.extend((c, b) for b in chain_bufs)
+        c.h2d(chain_bufs[0], f0)
+        chain_tickets = [g.submit_chain(c, chain_bufs[k], chain_bufs[k + 1], 1280, 720, 1280 * 4, "RGBA", st_b) for k in range(3)]
+        g.wait(chain_tickets[-1])
+        g.wait_all()
+        for i, ds, dd, frame, w, h, stride, fmt, st, t in jobs:
+            g.wait(t)   # (already done: must be a no-op)
+            got, src_after = np.zeros(frame.nbytes, np.uint8), np.zeros(frame.nbytes, np.uint8)
+            ctxs[i].d2h(got, dd)
+            ctxs[i].d2h(src_after, ds)
+            mid, exp = _expect(oracle, pairs[i][1], frame, w, h, st, stride=stride)
+            rows = lambda a: a.reshape(h, stride)[:, :w * 4]
+            assert (rows(got) == rows(exp)).all(), (i, w, h, stride)
+            assert (rows(src_after) == rows(mid)).all(), (i, "source after hsvfilter")
+            if stride != w * 4:
+                assert (got.reshape(h, stride)[:, w * 4:] == 0xEE).all()   # padding of the destination untouched
+        cur = f0
+        for k in range(3):
+            _, cur = _expect(oracle, pairs[5][1], cur, 1280, 720, st_b)
+        got = np.zeros(f0.nbytes, np.uint8)
+        c.d2h(got, chain_bufs[3])
+        assert (got == cur).all(), "three dependent frames of one stream ran out of order"
+        frames_n, batched, single = g.stats()
+        assert frames_n == len(jobs) + 3 and single == 1 and batched >= 6
+    finally:
+        g.close()
+        for c, b in bufs:
+            c.free(b)
+        for c in ctxs:
+            c.close()
+
+
+def test_one_frame_deep_streams_fill_batches(oracle, synth, mi355lib):
+    """The way an element uses it (gst/gstcolorlut.c is one frame deep): every stream submits frame n and then waits for its
+    frame n-1. Nobody ever calls flush - the first wait of a round launches what all streams have submitted since."""
+    import mi355fx
+    w, h, n, rounds = 1280, 720, 6, 5
+    st = synth.HSV_SETTINGS["hue90"]
+    pairs = _ctxs(mi355fx, oracle, synth, n)
+    ctxs = [p[0] for p in pairs]
+    g = mi355fx.Group(0)
+    fb = w * h * 4
+    try:
+        frames = [[synth.smooth_frame(w, h, seed=700 + 10 * r + i).reshape(-1) for i in range(n)] for r in range(rounds)]
+        d_src = [[c.alloc(fb) for c in ctxs] for _ in range(rounds)]
+        d_dst = [[c.alloc(fb) for c in ctxs] for _ in range(rounds)]
+        tickets = [[0] * n for _ in range(rounds)]
+        for r in range(rounds):
+            for i, c in enumerate(ctxs):
+                c.h2d(d_src[r][i], frames[r][i])
+                tickets[r][i] = g.submit_chain(c, d_src[r][i], d_dst[r][i], w, h, w * 4, "RGBA", st)
+                if r:
+                    if i % 2:
+                        g.wait(tickets[r - 1][i])                 # host wait ...
+                    else:
+                        g.order_after(c, tickets[r - 1][i])       # ... or the stream's own download ordered behind the frame
+                    got = np.zeros(fb, np.uint8)
+                    c.d2h(got, d_dst[r - 1][i])
+                    _, exp = _expect(oracle, pairs[i][1], frames[r - 1][i], w, h, st)
+                    assert (got == exp).all(), (r - 1, i)
+        g.wait_all()
+        frames_n, batched, single = g.stats()
+        assert frames_n == rounds * n and single == 0
+        assert batched <= rounds + 1, batched   # one launch pair per round (the first wait of round r flushes round r-1's leftovers + what round r has so far)
+    finally:
+        g.close()
+        for r in range(rounds):
+            for i, c in enumerate(ctxs):
+                c.free(d_src[r][i]); c.free(d_dst[r][i])
+        for c in ctxs:
+            c.close()
