@@ -14,6 +14,7 @@
 // borrowed until wait() returns. Pageable host buffers still work (the runtime stages them), only slower.
 #include "internal.hpp"
 
+#include <string>
 #include <vector>
 
 struct mi355_pipe {
@@ -25,18 +26,40 @@ struct mi355_pipe {
     hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
     bool busy = false;
     uint64_t ticket = 0;
+    // group mode (mi355_pipe_set_group): the frame is with the group's dispatcher; its download is enqueued when somebody asks
+    // for it (wait / slot reuse), behind the batch that carries it
+    bool deferred = false;
+    uint64_t group_ticket = 0;
+    uint8_t *host_dst = nullptr;
+    size_t host_stride = 0, row_bytes = 0, rows = 0;
   };
   std::vector<Slot> slots;
   hipStream_t s_up = nullptr, s_down = nullptr;
   uint64_t next_ticket = 1;
+  mi355_group *group = nullptr;  // not owned
 };
 
 using namespace mi355;
 
+// group mode: the frame of this slot is (or will be, the call flushes up to it) in a batch; order this context's stream behind
+// it and enqueue the download
+static int pipe_finish_deferred(mi355_pipe *p, mi355_pipe::Slot *s) {
+  if (!s->deferred) return MI355_OK;
+  s->deferred = false;
+  int rc = mi355_group_order_after(p->group, p->ctx, s->group_ticket);
+  if (rc) return set_error(p->ctx, rc, std::string("pipeline: ") + mi355_group_last_error(p->group));
+  if ((rc = check_hip(p->ctx, hipEventRecord(s->computed, p->ctx->stream), "pipeline: record compute"))) return rc;
+  if ((rc = check_hip(p->ctx, hipStreamWaitEvent(p->s_down, s->computed, 0), "pipeline: download waits for compute"))) return rc;
+  if ((rc = check_hip(p->ctx, hipMemcpy2DAsync(s->host_dst, s->host_stride, s->d_out, s->row_bytes, s->row_bytes, s->rows, hipMemcpyDeviceToHost, p->s_down), "pipeline: D2H"))) return rc;
+  return check_hip(p->ctx, hipEventRecord(s->downloaded, p->s_down), "pipeline: record download");
+}
+
 static int pipe_take_slot(mi355_pipe *p, mi355_pipe::Slot **out) {
   mi355_pipe::Slot &s = p->slots[(size_t)(p->next_ticket % (uint64_t)p->depth)];
   if (s.busy) {  // back-pressure: the ring is full, finish the oldest frame first
-    int rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait for a free slot");
+    int rc = pipe_finish_deferred(p, &s);
+    if (rc) return rc;
+    rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait for a free slot");
     if (rc) return rc;
     s.busy = false;
   }
@@ -126,12 +149,22 @@ void mi355_pipe_destroy(mi355_pipe *p) {
   delete p;
 }
 
+int mi355_pipe_set_group(mi355_pipe *p, mi355_group *group) {
+  if (!p) return MI355_ERR_INVALID_ARG;
+  int rc = mi355_pipe_wait_all(p);  // frames in flight finish the way they started
+  if (rc) return rc;
+  p->group = group;
+  return MI355_OK;
+}
+
 int mi355_pipe_wait(mi355_pipe *p, uint64_t ticket) {
   if (!p) return MI355_ERR_INVALID_ARG;
   if (ticket == 0 || ticket >= p->next_ticket) return set_error(p->ctx, MI355_ERR_INVALID_ARG, "pipeline: unknown ticket");
   mi355_pipe::Slot &s = p->slots[(size_t)(ticket % (uint64_t)p->depth)];
   if (!s.busy || s.ticket != ticket) return MI355_OK;  // already completed (its slot was reclaimed or waited on)
-  int rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
+  int rc = pipe_finish_deferred(p, &s);
+  if (rc) return rc;
+  rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
   if (rc) return rc;
   s.busy = false;
   return MI355_OK;
@@ -141,7 +174,9 @@ int mi355_pipe_wait_all(mi355_pipe *p) {
   if (!p) return MI355_ERR_INVALID_ARG;
   for (auto &s : p->slots)
     if (s.busy) {
-      int rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
+      int rc = pipe_finish_deferred(p, &s);
+      if (rc) return rc;
+      rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
       if (rc) return rc;
       s.busy = false;
     }
@@ -209,6 +244,18 @@ int mi355_pipe_submit_hsv_colorlut(mi355_pipe *p, const uint8_t *src, int src_st
   if ((rc = pipe_take_slot(p, &s))) return rc;
   if ((rc = pipe_upload(p, s, src, (size_t)src_stride, row_bytes, (size_t)height))) return rc;
   const size_t packed = row_bytes * (size_t)height;
+  if (p->group) {
+    // the frame joins the other streams' frames in the group's next launch pair (hsvfilter in place on the slot's input, then
+    // colorlut: the two element launches, bit-identical to the fused one); the download follows when the frame is asked for
+    uint64_t gt = 0;
+    if ((rc = mi355_group_submit_chain(p->group, ctx, s->d_in, s->d_out, width, height, (int)row_bytes, MI355_FMT_RGBA, settings, &gt)))
+      return set_error(ctx, rc, std::string("pipeline: ") + mi355_group_last_error(p->group));
+    s->deferred = true; s->group_ticket = gt; s->host_dst = dst; s->host_stride = (size_t)dst_stride; s->row_bytes = row_bytes; s->rows = (size_t)height;
+    s->busy = true;
+    s->ticket = p->next_ticket++;
+    if (ticket) *ticket = s->ticket;
+    return MI355_OK;
+  }
   if ((rc = launch_hsv_colorlut(ctx, s->d_in, packed, (int)row_bytes, s->d_out, packed, (int)row_bytes, 1, width, height, *settings))) return rc;
   return pipe_download(p, s, s->d_out, dst, (size_t)dst_stride, row_bytes, (size_t)height, ticket);
 }

@@ -155,6 +155,7 @@ def load_library():
         "mi355_group_last_error": (C.c_char_p, [vp]),
         "mi355_group_submit_chain": (i, [vp, vp, u8p, u8p, i, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
         "mi355_group_flush": (i, [vp]),
+        "mi355_pipe_set_group": (i, [vp, vp]),
         "mi355_group_wait": (i, [vp, C.c_uint64]),
         "mi355_group_order_after": (i, [vp, vp, C.c_uint64]),
         "mi355_group_wait_all": (i, [vp]),
@@ -511,6 +512,10 @@ class Context:
         t = C.c_uint64(0)
         self._ck(self.L.mi355_pipe_submit_hsv_colorlut(pipe, _ptr(src), src_stride, _ptr(dst), dst_stride, width, height, C.byref(s), C.byref(t)))
         return t.value
+
+    def pipe_set_group(self, pipe, group):
+        """The pipe's hsv+colorlut frames go through `group` (a Group, or None for the pipe's own launches)."""
+        self._ck(self.L.mi355_pipe_set_group(pipe, group.h if group is not None else None))
 
     def pipe_wait(self, pipe, ticket):
         self._ck(self.L.mi355_pipe_wait(pipe, ticket))

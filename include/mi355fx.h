@@ -500,6 +500,12 @@ int mi355_pipe_submit_hsv_colorlut(mi355_pipe *pipe, const uint8_t *src, int src
                                    const mi355_hsv_settings *settings, uint64_t *ticket);
 int mi355_pipe_wait(mi355_pipe *pipe, uint64_t ticket);
 int mi355_pipe_wait_all(mi355_pipe *pipe);
+/* Many pipelines in one process: with a group (mi355_group_*) set, mi355_pipe_submit_hsv_colorlut hands
+ * its frame to the group's dispatcher instead of launching (the frame then shares a launch pair with the other streams'
+ * frames) and the download is enqueued behind that batch when the frame is waited for. Same bytes. NULL = back to own launches.
+ * The group is not owned. */
+struct mi355_group;
+int mi355_pipe_set_group(mi355_pipe *pipe, struct mi355_group *group);
 
 /* ---------------------------------------------------------------- measurement helpers
  * Used by bench.py: run `iters` back-to-back launches of one kernel on the context's stream

@@ -177,3 +177,52 @@ def test_one_frame_deep_streams_fill_batches(oracle, synth, mi355lib):
                 c.free(d_src[r][i]); c.free(d_dst[r][i])
         for c in ctxs:
             c.close()
+
+
+def test_host_buffer_pipelines_share_launches_through_a_group(oracle, synth, mi355lib):
+    """mi355_pipe_set_group: four host-buffer pipelines (pinned upload -> kernels -> download, one frame deep like
+    gst/gstcolorlut.c) hand their frames to one group; every output is the oracle chain's, inputs untouched, and the frames did
+    share launch pairs."""
+    import mi355fx
+    w, h, n, rounds = 1920, 1080, 4, 4
+    st = synth.HSV_SETTINGS["mixed"]
+    pairs = _ctxs(mi355fx, oracle, synth, n)
+    ctxs = [p[0] for p in pairs]
+    g = mi355fx.Group(0)
+    pipes = [c.pipe_create(3, w * h * 4) for c in ctxs]
+    srcs = [[c.host_array(w * h * 4) for _ in range(rounds)] for c in ctxs]
+    dsts = [[c.host_array(w * h * 4) for _ in range(rounds)] for c in ctxs]
+    try:
+        for i, c in enumerate(ctxs):
+            c.pipe_set_group(pipes[i], g)
+            for r in range(rounds):
+                srcs[i][r][:] = (synth.noise_frame(w, h, seed=900 + 10 * r + i) if (r + i) % 2 else synth.smooth_frame(w, h, seed=900 + 10 * r + i)).reshape(-1)
+                dsts[i][r][:] = 0
+        keep = [[a.copy() for a in row] for row in srcs]
+        tickets = [[0] * rounds for _ in range(n)]
+        for r in range(rounds):
+            for i, c in enumerate(ctxs):
+                tickets[i][r] = c.pipe_submit_hsv_colorlut(pipes[i], srcs[i][r], w * 4, dsts[i][r], w * 4, w, h, st)
+                if r:
+                    c.pipe_wait(pipes[i], tickets[i][r - 1])
+        for i, c in enumerate(ctxs):
+            c.pipe_wait_all(pipes[i])
+        for i in range(n):
+            for r in range(rounds):
+                _, exp = _expect(oracle, pairs[i][1], keep[i][r], w, h, st)
+                assert (dsts[i][r] == exp).all(), (i, r)
+                assert (srcs[i][r] == keep[i][r]).all()
+        frames_n, batched, single = g.stats()
+        assert frames_n == n * rounds and single == 0 and batched < n * rounds, (frames_n, batched)
+        ctxs[0].pipe_set_group(pipes[0], None)   # and back to its own launches
+        t = ctxs[0].pipe_submit_hsv_colorlut(pipes[0], srcs[0][0], w * 4, dsts[0][1], w * 4, w, h, st)
+        ctxs[0].pipe_wait(pipes[0], t)
+        assert (dsts[0][1] == dsts[0][0]).all() and g.stats()[0] == n * rounds
+    finally:
+        for i, c in enumerate(ctxs):
+            c.pipe_destroy(pipes[i])
+            for a in srcs[i] + dsts[i]:
+                c.host_free(a)
+        g.close()
+        for c in ctxs:
+            c.close()
