@@ -671,6 +671,7 @@ def main():
         dt = main_leg["dt"]
         hsv_ms, lut_ms = main_leg["ms"]
         lut_tab, lut_tc, lut_tt = ctx.colorlut_kernel_choice()
+        lut_win, lut_gather_t, lut_window_t = ctx.colorlut_kernel_choice(fused=10)
         hsv_tab, hsv_tc, hsv_tt = ctx.colorlut_kernel_choice(fused=2)
         lb = BYTES_PER_FRAME_PER_KERNEL * args.batch
         interp = None
@@ -691,10 +692,12 @@ def main():
             fused_fps = sharding.aggregate_throughput(leg["frames"], world, leg["dt"])
             fused_ms = leg["ms"][0]
             f_tab, f_tc, f_tt = ctx.colorlut_kernel_choice(fused=True)
+            f_win, f_gather_t, f_window_t = ctx.colorlut_kernel_choice(fused=11)   # inside the table path: gather kernel / LDS-cached kernel
             fused = {"frames_per_s": fused_fps, "ms_per_launch": fused_ms,
                      "kernel": (max(leg["colorlut_kernels_served"], key=leg["colorlut_kernels_served"].get) + " (composed hsv+lut table)") if f_tab and leg.get("colorlut_kernels_served") else ("memoised table kernel (composed hsv+lut table)" if f_tab else "fused compute kernel"),
                      "kernels_served": leg.get("colorlut_kernels_served"),
                      "auto_ms_per_mpx": {"compute": f_tc, "table": f_tt},
+                     "table_kernel_ms_per_mpx": {"gather": f_gather_t, "lds_cached": f_window_t, "lds_cached_in_use": bool(f_win)},
                      "algorithmic_bytes_per_launch": lb, "GBps": lb / (fused_ms * 1e-3) / 1e9,
                      # two different quantities: the kernel inside its event bracket, and the leg's wall-clock throughput
                      # (launch gaps included) against the 8 B/pixel roofline of 120,563 frames/s
@@ -884,6 +887,7 @@ def main():
                         "chain_GBps": chain_gbs, "chain_frac_of_hbm_peak": chain_gbs / HBM_PEAK_GBS,
                         "colorlut_kernel": lut_name, "colorlut_kernels_served": main_leg["colorlut_kernels_served"],
                         "colorlut_auto_ms_per_mpx": {"compute": lut_tc, "table": lut_tt},
+                        "colorlut_table_kernel_ms_per_mpx": {"gather": lut_gather_t, "lds_cached": lut_window_t, "lds_cached_in_use": bool(lut_win)},
                         "hsvfilter_kernel": "colorlut_table_tiled_kernel (hsvfilter table)" if hsv_tab else "hsvfilter_flat_kernel",
                         "hsvfilter_auto_ms_per_mpx": {"compute": hsv_tc, "table": hsv_tt},
                         "event_marker_ms_subtracted": marker_ms(), "samples": main_leg["samples"],

@@ -192,6 +192,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
   if (flag == MI355_FLAG_HRTF_METHOD && value >= 0 && value <= 2) { ctx->hrtf_method = value; return MI355_OK; }
+  if (flag == MI355_FLAG_BLOCKHASH_ANY_SIZE && (value == 0 || value == 1)) { ctx->blockhash_any_size = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_NT && (value == 0 || value == 1)) { ctx->hsv_nt = value; return MI355_OK; }
   if (flag == MI355_FLAG_WINDOW_MIN_STEPS && value >= 0 && value <= 4096) { ctx->window_min_steps = value; return MI355_OK; }
   return set_error(ctx, MI355_ERR_INVALID_ARG, "unknown flag");
@@ -370,6 +371,13 @@ int mi355_colorlut_unload(mi355_ctx *ctx) {
 
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table) {
   REQUIRE_CTX(ctx);
+  if (fused == 10 || fused == 11) {  // the table's own choice: gather kernel ("compute" role) against the LDS-cached kernel ("table" role)
+    const AutoPick &S = ctx->lut.pick_sub[fused - 10];
+    if (table_in_use) *table_in_use = S.t_table > 0.0 && S.table;
+    if (ms_per_mpx_compute) *ms_per_mpx_compute = S.t_compute * 250000.0;
+    if (ms_per_mpx_table) *ms_per_mpx_table = S.t_table * 250000.0;
+    return MI355_OK;
+  }
   const AutoPick &A = fused == 2 ? ctx->hsv_table.pick : ctx->lut.pick[fused ? 1 : 0];
   // times are kept per 16-byte group = 4 pixels
   if (table_in_use)

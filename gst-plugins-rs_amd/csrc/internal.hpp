@@ -112,6 +112,7 @@ struct mi355_ctx {
   int hrtf_method = 0;         // MI355_FLAG_HRTF_METHOD: 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (takes effect at mi355_hrtf_setup)
   int window_min_steps = mi355::kWindowMinStepsPerBlock;  // MI355_FLAG_WINDOW_MIN_STEPS
   unsigned long long *d_window_counters = nullptr;  // colorlut_window.hip: {pixels, pixels past the LDS cache, bricks installed} x 1024 slots
+  int blockhash_any_size = 0;  // MI355_FLAG_BLOCKHASH_ANY_SIZE
   int hsv_nt = 0;              // MI355_FLAG_HSV_NT: 1 = the flat hsvfilter kernel loads and stores with the non-temporal hint (measurement A/B)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;

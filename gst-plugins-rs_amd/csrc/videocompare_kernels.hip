@@ -13,7 +13,9 @@
 // a workgroup are flushed with one global atomic each. Integer adds: the result is order-independent, bit-exact.
 #include "internal.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace mi355 {
@@ -179,11 +181,82 @@ __global__ __launch_bounds__(64) void blockhash_finish_kernel(const uint32_t *__
   if (lane == 0) hashes[f] = h;
 }
 
+// The crate's floating-point path for frames that do not divide into 8 x 8 whole blocks (blockhash_slow; restated in
+// oracle/videocompare_oracle.c, parity unpinned like the rest of the hash). Every pixel goes whole to block
+// (floor(x / (w/8)), floor(y / (h/8))) - f32 quotients - and a block's f32 sum is accumulated in PIXEL ORDER, which decides its
+// low bits once it passes 2^24. So one lane owns one block and walks its pixels row by row: 64 lanes per frame, no reduction
+// tree, no atomics - sequential by definition, 1-2 ms per 4K frame. Off by default (MI355_FLAG_BLOCKHASH_ANY_SIZE).
+__global__ __launch_bounds__(64) void blockhash_slow_kernel(const uint8_t *__restrict__ frames, size_t frame_pitch, int stride, int width, int height,
+                                                            int channels, float *__restrict__ sums) {
+  const uint8_t *frame = frames + (size_t)blockIdx.x * frame_pitch;
+  const int b = threadIdx.x, bx = b & 7, by = b >> 3;
+  const float bw = (float)width / 8.0f, bh = (float)height / 8.0f;
+  // this block's pixel range: the x with floorf(x / bw) == bx are contiguous; found with the very expression that assigns them
+  int x0 = width, x1 = 0, y0 = height, y1 = 0;
+  for (int x = 0; x < width; x++)
+    if ((int)floorf((float)x / bw) == bx) { x0 = x < x0 ? x : x0; x1 = x + 1; }
+  for (int y = 0; y < height; y++)
+    if ((int)floorf((float)y / bh) == by) { y0 = y < y0 ? y : y0; y1 = y + 1; }
+  float acc = 0.0f;
+  for (int y = y0; y < y1; y++) {
+    const uint8_t *row = frame + (size_t)y * (size_t)stride;
+    for (int x = x0; x < x1; x++) {
+      const uint8_t *p = row + (size_t)x * channels;
+      uint32_t s = (uint32_t)p[0] + p[1] + p[2];
+      if (channels == 4 && p[3] == 0) s = 765u;
+      acc += (float)s;
+    }
+  }
+  sums[(size_t)blockIdx.x * 64 + b] = acc;
+}
+
+static int launch_blockhash_slow(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height, int channels,
+                                 unsigned long long *hashes) {
+  const size_t need = (size_t)n_frames * 64 * sizeof(float);
+  if (ctx->d_stage_bytes[1] < need) {
+    if (ctx->d_stage[1]) (void)hipFree(ctx->d_stage[1]);
+    ctx->d_stage[1] = nullptr;
+    ctx->d_stage_bytes[1] = 0;
+    int rc = check_hip(ctx, hipMalloc(&ctx->d_stage[1], need), "hipMalloc(blockhash scratch)");
+    if (rc) return rc;
+    ctx->d_stage_bytes[1] = need;
+  }
+  float *d_sums = (float *)ctx->d_stage[1];
+  hipLaunchKernelGGL(blockhash_slow_kernel, dim3(n_frames), dim3(64), 0, ctx->stream, d_frames, frame_pitch, stride, width, height, channels, d_sums);
+  int rc = check_hip(ctx, hipGetLastError(), "blockhash (any size) kernel launch");
+  if (rc) return rc;
+  std::vector<float> sums((size_t)n_frames * 64);
+  if ((rc = check_hip(ctx, hipMemcpyAsync(sums.data(), d_sums, need, hipMemcpyDeviceToHost, ctx->stream), "blockhash D2H"))) return rc;
+  if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "blockhash sync"))) return rc;
+  // the 64 bits per frame: bands of 32 blocks, upper median, the crate's float comparison (host: 64 values per frame)
+  const float bw = (float)width / 8.0f, bh = (float)height / 8.0f;
+  const float half = 765.0f * bw * bh / 2.0f;
+  for (int f = 0; f < n_frames; f++) {
+    const float *blocks = sums.data() + (size_t)f * 64;
+    unsigned long long h = 0;
+    for (int g = 0; g < 2; g++) {
+      float sorted[32];
+      std::memcpy(sorted, blocks + 32 * g, sizeof sorted);
+      std::sort(sorted, sorted + 32);
+      const float median = sorted[16];
+      for (int i = 0; i < 32; i++) {
+        const float v = blocks[32 * g + i];
+        if (v > median || (std::fabs(v - median) < 1.0f && median > half)) h |= 1ull << (32 * g + i);
+      }
+    }
+    hashes[f] = h;
+  }
+  return MI355_OK;
+}
+
 // Hashes `n_frames` device-resident frames; `hashes` is a HOST array of n_frames u64.
 int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
                      int channels, unsigned long long *hashes) {
-  if (width % 8 != 0 || height % 8 != 0)
-    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: blockhash needs width and height divisible by 8 (the crate's floating-point path is not ported)");
+  if (width % 8 != 0 || height % 8 != 0) {
+    if (ctx->blockhash_any_size && width >= 8 && height >= 8) return launch_blockhash_slow(ctx, d_frames, frame_pitch, stride, n_frames, width, height, channels, hashes);
+    return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: blockhash on a frame that does not divide into 8 x 8 whole blocks takes the crate's floating-point path: "
+                                                  "set MI355_FLAG_BLOCKHASH_ANY_SIZE (restated from memory, sequential per block)");
+  }
   // scratch: [n_frames][64] u32 sums + [n_frames] u64 hashes in staging slot 1 (slot 0 holds the host entry's frame)
   const size_t need = (size_t)n_frames * (64 * 4 + 8);
   if (ctx->d_stage_bytes[1] < need) {

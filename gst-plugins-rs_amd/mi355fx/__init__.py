@@ -36,6 +36,7 @@ FLAG_DSSIM_TRANSLUCENT = 11
 FLAG_HRTF_METHOD = 12
 FLAG_WINDOW_MIN_STEPS = 13
 FLAG_HSV_NT = 14
+FLAG_BLOCKHASH_ANY_SIZE = 15
 
 
 class HsvSettings(C.Structure):

@@ -105,6 +105,7 @@ typedef enum mi355_flag {
   MI355_FLAG_BRICK_FOLD_AXIS = 10, /* accepted and ignored: the 32-set geometry of the brick-cache kernel is hashed over all three axes now (it used to give one axis 2 set residues instead of 4) */
   MI355_FLAG_BRICK_PRIO = 9, /* brick-cache kernel, how the waves of a block share work: bit 0 = waves lower their issue priority as they advance through their run, bit 1 = a wave that is done takes tiles from the run with most left (default 3) */
   MI355_FLAG_HRTF_METHOD = 12, /* hrtfrender convolution, read at mi355_hrtf_setup: 0 (default) = overlap-save FFT in LDS from 384-tap HRIRs on (the measured crossover), time-domain FIR below; 1 = FFT, 2 = FIR pinned (each only where it fits the LDS) */
+  MI355_FLAG_BLOCKHASH_ANY_SIZE = 15, /* videocompare Blockhash on frames whose width or height is not a multiple of 8: 0 (default) = MI355_ERR_UNSUPPORTED, 1 = the crate's floating-point path (blockhash_slow: every pixel whole to block (floor(x / (w/8)), floor(y / (h/8))) in f32, block sums accumulated in pixel order - one lane per block, sequential by definition, 1-2 ms per 4K frame; restated from memory like the rest of the hash: parity unpinned) */
   MI355_FLAG_HSV_NT = 14, /* hsvfilter on packed 4-byte frames: 1 = loads and stores carry the non-temporal hint. The kernel alone is ~5 % faster, but its output then bypasses the Infinity Cache and the element behind it reads from HBM (bench.py's `hsvfilter_nontemporal_ab` leg measures exactly that); default 0 */
   MI355_FLAG_WINDOW_MIN_STEPS = 13, /* LDS-cached table kernel (LUT variants 0 / 8): smallest launch it serves, in 256 x 32 pixel steps per CU (default 3; 0 = any size - its first step per block runs on a cold cache, so small launches are faster through the gather kernels) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
@@ -169,8 +170,10 @@ int mi355_colorlut_unload(mi355_ctx *ctx);
 /* Diagnostics for MI355_FLAG_LUT_VARIANT 0 (auto): which kernel kind serves packed RGBA8 launches right now
  * (*table_in_use: 0 interpolating kernel, 1 memoised table) and the last measured time of each kind in ms per
  * megapixel (0 = not measured yet); fused = 0 for mi355_colorlut_*, 1 for mi355_hsv_colorlut_*, 2 for
- * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran). No reference
- * counterpart. */
+ * mi355_hsvfilter_* (MI355_FLAG_HSV_TABLE; *table_in_use then tells what the last call ran); fused = 10 / 11: the choice
+ * INSIDE the table path of mi355_colorlut_* / mi355_hsv_colorlut_* - *table_in_use: 1 = the LDS-cached kernel
+ * (colorlut_window.hip), 0 = the gather kernel; "compute" = the gather kernel's time, "table" = the LDS-cached kernel's. No
+ * reference counterpart. */
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table);
 /* Number of memoised 64 MiB tables alive in this process (tables are shared by all contexts that ask for the same
  * function on the same device: same LUT and layout, same hsv settings). Diagnostic; no reference counterpart. */
@@ -372,8 +375,9 @@ int mi355_loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stre
  * Replaces HasherEngine::hash_image / compare (video/videofx/src/videocompare/hashed_image.rs:24-79) for
  * HashAlgorithm::Blockhash, the element default (videocompare/imp.rs:31): image_hasher 3.1.1 blockhash, 8x8 bits, on
  * the packed RGB / RGBA frame (rows addressed by `stride`, which covers tightly_packed_framebuffer :110-130).
- * `algo` takes GstVideoCompareHashAlgorithm values (videocompare/mod.rs:60-100). Blockhash needs frame sizes divisible
- * by 8 (else MI355_ERR_UNSUPPORTED); its hash is the 64 block bits, bit i = block i row-major. Mean / Gradient /
+ * `algo` takes GstVideoCompareHashAlgorithm values (videocompare/mod.rs:60-100). Blockhash on frame sizes that are not
+ * divisible by 8 is MI355_ERR_UNSUPPORTED unless MI355_FLAG_BLOCKHASH_ANY_SIZE is set (the crate's floating-point path,
+ * hashed_image.rs:37-44 -> image_hasher blockhash_slow); its hash is the 64 block bits, bit i = block i row-major. Mean / Gradient /
  * VertGradient / DoubleGradient (grayscale + Lanczos3 resize of the `image` crate + bit rule) give 64/64/64/40 bits in the
  * crate's iteration order. Dssim has no hash: see mi355_dssim_* below. */
 typedef enum mi355_hash_algo {

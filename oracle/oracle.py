@@ -493,11 +493,12 @@ def position_convert(from_system, to_system, v):
 
 
 def blockhash(frame, width, height, stride, channels):
-    """image_hasher Blockhash (8x8) of a packed RGB/RGBA frame; ValueError when the integer fast path does not apply."""
+    """image_hasher Blockhash (8x8) of a packed RGB/RGBA frame: the integer path for sizes divisible by 8, the crate's
+    floating-point path (every pixel whole to its f32-quotient block, sums in pixel order) otherwise; ValueError below 8 x 8."""
     a = np.ascontiguousarray(frame, dtype=np.uint8)
     h = C.c_uint64(0)
     if lib().oracle_blockhash(a.ctypes.data, width, height, stride, channels, C.byref(h)) != 0:
-        raise ValueError("blockhash fast path needs width and height divisible by 8")
+        raise ValueError("blockhash needs a packed RGB / RGBA frame of at least 8 x 8 pixels")
     return h.value
 
 

@@ -66,6 +66,32 @@ def test_config5_batch_of_4k_streams_on_device(ctx, oracle):
         assert (dist == 0.0) == (k % 2 == 1)
 
 
+@pytest.mark.parametrize("w,h,c", [(60, 15, 4), (1921, 1083, 4), (3841, 2161, 4), (101, 57, 3), (1366, 768, 3), (9, 8, 4)])
+def test_blockhash_any_size_matches_oracle(ctx, oracle, w, h, c):
+    """MI355_FLAG_BLOCKHASH_ANY_SIZE: frames that do not divide into 8 x 8 whole blocks take the crate's floating-point path
+    (video/videofx/src/videocompare/hashed_image.rs:37-44 -> image_hasher blockhash_slow, restated from memory: parity unpinned).
+    Every pixel whole to block (floor(x / (w/8)), floor(y / (h/8))), f32 block sums accumulated in pixel order: one lane per
+    block on the device, bit-exact against the C restatement - including 4K+1, where a block sum passes 2^24 and the order of
+    the additions shows in its low bits. Off by default: the same call is refused without the flag."""
+    import mi355fx
+    rng = np.random.default_rng(w + 3 * h + c)
+    f = _frames(rng, 1, w, h, c)[0]
+    if c == 4:
+        f[:, 3::4] = np.where(rng.random((h, w)) < 0.1, 0, 255)
+    f[: h // 2] //= 3
+    fmt = "RGBA" if c == 4 else "RGB"
+    with pytest.raises(mi355fx.Mi355Error) as e:
+        ctx.videocompare_hash_frame(f, w * c, w, h, fmt)
+    assert e.value.status == mi355fx.ERR_UNSUPPORTED
+    ctx.set_flag(mi355fx.FLAG_BLOCKHASH_ANY_SIZE, 1)
+    got = ctx.videocompare_hash_frame(f, w * c, w, h, fmt)
+    assert got == oracle.blockhash(f, w, h, w * c, c)
+    assert ctx.videocompare_distance(got, ctx.videocompare_hash_frame(f.copy(), w * c, w, h, fmt)) == 0.0
+    # sizes that DO divide still take the integer path, flag or not
+    g = _frames(rng, 1, 64, 64, c)[0]
+    assert ctx.videocompare_hash_frame(g, 64 * c, 64, 64, fmt) == oracle.blockhash(g, 64, 64, 64 * c, c)
+
+
 def test_unsupported_and_errors(ctx):
     import mi355fx
     f = np.zeros((16, 64), np.uint8)

@@ -53,7 +53,7 @@ def test_rgb_and_stride(oracle):
     padded[:, : 120] = rgb
     assert oracle.blockhash(rgb, 40, 48, 120, 3) == oracle.blockhash(padded, 40, 48, 133, 3)
     with pytest.raises(ValueError):
-        oracle.blockhash(rgb, 39, 48, 120, 3)
+        oracle.blockhash(rgb, 7, 48, 120, 3)   # below 8 x 8 (sizes that are merely not divisible by 8 take the float path now)
 
 
 def test_resize_based_hashes_basic_properties(oracle):
@@ -77,3 +77,38 @@ def test_resize_based_hashes_basic_properties(oracle):
     # resizing a constant image returns the constant (weights are normalised)
     const = np.full((64, 64 * 3), 77, np.uint8)
     assert (oracle.imghash(const, 64, 64, 192, 3, "mean")[2] == 77).all()
+
+
+def test_any_size_path_against_a_numpy_restatement(oracle):
+    """The floating-point path (sizes not divisible by 8) restated a second time in numpy: every pixel whole to block
+    (floor(x / (w/8)), floor(y / (h/8))) with f32 quotients, each block's f32 sum accumulated in row-major pixel order
+    (np.add.accumulate in float32 is sequential), upper median of each band of 32, the crate's float comparison."""
+    rng = np.random.default_rng(4)
+    for w, h, c in ((63, 64, 4), (101, 57, 3), (1283, 721, 4), (3841, 2161, 4)):
+        f = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        f[: h // 2] //= 3
+        if c == 4:
+            f[..., 3] = np.where(rng.random((h, w)) < 0.1, 0, 255)
+        s = f[..., :3].astype(np.uint32).sum(axis=2)
+        if c == 4:
+            s[f[..., 3] == 0] = 765
+        bw, bh = np.float32(w) / np.float32(8), np.float32(h) / np.float32(8)
+        bx = np.floor(np.arange(w, dtype=np.float32) / bw).astype(np.int64)
+        by = np.floor(np.arange(h, dtype=np.float32) / bh).astype(np.int64)
+        blocks = np.zeros(64, np.float32)
+        for j in range(8):
+            rows = s[by == j]
+            for i in range(8):
+                vals = rows[:, bx == i].reshape(-1).astype(np.float32)     # row-major within the block = pixel order
+                blocks[j * 8 + i] = np.add.accumulate(vals, dtype=np.float32)[-1]
+        half = np.float32(765.0) * bw * bh / np.float32(2.0)
+        bits = 0
+        for g in range(2):
+            band = blocks[32 * g: 32 * g + 32]
+            median = np.sort(band)[16]
+            for i, v in enumerate(band):
+                if v > median or (abs(v - median) < 1.0 and median > half):
+                    bits |= 1 << (32 * g + i)
+        assert oracle.blockhash(f.reshape(h, w * c), w, h, w * c, c) == bits, (w, h, c)
+    with pytest.raises(ValueError):
+        oracle.blockhash(np.zeros((7, 28), np.uint8), 7, 7, 28, 4)
