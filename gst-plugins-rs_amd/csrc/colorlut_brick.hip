@@ -733,6 +733,248 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 
 // One axis-table entry for input byte v: the reference's coordinate arithmetic, op for op (norm_comp imp.rs:471-474,
 // apply_3d :438-440, sample_3d :496-506; this translation unit is compiled with -ffp-contract=off).
+// ---------------------------------------------------------------- the block-shared brick cache (round 4)
+// colorlut3d_brick_kernel gives every WAVE 6-14 KB of bricks: enough for a smooth region, gone with +-8 of noise (73 % of the
+// steps miss at 32 sets, the 64-set geometry has 8-10 waves per CU). The cells a noisy region needs are few - +-11 levels
+// around a slowly moving base are 4-5 cells per axis of a 33^3 LUT, ~100 bricks, 10 KB - they are just not any one wave's.
+// colorlut3d_shared_kernel gives the BLOCK (one per CU, 16 waves) one cache: 512 sets x 2 ways x 96 B = the cell's place in a
+// box of 8 x 8 x 8 cells, so a cloud of colours up to 64 levels wide never collides with itself and two clouds (an edge) get
+// a way each. It is the cache of colorlut_window.hip with LUT cells instead of table bricks - and the arithmetic of the brick
+// kernel behind it (brick_pixel: the reference's lerps op for op, imp.rs:493-543):
+//   per pixel: three axis-table reads {t, set | tag}, the set's {tag0, tag1, generation} (one 16-byte read), the six 16-byte
+//   rows of the brick from the way that holds it, the generation again; 27 packed / scalar lerp instructions.
+//   miss: the first lane of up to kShFills distinct missing bricks takes its set's lock (ds_cmpst), invalidates the older way
+//   and bumps the generation; the wave copies the bricks from the global brick table (six lanes per brick, all in flight
+//   together), the leaders publish and unlock; the pixels are looked up again and a lane whose brick is still not there reads
+//   its six rows from the global table itself - always exact, the cache is only ever a copy.
+//   No barrier after the prologue; a reader whose generation read AFTER its brick reads still shows the value read BEFORE them
+//   cannot have overlapped an install into that set (the LDS executes a wave's operations in order; an install's first two
+//   operations are "tag gone", "generation bumped", in that order).
+// Walk, prefetch and stores are those of colorlut_window_kernel: a block walks down a 256-pixel-wide strip, 32 rows per step, two
+// rows per wave, two steps of pixels in flight, range-checked buffer stores. 8 B/pixel algorithmic.
+namespace {
+constexpr uint32_t kShAxis = 0;               // 3 x 256 x {t, set | tag}
+constexpr uint32_t kShCell = 6144;            // 3 x 256 bytes: cell index per axis (install / fallback path)
+constexpr uint32_t kShQueue = 6912;           // 16 waves x 8 x {cell, destination}
+constexpr uint32_t kShSets = 9216;            // 512 sets x 208 B: brick way 0, way 1, {tag0, tag1, generation, lock}
+constexpr uint32_t kShLdsBytes = kShSets + 512 * kBrickSetBytes;  // 115,712 B: one block per CU
+constexpr int kShWaves = 16, kShFills = 8, kShDepth = 2;
+constexpr uint32_t kShNoTag = 0xffffffffu;    // a packed word never looks like this (the low half is a set offset < 6656)
+static_assert(kShLdsBytes <= 160 * 1024 && kShSets % 256 == 0 && kShQueue + kShWaves * 64 <= kShSets, "LDS map");
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+typedef volatile __attribute__((address_space(3))) f4_t lds_vf4;
+typedef volatile __attribute__((address_space(3))) u4_t lds_vu4;
+__device__ __forceinline__ uint32_t lds_r32v(uint32_t a) { return *(lds_vu32 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w32v(uint32_t a, uint32_t v) { *(lds_vu32 *)(lds_byte *)(uintptr_t)a = v; }
+__device__ __forceinline__ u4_t lds_r128uv(uint32_t a) { return *(lds_vu4 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ f4_t lds_r128fv(uint32_t a) { return *(lds_vf4 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_w128fv(uint32_t a, f4_t v) { *(lds_vf4 *)(lds_byte *)(uintptr_t)a = v; }
+}  // namespace
+
+__global__ __launch_bounds__(64 * kShWaves) void colorlut3d_shared_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
+                                                                          unsigned rows, unsigned dst_bytes, unsigned steps_per_strip, unsigned share, unsigned extra,
+                                                                          const f4_t *__restrict__ bricks, const u2_t *__restrict__ axis,
+                                                                          const uint32_t *__restrict__ cellnum, unsigned lut_size, unsigned long long *__restrict__ counters) {
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (unsigned i = threadIdx.x; i < 768; i += 64 * kShWaves) {
+    lds_w64(kShAxis + 8u * i, axis[3 * 768 + i]);
+    lds_w8(kShCell + i, cellnum[i]);
+  }
+  if (threadIdx.x < 512) {
+    const uint32_t sa = kShSets + threadIdx.x * kBrickSetBytes;
+    lds_w32v(sa + 192u, kShNoTag);
+    lds_w32v(sa + 196u, kShNoTag);
+    lds_w32v(sa + 200u, 0u);
+    lds_w32v(sa + 204u, 0u);
+  }
+  __syncthreads();
+
+  const unsigned first = blockIdx.x * share + (blockIdx.x < extra ? blockIdx.x : extra);
+  const unsigned last = first + share + (blockIdx.x < extra ? 1u : 0u);
+  const uint32_t three = 3u, four = 4u;
+  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
+  unsigned miss_steps = 0, slow_steps = 0;
+
+  struct Slot { u4_t p, q; uint32_t o0, o1; };
+  Slot ring[kShDepth];
+  auto fetch = [&](unsigned st_, Slot &S) {
+    const unsigned st = st_ < last ? st_ : last - 1u;
+    const unsigned strip = st / steps_per_strip, k = st - strip * steps_per_strip;
+    const unsigned col = strip * 64u + lane, r0 = k * (2u * kShWaves) + 2u * wave, r1 = r0 + 1u;
+    const unsigned cc = col < w4 ? col : w4 - 1u, c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
+    S.o0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
+    S.o1 = col < w4 && r1 < rows ? (r1 * dw4 + col) << 4 : 0x80000000u;
+    S.p = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
+    S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
+  };
+
+  // one pixel from the cache: false if its brick is not there (or an install into its set overlapped the reads)
+  auto look = [&](uint32_t px, uint32_t packed, float tx, float ty, float tz, uint32_t &out) __attribute__((always_inline)) -> bool {
+    const uint32_t set = word0_times16(packed, four);
+    const u4_t m = lds_r128uv(set + 192u);  // {tag way 0, tag way 1, generation, lock}
+    const bool h1 = m.y == packed;
+    const uint32_t b = h1 ? set + 96u : set;
+    f4_t f[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) f[r] = lds_r128fv(b + 16u * r);
+    const uint32_t gen2 = lds_r32v(set + 200u);
+    out = brick_pixel(f, tx, ty, tz, px);
+    return (h1 | (m.x == packed)) & (gen2 == m.z);
+  };
+
+  // four pixels (one 16-byte row piece) through the cache
+  auto half = [&](const u4_t pin, uint32_t so) __attribute__((always_inline)) {
+    const uint32_t px[4] = {pin.x, pin.y, pin.z, pin.w};
+    float tx[4], ty[4], tz[4];
+    uint32_t packed[4], out[4];
+    {
+      u2_t ex[4], ey[4], ez[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        ex[j] = lds_r64(byte_times8<0>(px[j], three) + kShAxis);
+        ey[j] = lds_r64(byte_times8<1>(px[j], three) + (kShAxis + 2048u));
+        ez[j] = lds_r64(byte_times8<2>(px[j], three) + (kShAxis + 4096u));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        tx[j] = __uint_as_float(ex[j].x);
+        ty[j] = __uint_as_float(ey[j].x);
+        tz[j] = __uint_as_float(ez[j].x);
+        packed[j] = (ex[j].y + ey[j].y) + (ez[j].y + (kShSets >> 4));
+      }
+    }
+    bool ok[4], miss_any = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      ok[j] = look(px[j], packed[j], tx[j], ty[j], tz[j], out[j]);
+      miss_any = miss_any | !ok[j];
+    }
+    if (__builtin_amdgcn_ballot_w64(miss_any) != 0ull) {
+      miss_steps += 1;  // (the watch counts in 256-pixel steps)
+      // leaders = the first lane of up to kShFills distinct missing bricks (a lane speaks for its first missed pixel); every
+      // wave starts its search at another lane: the waves of a block miss the same new bricks at the same time
+      uint32_t mb = kShNoTag, pxm = 0;
+#pragma unroll
+      for (int j = 3; j >= 0; j--)
+        if (!ok[j]) { mb = packed[j]; pxm = px[j]; }
+      unsigned long long want = __builtin_amdgcn_ballot_w64(mb != kShNoTag), leaders = 0ull;
+      const unsigned rot = (wave * 4u + 1u) & 63u;
+#pragma unroll
+      for (int f = 0; f < kShFills; f++)
+        if (want != 0ull) {
+          const unsigned long long turned = (want >> rot) | (want << (64u - rot));
+          const int l = (int)((__builtin_ctzll(turned) + rot) & 63u);
+          leaders |= 1ull << l;
+          want &= ~__builtin_amdgcn_ballot_w64(mb == (uint32_t)__builtin_amdgcn_readlane((int)mb, l));
+        }
+      bool claimed = false;
+      uint32_t dest = 0;
+      const uint32_t set = word0_times16(mb, four);
+      const bool leader = (leaders >> lane) & 1ull;
+      const uint32_t qslot = kShQueue + 64u * wave + 8u * (uint32_t)__builtin_popcountll(leaders & ((1ull << lane) - 1ull));
+      if (leader) {
+        uint32_t expect = 0;
+        lds_u32 *lock = (lds_u32 *)(lds_byte *)(uintptr_t)(set + 204u);
+        if (__hip_atomic_compare_exchange_strong(lock, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          const u4_t m = lds_r128uv(set + 192u);
+          if (m.x == mb || m.y == mb) {
+            lds_w32v(set + 204u, 0u);  // another wave has installed it since this wave's lookup
+          } else {
+            const uint32_t way = m.z & 1u;
+            lds_w32v(set + 192u + 4u * way, kShNoTag);  // the tag goes first,
+            lds_w32v(set + 200u, m.z + 1u);             // then the generation: a reader that saw the tag sees this before any new byte
+            dest = set + 96u * way;
+            claimed = true;
+          }
+        }
+        // the queue entry: {cell number x0 + S (y0 + S z0), destination}, or "nothing" for a leader that did not claim
+        const uint32_t cell = lds_r8(kShCell + (pxm & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((pxm >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((pxm >> 16) & 0xffu)));
+        const u2_t qe = {claimed ? cell : kShNoTag, dest};
+        lds_w64(qslot, qe);
+      }
+      if (__builtin_amdgcn_ballot_w64(claimed) != 0ull) {
+        // six lanes per brick copy its six rows; all bricks of this step travel together
+        const unsigned e = lane / 6u, r = lane - 6u * e;
+        if (e < (unsigned)__builtin_popcountll(leaders)) {
+          const u2_t qe = lds_r64(kShQueue + 64u * wave + 8u * e);
+          if (qe.x != kShNoTag) lds_w128fv(qe.y + 16u * r, bricks[(size_t)qe.x * 8 + r]);
+        }
+        if (claimed) {  // publish after the rows (program order = LDS order), then let go
+          lds_w32v(set + 192u + 4u * ((dest - set) / 96u), mb);
+          lds_w32v(set + 204u, 0u);
+        }
+      }
+      // second look; what is still missing reads its rows from the global brick table
+      bool still = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (!ok[j]) {
+          ok[j] = look(px[j], packed[j], tx[j], ty[j], tz[j], out[j]);
+          still = still | !ok[j];
+        }
+      if (__builtin_amdgcn_ballot_w64(still) != 0ull) {
+        slow_steps += 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!ok[j]) {
+            const uint32_t cell = lds_r8(kShCell + (px[j] & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((px[j] >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((px[j] >> 16) & 0xffu)));
+            f4_t f[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) f[r] = bricks[(size_t)cell * 8 + r];
+            out[j] = brick_pixel(f, tx[j], ty[j], tz[j], px[j]);
+          }
+        // (a use inside the branch: the wait for these loads then sits here and not in front of every step's stores)
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(out[j]));
+      }
+    }
+    const u4_t o = {out[0], out[1], out[2], out[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, (int)so, 0, 2 /* nt */);
+  };
+  auto step = [&](unsigned st, Slot &S) {
+    half(S.p, S.o0);
+    half(S.q, S.o1);
+    fetch(st + kShDepth, S);
+  };
+
+  if (first < last) {
+#pragma unroll
+    for (int d = 0; d < kShDepth; d++) fetch(first + d, ring[d]);
+  }
+  unsigned st = first;
+  for (; st + kShDepth <= last; st += kShDepth) {
+#pragma unroll
+    for (int d = 0; d < kShDepth; d++) step(st + d, ring[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < kShDepth - 1; d++)
+    if (st + d < last) step(st + d, ring[d]);
+  if (lane == 0 && counters) {
+    unsigned long long *c = counters + 2 * ((blockIdx.x * kShWaves + wave) % kBrickCounterSlots);
+    atomicAdd(c, (unsigned long long)miss_steps);
+    atomicAdd(c + 1, (unsigned long long)slow_steps);
+  }
+}
+
+bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height) {
+  const size_t rows = (size_t)n_frames * (size_t)height;
+  if (width % 4 != 0 || rows == 0 || rows * (size_t)dst_stride > (1ull << 31)) return false;
+  const size_t steps = (size_t)(((unsigned)width / 4 + 63) / 64) * ((rows + 2 * kShWaves - 1) / (2 * kShWaves));
+  return steps < (1u << 31) && steps >= (size_t)ctx->n_cu * 3;  // a block's first step is cold: it needs a few behind it
+}
+
+int shared_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height) {
+  const unsigned w4 = (unsigned)width / 4, rows = (unsigned)((size_t)n_frames * height);
+  const unsigned n_strips = (w4 + 63) / 64, steps_per_strip = (rows + 2 * kShWaves - 1) / (2 * kShWaves);
+  const unsigned total = n_strips * steps_per_strip;
+  unsigned grid = (unsigned)ctx->n_cu;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(colorlut3d_shared_kernel, dim3(grid), dim3(64 * kShWaves), kShLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, (unsigned)src_stride / 16,
+                     (unsigned)dst_stride / 16, rows, (unsigned)((size_t)rows * (size_t)dst_stride), steps_per_strip, total / grid, total % grid, (const f4_t *)B.d_bricks,
+                     (const u2_t *)B.d_axis, B.d_cellnum, (unsigned)B.size, B.d_counters);
+  return check_hip(ctx, hipGetLastError(), "colorlut shared-cache kernel launch");
+}
+
 static void brick_axis_entry(int v, float scale, float offset, int S, float *t_out, int *i0_out) {
   volatile float n = (float)v / 255.0f;
   volatile float m = n * scale;
@@ -788,8 +1030,20 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
           rb[2 + (q >> 1)] = dq[2];
         }
       }
-  // axis tables for the three cache geometries (ZN = 2, 3, 4): [zn-2][axis][byte] = {t, set byte offset | tag contribution << 16}
-  std::vector<uint32_t> axis(3 * 3 * 256 * 2), cellnum(3 * 256);
+  // axis tables for the three per-wave cache geometries (ZN = 2, 3, 4): [zn-2][axis][byte] = {t, set byte offset | tag contribution << 16},
+  // and a fourth one ([3]) for the block-shared cache of colorlut3d_shared_kernel: 512 sets = the cell's place in a box of
+  // 8 x 8 x 8 cells (set byte offset / 16 in the low half: 13 * (x0 & 7 | (y0 & 7) << 3 | (z0 & 7) << 6), no carry into the
+  // high half), tag = which box (x0 >> 3 | (y0 >> 3) << 4 | (z0 >> 3) << 8, S <= 65)
+  std::vector<uint32_t> axis(4 * 3 * 256 * 2), cellnum(3 * 256);
+  for (int a = 0; a < 3; a++)
+    for (int v = 0; v < 256; v++) {
+      float t;
+      int i0;
+      brick_axis_entry(v, scale[a], offset[a], S, &t, &i0);
+      uint32_t *e = &axis[((size_t)3 * 768 + (size_t)a * 256 + v) * 2];
+      std::memcpy(&e[0], &t, 4);
+      e[1] = (uint32_t)(kBrickSetBytes / 16) * ((uint32_t)(i0 & 7) << (3 * a)) + (((uint32_t)(i0 >> 3) << (4 * a)) << 16);
+    }
   for (int zn = 2; zn <= 4; zn++)
     for (int a = 0; a < 3; a++)
       for (int v = 0; v < 256; v++) {

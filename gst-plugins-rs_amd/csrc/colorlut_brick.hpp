@@ -49,6 +49,10 @@ bool brick_applicable(const BrickLut &B, const uint8_t *d_src, size_t src_pitch,
 // hs == nullptr: colorlut alone; otherwise the fused hsvfilter -> colorlut chain. src == dst is allowed.
 int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height,
                  const mi355_hsv_settings *hs, int sets, int fmt64 = 0);  // sets: 32 or 64; fmt64: 0 RGBA8, 1 RGBA64_LE, 2 RGBA64_BE
+// the block-shared brick cache (colorlut3d_shared_kernel): RGBA8, plain colorlut; same applicability as the brick kernel plus
+// a launch large enough for a cache to warm up
+bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height);
+int shared_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height);
 // synchronous read (and optional reset) of the miss counters
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);
 

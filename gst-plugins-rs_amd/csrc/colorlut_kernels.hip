@@ -1395,6 +1395,12 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       // a table build runs over the all-colours frame, which is as hostile to the brick cache as noise: three-pass kernel
       // when it applies, and no entry in the stream's content watch either way
       const bool build = ctx->lut.building_table;
+      // MI355_FLAG_BRICK_SETS = 512: the block-shared cache (round 4), pinned
+      if (ctx->brick_sets == 512 && shared_applicable(ctx, width, dst_stride, n_frames, height)) {
+        brick_mark_unwatched(B);
+        ctx->lut.last_kernel = "colorlut3d_shared_kernel";
+        return shared_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height);
+      }
       // MI355_FLAG_BRICK_SETS pins the cache geometry; 0 lets the content watch pick (and leave for the three-pass kernel)
       const bool pinned = v == 7 || !three_pass_ok || ctx->brick_sets != 0;
       int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));

@@ -187,7 +187,7 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_BRICK_FOLD_AXIS && value >= 0 && value <= 2) { ctx->brick_fold_axis = value; return MI355_OK; }
   if (flag == MI355_FLAG_DSSIM_TRANSLUCENT && (value == 0 || value == 1)) { ctx->dssim_translucent = value; return MI355_OK; }
   if (flag == MI355_FLAG_BRICK_PRIO && value >= 0 && value <= 3) { ctx->brick_prio = value; return MI355_OK; }
-  if (flag == MI355_FLAG_BRICK_SETS && (value == 0 || value == 32 || value == 48 || value == 64)) { ctx->brick_sets = value; return MI355_OK; }
+  if (flag == MI355_FLAG_BRICK_SETS && (value == 0 || value == 32 || value == 48 || value == 64 || value == 512)) { ctx->brick_sets = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_TABLE && value >= 0 && value <= 3) { ctx->hsv_table_mode = value; return MI355_OK; }
   if (flag == MI355_FLAG_FUSED_VARIANT && value >= 0 && value <= 1) { ctx->fused_variant = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_BLOCKS_PER_CU && value >= 1 && value <= 4096) { ctx->hsv_blocks_per_cu = value; return MI355_OK; }
