@@ -756,10 +756,15 @@ namespace {
 constexpr uint32_t kShAxis = 0;               // 3 x 256 x {t, set | tag}
 constexpr uint32_t kShCell = 6144;            // 3 x 256 bytes: cell index per axis (install / fallback path)
 constexpr uint32_t kShQueue = 6912;           // 16 waves x 8 x {cell, destination}
-constexpr uint32_t kShSets = 9216;            // 512 sets x 208 B: brick way 0, way 1, {tag0, tag1, generation, lock}
-constexpr uint32_t kShLdsBytes = kShSets + 512 * kBrickSetBytes;  // 115,712 B: one block per CU
-constexpr int kShWaves = 16, kShFills = 8, kShDepth = 2;
-constexpr uint32_t kShNoTag = 0xffffffffu;    // a packed word never looks like this (the low half is a set offset < 6656)
+constexpr uint32_t kShProgress = 8192;        // 16 waves x steps done (the pace keeper below)
+constexpr uint32_t kShSets = 9216;            // 512 sets x 240 B: brick way 0 @0, way 1 @96, {tag0, tag1, generation0, generation1} @192, lock @208
+constexpr uint32_t kShSetBytes = 240;         // (15 x 16 B: odd, see brick_upload)
+constexpr uint32_t kShLdsBytes = kShSets + 512 * kShSetBytes;  // 132,096 B: one block per CU
+#ifndef SH_SLACK  // (tools/exp_brick_build.sh)
+#define SH_SLACK 2
+#endif
+constexpr int kShWaves = 16, kShFills = 8, kShDepth = 2, kShRounds = 2, kShSpins = 2048, kShSlack = SH_SLACK;
+constexpr uint32_t kShNoTag = 0xffffffffu;    // a packed word never looks like this (the low half is a set offset / 16 < 8256)
 static_assert(kShLdsBytes <= 160 * 1024 && kShSets % 256 == 0 && kShQueue + kShWaves * 64 <= kShSets, "LDS map");
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
 typedef volatile __attribute__((address_space(3))) f4_t lds_vf4;
@@ -767,6 +772,7 @@ typedef volatile __attribute__((address_space(3))) u4_t lds_vu4;
 __device__ __forceinline__ uint32_t lds_r32v(uint32_t a) { return *(lds_vu32 *)(lds_byte *)(uintptr_t)a; }
 __device__ __forceinline__ void lds_w32v(uint32_t a, uint32_t v) { *(lds_vu32 *)(lds_byte *)(uintptr_t)a = v; }
 __device__ __forceinline__ u4_t lds_r128uv(uint32_t a) { return *(lds_vu4 *)(lds_byte *)(uintptr_t)a; }
+__device__ __forceinline__ u2_t lds_r64v(uint32_t a) { return *(volatile __attribute__((address_space(3))) u2_t *)(lds_byte *)(uintptr_t)a; }
 __device__ __forceinline__ f4_t lds_r128fv(uint32_t a) { return *(lds_vf4 *)(lds_byte *)(uintptr_t)a; }
 __device__ __forceinline__ void lds_w128fv(uint32_t a, f4_t v) { *(lds_vf4 *)(lds_byte *)(uintptr_t)a = v; }
 }  // namespace
@@ -780,53 +786,44 @@ __global__ __launch_bounds__(64 * kShWaves) void colorlut3d_shared_kernel(const 
     lds_w64(kShAxis + 8u * i, axis[3 * 768 + i]);
     lds_w8(kShCell + i, cellnum[i]);
   }
+  if (threadIdx.x < kShWaves) lds_w32v(kShProgress + 4u * threadIdx.x, 0u);
   if (threadIdx.x < 512) {
-    const uint32_t sa = kShSets + threadIdx.x * kBrickSetBytes;
+    const uint32_t sa = kShSets + threadIdx.x * kShSetBytes;
     lds_w32v(sa + 192u, kShNoTag);
     lds_w32v(sa + 196u, kShNoTag);
     lds_w32v(sa + 200u, 0u);
     lds_w32v(sa + 204u, 0u);
+    lds_w32v(sa + 208u, 0u);
   }
   __syncthreads();
 
   const unsigned first = blockIdx.x * share + (blockIdx.x < extra ? blockIdx.x : extra);
   const unsigned last = first + share + (blockIdx.x < extra ? 1u : 0u);
   const uint32_t three = 3u, four = 4u;
+#ifdef BRICK_TIMING
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
   const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
   unsigned miss_steps = 0, slow_steps = 0;
 
-  struct Slot { u4_t p, q; uint32_t o0, o1; };
+  struct Slot { u4_t p, q; unsigned strip, k; };  // (strip and k are the same in every lane: scalar registers)
   Slot ring[kShDepth];
   auto fetch = [&](unsigned st_, Slot &S) {
     const unsigned st = st_ < last ? st_ : last - 1u;
     const unsigned strip = st / steps_per_strip, k = st - strip * steps_per_strip;
     const unsigned col = strip * 64u + lane, r0 = k * (2u * kShWaves) + 2u * wave, r1 = r0 + 1u;
     const unsigned cc = col < w4 ? col : w4 - 1u, c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
-    S.o0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
-    S.o1 = col < w4 && r1 < rows ? (r1 * dw4 + col) << 4 : 0x80000000u;
+    S.strip = st_ < last ? strip : 0xffffffffu;  // (a step past the end stores nothing)
+    S.k = k;
     S.p = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
     S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
   };
 
-  // one pixel from the cache: false if its brick is not there (or an install into its set overlapped the reads)
-  auto look = [&](uint32_t px, uint32_t packed, float tx, float ty, float tz, uint32_t &out) __attribute__((always_inline)) -> bool {
-    const uint32_t set = word0_times16(packed, four);
-    const u4_t m = lds_r128uv(set + 192u);  // {tag way 0, tag way 1, generation, lock}
-    const bool h1 = m.y == packed;
-    const uint32_t b = h1 ? set + 96u : set;
-    f4_t f[6];
-#pragma unroll
-    for (int r = 0; r < 6; r++) f[r] = lds_r128fv(b + 16u * r);
-    const uint32_t gen2 = lds_r32v(set + 200u);
-    out = brick_pixel(f, tx, ty, tz, px);
-    return (h1 | (m.x == packed)) & (gen2 == m.z);
-  };
-
   // four pixels (one 16-byte row piece) through the cache
-  auto half = [&](const u4_t pin, uint32_t so) __attribute__((always_inline)) {
+  auto half = [&](const u4_t pin) __attribute__((always_inline)) -> u4_t {
     const uint32_t px[4] = {pin.x, pin.y, pin.z, pin.w};
     float tx[4], ty[4], tz[4];
-    uint32_t packed[4], out[4];
+    uint32_t packed[4], set[4], out[4];
     {
       u2_t ex[4], ey[4], ez[4];
 #pragma unroll
@@ -841,99 +838,156 @@ __global__ __launch_bounds__(64 * kShWaves) void colorlut3d_shared_kernel(const 
         ty[j] = __uint_as_float(ey[j].x);
         tz[j] = __uint_as_float(ez[j].x);
         packed[j] = (ex[j].y + ey[j].y) + (ez[j].y + (kShSets >> 4));
+        set[j] = word0_times16(packed[j], four);
       }
     }
-    bool ok[4], miss_any = false;
+    // the sets' {tag way 0, tag way 1, generation way 0, generation way 1}: which way holds the brick, and the generation its rows are read under
+    u4_t meta[4];
+    bool hit[4], miss_any = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) meta[j] = lds_r128uv(set[j] + 192u);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      ok[j] = look(px[j], packed[j], tx[j], ty[j], tz[j], out[j]);
-      miss_any = miss_any | !ok[j];
+      hit[j] = (meta[j].x == packed[j]) | (meta[j].y == packed[j]);
+      miss_any = miss_any | !hit[j];
     }
     if (__builtin_amdgcn_ballot_w64(miss_any) != 0ull) {
       miss_steps += 1;  // (the watch counts in 256-pixel steps)
-      // leaders = the first lane of up to kShFills distinct missing bricks (a lane speaks for its first missed pixel); every
-      // wave starts its search at another lane: the waves of a block miss the same new bricks at the same time
-      uint32_t mb = kShNoTag, pxm = 0;
+#pragma unroll 1
+      for (int round = 0; round < kShRounds; round++) {
+        // leaders = the first lane of up to kShFills distinct missing bricks (a lane speaks for its first missed pixel); every
+        // wave starts its search at another lane: the waves of a block miss the same new bricks at the same time
+        uint32_t mb = kShNoTag, pxm = 0;
 #pragma unroll
-      for (int j = 3; j >= 0; j--)
-        if (!ok[j]) { mb = packed[j]; pxm = px[j]; }
-      unsigned long long want = __builtin_amdgcn_ballot_w64(mb != kShNoTag), leaders = 0ull;
-      const unsigned rot = (wave * 4u + 1u) & 63u;
+        for (int j = 3; j >= 0; j--)
+          if (!hit[j]) { mb = packed[j]; pxm = px[j]; }
+        unsigned long long want = __builtin_amdgcn_ballot_w64(mb != kShNoTag), leaders = 0ull;
+        const unsigned rot = (wave * 4u + 1u) & 63u;
 #pragma unroll
-      for (int f = 0; f < kShFills; f++)
-        if (want != 0ull) {
-          const unsigned long long turned = (want >> rot) | (want << (64u - rot));
-          const int l = (int)((__builtin_ctzll(turned) + rot) & 63u);
-          leaders |= 1ull << l;
-          want &= ~__builtin_amdgcn_ballot_w64(mb == (uint32_t)__builtin_amdgcn_readlane((int)mb, l));
+        for (int f = 0; f < kShFills; f++)
+          if (want != 0ull) {
+            const unsigned long long turned = (want >> rot) | (want << (64u - rot));
+            const int l = (int)((__builtin_ctzll(turned) + rot) & 63u);
+            leaders |= 1ull << l;
+            want &= ~__builtin_amdgcn_ballot_w64(mb == (uint32_t)__builtin_amdgcn_readlane((int)mb, l));
+          }
+        bool claimed = false;
+        uint32_t dest = 0;
+        const uint32_t mset = word0_times16(mb, four);
+        if ((leaders >> lane) & 1ull) {
+          uint32_t expect = 0;
+          lds_u32 *lock = (lds_u32 *)(lds_byte *)(uintptr_t)(mset + 208u);
+          if (__hip_atomic_compare_exchange_strong(lock, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            const u4_t m = lds_r128uv(mset + 192u);
+            if (m.x == mb || m.y == mb) {
+              lds_w32v(mset + 208u, 0u);  // another wave has installed it since this wave's lookup
+            } else {
+              const uint32_t way = (m.z + m.w) & 1u;  // the ways take turns
+              lds_w32v(mset + 192u + 4u * way, kShNoTag);               // the tag goes first,
+              lds_w32v(mset + 200u + 4u * way, (way ? m.w : m.z) + 1u);  // then the way's generation: a reader that saw the tag sees this before any new byte
+              dest = mset + 96u * way;
+              claimed = true;
+            }
+          }
+          // the queue entry: {cell number x0 + S (y0 + S z0), destination}, or "nothing" for a leader that did not claim
+          const uint32_t cell = lds_r8(kShCell + (pxm & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((pxm >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((pxm >> 16) & 0xffu)));
+          const u2_t qe = {claimed ? cell : kShNoTag, dest};
+          lds_w64(kShQueue + 64u * wave + 8u * (uint32_t)__builtin_popcountll(leaders & ((1ull << lane) - 1ull)), qe);
         }
-      bool claimed = false;
-      uint32_t dest = 0;
-      const uint32_t set = word0_times16(mb, four);
-      const bool leader = (leaders >> lane) & 1ull;
-      const uint32_t qslot = kShQueue + 64u * wave + 8u * (uint32_t)__builtin_popcountll(leaders & ((1ull << lane) - 1ull));
-      if (leader) {
-        uint32_t expect = 0;
-        lds_u32 *lock = (lds_u32 *)(lds_byte *)(uintptr_t)(set + 204u);
-        if (__hip_atomic_compare_exchange_strong(lock, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          const u4_t m = lds_r128uv(set + 192u);
-          if (m.x == mb || m.y == mb) {
-            lds_w32v(set + 204u, 0u);  // another wave has installed it since this wave's lookup
-          } else {
-            const uint32_t way = m.z & 1u;
-            lds_w32v(set + 192u + 4u * way, kShNoTag);  // the tag goes first,
-            lds_w32v(set + 200u, m.z + 1u);             // then the generation: a reader that saw the tag sees this before any new byte
-            dest = set + 96u * way;
-            claimed = true;
+        if (__builtin_amdgcn_ballot_w64(claimed) != 0ull) {
+          // six lanes per brick copy its six rows; all bricks of this round travel together
+          const unsigned e = lane / 6u, r = lane - 6u * e;
+          if (e < (unsigned)__builtin_popcountll(leaders)) {
+            const u2_t qe = lds_r64(kShQueue + 64u * wave + 8u * e);
+            if (qe.x != kShNoTag) lds_w128fv(qe.y + 16u * r, bricks[(size_t)qe.x * 8 + r]);
+          }
+          if (claimed) {  // publish after the rows (program order = LDS order), then let go
+            lds_w32v(mset + 192u + 4u * ((dest - mset) / 96u), mb);
+            lds_w32v(mset + 208u, 0u);
           }
         }
-        // the queue entry: {cell number x0 + S (y0 + S z0), destination}, or "nothing" for a leader that did not claim
-        const uint32_t cell = lds_r8(kShCell + (pxm & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((pxm >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((pxm >> 16) & 0xffu)));
-        const u2_t qe = {claimed ? cell : kShNoTag, dest};
-        lds_w64(qslot, qe);
-      }
-      if (__builtin_amdgcn_ballot_w64(claimed) != 0ull) {
-        // six lanes per brick copy its six rows; all bricks of this step travel together
-        const unsigned e = lane / 6u, r = lane - 6u * e;
-        if (e < (unsigned)__builtin_popcountll(leaders)) {
-          const u2_t qe = lds_r64(kShQueue + 64u * wave + 8u * e);
-          if (qe.x != kShNoTag) lds_w128fv(qe.y + 16u * r, bricks[(size_t)qe.x * 8 + r]);
+        // A brick this lane misses may be on its way in another wave's hands (its set locked): wait for it - the holder is
+        // one memory round trip from publishing, and reading the brick from memory here would take as long and cost 6 loads
+        // per lane. Nobody waits with a lock in hand (this wave's were released above), so the wait ends.
+        if (mb != kShNoTag) {
+          for (int spin = 0; spin < kShSpins; spin++) {
+            const u2_t m = lds_r64v(mset + 192u);
+            if ((m.x == mb) | (m.y == mb) | (lds_r32v(mset + 208u) == 0u)) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
         }
-        if (claimed) {  // publish after the rows (program order = LDS order), then let go
-          lds_w32v(set + 192u + 4u * ((dest - set) / 96u), mb);
-          lds_w32v(set + 204u, 0u);
-        }
+        // the tags again (only: the pixels are computed once, below)
+        bool still = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!hit[j]) {
+            meta[j] = lds_r128uv(set[j] + 192u);
+            hit[j] = (meta[j].x == packed[j]) | (meta[j].y == packed[j]);
+            still = still | !hit[j];
+          }
+        if (__builtin_amdgcn_ballot_w64(still) == 0ull) break;
       }
-      // second look; what is still missing reads its rows from the global brick table
-      bool still = false;
+    }
+    // the pixels: six rows from the way that holds the brick, then the generation again - an install into the set in between
+    // (it bumps the generation before it writes a byte) makes the pixel one for the careful path
+    bool redo = false;
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool h1 = meta[j].y == packed[j];
+      const uint32_t b = h1 ? set[j] + 96u : set[j];
+      f4_t f[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) f[r] = lds_r128fv(b + 16u * r);
+      const uint32_t gen2 = lds_r32v(h1 ? set[j] + 204u : set[j] + 200u);
+      out[j] = brick_pixel(f, tx[j], ty[j], tz[j], px[j]);
+      ok[j] = hit[j] & (gen2 == (h1 ? meta[j].w : meta[j].z));
+      redo = redo | !ok[j];
+    }
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+      // not in the cache (more bricks asked of one set than it has ways, or than the rounds install) or overtaken by an
+      // install: the rows come from the global brick table
+      slow_steps += 1;
 #pragma unroll
       for (int j = 0; j < 4; j++)
         if (!ok[j]) {
-          ok[j] = look(px[j], packed[j], tx[j], ty[j], tz[j], out[j]);
-          still = still | !ok[j];
+          const uint32_t cell = lds_r8(kShCell + (px[j] & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((px[j] >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((px[j] >> 16) & 0xffu)));
+          f4_t f[6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) f[r] = bricks[(size_t)cell * 8 + r];
+          out[j] = brick_pixel(f, tx[j], ty[j], tz[j], px[j]);
         }
-      if (__builtin_amdgcn_ballot_w64(still) != 0ull) {
-        slow_steps += 1;
+      // (a use inside the branch: the wait for these loads then sits here and not in front of every step's stores)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (!ok[j]) {
-            const uint32_t cell = lds_r8(kShCell + (px[j] & 0xffu)) + lut_size * (lds_r8(kShCell + 256u + ((px[j] >> 8) & 0xffu)) + lut_size * lds_r8(kShCell + 512u + ((px[j] >> 16) & 0xffu)));
-            f4_t f[6];
-#pragma unroll
-            for (int r = 0; r < 6; r++) f[r] = bricks[(size_t)cell * 8 + r];
-            out[j] = brick_pixel(f, tx[j], ty[j], tz[j], px[j]);
-          }
-        // (a use inside the branch: the wait for these loads then sits here and not in front of every step's stores)
-#pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(out[j]));
-      }
+      for (int j = 0; j < 4; j++) asm volatile("" : "+v"(out[j]));
     }
     const u4_t o = {out[0], out[1], out[2], out[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(o, dst_rsrc, (int)so, 0, 2 /* nt */);
+    return o;
   };
-  auto step = [&](unsigned st, Slot &S) {
-    half(S.p, S.o0);
-    half(S.q, S.o1);
+
+  // The pace keeper. A SIMD issues for its oldest wave first: left alone, the first waves of a block finish a third of the
+  // kernel before the last (measured: 50 of 135 us), the tail runs on a half-empty CU, and while they are ten steps apart the
+  // block needs the bricks of both places - where two colour regions share their sets that is three bricks for two ways.
+  // So a wave that is more than kShSlack steps ahead of the slowest sleeps until it is not (the slowest never waits; nobody
+  // waits with a lock in hand). A little apart is good: the wave in front takes the misses, the others find the bricks there.
+  unsigned steps_done = 0;
+  auto keep_pace = [&]() __attribute__((always_inline)) {
+    if (lane == 0) lds_w32v(kShProgress + 4u * wave, steps_done);
+    for (int spin = 0; spin < kShSpins; spin++) {
+      const uint32_t other = lds_r32v(kShProgress + 4u * (lane & (kShWaves - 1)));
+      if (__builtin_amdgcn_ballot_w64(other + kShSlack < steps_done) == 0ull) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    steps_done++;
+  };
+  auto step = [&](unsigned st, Slot &S) __attribute__((always_inline)) {
+    keep_pace();
+    const unsigned col = S.strip * 64u + lane, r0 = S.k * (2u * kShWaves) + 2u * wave, r1 = r0 + 1u;
+    const bool in = (S.strip != 0xffffffffu) & (col < w4);
+    const u4_t oa = half(S.p), ob = half(S.q);
+    const uint32_t so0 = (in & (r0 < rows)) ? (r0 * dw4 + col) << 4 : 0x80000000u, so1 = (in & (r1 < rows)) ? (r1 * dw4 + col) << 4 : 0x80000000u;
+    __builtin_amdgcn_raw_buffer_store_b128(oa, dst_rsrc, (int)so0, 0, 2 /* nt */);
+    __builtin_amdgcn_raw_buffer_store_b128(ob, dst_rsrc, (int)so1, 0, 2);
     fetch(st + kShDepth, S);
   };
 
@@ -949,6 +1003,16 @@ __global__ __launch_bounds__(64 * kShWaves) void colorlut3d_shared_kernel(const 
 #pragma unroll
   for (int d = 0; d < kShDepth - 1; d++)
     if (st + d < last) step(st + d, ring[d]);
+  if (lane == 0) lds_w32v(kShProgress + 4u * wave, 0x7fffffffu);  // done: nobody waits for this wave any more
+#ifdef BRICK_TIMING
+  if (lane == 0 && counters) {
+    unsigned long long *tr = counters + 2 * kBrickCounterSlots + 4 * (size_t)(blockIdx.x * kShWaves + wave);
+    tr[0] = t_start;
+    tr[1] = __builtin_amdgcn_s_memrealtime();
+    tr[2] = (unsigned long long)miss_steps | ((unsigned long long)slow_steps << 32);
+    tr[3] = first | ((unsigned long long)last << 32);
+  }
+#endif
   if (lane == 0 && counters) {
     unsigned long long *c = counters + 2 * ((blockIdx.x * kShWaves + wave) % kBrickCounterSlots);
     atomicAdd(c, (unsigned long long)miss_steps);
@@ -972,6 +1036,14 @@ int shared_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int s
   hipLaunchKernelGGL(colorlut3d_shared_kernel, dim3(grid), dim3(64 * kShWaves), kShLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, (unsigned)src_stride / 16,
                      (unsigned)dst_stride / 16, rows, (unsigned)((size_t)rows * (size_t)dst_stride), steps_per_strip, total / grid, total % grid, (const f4_t *)B.d_bricks,
                      (const u2_t *)B.d_axis, B.d_cellnum, (unsigned)B.size, B.d_counters);
+#ifdef BRICK_TIMING
+  if (const char *path = getenv("BRICK_TIMING_FILE")) {
+    std::vector<unsigned long long> tr(kBrickTimingBytes / 8);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(tr.data(), (const char *)B.d_counters + kBrickCounterBytes, kBrickTimingBytes, hipMemcpyDeviceToHost);
+    if (FILE *f = fopen(path, "wb")) { unsigned long long hdr[4] = {grid * (unsigned long long)kShWaves, steps_per_strip, n_strips, 512ull}; fwrite(hdr, 8, 4, f); fwrite(tr.data(), 8, std::min<size_t>(tr.size(), (size_t)grid * kShWaves * 4), f); fclose(f); }
+  }
+#endif
   return check_hip(ctx, hipGetLastError(), "colorlut shared-cache kernel launch");
 }
 
@@ -1032,7 +1104,9 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
       }
   // axis tables for the three per-wave cache geometries (ZN = 2, 3, 4): [zn-2][axis][byte] = {t, set byte offset | tag contribution << 16},
   // and a fourth one ([3]) for the block-shared cache of colorlut3d_shared_kernel: 512 sets = the cell's place in a box of
-  // 8 x 8 x 8 cells (set byte offset / 16 in the low half: 13 * (x0 & 7 | (y0 & 7) << 3 | (z0 & 7) << 6), no carry into the
+  // 8 x 8 x 8 cells (set byte offset / 16 in the low half: 15 * set number; the set number takes its low three bits from the low
+  // bits of x0, y0, z0 and a set is an odd number of 16-byte LDS bank groups long, so the eight bricks around any point - what the
+  // lanes of a wave read together on smooth content - lie in eight different bank groups; no carry into the
   // high half), tag = which box (x0 >> 3 | (y0 >> 3) << 4 | (z0 >> 3) << 8, S <= 65)
   std::vector<uint32_t> axis(4 * 3 * 256 * 2), cellnum(3 * 256);
   for (int a = 0; a < 3; a++)
@@ -1042,7 +1116,8 @@ int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const f
       brick_axis_entry(v, scale[a], offset[a], S, &t, &i0);
       uint32_t *e = &axis[((size_t)3 * 768 + (size_t)a * 256 + v) * 2];
       std::memcpy(&e[0], &t, 4);
-      e[1] = (uint32_t)(kBrickSetBytes / 16) * ((uint32_t)(i0 & 7) << (3 * a)) + (((uint32_t)(i0 >> 3) << (4 * a)) << 16);
+      const uint32_t set_index = ((uint32_t)(i0 & 1) << a) + ((uint32_t)((i0 >> 1) & 3) << (3 + 2 * a));
+      e[1] = 15u /* kShSetBytes / 16 */ * set_index + (((uint32_t)(i0 >> 3) << (4 * a)) << 16);
     }
   for (int zn = 2; zn <= 4; zn++)
     for (int a = 0; a < 3; a++)
@@ -1193,7 +1268,7 @@ static void brick_harvest(BrickLut &B) {
   const double steps = (double)B.px_snapshot / 256.0;
   unsigned long long tot[2] = {0, 0};
   for (int i = 0; i < kBrickCounterSlots; i++) { tot[0] += B.h_counters[2 * i]; tot[1] += B.h_counters[2 * i + 1]; }
-  if (steps > 0.0) watch_snapshot(B.watch, B.level_snapshot, (double)tot[0] / steps, (double)tot[1] / steps);
+  if (steps > 0.0) watch_snapshot(B.watch, B.level_snapshot, (double)tot[0] / steps, (double)tot[1] / steps, B.shared_snapshot);
 }
 
 int brick_choose(BrickLut &B) {
@@ -1219,7 +1294,7 @@ int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level) {
 // before the stream moved up (the selftest model always did this; the real path did not).
 void brick_mark_unwatched(BrickLut &B) { B.level_since = 2; }
 
-int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level) {
+int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level, bool shared1) {
   int rc;
   B.px_since += pixels;
   // a probe of a lower level is judged on its first launch (it runs the kernel believed slower), the level in use on four
@@ -1231,6 +1306,7 @@ int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, i
   B.pending = true;
   B.px_snapshot = B.px_since;
   B.level_snapshot = level;
+  B.shared_snapshot = shared1;
   B.px_since = 0;
   B.launches_since = 0;
   return MI355_OK;

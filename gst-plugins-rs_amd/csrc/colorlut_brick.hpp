@@ -32,6 +32,7 @@ struct BrickLut {
   unsigned launches_since = 0;
   int level_since = -1;                    // level of the launches counted in px_since (a change of level restarts the count)
   int level_snapshot = 0;                  // level of the snapshot in flight
+  bool shared_snapshot = false;            // ... and whether level 1 is the block-shared cache for the launches it covers
   BrickWatch watch;                        // the policy (brickwatch.hpp)
 };
 
@@ -40,7 +41,7 @@ int brick_choose(BrickLut &B);
 // before / after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
 int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level);
 void brick_mark_unwatched(BrickLut &B);
-int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level);
+int brick_after_launch(mi355_ctx *ctx, BrickLut &B, unsigned long long pixels, int level, bool shared1 = false);
 
 int brick_upload(mi355_ctx *ctx, BrickLut &B, int S, const float *cells, const float scale[3], const float offset[3]);
 void brick_release(BrickLut &B);

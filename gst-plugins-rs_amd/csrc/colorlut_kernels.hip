@@ -1403,17 +1403,21 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       }
       // MI355_FLAG_BRICK_SETS pins the cache geometry; 0 lets the content watch pick (and leave for the three-pass kernel)
       const bool pinned = v == 7 || !three_pass_ok || ctx->brick_sets != 0;
+      // level 1 of the watch is the block-shared cache where the launch is large enough for one
+      const bool shared1 = !pinned && !build && shared_applicable(ctx, width, dst_stride, n_frames, height);
       int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
       if (level == 2 && !three_pass_ok) level = 1;
       if (level == 2 || build || pinned) brick_mark_unwatched(B);
       if (level < 2) {
         const int sets = pinned && ctx->brick_sets ? ctx->brick_sets : (level ? 64 : 32);
-        ctx->lut.last_kernel = sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel");
+        const bool shared = shared1 && level == 1;
+        ctx->lut.last_kernel = shared ? "colorlut3d_shared_kernel" : (sets == 64 ? "colorlut3d_brick_kernel (64 sets)" : (sets == 48 ? "colorlut3d_brick_kernel (48 sets)" : "colorlut3d_brick_kernel"));
         int rc = (build || pinned) ? MI355_OK : brick_before_launch(ctx, B, level);
         if (rc) return rc;
-        rc = brick_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, nullptr, sets);
+        rc = shared ? shared_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height)
+                    : brick_launch(ctx, B, d_src, src_stride, d_dst, dst_stride, n_frames, width, height, nullptr, sets);
         if (rc || build || pinned) return rc;
-        return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level);
+        return brick_after_launch(ctx, B, (unsigned long long)width * height * n_frames, level, shared1);
       }
     }
     if (three_pass_ok) {

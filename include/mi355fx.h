@@ -108,7 +108,7 @@ typedef enum mi355_flag {
   MI355_FLAG_BLOCKHASH_ANY_SIZE = 15, /* videocompare Blockhash on frames whose width or height is not a multiple of 8: 0 (default) = MI355_ERR_UNSUPPORTED, 1 = the crate's floating-point path (blockhash_slow: every pixel whole to block (floor(x / (w/8)), floor(y / (h/8))) in f32, block sums accumulated in pixel order - one lane per block, sequential by definition, 1-2 ms per 4K frame; restated from memory like the rest of the hash: parity unpinned) */
   MI355_FLAG_HSV_NT = 14, /* hsvfilter on packed 4-byte frames: 1 = loads and stores carry the non-temporal hint. The kernel alone is ~5 % faster, but its output then bypasses the Infinity Cache and the element behind it reads from HBM (bench.py's `hsvfilter_nontemporal_ab` leg measures exactly that); default 0 */
   MI355_FLAG_WINDOW_MIN_STEPS = 13, /* LDS-cached table kernel (LUT variants 0 / 8): smallest launch it serves, in 256 x 32 pixel steps per CU (default 3; 0 = any size - its first step per block runs on a cold cache, so small launches are faster through the gather kernels) */
-  MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernel: sets per wave cache: 0 (default) = chosen by the content watch, 32 (16 waves per CU) or 64 (8 waves per CU) pinned; two ways each */
+  MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernels: 0 (default) = chosen by the content watch; pinned: 32 (16 waves per CU) or 64 (8 waves per CU) sets per WAVE cache, 512 = the block-shared cache of colorlut3d_shared_kernel (512 sets per CU, RGBA8 plain colorlut, launches of at least 3 steps of 256 x 32 pixels per CU; smaller ones take the 32-set kernel); two ways each */
 } mi355_flag;
 int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value);
 

@@ -10,7 +10,7 @@ import mi355fx
 from mi355fx import synth
 from mi355fx.cube import parse_cube
 
-W, H, N = 3840, 2160, 8
+W, H, N = 3840, 2160, int(os.environ.get("N", "8"))
 
 
 def main():

@@ -22,6 +22,8 @@ if amp < 0:
     frames = np.stack([synth.noise_frame(W, H, seed=11 + i) for i in range(N)]).reshape(-1)
 else:
     f = np.stack([synth.smooth_frame(W, H, seed=7 + i) for i in range(N)]).reshape(N, H, W, 4).astype(np.int16)
+    if os.environ.get("ROT"):   # bench.py's batches: one base frame, rotated along the row by 97 i pixels
+        f = np.stack([np.roll(f[0], 97 * i, axis=1) for i in range(N)])
     if amp:
         f[..., :3] += np.random.default_rng(2).integers(-amp, amp + 1, size=f[..., :3].shape, dtype=np.int16)
     frames = np.clip(f, 0, 255).astype(np.uint8).reshape(-1)
