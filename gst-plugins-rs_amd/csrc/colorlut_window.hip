@@ -46,6 +46,7 @@ typedef volatile __attribute__((address_space(3))) u2_t lds_vu2;
 constexpr uint32_t kWinAxis = 0;              // 3 x 256 x u32: slot contributions per channel value
 constexpr uint32_t kWinMeta = 3072;           // 256 sets x {tag way 0 | tag way 1 << 16, generation}; next victim = generation & 1
 constexpr uint32_t kWinLock = 5120;           // 256 sets x lock word (0 = free)
+constexpr uint32_t kWinProgress = 6144;       // 16 waves x steps done (WIN_PACE)
 constexpr uint32_t kWinData = 8192;           // 16 K entries (slot & 0x3fff) x {way 0, way 1}: 128 KiB
 constexpr uint32_t kWinLdsBytes = kWinData + 16384 * 8;  // 139,264 B: one block per CU
 constexpr int kWinWaves = 16;
@@ -55,6 +56,9 @@ constexpr unsigned kWinRowsPerStep = 2 * kWinWaves;
 #endif
 #ifndef WIN_DEPTH
 #define WIN_DEPTH 2
+#endif
+#ifndef WIN_PACE  // steps a wave may be ahead of the slowest wave of its block (0 = no pace keeping)
+#define WIN_PACE 0
 #endif
 #ifndef WIN_EXP
 #define WIN_EXP 0
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
     const u2_t none = {0xffffffffu, 0u};  // tags are 10 bits: 0xffff matches nothing
     lds_w64v(kWinMeta + 8u * threadIdx.x, none);
     lds_w32v(kWinLock + 4u * threadIdx.x, 0u);
+    if (threadIdx.x < kWinWaves) lds_w32v(kWinProgress + 4u * threadIdx.x, 0u);
   }
   __syncthreads();
 
@@ -127,7 +132,20 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
       S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
     };
 
+#if WIN_PACE
+    unsigned steps_done = 0;
+#endif
     auto step = [&](unsigned st, Slot &S) {
+#if WIN_PACE
+      // the pace keeper of colorlut3d_shared_kernel (colorlut_brick.hip): a wave more than WIN_PACE steps ahead of the slowest sleeps
+      if (lane == 0) lds_w32v(kWinProgress + 4u * wave, steps_done);
+      for (int spin = 0; spin < 2048; spin++) {
+        const uint32_t other = lds_r32v(kWinProgress + 4u * (lane & (kWinWaves - 1)));
+        if (__builtin_amdgcn_ballot_w64(other + WIN_PACE < steps_done) == 0ull) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      steps_done++;
+#endif
       const uint32_t px[8] = {S.p.x, S.p.y, S.p.z, S.p.w, S.q.x, S.q.y, S.q.z, S.q.w};
       const uint32_t so0 = S.o0, so1 = S.o1;
 
@@ -290,6 +308,9 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
     for (int d = 0; d < WIN_DEPTH - 1; d++)
       if (st + d < last) step(st + d, ring[d]);
   }
+#if WIN_PACE
+  if (lane == 0) lds_w32v(kWinProgress + 4u * wave, 0x7fffffffu);
+#endif
   // diagnostics: {pixels looked up, pixels served past the cache, bricks installed}, spread over slots so that the waves
   // of the chip do not queue up on one address
   unsigned long long miss_w = n_miss;
