@@ -61,6 +61,7 @@ struct mi355_group {
   std::deque<Batch> batches;       // launched, oldest first
   std::vector<hipEvent_t> events;  // free list
   std::unordered_map<uint64_t, uint64_t> where;  // ticket -> seq of its batch, for launched batches not yet retired
+  std::unordered_map<uint64_t, int> failed;      // ticket -> status of the launch that did not happen (reported by wait / order_after)
   uint64_t next_ticket = 1, next_seq = 1;
   uint64_t n_frames = 0, n_batched_launch_pairs = 0, n_single = 0;
   std::string last_error;
@@ -136,8 +137,11 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
     for (const Desc &d : take)
       if (d.ready) g->events.push_back(d.ready);
     if (rc) {
+      // the frames of this batch have left `pending` and will never be in `where`: whoever waits for one of them is told
       (void)hipGetLastError();
       g->events.push_back(done);
+      if (g->failed.size() > 65536) g->failed.clear();  // (tickets nobody ever waited for)
+      for (const Desc &d : take) g->failed[d.ticket] = rc;
       if (g->last_error.empty()) g->last_error = "group launch failed";
       return rc;
     }
@@ -152,6 +156,12 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
 // Waits (on the host) for the batch that holds `ticket` - and with it, the stream being in order, for every earlier one. The
 // lock is NOT held while waiting: other streams' threads keep submitting. `lk` owns g->mu on entry and on return.
 int wait_unlocking(mi355_group *g, std::unique_lock<std::mutex> &lk, uint64_t ticket) {
+  auto bad = g->failed.find(ticket);
+  if (bad != g->failed.end()) {
+    const int rc = bad->second;
+    g->failed.erase(bad);
+    return fail(g, rc, "group: the launch that carried this frame failed");
+  }
   auto it = g->where.find(ticket);
   if (it == g->where.end()) return MI355_OK;  // launched and already retired (by this or another waiter)
   const uint64_t seq = it->second;
@@ -284,7 +294,7 @@ int mi355_group_wait(mi355_group *g, uint64_t ticket) {
   for (const Desc &d : g->pending) is_pending |= d.ticket == ticket;
   if (is_pending) {
     int rc = flush_locked(g, ticket);
-    if (rc) return rc;
+    if (rc && g->failed.find(ticket) == g->failed.end()) return rc;  // (a failure of this frame's own batch is reported - once - below)
   }
   return wait_unlocking(g, lk, ticket);
 }
@@ -300,6 +310,8 @@ int mi355_group_order_after(mi355_group *g, mi355_ctx *ctx, uint64_t ticket) {
     int rc = flush_locked(g, ticket);
     if (rc) return rc;
   }
+  auto bad = g->failed.find(ticket);
+  if (bad != g->failed.end()) return fail(g, bad->second, "group: the launch that carried this frame failed");
   auto it = g->where.find(ticket);
   if (it == g->where.end()) return MI355_OK;  // retired: the frame is done, nothing to order
   for (Batch &b : g->batches)

@@ -235,7 +235,12 @@ int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *co
  *   wait   : host wait until the frame `ticket` is in d_dst; flushes first if the frame has not been launched - an element
  *           that works one frame deep (submit n, wait n-1) thereby batches with whatever the other streams submitted in
  *           between. The group's lock is not held while waiting.
- *   stats  : {frames, batched launch pairs, frames that went through their context's own path}. */
+ *   stats  : {frames, batched launch pairs, frames that went through their context's own path}.
+ * Threads: every entry point may be called from any thread (one lock per group, not held during host waits). A flush launches
+ * on behalf of EVERY stream with a pending frame, from whichever thread caused it, and reads those streams' contexts (LUT
+ * table, flags): between submit and the return of wait for that ticket a context is used only through the group - no LUT
+ * reload / unload, no flag change, no other entry point, no destroy. A launch that fails is reported to the call that caused
+ * it and, once, to wait / order_after for each frame it carried (never as a silent success). */
 typedef struct mi355_group mi355_group;
 mi355_group *mi355_group_create(int device, int max_batch, int *status);
 void mi355_group_destroy(mi355_group *group);
