@@ -1020,10 +1020,13 @@ __global__ __launch_bounds__(64 * kShWaves) void colorlut3d_shared_kernel(const 
   }
 }
 
-bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height) {
+bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height, bool *small) {
   const size_t rows = (size_t)n_frames * (size_t)height;
+  if (small) *small = false;
   if (width % 4 != 0 || rows == 0 || rows * (size_t)dst_stride > (1ull << 31)) return false;
   const size_t steps = (size_t)(((unsigned)width / 4 + 63) / 64) * ((rows + 2 * kShWaves - 1) / (2 * kShWaves));
+  // small: up to six steps per CU (one 4K frame is four) - there the shared cache is ahead on clean content as well
+  if (small) *small = steps < (size_t)ctx->n_cu * 6;
   return steps < (1u << 31) && steps >= (size_t)ctx->n_cu * 3;  // a block's first step is cold: it needs a few behind it
 }
 
@@ -1271,9 +1274,9 @@ static void brick_harvest(BrickLut &B) {
   if (steps > 0.0) watch_snapshot(B.watch, B.level_snapshot, (double)tot[0] / steps, (double)tot[1] / steps, B.shared_snapshot);
 }
 
-int brick_choose(BrickLut &B) {
+int brick_choose(BrickLut &B, int min_level) {
   brick_harvest(B);
-  return watch_level(B.watch, !B.pending);
+  return watch_level(B.watch, !B.pending, min_level);
 }
 
 // before a brick launch at `level`: a change of level starts a new count (what the counters hold belongs to the old one)

@@ -37,7 +37,7 @@ struct BrickLut {
 };
 
 // Content watch for the interpolating path: level for this launch (0 / 1 = brick kernel with 32 / 64 sets, 2 = three-pass).
-int brick_choose(BrickLut &B);
+int brick_choose(BrickLut &B, int min_level = 0);
 // before / after a brick launch of `pixels` pixels at `level` on ctx's stream: count it and, every few launches, start a non-blocking snapshot
 int brick_before_launch(mi355_ctx *ctx, BrickLut &B, int level);
 void brick_mark_unwatched(BrickLut &B);
@@ -52,7 +52,7 @@ int brick_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int sr
                  const mi355_hsv_settings *hs, int sets, int fmt64 = 0);  // sets: 32 or 64; fmt64: 0 RGBA8, 1 RGBA64_LE, 2 RGBA64_BE
 // the block-shared brick cache (colorlut3d_shared_kernel): RGBA8, plain colorlut; same applicability as the brick kernel plus
 // a launch large enough for a cache to warm up
-bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height);
+bool shared_applicable(const mi355_ctx *ctx, int width, int dst_stride, int n_frames, int height, bool *small = nullptr);
 int shared_launch(mi355_ctx *ctx, const BrickLut &B, const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int n_frames, int width, int height);
 // synchronous read (and optional reset) of the miss counters
 int brick_read_counters(mi355_ctx *ctx, const BrickLut &B, unsigned long long out[2], bool reset);

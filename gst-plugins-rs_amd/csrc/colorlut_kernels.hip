@@ -1404,8 +1404,9 @@ static int launch_colorlut_compute(mi355_ctx *ctx, const uint8_t *d_src, size_t 
       // MI355_FLAG_BRICK_SETS pins the cache geometry; 0 lets the content watch pick (and leave for the three-pass kernel)
       const bool pinned = v == 7 || !three_pass_ok || ctx->brick_sets != 0;
       // level 1 of the watch is the block-shared cache where the launch is large enough for one
-      const bool shared1 = !pinned && !build && shared_applicable(ctx, width, dst_stride, n_frames, height);
-      int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B));
+      bool small = false;
+      const bool shared1 = !pinned && !build && shared_applicable(ctx, width, dst_stride, n_frames, height, &small);
+      int level = pinned ? (ctx->brick_sets == 64 ? 1 : 0) : (build ? 2 : brick_choose(B, shared1 && small ? 1 : 0));
       if (level == 2 && !three_pass_ok) level = 1;
       if (level == 2 || build || pinned) brick_mark_unwatched(B);
       if (level < 2) {

@@ -208,3 +208,22 @@ def test_content_watch_ladder_goes_through_the_shared_cache(ctx, oracle, synth):
     assert names[-1] == "colorlut3d_shared_kernel", names[-12:]
     names = run(smooth, es, 80)  # ... and of level 0 after 64 at level 1
     assert names[-1] == "colorlut3d_brick_kernel", names[-12:]
+
+
+def test_single_frame_launches_start_on_the_shared_cache(ctx, oracle, synth):
+    """One 4K frame per launch (what a pipeline hands over per buffer), interpolating path: the 16 waves of a CU warm ONE cache
+    instead of one each, so level 1 is where such launches start - on clean content too - and the results are the oracle's."""
+    import mi355fx
+    cube = _load(ctx, oracle, synth.cube_text_3d(33))
+    ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 6)
+    ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)
+    w, h = 3840, 2160
+    frame = synth.smooth_frame(w, h, seed=3)[None]
+    exp = np.zeros_like(frame)
+    oracle.colorlut_rgba8(cube, frame[0], w * 4, exp[0], w * 4, w, h, nthreads=8)
+    names = []
+    for _ in range(12):
+        got = _device_lut(ctx, frame, w, h).reshape(frame.shape)
+        assert (got == exp).all(), _report(got, exp)
+        names.append(ctx.colorlut_kernel_name())
+    assert names == ["colorlut3d_shared_kernel"] * 12, names
