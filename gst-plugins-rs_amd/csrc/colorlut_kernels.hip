@@ -2012,12 +2012,17 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
 extern "C" int mi355_selftest_brickwatch(int n_calls, const double *miss0, const double *slow0, const double *miss1, const double *slow1, int lag,
                                          int *level_out) {
   if (n_calls < 0 || !miss0 || !slow0 || !miss1 || !slow1 || !level_out || lag < 0) return MI355_ERR_INVALID_ARG;
+  // lag: bits 0-15 the snapshot lag in launches; bit 16: level 1 is the block-shared cache (its thresholds); bits 17-18: the
+  // lowest level worth running (small launches)
+  const bool shared1 = (lag >> 16) & 1;
+  const int min_level = (lag >> 17) & 3;
+  lag &= 0xffff;
   mi355::BrickWatch W;
   int level_since = -1, launches_since = 0, pend_level = -1, pend_ready = 0;
   double acc_m = 0, acc_s = 0, pend_m = 0, pend_s = 0;
   for (int i = 0; i < n_calls; i++) {
-    if (pend_level >= 0 && i >= pend_ready) { const int l = pend_level; pend_level = -1; mi355::watch_snapshot(W, l, pend_m, pend_s); }
-    const int level = mi355::watch_level(W, pend_level < 0);
+    if (pend_level >= 0 && i >= pend_ready) { const int l = pend_level; pend_level = -1; mi355::watch_snapshot(W, l, pend_m, pend_s, shared1); }
+    const int level = mi355::watch_level(W, pend_level < 0, min_level);
     level_out[i] = level;
     if (level == 2) { level_since = 2; continue; }
     if (level != level_since) { level_since = level; launches_since = 0; acc_m = acc_s = 0; }

@@ -84,3 +84,37 @@ def test_probes_are_single_launches_even_when_the_host_runs_far_ahead(mi355lib):
     assert 2 <= len(zeros) <= 12                                   # a handful of probes in 1300 launches
     assert all(b - a > 1 for a, b in zip(zeros, zeros[1:]))        # never two in a row
     assert 2 not in lv
+
+
+SHARED1 = 1 << 16
+
+
+def test_shared_cache_thresholds(mi355lib):
+    """Level 1 = the block-shared cache (round 4): level 0 leaves above 30 % miss steps (35 % before), level 1 holds up to 50 %
+    miss / 30 % slow steps (32 % / 2 % for the per-wave 64-set cache)."""
+    n = 300
+    # 32 % miss steps at level 0: stays with the per-wave level 1, moves with the shared one
+    assert set(_run(mi355lib, [0.32] * n, [0.0] * n, [0.1] * n, [0.0] * n)) == {0}
+    lv = _run(mi355lib, [0.32] * n, [0.0] * n, [0.1] * n, [0.0] * n, lag=2 | SHARED1)
+    assert lv[-1] == 1 and 2 not in lv
+    # 45 % miss / 20 % slow steps at level 1: too much for the per-wave cache, fine for the shared one
+    lv = _run(mi355lib, [0.9] * n, [0.2] * n, [0.45] * n, [0.2] * n)
+    assert lv[-1] == 2
+    lv = _run(mi355lib, [0.9] * n, [0.2] * n, [0.45] * n, [0.2] * n, lag=2 | SHARED1)
+    assert lv[-1] == 1 and 2 not in lv
+    # 60 % miss steps at level 1: on to the three-pass kernel either way
+    lv = _run(mi355lib, [1.0] * n, [1.0] * n, [0.6] * n, [0.35] * n, lag=2 | SHARED1)
+    assert lv[-1] == 2
+
+
+def test_small_launches_never_run_below_their_lowest_level(mi355lib):
+    """min_level 1 (one or two frames per launch with the shared cache as level 1): level 0 is neither used nor probed, the
+    ladder above it works as usual (noise climbs to the three-pass kernel, calm content comes back to level 1)."""
+    n = 500
+    flags = 2 | SHARED1 | (1 << 17)
+    lv = _run(mi355lib, [0.02] * n, [0.0] * n, [0.02] * n, [0.0] * n, lag=flags)
+    assert set(lv) == {1}
+    miss1 = [0.9] * 100 + [0.05] * 400
+    slow1 = [0.6] * 100 + [0.0] * 400
+    lv = _run(mi355lib, [1.0] * n, [1.0] * n, miss1, slow1, lag=flags)
+    assert 0 not in lv and 2 in lv[:40] and lv[-1] == 1
