@@ -123,6 +123,33 @@ def batch_stats(torch, b):
 
 
 EVENT_EVERY = 4  # steps between per-kernel event samples inside the timed region
+HOST_TRACE = [] if os.environ.get("BENCH_HOST_TRACE") else None
+
+
+class EventPool:
+    """Timestamped events, created AND recorded once before any timed region. A process's first ~170 recorded timing events
+    end in a host-side stall of 35-55 ms (the runtime grows a pool behind them; torch creates its events lazily at the
+    first record): with the events of a 75-step region created inside it, that stall sat at launch pair 224 of 300, where the host
+    is only 39 ms of device work ahead - 3 % of the region on a quiet host and 20-50 % on a loaded one (value 20-37 k instead
+    of 43-46 k on the same box in the same minute; tools/trace_big_gaps.py, BENCH_HOST_TRACE=1)."""
+
+    def __init__(self, torch, n):
+        self.torch = torch
+        self.events = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in self.events:      # all outstanding at once: whatever pool the runtime keeps behind them grows to this size now
+            e.record()
+        torch.cuda.synchronize()
+        self.next = 0
+
+    def take(self):
+        if not self.events:
+            return self.torch.cuda.Event(enable_timing=True)
+        e = self.events[self.next]
+        self.next = (self.next + 1) % len(self.events)
+        return e
+
+
+EVENTS = None   # set once the stream exists (main)
 
 
 def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVENT_EVERY, served=None):
@@ -133,11 +160,13 @@ def run_region(torch, ctx, srcs, dsts, settings, steps, batch, record, every=EVE
     evs = []
     pitch = FRAME_BYTES
     for k in range(steps):
+        if HOST_TRACE is not None:   # BENCH_HOST_TRACE=1: when the host was where (diagnostic; a list append per step)
+            HOST_TRACE.append(time.perf_counter())
         s = srcs[k % len(srcs)]
         d = dsts[k % len(dsts)]
         sample = record and (k % every == 0)
         if sample:
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0, e1, e2 = (EVENTS.take() for _ in range(3))
             e0.record()
         ctx.hsvfilter_frames_device(s.data_ptr(), batch, pitch, W, H, W * 4, "RGBA", settings)
         if sample:
@@ -498,6 +527,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx.set_stream(stream.cuda_stream)
+        global EVENTS
+        EVENTS = EventPool(torch, max(1024, 3 * (args.steps * args.pairs_per_step // EVENT_EVERY + 1) + 512))
         ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
         if args.lut_variant:
             ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, args.lut_variant)
@@ -524,7 +555,7 @@ def main():
                     # keep the queue busy; byte order xRGB = another instantiation (hsvfilter_flat_kernel<5, 1, false>), so that these
                     # 1-frame launches do not dilute the 8-frame launches' average in a rocprofv3 kernel trace of this command
                     ctx.hsvfilter_frames_device(cal.data_ptr(), 1, FRAME_BYTES, W, H, W * 4, "xRGB", settings)
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a, b = EVENTS.take(), EVENTS.take()
                     a.record(); b.record()
                     pairs.append((a, b))
                 torch.cuda.synchronize()
@@ -587,7 +618,7 @@ def main():
                     s_, d_ = srcs_[k % len(srcs_)], dsts[k % len(dsts)]
                     sample = rec and (k % every == 0)
                     if sample:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0, e1 = EVENTS.take(), EVENTS.take()
                         e0.record()
                     ctx.hsv_colorlut_frames_device(s_.data_ptr(), pitch, W * 4, d_.data_ptr(), pitch, W * 4, args.batch, W, H, settings)
                     if in_timed[0]:
@@ -634,7 +665,13 @@ def main():
                     in_timed[0] = True
                     evs.extend(region(sl, n, record and steps >= 64))
                     in_timed[0] = False
+                if HOST_TRACE is not None:
+                    del HOST_TRACE[:]
                 dts.append(sharding.timed_region(body, dist=None if solo else dist, device_sync=torch.cuda.synchronize, keep_busy=lambda: ramp_body(min(16, args.rewarm_steps))))
+                if HOST_TRACE is not None and len(HOST_TRACE) > 1:
+                    gaps = [(i, (b - a) * 1e3) for i, (a, b) in enumerate(zip(HOST_TRACE, HOST_TRACE[1:])) if b - a > 1e-3]
+                    print("host trace: %d launch pairs enqueued in %.1f ms of a %.1f ms region; iterations over 1 ms: %s" %
+                          (len(HOST_TRACE), (HOST_TRACE[-1] - HOST_TRACE[0]) * 1e3, dts[-1] * 1e3, ["pair %d: %.1f ms" % g for g in gaps][:10]), file=sys.stderr)
 
             consume(pool, srcs, warmup, 0, warm)
             chunks = consume(pool, srcs, steps, warmup, timed)
