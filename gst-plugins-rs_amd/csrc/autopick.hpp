@@ -34,7 +34,8 @@ struct AutoPolicy {
   unsigned learn = 0;                     // learning phase step: 0,1 compute; 2,3 table; 4 = done
   bool probe_second = false;              // the previous launch was the warming half of a probe: this one is the measured half
   bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
-  // how much faster the kind not in use must measure to take over; samples averaged with the previous one (smooth). The
+  // how much faster the kind not in use must measure to take over; samples of the kind in use averaged with the previous
+  // one (smooth). The
   // nested choice between the two table kernels sets 8 % + smoothing: behind hsvfilter they are within 5-10 % of each other,
   // single in-stream samples scatter by as much, and every flip costs 64 launches of probing at the short period
   double hysteresis = 0.03;
@@ -58,8 +59,11 @@ inline void auto_complete(AutoPolicy &A, double ms) {
   if (A.pending_kind < 0) return;
   if (!A.pending_discard && ms > 0.0) {
     const double per_vec = ms / (double)A.pending_vec;
+    // (smoothing is for the kind in use, which is sampled every few launches; the other kind's rare probe samples count as they
+    //  are - averaged with a first, cold one they would take three probe periods to say what the second already said)
     double &t = A.pending_kind == 0 ? A.t_compute : A.t_table;
-    t = A.smooth && t > 0.0 ? 0.5 * (t + per_vec) : per_vec;
+    const bool in_use = A.learn >= 4 && (A.pending_kind == 1) == A.table;
+    t = A.smooth && in_use && t > 0.0 ? 0.5 * (t + per_vec) : per_vec;
     if (A.t_compute > 0.0 && A.t_table > 0.0) {
       // hysteresis (3 % by default): measurements of near-equal kernels must not flip the choice back and forth
       const bool table = A.t_table < A.t_compute * (A.table ? 1.0 + A.hysteresis : 1.0 - A.hysteresis);
