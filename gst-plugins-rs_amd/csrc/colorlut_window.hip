@@ -60,6 +60,9 @@ constexpr unsigned kWinRowsPerStep = 2 * kWinWaves;
 #ifndef WIN_PACE  // steps a wave may be ahead of the slowest wave of its block (0 = no pace keeping)
 #define WIN_PACE 0
 #endif
+#ifndef WIN_WAIT  // 1: a lane whose brick another wave is installing waits for it before the second look (0: gathers from the table)
+#define WIN_WAIT 0
+#endif
 #ifndef WIN_EXP
 #define WIN_EXP 0
 #endif
@@ -248,6 +251,17 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
           lds_w32v(meta_addr(mb), tw_new);
           lds_w32v(kWinLock + ((mb & 255u) << 2), 0u);
         }
+#if WIN_WAIT
+        // (as in colorlut3d_shared_kernel: nobody waits with a lock in hand - this wave's were released above - so the wait ends)
+        if (mb != 0xffffffffu) {
+          const uint32_t meta = meta_addr(mb), tag = mb >> 8;
+          for (int spin = 0; spin < 2048; spin++) {
+            const uint32_t tg = lds_r32v(meta);
+            if ((tg & 0xffffu) == tag || (tg >> 16) == tag || lds_r32v(kWinLock + ((mb & 255u) << 2)) == 0u) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+#endif
         // Second look for the pixels that missed: most of them belong to the bricks just installed (two coalesced lines
         // per brick from L2 instead of one 128 B line per pixel through the gather path).
         bool still = false;
