@@ -227,3 +227,43 @@ def test_single_frame_launches_start_on_the_shared_cache(ctx, oracle, synth):
         assert (got == exp).all(), _report(got, exp)
         names.append(ctx.colorlut_kernel_name())
     assert names == ["colorlut3d_shared_kernel"] * 12, names
+
+
+@pytest.mark.parametrize("which", ["shared", "window"])
+@pytest.mark.parametrize("w,h,n,spad,dpad", [(1920, 1080, 4, 16, 48), (1000, 700, 12, 96, 0), (3840, 2160, 1, 0, 64)])
+def test_lds_cache_kernels_take_padded_rows(ctx, oracle, synth, which, w, h, n, spad, dpad):
+    """Source and destination strides padded independently to multiples of 16 B (colorlut/imp.rs:275-286), frames
+    `stride * height` apart, launches large enough for the per-CU caches: the block-shared brick cache and the LDS-cached
+    table kernel walk rows by stride; the padding of the destination stays untouched."""
+    import mi355fx
+    cube = _load(ctx, oracle, synth.cube_text_3d(33))
+    ss, ds = w * 4 + spad, w * 4 + dpad
+    rng = np.random.default_rng(w + n)
+    base = synth.smooth_frame(w, h, seed=9).reshape(h, w * 4)
+    src = rng.integers(0, 256, size=(n, h, ss), dtype=np.uint8)
+    for f in range(n):
+        src[f, :, :w * 4] = np.roll(base, 4 * 41 * f, axis=1)
+    src = src.reshape(-1)
+    exp = np.full(n * h * ds, 0xEE, np.uint8)
+    for f in range(n):
+        oracle.colorlut_rgba8(cube, src[f * h * ss:(f + 1) * h * ss].copy(), ss, exp[f * h * ds:(f + 1) * h * ds], ds, w, h, nthreads=8)
+    if which == "shared":
+        _pin(ctx)
+    else:
+        ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 8)
+    d_src, d_dst = ctx.alloc(src.nbytes), ctx.alloc(exp.nbytes)
+    try:
+        ctx.h2d(d_src, src)
+        got = np.empty_like(exp)
+        for rep in range(2):   # (the table kernel's first launch builds the table)
+            ctx.h2d(d_dst, np.full(n * h * ds, 0xEE, np.uint8))
+            ctx.colorlut_frames_device(d_src, h * ss, ss, d_dst, h * ds, ds, n, w, h, "RGBA")
+            ctx.synchronize()
+            ctx.d2h(got, d_dst)
+            assert (got == exp).all(), (rep, _report(got, exp))
+        assert ctx.colorlut_kernel_name() == ("colorlut3d_shared_kernel" if which == "shared" else "colorlut_window_kernel"), ctx.colorlut_kernel_name()
+    finally:
+        ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
+        ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)
+        ctx.free(d_src)
+        ctx.free(d_dst)
