@@ -36,7 +36,7 @@ struct AutoPolicy {
   bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
   // how much faster the kind not in use must measure to take over; samples of the kind in use averaged with the previous
   // one (smooth). The
-  // nested choice between the two table kernels sets 8 % + smoothing: behind hsvfilter they are within 5-10 % of each other,
+  // nested choice between the two table kernels sets 5 % + smoothing: behind hsvfilter they are within 5-10 % of each other,
   // single in-stream samples scatter by as much, and every flip costs 64 launches of probing at the short period
   double hysteresis = 0.03;
   bool smooth = false;

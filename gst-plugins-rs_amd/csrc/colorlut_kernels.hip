@@ -1752,7 +1752,7 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
   };
   if (!window_ok) return gather();
   if (sub == kTableWindow || !pick) return window();
-  pick->hysteresis = 0.08;  // (autopick.hpp: the two table kernels are close behind hsvfilter, far apart from HBM)
+  pick->hysteresis = 0.05;  // (autopick.hpp: the two table kernels are close behind hsvfilter, far apart from HBM)
   pick->smooth = true;
   return auto_launch(ctx, *pick, geo.n_vec, gather, []() { return (int)MI355_OK; }, window);
 }
