@@ -244,6 +244,9 @@ int mi355_group_submit_chain(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uin
   PixFmt fmt;
   if (!ctx || !d_src || !d_dst || !settings || width <= 0 || height <= 0 || !pixfmt_of(format, &fmt) || (size_t)stride < (size_t)width * fmt.pixel_stride)
     return fail(g, MI355_ERR_INVALID_ARG, "group: bad frame");
+  // the chain exists for the one format both elements accept (hsvfilter/imp.rs:252-266, colorlut/imp.rs:125-137): refused here,
+  // not as a failed launch of a whole batch later
+  if (format != MI355_FMT_RGBA) return fail(g, MI355_ERR_INVALID_ARG, "group: hsvfilter ! colorlut takes RGBA frames only");
   if (ctx->device != g->device) return fail(g, MI355_ERR_INVALID_ARG, "group: context of another device");
   if (!ctx->lut.loaded) return fail(g, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }

@@ -225,7 +225,8 @@ int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *co
  * its context's own path, in order. Results are those of mi355_hsvfilter_frames_device + mi355_colorlut_frames_device on that
  * frame, bit for bit. No reference counterpart (the reference has no device to batch for).
  *   create : max_batch 0 = default (8 frames per launch), at most 16.
- *   submit_chain : hsvfilter in place on the packed frame at d_src (stride bytes per row), then colorlut from it into d_dst,
+ *   submit_chain : hsvfilter in place on the packed RGBA frame at d_src (stride bytes per row; MI355_FMT_RGBA, the one format both
+ *           elements accept - anything else is MI355_ERR_INVALID_ARG), then colorlut from it into d_dst,
  *           for stream `ctx` (its LUT, loaded with mi355_colorlut_load; the frame starts after what ctx's HIP stream held at
  *           this call). Never blocks; launches only when max_batch frames are pending. One frame per stream and launch:
  *           frames of one stream run in submission order. *ticket identifies the frame.

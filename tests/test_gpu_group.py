@@ -72,8 +72,8 @@ def test_round_of_streams_equals_the_two_calls_per_stream(oracle, synth, mi355li
 
 
 def test_mixed_streams_stay_exact_and_in_order(oracle, synth, mi355lib):
-    """Streams that do not agree: two sizes, two hsv settings, two LUTs, a BGRx stream and a padded-rows stream (neither is the
-    batched kernels' business), and one stream that submits three dependent frames in a row (frame k+1 reads what frame k
+    """Streams that do not agree: two sizes, two hsv settings, two LUTs, a padded-rows stream (not the batched kernels'
+    business), a BGRx frame (refused at submit: the chain exists for RGBA), and one stream that submits three dependent frames in a row (frame k+1 reads what frame k
     wrote: order within a stream). Every result is the oracle's."""
     import mi355fx
     texts = [synth.cube_text_3d(33), synth.cube_text_3d(33), synth.cube_text_3d(17, amp=0.08), synth.cube_text_3d(33), synth.cube_text_3d(33), synth.cube_text_3d(33)]
@@ -102,6 +102,8 @@ def test_mixed_streams_stay_exact_and_in_order(oracle, synth, mi355lib):
         pad[:, :640 * 4] = synth.smooth_frame(640, 360, seed=7).reshape(360, 640 * 4)
         job(4, pad.reshape(-1).copy(), 640, 360, 640 * 4 + 64, "RGBA", st_a)                                 # padded rows: context's own path
         job(5, synth.smooth_frame(1920, 1080, seed=8).reshape(-1), 1920, 1080, 1920 * 4, "RGBA", st_a)
+        with pytest.raises(mi355fx.Mi355Error):   # not queued, nobody else's batch fails for it
+            g.submit_chain(ctxs[5], jobs[-1][1], jobs[-1][2], 1920, 1080, 1920 * 4, "BGRx", st_a)
         # a stream whose frames depend on each other: dst of frame k is src of frame k + 1
         c = ctxs[5]
         f0 = synth.smooth_frame(1280, 720, seed=9).reshape(-1)
