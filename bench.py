@@ -810,6 +810,20 @@ def main():
                 streams_leg["group"] = {"frames": g_frames, "batched_launch_pairs": g_pairs, "frames_through_own_context": g_single,
                                         "frames_per_launch_pair": g_frames / max(g_pairs, 1)}
                 group.close()
+                # ... and as the FUSED pair (mi355_group_submit_fused: one launch per batch through the composed table, sources
+                # left untouched - what the shim's hsvfilter -> colorlut hand-over submits): 8 B/pixel for the chain
+                group_f = mi355fx.Group(local_rank)
+
+                class GroupRoundFused:
+                    def issue(self, src_ptrs, dst_ptrs):
+                        group_f.submit_round(sctx, src_ptrs, dst_ptrs, W, H, W * 4, "RGBA", settings, fused=True)
+
+                leg_f = measure(args.content, n_s, 24, False, streams=sctx, native_round=GroupRoundFused())
+                group_f.wait_all()
+                f_frames, f_launches, f_single = group_f.stats()
+                streams_leg["fused"] = {"frames_per_s": leg_f["frames"] / leg_f["dt"], "launches": "one per batch of up to 8 streams' frames (mi355_group_submit_fused)",
+                                        "frames": f_frames, "batched_launches": f_launches, "frames_through_own_context": f_single}
+                group_f.close()
             for c in sctx:
                 c.close()
 

@@ -1910,6 +1910,16 @@ int colorlut_multi_table(mi355_ctx *ctx, const uint32_t **table_out) {
   return MI355_OK;
 }
 
+// the composed hsvfilter -> colorlut table of these settings (built, or found in the registry, if the context does not hold it)
+int colorlut_multi_fused_table(mi355_ctx *ctx, const mi355_hsv_settings *hs, const uint32_t **table_out) {
+  LutDevice &L = ctx->lut;
+  if (!L.loaded) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "No LUT configured");
+  if (!hs) return set_error(ctx, MI355_ERR_INVALID_ARG, "null settings");
+  int rc = table_ensure(ctx, 1, 1, hs);
+  if (rc) return rc;
+  *table_out = L.d_table[1];
+  return MI355_OK;
+}
 int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
                           int height) {
   if (n_frames < 1 || n_frames > kMultiFrames || width % 4 != 0 || width < 128 || height <= 0) return MI355_ERR_UNSUPPORTED;

@@ -39,6 +39,7 @@ struct Desc {
   mi355_hsv_settings hs;
   const uint32_t *table;  // the context's memoised colorlut table (nullptr: not batchable)
   bool batchable;
+  bool fused;             // one launch through the composed hsv+lut table, source left untouched (mi355_group_submit_fused)
   uint64_t ticket;
   hipEvent_t ready;       // recorded on ctx->stream at submit
 };
@@ -82,7 +83,7 @@ int fail(mi355_group *g, int status, const std::string &msg) {
 }
 
 bool same_class(const Desc &a, const Desc &b) {
-  return a.batchable && b.batchable && a.width == b.width && a.height == b.height && a.stride == b.stride && a.format == b.format && a.table == b.table &&
+  return a.batchable && b.batchable && a.fused == b.fused && a.width == b.width && a.height == b.height && a.stride == b.stride && a.format == b.format && a.table == b.table &&
          std::memcmp(&a.hs, &b.hs, sizeof(a.hs)) == 0 && a.ctx->force_generic == b.ctx->force_generic;
 }
 
@@ -117,7 +118,8 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
         dsts[i] = take[i].dst;
         if (take[i].ready && hipStreamWaitEvent(g->stream, take[i].ready, 0) != hipSuccess) rc = MI355_ERR_HIP;
       }
-      if (!rc) rc = launch_hsvfilter_multi(first.ctx, g->stream, srcs, (int)take.size(), first.width, first.height, fmt, first.hs);
+      // (fused: `table` is the composed hsvfilter -> colorlut table of these settings: the gather IS the chain, one launch)
+      if (!rc && !first.fused) rc = launch_hsvfilter_multi(first.ctx, g->stream, srcs, (int)take.size(), first.width, first.height, fmt, first.hs);
       if (!rc) rc = launch_colorlut_multi(first.ctx, g->stream, first.table, srcs, dsts, (int)take.size(), first.width, first.height);
       if (!rc && hipEventRecord(done, g->stream) != hipSuccess) rc = MI355_ERR_HIP;
       g->n_batched_launch_pairs++;
@@ -127,8 +129,9 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
       const Desc &d = take[0];
       const size_t pitch = (size_t)d.stride * (size_t)d.height;
       if (!g->batches.empty() && hipStreamWaitEvent(d.ctx->stream, g->batches.back().done, 0) != hipSuccess) rc = MI355_ERR_HIP;
-      if (!rc) rc = launch_hsvfilter(d.ctx, d.src, 1, pitch, d.width, d.height, d.stride, fmt, d.hs);
-      if (!rc) rc = launch_colorlut(d.ctx, d.src, pitch, d.stride, d.dst, pitch, d.stride, 1, d.width, d.height, d.format);
+      if (!rc && d.fused) rc = launch_hsv_colorlut(d.ctx, d.src, pitch, d.stride, d.dst, pitch, d.stride, 1, d.width, d.height, d.hs);
+      if (!rc && !d.fused) rc = launch_hsvfilter(d.ctx, d.src, 1, pitch, d.width, d.height, d.stride, fmt, d.hs);
+      if (!rc && !d.fused) rc = launch_colorlut(d.ctx, d.src, pitch, d.stride, d.dst, pitch, d.stride, 1, d.width, d.height, d.format);
       if (!rc && hipEventRecord(done, d.ctx->stream) != hipSuccess) rc = MI355_ERR_HIP;
       if (!rc && hipStreamWaitEvent(g->stream, done, 0) != hipSuccess) rc = MI355_ERR_HIP;
       if (rc && rc != MI355_ERR_HIP) g->last_error = d.ctx->last_error;
@@ -237,8 +240,8 @@ void mi355_group_destroy(mi355_group *g) {
 
 const char *mi355_group_last_error(mi355_group *g) { return g ? g->last_error.c_str() : "null group"; }
 
-int mi355_group_submit_chain(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height, int stride, int format,
-                             const mi355_hsv_settings *settings, uint64_t *ticket) {
+static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height, int stride, int format,
+                        const mi355_hsv_settings *settings, uint64_t *ticket, bool fused) {
   if (!g) return MI355_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(g->mu);
   PixFmt fmt;
@@ -252,10 +255,12 @@ int mi355_group_submit_chain(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uin
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
   Desc d{};
   d.ctx = ctx; d.src = d_src; d.dst = d_dst; d.width = width; d.height = height; d.stride = stride; d.format = format; d.hs = *settings;
+  d.fused = fused;
   const uint8_t *one[1] = {d_src};
-  d.batchable = format == MI355_FMT_RGBA && d_src != d_dst && hsvfilter_multi_applicable(one, 1, width, height, stride, fmt) && width % 4 == 0 && width >= 128 &&
-                (uintptr_t)d_dst % 16 == 0 && ctx->lut_variant == 0 && ctx->hsv_table_mode != 2;
-  if (d.batchable && colorlut_multi_table(ctx, &d.table) != MI355_OK) {  // (the build, if any, is on ctx->stream: before `ready`)
+  // (the two-launch form filters d_src in place and then reads it: not onto itself; the fused form reads a tile and writes the same tile)
+  d.batchable = format == MI355_FMT_RGBA && (fused || d_src != d_dst) && hsvfilter_multi_applicable(one, 1, width, height, stride, fmt) && width % 4 == 0 &&
+                width >= 128 && (uintptr_t)d_dst % 16 == 0 && ctx->lut_variant == 0 && ctx->hsv_table_mode != 2 && (!fused || ctx->lut.is3d);
+  if (d.batchable && (fused ? colorlut_multi_fused_table(ctx, settings, &d.table) : colorlut_multi_table(ctx, &d.table)) != MI355_OK) {  // (the build, if any, is on ctx->stream: before `ready`)
     (void)hipGetLastError();
     d.batchable = false;
     d.table = nullptr;
@@ -279,6 +284,16 @@ int mi355_group_submit_chain(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uin
   // enough for a full launch: the batch of the oldest pending frame goes now (the rest keeps collecting)
   if ((int)g->pending.size() >= g->max_batch) return flush_locked(g, g->pending.front().ticket);
   return MI355_OK;
+}
+
+int mi355_group_submit_chain(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height, int stride, int format,
+                             const mi355_hsv_settings *settings, uint64_t *ticket) {
+  return submit_frame(g, ctx, d_src, d_dst, width, height, stride, format, settings, ticket, false);
+}
+
+int mi355_group_submit_fused(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height, int stride, int format,
+                             const mi355_hsv_settings *settings, uint64_t *ticket) {
+  return submit_frame(g, ctx, d_src, d_dst, width, height, stride, format, settings, ticket, true);
 }
 
 int mi355_group_flush(mi355_group *g) {
@@ -339,6 +354,16 @@ int mi355_group_submit_round(mi355_group *g, mi355_ctx *const *ctxs, int n_strea
   if (!g || !ctxs || !d_src || !d_dst || n_streams < 0) return MI355_ERR_INVALID_ARG;
   for (int i = 0; i < n_streams; i++) {
     int rc = mi355_group_submit_chain(g, ctxs[i], d_src[i], d_dst[i], width, height, stride, format, settings, nullptr);
+    if (rc) return rc;
+  }
+  return mi355_group_flush(g);
+}
+
+int mi355_group_submit_round_fused(mi355_group *g, mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src, uint8_t *const *d_dst, int width,
+                                   int height, int stride, int format, const mi355_hsv_settings *settings) {
+  if (!g || !ctxs || !d_src || !d_dst || n_streams < 0) return MI355_ERR_INVALID_ARG;
+  for (int i = 0; i < n_streams; i++) {
+    int rc = mi355_group_submit_fused(g, ctxs[i], d_src[i], d_dst[i], width, height, stride, format, settings, nullptr);
     if (rc) return rc;
   }
   return mi355_group_flush(g);

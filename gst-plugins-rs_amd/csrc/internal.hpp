@@ -148,6 +148,7 @@ int launch_hsvfilter_multi(mi355_ctx *ctx, hipStream_t stream, uint8_t *const *f
 // colorlut of n separate packed RGBA frames of one size through ctx's memoised (Morton) table, ONE launch on `stream`; the table
 // is built on ctx->stream first if need be (*table_out = what the launch reads). MI355_ERR_UNSUPPORTED: not this path's geometry.
 int colorlut_multi_table(mi355_ctx *ctx, const uint32_t **table_out);
+int colorlut_multi_fused_table(mi355_ctx *ctx, const mi355_hsv_settings *hs, const uint32_t **table_out);
 int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
                           int height);
 int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,

@@ -155,6 +155,7 @@ def load_library():
         "mi355_group_destroy": (None, [vp]),
         "mi355_group_last_error": (C.c_char_p, [vp]),
         "mi355_group_submit_chain": (i, [vp, vp, u8p, u8p, i, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
+        "mi355_group_submit_fused": (i, [vp, vp, u8p, u8p, i, i, i, i, C.POINTER(HsvSettings), C.POINTER(C.c_uint64)]),
         "mi355_group_flush": (i, [vp]),
         "mi355_pipe_set_group": (i, [vp, vp]),
         "mi355_group_wait": (i, [vp, C.c_uint64]),
@@ -162,6 +163,7 @@ def load_library():
         "mi355_group_wait_all": (i, [vp]),
         "mi355_group_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "mi355_group_submit_round": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
+        "mi355_group_submit_round_fused": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
         "mi355_dssim_image_plane": (i, [vp, vp, i, i, i, f32p, C.POINTER(i), C.POINTER(i)]),
         "mi355_sofa_setup": (i, [vp, i, i, i, i]),
@@ -245,7 +247,14 @@ class Group:
         self._ck(self.L.mi355_group_submit_chain(self.h, ctx.h, d_src, d_dst, width, height, stride, FMT[fmt], C.byref(s), C.byref(t)))
         return t.value
 
-    def submit_round(self, contexts, src_ptrs, dst_ptrs, width, height, stride, fmt, settings):
+    def submit_fused(self, ctx, d_src, d_dst, width, height, stride, fmt, settings):
+        """The fused pair (source untouched) for one frame of one stream: ONE launch per batch through the composed table."""
+        s = HsvSettings(*[float(v) for v in settings])
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_group_submit_fused(self.h, ctx.h, d_src, d_dst, width, height, stride, FMT[fmt], C.byref(s), C.byref(t)))
+        return t.value
+
+    def submit_round(self, contexts, src_ptrs, dst_ptrs, width, height, stride, fmt, settings, fused=False):
         """One frame of every stream from one native loop, then a flush (measurement plumbing)."""
         key = (tuple(c.h for c in contexts), tuple(src_ptrs), tuple(dst_ptrs))
         arr = self._rounds.get(key)
@@ -253,7 +262,8 @@ class Group:
             n = len(contexts)
             arr = self._rounds[key] = ((C.c_void_p * n)(*[c.h for c in contexts]), (C.c_void_p * n)(*src_ptrs), (C.c_void_p * n)(*dst_ptrs),
                                        HsvSettings(*[float(v) for v in settings]))
-        self._ck(self.L.mi355_group_submit_round(self.h, arr[0], len(contexts), arr[1], arr[2], width, height, stride, FMT[fmt], C.byref(arr[3])))
+        fn = self.L.mi355_group_submit_round_fused if fused else self.L.mi355_group_submit_round
+        self._ck(fn(self.h, arr[0], len(contexts), arr[1], arr[2], width, height, stride, FMT[fmt], C.byref(arr[3])))
 
     def flush(self):
         self._ck(self.L.mi355_group_flush(self.h))

@@ -248,6 +248,13 @@ void mi355_group_destroy(mi355_group *group);
 const char *mi355_group_last_error(mi355_group *group);
 int mi355_group_submit_chain(mi355_group *group, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height,
                              int stride, int format, const mi355_hsv_settings *settings, uint64_t *ticket);
+/* The same for the FUSED pair (mi355_hsv_colorlut_frames_device's semantics: d_src is read and left untouched, d_src == d_dst
+ * allowed): frames that agree in size, hsv settings and LUT share ONE launch through the composed table of those settings
+ * (built - or found with another stream of the process - when a stream first submits with them; a stream that changes its
+ * settings every frame rebuilds 64 MiB every frame: use submit_chain there). 3D LUTs; everything else goes through its
+ * context's own fused path. Bit-identical to mi355_hsv_colorlut_frames_device on that frame. */
+int mi355_group_submit_fused(mi355_group *group, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height,
+                             int stride, int format, const mi355_hsv_settings *settings, uint64_t *ticket);
 int mi355_group_flush(mi355_group *group);
 int mi355_group_order_after(mi355_group *group, mi355_ctx *ctx, uint64_t ticket);
 int mi355_group_wait(mi355_group *group, uint64_t ticket);
@@ -258,6 +265,9 @@ int mi355_group_stats(mi355_group *group, uint64_t stats[3]);
 int mi355_group_submit_round(mi355_group *group, mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src,
                              uint8_t *const *d_dst, int width, int height, int stride, int format,
                              const mi355_hsv_settings *settings);
+int mi355_group_submit_round_fused(mi355_group *group, mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src,
+                                   uint8_t *const *d_dst, int width, int height, int stride, int format,
+                                   const mi355_hsv_settings *settings);
 
 /* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
  * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and

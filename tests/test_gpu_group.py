@@ -228,3 +228,70 @@ def test_host_buffer_pipelines_share_launches_through_a_group(oracle, synth, mi3
         g.close()
         for c in ctxs:
             c.close()
+
+
+def test_fused_frames_share_one_launch_and_leave_their_sources_alone(oracle, synth, mi355lib):
+    """mi355_group_submit_fused: frames of streams that agree in size, LUT and hsv settings go through ONE launch (the composed
+    table of those settings); a stream with other settings, one with another LUT, one in place, one with padded rows (its
+    context's own fused path) and a second frame of a stream all get the oracle chain's bytes, and no source is modified."""
+    import mi355fx
+    texts = [synth.cube_text_3d(33)] * 5 + [synth.cube_text_3d(17, amp=0.08)] + [synth.cube_text_3d(33)] * 2
+    pairs = _ctxs(mi355fx, oracle, synth, 8, texts)
+    ctxs = [p[0] for p in pairs]
+    g = mi355fx.Group(0)
+    st_a, st_b = synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"]
+    w, h = 1920, 1080
+    bufs, jobs = [], []
+    try:
+        def job(i, frame, w_, h_, stride, st, in_place=False):
+            c = ctxs[i]
+            ds = c.alloc(frame.nbytes)
+            dd = ds if in_place else c.alloc(frame.nbytes)
+            bufs.append((c, ds))
+            if not in_place:
+                bufs.append((c, dd))
+                c.h2d(dd, np.full(frame.nbytes, 0xEE, np.uint8))
+            c.h2d(ds, frame)
+            t = g.submit_fused(c, ds, dd, w_, h_, stride, "RGBA", st)
+            jobs.append((i, ds, dd, frame, w_, h_, stride, st, t, in_place))
+        for i in range(4):                                                                         # four streams: one launch
+            job(i, synth.smooth_frame(w, h, seed=20 + i).reshape(-1), w, h, w * 4, st_a)
+        job(4, synth.smooth_frame(w, h, seed=30).reshape(-1), w, h, w * 4, st_b)                  # other settings: another table
+        job(5, synth.smooth_frame(w, h, seed=31).reshape(-1), w, h, w * 4, st_a)                  # another LUT
+        job(6, synth.noise_frame(w, h, seed=32).reshape(-1), w, h, w * 4, st_a, in_place=True)    # in place: allowed for the fused form
+        rng = np.random.default_rng(3)
+        pad = rng.integers(0, 256, size=(360, 640 * 4 + 64), dtype=np.uint8)
+        pad[:, :640 * 4] = synth.smooth_frame(640, 360, seed=33).reshape(360, 640 * 4)
+        job(7, pad.reshape(-1).copy(), 640, 360, 640 * 4 + 64, st_a)                              # padded rows: own path
+        job(0, synth.noise_frame(w, h, seed=34).reshape(-1), w, h, w * 4, st_a)                   # second frame of stream 0: next batch
+        g.wait_all()
+        for i, ds, dd, frame, w_, h_, stride, st, t, in_place in jobs:
+            g.wait(t)
+            got = np.zeros(frame.nbytes, np.uint8)
+            ctxs[i].d2h(got, dd)
+            _, exp = _expect(oracle, pairs[i][1], frame, w_, h_, st, stride=stride)
+            rows = lambda a: a.reshape(h_, stride)[:, :w_ * 4]
+            assert (rows(got) == rows(exp)).all(), (i, w_, h_, stride)
+            if not in_place:
+                src_after = np.zeros(frame.nbytes, np.uint8)
+                ctxs[i].d2h(src_after, ds)
+                assert (src_after == frame).all(), (i, "the fused form leaves its source alone")
+                if stride != w_ * 4:
+                    assert (got.reshape(h_, stride)[:, w_ * 4:] == 0xEE).all()
+        frames_n, batched, single = g.stats()
+        assert frames_n == len(jobs) and single == 1 and batched <= 6, (frames_n, batched, single)
+        # the same frames through mi355_hsv_colorlut_frames_device on the streams' own contexts: identical bytes
+        for i, ds, dd, frame, w_, h_, stride, st, t, in_place in jobs[:5]:
+            c = ctxs[i]
+            d2 = c.alloc(frame.nbytes); bufs.append((c, d2))
+            c.hsv_colorlut_frames_device(ds, frame.nbytes, stride, d2, frame.nbytes, stride, 1, w_, h_, st)
+            c.synchronize()
+            a, b = np.zeros(frame.nbytes, np.uint8), np.zeros(frame.nbytes, np.uint8)
+            c.d2h(a, dd); c.d2h(b, d2)
+            assert (a == b).all(), i
+    finally:
+        g.close()
+        for c, b in bufs:
+            c.free(b)
+        for c in ctxs:
+            c.close()

@@ -11,6 +11,10 @@ for name in ("interpolating_kernel_only", "fused_chain", "hsvfilter_nontemporal_
     v = d.get(name)
     if v:
         print("%s: %.0f fps %s" % (name, v["frames_per_s"], {kk: v[kk] for kk in ("ms_per_launch", "colorlut_ms_per_launch", "kernel", "kernels_served", "colorlut_kernel", "colorlut_kernels_served") if kk in v}))
+cs = d.get("concurrent_streams") or {}
+if cs.get("fused"):
+    print("concurrent_streams fused through the group: %.0f fps (%s launches for %s frames); separate launches: %s" %
+          (cs["fused"]["frames_per_s"], cs["fused"].get("batched_launches"), cs["fused"].get("frames"), cs.get("frames_per_s_separate_launches")))
 for kk, v in (d.get("content_sweep") or {}).items():
     a, i = v.get("auto"), v.get("interpolating")
     print("sweep %s: auto %.0f fps lut %.4f %s | interpolating %s" % (kk, a["frames_per_s"], a["colorlut_ms_per_launch"], a["colorlut_kernels_served"], ("%.0f fps lut %.4f" % (i["frames_per_s"], i["colorlut_ms_per_launch"])) if i else None))
