@@ -256,9 +256,17 @@ static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t 
   Desc d{};
   d.ctx = ctx; d.src = d_src; d.dst = d_dst; d.width = width; d.height = height; d.stride = stride; d.format = format; d.hs = *settings;
   d.fused = fused;
+  // a composed table is 64 MiB built by two launches over 2^24 colours: worth it for settings that stay (the fused entry point
+  // has the same rule: eight calls), not for a hue shift animated frame by frame - those frames take their context's own path
+  bool settled = true;
+  if (fused) {
+    if (std::memcmp(&ctx->group_fused_hs, settings, sizeof(*settings)) == 0) { if (ctx->group_fused_stable < 1000000u) ctx->group_fused_stable++; }
+    else { ctx->group_fused_hs = *settings; ctx->group_fused_stable = 1; }
+    settled = ctx->group_fused_stable >= 8u;
+  }
   const uint8_t *one[1] = {d_src};
   // (the two-launch form filters d_src in place and then reads it: not onto itself; the fused form reads a tile and writes the same tile)
-  d.batchable = format == MI355_FMT_RGBA && (fused || d_src != d_dst) && hsvfilter_multi_applicable(one, 1, width, height, stride, fmt) && width % 4 == 0 &&
+  d.batchable = settled && format == MI355_FMT_RGBA && (fused || d_src != d_dst) && hsvfilter_multi_applicable(one, 1, width, height, stride, fmt) && width % 4 == 0 &&
                 width >= 128 && (uintptr_t)d_dst % 16 == 0 && ctx->lut_variant == 0 && ctx->hsv_table_mode != 2 && (!fused || ctx->lut.is3d);
   if (d.batchable && (fused ? colorlut_multi_fused_table(ctx, settings, &d.table) : colorlut_multi_table(ctx, &d.table)) != MI355_OK) {  // (the build, if any, is on ctx->stream: before `ready`)
     (void)hipGetLastError();

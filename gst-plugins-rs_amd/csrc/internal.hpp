@@ -114,6 +114,8 @@ struct mi355_ctx {
   unsigned long long *d_window_counters = nullptr;  // colorlut_window.hip: {pixels, pixels past the LDS cache, bricks installed} x 1024 slots
   int blockhash_any_size = 0;  // MI355_FLAG_BLOCKHASH_ANY_SIZE
   int hsv_nt = 0;              // MI355_FLAG_HSV_NT: 1 = the flat hsvfilter kernel loads and stores with the non-temporal hint (measurement A/B)
+  mi355_hsv_settings group_fused_hs{};  // mi355_group_submit_fused: the settings of this stream's last fused submit ...
+  unsigned group_fused_stable = 0;      // ... and how many submits in a row have carried them (a composed table is built for settings that stay)
   int hsv_blocks_per_cu = 64;  // grid cap of the flat hsvfilter kernel (tunable: MI355_FLAG_HSV_BLOCKS_PER_CU)
   std::string last_error;
 };

@@ -245,10 +245,11 @@ int mi355_pipe_submit_hsv_colorlut(mi355_pipe *p, const uint8_t *src, int src_st
   if ((rc = pipe_upload(p, s, src, (size_t)src_stride, row_bytes, (size_t)height))) return rc;
   const size_t packed = row_bytes * (size_t)height;
   if (p->group) {
-    // the frame joins the other streams' frames in the group's next launch pair (hsvfilter in place on the slot's input, then
-    // colorlut: the two element launches, bit-identical to the fused one); the download follows when the frame is asked for
+    // the frame joins the other streams' frames in the group's next launch (the fused pair: one launch per batch through the
+    // composed table once the settings have stayed for eight frames, the context's own fused path until then); the download
+    // follows when the frame is asked for
     uint64_t gt = 0;
-    if ((rc = mi355_group_submit_chain(p->group, ctx, s->d_in, s->d_out, width, height, (int)row_bytes, MI355_FMT_RGBA, settings, &gt)))
+    if ((rc = mi355_group_submit_fused(p->group, ctx, s->d_in, s->d_out, width, height, (int)row_bytes, MI355_FMT_RGBA, settings, &gt)))
       return set_error(ctx, rc, std::string("pipeline: ") + mi355_group_last_error(p->group));
     s->deferred = true; s->group_ticket = gt; s->host_dst = dst; s->host_stride = (size_t)dst_stride; s->row_bytes = row_bytes; s->rows = (size_t)height;
     s->busy = true;

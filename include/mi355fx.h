@@ -250,9 +250,8 @@ int mi355_group_submit_chain(mi355_group *group, mi355_ctx *ctx, uint8_t *d_src,
                              int stride, int format, const mi355_hsv_settings *settings, uint64_t *ticket);
 /* The same for the FUSED pair (mi355_hsv_colorlut_frames_device's semantics: d_src is read and left untouched, d_src == d_dst
  * allowed): frames that agree in size, hsv settings and LUT share ONE launch through the composed table of those settings
- * (built - or found with another stream of the process - when a stream first submits with them; a stream that changes its
- * settings every frame rebuilds 64 MiB every frame: use submit_chain there). 3D LUTs; everything else goes through its
- * context's own fused path. Bit-identical to mi355_hsv_colorlut_frames_device on that frame. */
+ * (built - or found with another stream of the process - once a stream has submitted with them eight times in a row: a hue
+ * shift animated frame by frame never builds one). 3D LUTs; everything else goes through its context's own fused path. Bit-identical to mi355_hsv_colorlut_frames_device on that frame. */
 int mi355_group_submit_fused(mi355_group *group, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height,
                              int stride, int format, const mi355_hsv_settings *settings, uint64_t *ticket);
 int mi355_group_flush(mi355_group *group);
