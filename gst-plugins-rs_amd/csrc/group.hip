@@ -38,6 +38,10 @@ struct Desc {
   int width, height, stride, format;
   mi355_hsv_settings hs;
   const uint32_t *table;  // the context's memoised colorlut table (nullptr: not batchable)
+  // ... and a reference to it, held until the frame's batch has retired: the context may move on to other settings (or another
+  // LUT) before this frame has been launched or has finished, and a table somebody else still refers to is never rebuilt in place
+  // (colorlut_kernels.hip: shared_table_acquire takes that branch only for use_count() == 1) nor freed
+  std::shared_ptr<void> table_ref;
   bool batchable;
   bool fused;             // one launch through the composed hsv+lut table, source left untouched (mi355_group_submit_fused)
   uint64_t ticket;
@@ -49,6 +53,7 @@ struct Batch {
   std::vector<uint64_t> tickets;  // the frames it carries (not a contiguous range: an incompatible frame waits for the next batch)
   hipEvent_t done;
   int waiters;  // threads inside hipEventSynchronize(done) right now: the event is not recycled under them
+  std::shared_ptr<void> table_ref;  // the table its launches read (see Desc)
 };
 
 }  // namespace
@@ -66,9 +71,42 @@ struct mi355_group {
   uint64_t next_ticket = 1, next_seq = 1;
   uint64_t n_frames = 0, n_batched_launch_pairs = 0, n_single = 0;
   std::string last_error;
+  // table references of retired batches: dropping the last reference to a table frees 64 MiB behind a device-wide wait, which
+  // does not belong under `mu` - the entry points empty this list into a local one that dies after they have unlocked (Locked)
+  std::vector<std::shared_ptr<void>> dead_refs;
 };
 
 namespace {
+
+// g->mu for the scope, and behind it the table references the scope retired (destroyed last, i.e. outside the lock)
+struct Locked {
+  std::vector<std::shared_ptr<void>> reap;
+  mi355_group *g;
+  std::unique_lock<std::mutex> lk;
+  explicit Locked(mi355_group *g_) : g(g_), lk(g_->mu) {}
+  ~Locked() {
+    if (!lk.owns_lock()) lk.lock();
+    reap.swap(g->dead_refs);
+    lk.unlock();
+  }
+};
+
+void retire_front(mi355_group *g) {
+  Batch &b = g->batches.front();
+  for (uint64_t t : b.tickets) g->where.erase(t);
+  g->events.push_back(b.done);
+  if (b.table_ref) g->dead_refs.push_back(std::move(b.table_ref));
+  g->batches.pop_front();
+}
+
+// batches that have finished leave without anybody waiting for them (a stream that only ever orders its own stream behind its
+// frames never waits here; its batches, and the table references they hold, must not pile up)
+void retire_done(mi355_group *g) {
+  while (!g->batches.empty() && g->batches.front().waiters == 0) {
+    if (hipEventQuery(g->batches.front().done) != hipSuccess) { (void)hipGetLastError(); break; }
+    retire_front(g);
+  }
+}
 
 hipEvent_t take_event(mi355_group *g) {
   if (!g->events.empty()) { hipEvent_t e = g->events.back(); g->events.pop_back(); return e; }
@@ -148,7 +186,7 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
       if (g->last_error.empty()) g->last_error = "group launch failed";
       return rc;
     }
-    Batch b{g->next_seq++, {}, done, 0};
+    Batch b{g->next_seq++, {}, done, 0, first.batchable ? first.table_ref : std::shared_ptr<void>()};
     for (const Desc &d : take) { b.tickets.push_back(d.ticket); g->where[d.ticket] = b.seq; reached |= until != 0 && d.ticket == until; }
     g->batches.push_back(std::move(b));
     g->n_frames += take.size();
@@ -181,11 +219,7 @@ int wait_unlocking(mi355_group *g, std::unique_lock<std::mutex> &lk, uint64_t ti
     if (b.seq == seq) { b.waiters--; break; }
   if (e != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipEventSynchronize(group batch)"); }
   // everything up to that batch is done: retire from the front (batches somebody still waits in stay until they leave)
-  while (!g->batches.empty() && g->batches.front().seq <= seq && g->batches.front().waiters == 0) {
-    for (uint64_t t : g->batches.front().tickets) g->where.erase(t);
-    g->events.push_back(g->batches.front().done);
-    g->batches.pop_front();
-  }
+  while (!g->batches.empty() && g->batches.front().seq <= seq && g->batches.front().waiters == 0) retire_front(g);
   return MI355_OK;
 }
 
@@ -225,15 +259,15 @@ void mi355_group_destroy(mi355_group *g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   {
-    std::unique_lock<std::mutex> lk(g->mu);
+    Locked L(g);
     (void)flush_locked(g);
-    (void)wait_all_unlocking(g, lk);
+    (void)wait_all_unlocking(g, L.lk);
   }
   (void)hipStreamSynchronize(g->stream);
+  g->pending.clear();
+  g->batches.clear();  // (their events are destroyed below; their table references go here, after the stream has drained)
+  g->dead_refs.clear();
   for (hipEvent_t e : g->events) (void)hipEventDestroy(e);
-  for (Batch &b : g->batches) (void)hipEventDestroy(b.done);
-  for (Desc &d : g->pending)
-    if (d.ready) (void)hipEventDestroy(d.ready);
   (void)hipStreamDestroy(g->stream);
   delete g;
 }
@@ -243,7 +277,7 @@ const char *mi355_group_last_error(mi355_group *g) { return g ? g->last_error.c_
 static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t *d_dst, int width, int height, int stride, int format,
                         const mi355_hsv_settings *settings, uint64_t *ticket, bool fused) {
   if (!g) return MI355_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(g->mu);
+  Locked L(g);
   PixFmt fmt;
   if (!ctx || !d_src || !d_dst || !settings || width <= 0 || height <= 0 || !pixfmt_of(format, &fmt) || (size_t)stride < (size_t)width * fmt.pixel_stride)
     return fail(g, MI355_ERR_INVALID_ARG, "group: bad frame");
@@ -256,6 +290,7 @@ static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t 
   Desc d{};
   d.ctx = ctx; d.src = d_src; d.dst = d_dst; d.width = width; d.height = height; d.stride = stride; d.format = format; d.hs = *settings;
   d.fused = fused;
+  retire_done(g);
   // a composed table is 64 MiB built by two launches over 2^24 colours: worth it for settings that stay (the fused entry point
   // has the same rule: eight calls), not for a hue shift animated frame by frame - those frames take their context's own path
   bool settled = true;
@@ -273,6 +308,9 @@ static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t 
     d.batchable = false;
     d.table = nullptr;
   }
+  // (this thread is the one that drives ctx, and the reference is copied from ctx's own: the registry's "sole user" test cannot
+  // run concurrently with this copy)
+  if (d.batchable) d.table_ref = ctx->lut.table_ref[fused ? 1 : 0];
   // The frame starts after what ctx's stream holds now (an upload, the table build). A stream that holds nothing - the common
   // case for a stream that only ever submits here - needs no event: every cross-stream wait is a barrier packet the command
   // processor resolves in microseconds, eight of them in front of a 90 us launch are a bubble.
@@ -289,8 +327,11 @@ static int submit_frame(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uint8_t 
   d.ticket = g->next_ticket++;
   if (ticket) *ticket = d.ticket;
   g->pending.push_back(d);
-  // enough for a full launch: the batch of the oldest pending frame goes now (the rest keeps collecting)
-  if ((int)g->pending.size() >= g->max_batch) return flush_locked(g, g->pending.front().ticket);
+  // enough for a full launch: the batch of the oldest pending frame goes now (the rest keeps collecting). This frame has been
+  // accepted whatever that launch does: a failed batch is reported to the frames it carried (g->failed: their wait / order_after),
+  // which may or may not include this one - never as a refusal of this submit, whose caller would then reuse buffers the group
+  // still refers to.
+  if ((int)g->pending.size() >= g->max_batch) (void)flush_locked(g, g->pending.front().ticket);
   return MI355_OK;
 }
 
@@ -306,14 +347,15 @@ int mi355_group_submit_fused(mi355_group *g, mi355_ctx *ctx, uint8_t *d_src, uin
 
 int mi355_group_flush(mi355_group *g) {
   if (!g) return MI355_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(g->mu);
+  Locked L(g);
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
   return flush_locked(g);
 }
 
 int mi355_group_wait(mi355_group *g, uint64_t ticket) {
   if (!g) return MI355_ERR_INVALID_ARG;
-  std::unique_lock<std::mutex> lk(g->mu);
+  Locked L(g);
+  std::unique_lock<std::mutex> &lk = L.lk;
   if (ticket == 0 || ticket >= g->next_ticket) return fail(g, MI355_ERR_INVALID_ARG, "group: unknown ticket");
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
   bool is_pending = false;
@@ -327,7 +369,7 @@ int mi355_group_wait(mi355_group *g, uint64_t ticket) {
 
 int mi355_group_order_after(mi355_group *g, mi355_ctx *ctx, uint64_t ticket) {
   if (!g || !ctx) return MI355_ERR_INVALID_ARG;
-  std::unique_lock<std::mutex> lk(g->mu);
+  Locked L(g);
   if (ticket == 0 || ticket >= g->next_ticket) return fail(g, MI355_ERR_INVALID_ARG, "group: unknown ticket");
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
   bool is_pending = false;
@@ -350,7 +392,8 @@ int mi355_group_order_after(mi355_group *g, mi355_ctx *ctx, uint64_t ticket) {
 
 int mi355_group_wait_all(mi355_group *g) {
   if (!g) return MI355_ERR_INVALID_ARG;
-  std::unique_lock<std::mutex> lk(g->mu);
+  Locked L(g);
+  std::unique_lock<std::mutex> &lk = L.lk;
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
   int rc = flush_locked(g);
   if (rc) return rc;

@@ -29,6 +29,7 @@ struct mi355_pipe {
     // group mode (mi355_pipe_set_group): the frame is with the group's dispatcher; its download is enqueued when somebody asks
     // for it (wait / slot reuse), behind the batch that carries it
     bool deferred = false;
+    int failed = 0;  // group mode: the frame's launch or download could not be enqueued; reported (once) to whoever waits for the frame
     uint64_t group_ticket = 0;
     uint8_t *host_dst = nullptr;
     size_t host_stride = 0, row_bytes = 0, rows = 0;
@@ -44,24 +45,41 @@ using namespace mi355;
 // group mode: the frame of this slot is (or will be, the call flushes up to it) in a batch; order this context's stream behind
 // it and enqueue the download
 static int pipe_finish_deferred(mi355_pipe *p, mi355_pipe::Slot *s) {
+  if (s->failed) return s->failed;
   if (!s->deferred) return MI355_OK;
-  s->deferred = false;
   int rc = mi355_group_order_after(p->group, p->ctx, s->group_ticket);
-  if (rc) return set_error(p->ctx, rc, std::string("pipeline: ") + mi355_group_last_error(p->group));
-  if ((rc = check_hip(p->ctx, hipEventRecord(s->computed, p->ctx->stream), "pipeline: record compute"))) return rc;
-  if ((rc = check_hip(p->ctx, hipStreamWaitEvent(p->s_down, s->computed, 0), "pipeline: download waits for compute"))) return rc;
-  if ((rc = check_hip(p->ctx, hipMemcpy2DAsync(s->host_dst, s->host_stride, s->d_out, s->row_bytes, s->row_bytes, s->rows, hipMemcpyDeviceToHost, p->s_down), "pipeline: D2H"))) return rc;
-  return check_hip(p->ctx, hipEventRecord(s->downloaded, p->s_down), "pipeline: record download");
+  if (rc) set_error(p->ctx, rc, std::string("pipeline: ") + mi355_group_last_error(p->group));
+  if (!rc) rc = check_hip(p->ctx, hipEventRecord(s->computed, p->ctx->stream), "pipeline: record compute");
+  if (!rc) rc = check_hip(p->ctx, hipStreamWaitEvent(p->s_down, s->computed, 0), "pipeline: download waits for compute");
+  if (!rc) rc = check_hip(p->ctx, hipMemcpy2DAsync(s->host_dst, s->host_stride, s->d_out, s->row_bytes, s->row_bytes, s->rows, hipMemcpyDeviceToHost, p->s_down), "pipeline: D2H");
+  if (!rc) rc = check_hip(p->ctx, hipEventRecord(s->downloaded, p->s_down), "pipeline: record download");
+  if (rc) {
+    // No download will happen. The slot stays busy and remembers why, so that the frame's own wait reports it instead of
+    // synchronising a stale event and returning OK; the group is made to let go of the slot's buffers first (its dispatcher may
+    // still hold the frame, launched or not).
+    const std::string why = p->ctx->last_error;
+    (void)mi355_group_wait(p->group, s->group_ticket);
+    p->ctx->last_error = why;
+    s->failed = rc;
+  }
+  s->deferred = false;
+  return rc;
+}
+
+// the slot's frame is over (waited for, or reported as failed): free for the next one
+static int pipe_retire_slot(mi355_pipe *p, mi355_pipe::Slot *s, const char *what) {
+  int rc = pipe_finish_deferred(p, s);
+  if (!rc) rc = check_hip(p->ctx, hipEventSynchronize(s->downloaded), what);
+  s->failed = 0;
+  s->busy = false;
+  return rc;
 }
 
 static int pipe_take_slot(mi355_pipe *p, mi355_pipe::Slot **out) {
   mi355_pipe::Slot &s = p->slots[(size_t)(p->next_ticket % (uint64_t)p->depth)];
   if (s.busy) {  // back-pressure: the ring is full, finish the oldest frame first
-    int rc = pipe_finish_deferred(p, &s);
+    int rc = pipe_retire_slot(p, &s, "pipeline: wait for a free slot");
     if (rc) return rc;
-    rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait for a free slot");
-    if (rc) return rc;
-    s.busy = false;
   }
   *out = &s;
   return MI355_OK;
@@ -134,6 +152,10 @@ mi355_pipe *mi355_pipe_create(mi355_ctx *ctx, int depth, size_t max_frame_bytes)
 void mi355_pipe_destroy(mi355_pipe *p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
+  // group mode: frames handed to the dispatcher may still be waiting there for a batch - a later flush by any stream would run
+  // kernels on the slot buffers freed below. Make the group finish (or give up) every frame of this pipeline first.
+  for (auto &s : p->slots)
+    if (s.busy && s.deferred && p->group) (void)mi355_group_wait(p->group, s.group_ticket);
   if (p->s_up) (void)hipStreamSynchronize(p->s_up);
   (void)hipStreamSynchronize(p->ctx->stream);
   if (p->s_down) (void)hipStreamSynchronize(p->s_down);
@@ -162,25 +184,18 @@ int mi355_pipe_wait(mi355_pipe *p, uint64_t ticket) {
   if (ticket == 0 || ticket >= p->next_ticket) return set_error(p->ctx, MI355_ERR_INVALID_ARG, "pipeline: unknown ticket");
   mi355_pipe::Slot &s = p->slots[(size_t)(ticket % (uint64_t)p->depth)];
   if (!s.busy || s.ticket != ticket) return MI355_OK;  // already completed (its slot was reclaimed or waited on)
-  int rc = pipe_finish_deferred(p, &s);
-  if (rc) return rc;
-  rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
-  if (rc) return rc;
-  s.busy = false;
-  return MI355_OK;
+  return pipe_retire_slot(p, &s, "pipeline: wait");
 }
 
 int mi355_pipe_wait_all(mi355_pipe *p) {
   if (!p) return MI355_ERR_INVALID_ARG;
+  int first = MI355_OK;
   for (auto &s : p->slots)
     if (s.busy) {
-      int rc = pipe_finish_deferred(p, &s);
-      if (rc) return rc;
-      rc = check_hip(p->ctx, hipEventSynchronize(s.downloaded), "pipeline: wait");
-      if (rc) return rc;
-      s.busy = false;
+      int rc = pipe_retire_slot(p, &s, "pipeline: wait");
+      if (rc && !first) first = rc;
     }
-  return MI355_OK;
+  return first;
 }
 
 // hsvfilter, in place on the host plane (same argument meaning and checks as mi355_hsvfilter_frame_ip)

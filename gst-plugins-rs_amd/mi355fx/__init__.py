@@ -37,6 +37,9 @@ FLAG_HRTF_METHOD = 12
 FLAG_WINDOW_MIN_STEPS = 13
 FLAG_HSV_NT = 14
 FLAG_BLOCKHASH_ANY_SIZE = 15
+FLAG_WINDOW_KIND = 16
+FLAG_WINDOW_ORDER = 17
+FLAG_WINDOW_STATS = 18
 
 
 class HsvSettings(C.Structure):
@@ -260,10 +263,10 @@ class Group:
         arr = self._rounds.get(key)
         if arr is None:
             n = len(contexts)
-            arr = self._rounds[key] = ((C.c_void_p * n)(*[c.h for c in contexts]), (C.c_void_p * n)(*src_ptrs), (C.c_void_p * n)(*dst_ptrs),
-                                       HsvSettings(*[float(v) for v in settings]))
+            arr = self._rounds[key] = ((C.c_void_p * n)(*[c.h for c in contexts]), (C.c_void_p * n)(*src_ptrs), (C.c_void_p * n)(*dst_ptrs))
+        hs = HsvSettings(*[float(v) for v in settings])   # (only the pointer arrays are cached: the settings are this call's)
         fn = self.L.mi355_group_submit_round_fused if fused else self.L.mi355_group_submit_round
-        self._ck(fn(self.h, arr[0], len(contexts), arr[1], arr[2], width, height, stride, FMT[fmt], C.byref(arr[3])))
+        self._ck(fn(self.h, arr[0], len(contexts), arr[1], arr[2], width, height, stride, FMT[fmt], C.byref(hs)))
 
     def flush(self):
         self._ck(self.L.mi355_group_flush(self.h))

@@ -85,6 +85,11 @@ static gboolean gst_video_compare_start(GstAggregator *agg) {
     GST_ELEMENT_ERROR(self, LIBRARY, INIT, ("No MI355X context"), ("%s", mi355_status_string(status)));
     return FALSE;
   }
+  /* The reference hashes frames of ANY size (hashed_image.rs:24-46 -> image_hasher's blockhash_slow for sizes that are not a
+   * multiple of 8, e.g. 854x480); the library refuses those unless asked, because that path restates the crate's
+   * floating-point code from memory (parity unpinned, include/mi355fx.h MI355_FLAG_BLOCKHASH_ANY_SIZE). An element that
+   * errors out on a size the reference accepts is worse than one whose hash of such frames is unpinned: ask. */
+  (void)mi355_ctx_set_flag(self->ctx, MI355_FLAG_BLOCKHASH_ANY_SIZE, 1);
   return GST_AGGREGATOR_CLASS(gst_video_compare_parent_class)->start ? GST_AGGREGATOR_CLASS(gst_video_compare_parent_class)->start(agg) : TRUE;
 }
 

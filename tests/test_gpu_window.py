@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 W4K, H4K = 3840, 2160
 
 
+@pytest.fixture(autouse=True, params=[1, 0, 2, 3], ids=["tagged", "bricktags", "tile10", "tile11"])
+def window_kind(request, ctx):
+    """Both LDS-cached kernels serve variant 8 (MI355_FLAG_WINDOW_KIND): colorlut_tagged_kernel (round 5, the default) and
+    colorlut_window_kernel (round 4). Returns the name the library must report."""
+    import mi355fx
+    ctx.set_flag(mi355fx.FLAG_WINDOW_KIND, request.param)
+    ctx.set_flag(mi355fx.FLAG_WINDOW_STATS, 1)
+    return ("colorlut_window_kernel", "colorlut_tagged_kernel", "colorlut_tilecache_kernel", "colorlut_tilecache_kernel")[request.param]
+
+
 def _load_cube(ctx, oracle, text):
     cube = oracle.Cube.parse(text)
     sc, of = cube.domain
@@ -49,7 +59,7 @@ def _run(ctx, src, w, h, n=1, sstride=None, dstride=None, fused_st=None, reps=1)
 
 
 @pytest.mark.parametrize("w,h", [(4, 1), (8, 3), (100, 37), (128, 4), (256, 32), (260, 33), (516, 3), (1000, 65), (1920, 1081), (3840, 7), (132, 4000)])
-def test_window_kernel_geometry(ctx, oracle, synth, w, h):
+def test_window_kernel_geometry(ctx, oracle, synth, w, h, window_kind):
     """Sizes around the kernel's 256 x 32 pixel steps: masked last strip, masked last rows, fewer steps than CUs, one strip."""
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(17))
     _window_ctx(ctx)
@@ -57,12 +67,12 @@ def test_window_kernel_geometry(ctx, oracle, synth, w, h):
     exp = np.zeros_like(src)
     oracle.colorlut_rgba8(cube, src, w * 4, exp, w * 4, w, h)
     got = _run(ctx, src, w, h)
-    assert ctx.colorlut_kernel_name() == "colorlut_window_kernel"
+    assert ctx.colorlut_kernel_name() == window_kind
     assert (got == exp).all()
 
 
 @pytest.mark.parametrize("w,h,spad,dpad,n", [(640, 70, 16, 48, 3), (1280, 33, 0, 32, 2), (516, 40, 64, 0, 1)])
-def test_window_kernel_padded_rows_and_batches(ctx, oracle, synth, w, h, spad, dpad, n):
+def test_window_kernel_padded_rows_and_batches(ctx, oracle, synth, w, h, spad, dpad, n, window_kind):
     """Row strides padded to multiples of 16 B, independent for source and destination; a batch is one tall picture; the
     destination's padding stays untouched."""
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
@@ -78,7 +88,7 @@ def test_window_kernel_padded_rows_and_batches(ctx, oracle, synth, w, h, spad, d
     for f in range(n):
         oracle.colorlut_rgba8(cube, src[f * h * ss:(f + 1) * h * ss], ss, exp[f * h * ds:(f + 1) * h * ds], ds, w, h)
     got = _run(ctx, src, w, h, n=n, sstride=ss, dstride=ds)
-    assert ctx.colorlut_kernel_name() == "colorlut_window_kernel"
+    assert ctx.colorlut_kernel_name() == window_kind
     assert (got == exp).all()
 
 
@@ -91,7 +101,7 @@ def _noisy(synth, amp, seed, n=1):
 
 
 @pytest.mark.parametrize("amp", [0, 4, 8, 16, 48])
-def test_window_kernel_4k_content_sweep(ctx, oracle, synth, amp):
+def test_window_kernel_4k_content_sweep(ctx, oracle, synth, amp, window_kind):
     """The bench's natural-like frame plus uniform noise of growing amplitude: from "nearly every pixel found in LDS" to
     "installs in flight everywhere, most pixels past the cache". Exact against the oracle, identical to the gather
     kernel on the same table, launch after launch (the cache is rebuilt by every launch; timing differs every time)."""
@@ -104,7 +114,7 @@ def test_window_kernel_4k_content_sweep(ctx, oracle, synth, amp):
     ctx.colorlut_window_stats(reset=True)
     for rep in range(4):
         got = _run(ctx, src, W4K, H4K)
-        assert ctx.colorlut_kernel_name() == "colorlut_window_kernel"
+        assert ctx.colorlut_kernel_name() == window_kind
         assert (got == exp).all(), "launch %d" % rep
     px, past, installs = ctx.colorlut_window_stats()
     assert px >= 4 * W4K * H4K and installs > 0  # lookups (lanes of masked rows included); bricks were installed
@@ -155,7 +165,7 @@ def test_window_kernel_three_clusters_thrash_and_stay_exact(ctx, oracle, synth):
         assert (_run(ctx, src, w, h) == exp).all(), "launch %d" % rep
 
 
-def test_window_kernel_fused_chain_batch(ctx, oracle, synth):
+def test_window_kernel_fused_chain_batch(ctx, oracle, synth, window_kind):
     """The fused entry point (table of hsvfilter -> colorlut) through the LDS-cached kernel on a 4 x 4K batch: first and
     last frame against the oracle chain, everything against the gather kernel."""
     import mi355fx
@@ -166,7 +176,7 @@ def test_window_kernel_fused_chain_batch(ctx, oracle, synth):
     _window_ctx(ctx, min_steps=3)
     ctx.colorlut_window_stats(reset=True)
     got = _run(ctx, src, W4K, H4K, n=n, fused_st=st)
-    assert ctx.colorlut_kernel_name() == "colorlut_window_kernel"
+    assert ctx.colorlut_kernel_name() == window_kind
     px, past, installs = ctx.colorlut_window_stats()
     assert past < 0.1 * px and installs > 0, (px, past, installs)  # the cache serves the pixels (16 steps per block, the first one cold)
     fb = W4K * H4K * 4
@@ -200,7 +210,7 @@ def test_window_kernel_in_place(ctx, oracle, synth):
     assert (got == exp).all()
 
 
-def test_the_table_kernel_is_chosen_by_measurement(ctx, oracle, synth):
+def test_the_table_kernel_is_chosen_by_measurement(ctx, oracle, synth, window_kind):
     """MI355_FLAG_LUT_VARIANT 9 (what auto does once it is on the table): ONE Morton table; on 4K batches the LDS-cached kernel
     is timed against the gather kernel (both appear, results exact throughout); a 720p frame goes through the tiled gather
     kernel on the same table."""
@@ -221,7 +231,7 @@ def test_the_table_kernel_is_chosen_by_measurement(ctx, oracle, synth):
             out = np.zeros_like(src)
             ctx.d2h(out, d_o)
             assert (out[: exp.size] == exp).all()
-        assert seen == {"colorlut_window_kernel", "colorlut_table_tiled_kernel"}, seen
+        assert seen == {window_kind, "colorlut_table_tiled_kernel"}, seen
         tables = mi355fx.load_library().mi355_shared_table_count()
         small = synth.smooth_frame(1280, 720, seed=71).reshape(-1)
         got = _run(ctx, small, 1280, 720)
