@@ -1747,7 +1747,7 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
   const bool window_ok = morton && sub != kTableGather && width % 4 == 0 && window_applicable(ctx, (unsigned)width / 4, geo.dw4, rows);
   auto gather = [&]() { return launch_table_gather(ctx, t, d_src, d_dst, geo, width, rows, morton); };
   auto window = [&]() {
-    ctx->lut.last_kernel = ctx->window_kind >= 2 ? "colorlut_tilecache_kernel" : (ctx->window_kind == 1 ? "colorlut_tagged_kernel" : "colorlut_window_kernel");
+    ctx->lut.last_kernel = "colorlut_window_kernel";
     return launch_window_table(ctx, t, d_src, d_dst, (unsigned)width / 4, geo.sw4, geo.dw4, rows);
   };
   if (!window_ok) return gather();

@@ -349,498 +349,6 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// colorlut_tagged_kernel — the same job through a cache of SELF-TAGGED entries (round 5).
-//
-// The kernel above spends six LDS operations and a dependent chain of two round trips per pixel on its protocol (three
-// axis reads for the Morton slot, {tags, generation}, the entry, the generation again) and needs locks, leaders and
-// generations to keep readers and installers apart. Here an entry carries its own tag: a cached colour is the 8-byte pair
-// {colour (24 bits), table value (24 bits) | stamp << 24}, written with ONE ds_write_b64 and read, with its neighbour way,
-// by ONE ds_read_b128. An 8-byte-aligned LDS access of a lane is a single LDS operation, so a reader sees a pair as some
-// writer wrote it, and every pair ever written is {c, table[c]}: whatever the interleaving of readers and installers, a
-// pair whose colour matches gives table[colour]. No lock, no generation, no validation read, no leader claim; two waves
-// installing into the same set at once lose one of the two entries, which costs a later miss and nothing else.
-//   set   = r[4:0], g[3:0], b[3:0] of the colour: 8192 sets x 2 ways x 8 B = 128 KiB; a compact cloud of colours up to
-//           32 x 16 x 16 levels wide never collides with itself, two clouds (an edge) have a way each. The set's byte offset
-//           comes from the packed pixel in six VALU operations - no axis-table read in the hit path.
-//   hit   : 6 (offset) + 1 (colour) + 2 compares + select + alpha merge VALU, one ds_read_b128.
-//   miss  : as above, the wave installs up to kTagFills of the BRICKS it missed (4 x 4 x 4 colours = 64 consecutive entries
-//           = 256 B of the Morton-indexed table: one entry per lane, all bricks in flight together), every lane choosing
-//           the way of ITS entry (same colour > empty > older stamp: first in, first out); second look; a pixel still
-//           missing reads table[slot] itself and leaves the pair behind for the next reader (entry-granular caching is
-//           what serves noisy content, where a brick install would bring 64 entries for one use).
-// The Morton slot (three axis-table reads) is only computed for missed pixels. Walk, pixel ring, unconditional
-// range-checked stores: as in colorlut_window_kernel.
-namespace {
-
-typedef __attribute__((address_space(3))) u4_t lds_u4;
-typedef volatile __attribute__((address_space(3))) u4_t lds_vu4;
-constexpr uint32_t kTagData = 0;                        // 8192 sets x {colour A, value A, colour B, value B} (at 0: a set's offset IS its address)
-constexpr uint32_t kTagSets = 8192;
-constexpr uint32_t kTagAxis = kTagSets * 16;            // 3 x 256 x u32: Morton slot contributions per channel value (miss path)
-constexpr uint32_t kTagReq = kTagAxis + 3072;           // 256 x u32: "brick B was asked for at step s" notes, by B & 255 (one wave asks, the others find the note)
-constexpr uint32_t kTagLdsBytes = kTagReq + 1024;       // 135,168 B: one block per CU
-constexpr uint32_t kTagEmpty = 0xffffffffu;             // colours are 24 bits: matches nothing
-#ifndef TAG_FILLS
-#define TAG_FILLS 4
-#endif
-#ifndef TAG_DEPTH
-#define TAG_DEPTH 2
-#endif
-#ifndef TAG_EXP
-#define TAG_EXP 0
-#endif
-constexpr int kTagFills = TAG_FILLS;
-static_assert(kTagLdsBytes <= 160 * 1024, "fits the CU");
-
-__device__ __forceinline__ u4_t lds_r128(uint32_t a) { return *(const lds_u4 *)(lds_byte *)(uintptr_t)a; }
-__device__ __forceinline__ u4_t lds_r128v(uint32_t a) { return *(lds_vu4 *)(lds_byte *)(uintptr_t)a; }
-
-// byte offset of the set of colour p (bits 24..31 of p ignored): r[4:0] -> bits 4..8, g[3:0] -> 9..12, b[3:0] -> 13..16
-__device__ __forceinline__ uint32_t tag_set_offset(uint32_t p) { return ((p << 4) & 0x1f0u) | ((p << 1) & 0x1e00u) | ((p >> 3) & 0x1e000u); }
-
-// which way of set contents `e` the pair of colour `tok` goes to at time `now`: its own, an empty one, the older one
-__device__ __forceinline__ uint32_t tag_victim(const u4_t e, uint32_t tok, uint32_t now) {
-  const uint32_t age_a = (now - (e.y >> 24)) & 0xffu, age_b = (now - (e.w >> 24)) & 0xffu;
-  uint32_t way = age_b > age_a ? 1u : 0u;
-  if (e.z == kTagEmpty) way = 1u;
-  if (e.x == kTagEmpty) way = 0u;
-  if (e.z == tok) way = 1u;
-  if (e.x == tok) way = 0u;
-  return way;
-}
-
-}  // namespace
-
-// ORDER: how the blocks share the column-major list of 256 x 32 pixel steps. 0 = a contiguous share each (round 4: block b
-// covers steps [b * share ...)); 1 = aligned fronts: strip = b % n_strips, layer = b / n_strips, a layer is `share` steps tall -
-// the blocks of a layer walk down side by side, so what the chip reads and writes at any time is `extra` (= layers) bands of
-// full rows instead of 256 unrelated row segments (tools/walk_bench.hip).
-template <int ORDER>
-__global__ __launch_bounds__(1024) void colorlut_tagged_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
-                                                               unsigned rows, unsigned dst_bytes, unsigned steps_per_strip, unsigned share, unsigned extra,
-                                                               const uint32_t *__restrict__ table, unsigned long long *__restrict__ counters) {
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x < 768) lds_w32(kTagAxis + 4u * threadIdx.x, window_axis_entry((int)(threadIdx.x >> 8), threadIdx.x & 255u));
-  if (threadIdx.x < 256) lds_w32(kTagReq + 4u * threadIdx.x, 0xffffffffu);
-  {
-    const u4_t none = {kTagEmpty, 0u, kTagEmpty, 0u};
-#pragma unroll
-    for (unsigned i = 0; i < kTagSets / 1024; i++) *(lds_u4 *)(lds_byte *)(uintptr_t)(kTagData + 16u * (threadIdx.x + 1024u * i)) = none;
-  }
-  __syncthreads();
-  // the colour this lane's entry of a brick has beyond the brick's base colour: entry k of a brick = the two low bits of
-  // r, g, b interleaved (colorlut_window.hpp)
-  const uint32_t lane_colour = (lane & 1u) | ((lane >> 2) & 2u) | ((lane & 2u) << 7) | ((lane & 16u) << 5) | ((lane & 4u) << 14) | ((lane & 32u) << 12);
-
-  unsigned n_px = 0, n_miss = 0, n_fill = 0;
-  unsigned first, last;
-  if (ORDER == 0) {
-    first = blockIdx.x * share + (blockIdx.x < extra ? blockIdx.x : extra);
-    last = first + share + (blockIdx.x < extra ? 1u : 0u);
-  } else {
-    const unsigned n_strips = (w4 + 63u) / 64u;
-    const unsigned strip = blockIdx.x % n_strips, layer = blockIdx.x / n_strips;
-    first = strip * steps_per_strip + layer * share;
-    last = first + share;
-    if (last > (strip + 1u) * steps_per_strip) last = (strip + 1u) * steps_per_strip;
-    if (layer >= extra || first > last) first = last = 0;
-  }
-  if (first < last) {
-    const uint32_t two = 2u;
-    const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
-    // pixel groups in flight: three steps, each in its own registers (the loop is unrolled three times; a copy of a loaded
-    // value would wait for the load)
-    struct Slot { u4_t p, q; };
-    Slot ring[3];
-    // where step st's two pixel groups of this lane are: column (in 16-byte groups) and rows
-    auto place = [&](unsigned st, unsigned &col, unsigned &r0) {
-      const unsigned strip = st / steps_per_strip, k = st - strip * steps_per_strip;
-      col = strip * 64u + lane;
-      r0 = k * kWinRowsPerStep + 2u * wave;
-    };
-    auto fetch = [&](unsigned st_, Slot &S) {
-      unsigned col, r0;
-      place(st_ < last ? st_ : last - 1u, col, r0);  // (clamped into the block's share: loads are unconditional)
-      const unsigned r1 = r0 + 1u;
-      const unsigned cc = col < w4 ? col : w4 - 1u, c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
-      S.p = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
-      S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
-    };
-    auto morton_slot = [&](uint32_t p) {
-      return lds_r32(byte_times4<0>(p, two) + kTagAxis) + lds_r32(byte_times4<1>(p, two) + (kTagAxis + 1024u)) + lds_r32(byte_times4<2>(p, two) + (kTagAxis + 2048u));
-    };
-
-    // --- the cache, one step AHEAD of the pixels' turn: look up, and ask for the bricks that are missing; the bricks arrive
-    // while the step before is finished and are installed at the start of the next iteration - the table's latency is off
-    // the path of every step but a block's first.
-    uint32_t ft[kTagFills], fv[kTagFills];  // requests in flight: colour and value of this lane's entry of each brick
-    bool fo[kTagFills];
-#pragma unroll
-    for (int f = 0; f < kTagFills; f++) fo[f] = false;
-
-    // val[j] = the cache's answer for pixel j of S; returns the mask of pixels it did not have. Four pixels at a time (sixteen
-    // registers of set contents in flight, not thirty-two).
-    auto lookup = [&](const Slot &S, uint32_t (&val)[8], bool careful) -> uint32_t {
-      uint32_t px[8] = {S.p.x, S.p.y, S.p.z, S.p.w, S.q.x, S.q.y, S.q.z, S.q.w};
-      if (careful) {  // (the second look computes its set offsets again: kept from the first look they cost eight registers - spills)
-#pragma unroll
-        for (int j = 0; j < 8; j++) asm volatile("" : "+v"(px[j]));
-      }
-      uint32_t miss = 0;
-#pragma unroll
-      for (int h = 0; h < 8; h += 4) {
-        u4_t e[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = careful ? lds_r128v(kTagData + tag_set_offset(px[h + j])) : lds_r128(kTagData + tag_set_offset(px[h + j]));
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t tok = px[h + j] & 0x00ffffffu;
-          const bool ha = e[j].x == tok, hb = e[j].z == tok;
-          val[h + j] = hb ? e[j].w : e[j].y;
-          asm volatile("" : "+v"(val[h + j]));  // (selected NOW: left to the compiler, both candidates stay live until the step's turn)
-          miss |= (ha | hb) ? 0u : (1u << (h + j));
-        }
-        asm volatile("" : "+v"(miss));
-        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would issue all eight reads first: 32 registers, and spills)
-      }
-      return miss;
-    };
-    // asks for up to kTagFills of the distinct bricks behind `miss` (a lane speaks for the brick of its first missed pixel; each
-    // wave starts its search at another lane: the waves of a block miss the same new bricks at the same time)
-    // The sixteen waves of a block meet a new brick within the same step: the first to ask leaves a note {brick, step} and the
-    // others, finding it, do not ask again (advisory: two waves that look at the same moment both ask - harmless; a note
-    // older than a step is ignored - the brick may have been evicted since).
-    auto request = [&](const Slot &S, uint32_t miss, uint32_t now) {
-      const uint32_t px[8] = {S.p.x, S.p.y, S.p.z, S.p.w, S.q.x, S.q.y, S.q.z, S.q.w};
-      uint32_t mp = 0;
-#pragma unroll
-      for (int j = 7; j >= 0; j--)
-        if (miss & (1u << j)) mp = px[j];
-      uint32_t mb = 0xffffffffu;
-      bool asked = false;
-      if (miss) {
-        mb = morton_slot(mp) >> 6;
-        const uint32_t note = lds_r32v(kTagReq + ((mb & 255u) << 2));
-        asked = (note & 0x00ffffffu) == mb && ((now - (note >> 24)) & 0xffu) <= 1u;
-      }
-      unsigned long long want = __builtin_amdgcn_ballot_w64(miss != 0u && !asked);
-      const unsigned rot = (wave * 4u + 1u) & 63u;
-#pragma unroll
-      for (int f = 0; f < kTagFills; f++) {
-        // (branch-free on purpose: a wave-uniform branch here makes the compiler wait for each brick's load in turn)
-        const bool act = want != 0ull;
-        const unsigned long long turned = (want >> rot) | (want << (64u - rot));
-        const int l = (int)((__builtin_ctzll(turned | (1ull << 63)) + rot) & 63u);
-        const uint32_t B = (uint32_t)__builtin_amdgcn_readlane((int)mb, l);
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)mp, l) & 0x00fcfcfcu;
-        want &= ~__builtin_amdgcn_ballot_w64(mb == B);
-        if (act && (int)lane == l) lds_w32v(kTagReq + ((B & 255u) << 2), B | (now << 24));
-        fo[f] = act;
-        ft[f] = base | lane_colour;
-        fv[f] = table[((size_t)(act ? B : 0u) << 6) + lane];
-        n_fill += act ? 1u : 0u;
-      }
-    };
-    // the bricks asked for have arrived: every lane places its entry of each - look at the set, pick the way, ONE 8-byte write
-    auto install = [&](uint32_t now) {
-#pragma unroll
-      for (int f = 0; f < kTagFills; f++) {
-        if (fo[f]) {
-          const uint32_t a = kTagData + tag_set_offset(ft[f]);
-          const u4_t cur = lds_r128v(a);
-          const u2_t pair = {ft[f], (fv[f] & 0x00ffffffu) | (now << 24)};
-          lds_w64v(a + 8u * tag_victim(cur, ft[f], now), pair);
-        }
-        fo[f] = false;
-      }
-    };
-    // step st's turn: its pixels were looked up one step ago (val, miss) and the bricks they missed have been installed since
-    auto finalize = [&](unsigned st, Slot &S, uint32_t (&val)[8], uint32_t miss) {
-      const uint32_t px[8] = {S.p.x, S.p.y, S.p.z, S.p.w, S.q.x, S.q.y, S.q.z, S.q.w};
-#if TAG_EXP == 2
-      miss = 0;
-#endif
-      if (__builtin_amdgcn_ballot_w64(miss != 0u) != 0ull) {
-        const uint32_t now = (st - first) & 0xffu;
-        // second look (the wave's own installs are in LDS order before it; other waves' whenever they land)
-        {
-          uint32_t v2[8];
-          const uint32_t m2 = lookup(S, v2, true);
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (miss & (1u << j)) val[j] = v2[j];
-          miss &= m2;
-        }
-        // what is left (more distinct bricks than one request holds: a block's first step, an edge; an entry another wave's
-        // install took away) reads the table itself, per lane, and leaves the pair in the cache
-        if (__builtin_amdgcn_ballot_w64(miss != 0u) != 0ull) {
-          uint32_t sl[8], qx[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) { qx[j] = px[j]; asm volatile("" : "+v"(qx[j])); }
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (miss & (1u << j)) sl[j] = morton_slot(px[j]);
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (miss & (1u << j)) {
-              val[j] = table[sl[j]];
-              n_miss++;
-            }
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (miss & (1u << j)) {
-              const uint32_t tok = qx[j] & 0x00ffffffu, a = kTagData + tag_set_offset(qx[j]);
-              const u4_t cur = lds_r128v(a);
-              const u2_t pair = {tok, (val[j] & 0x00ffffffu) | (now << 24)};
-              lds_w64v(a + 8u * tag_victim(cur, tok, now), pair);
-            }
-          // (a use inside the branch: the wait for these loads then sits here and not in front of the stores of every step)
-#pragma unroll
-          for (int j = 0; j < 8; j++) asm volatile("" : "+v"(val[j]));
-        }
-      }
-      u4_t a, b;
-      a.x = (val[0] & 0x00ffffffu) | (px[0] & 0xff000000u);
-      a.y = (val[1] & 0x00ffffffu) | (px[1] & 0xff000000u);
-      a.z = (val[2] & 0x00ffffffu) | (px[2] & 0xff000000u);
-      a.w = (val[3] & 0x00ffffffu) | (px[3] & 0xff000000u);
-      b.x = (val[4] & 0x00ffffffu) | (px[4] & 0xff000000u);
-      b.y = (val[5] & 0x00ffffffu) | (px[5] & 0xff000000u);
-      b.z = (val[6] & 0x00ffffffu) | (px[6] & 0xff000000u);
-      b.w = (val[7] & 0x00ffffffu) | (px[7] & 0xff000000u);
-      // unconditional buffer stores, range-checked by the hardware: offset 0x80000000 (out of range: dropped) for lanes outside
-      // the picture (a store inside a branch would make the number of operations in flight unknown to the compiler, which then
-      // waits for ALL of them before the next step's pixels)
-      unsigned col, r0;
-      place(st, col, r0);
-      const uint32_t so0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
-      const uint32_t so1 = col < w4 && r0 + 1u < rows ? ((r0 + 1u) * dw4 + col) << 4 : 0x80000000u;
-      __builtin_amdgcn_raw_buffer_store_b128(a, dst_rsrc, (int)so0, 0, 2 /* nt */);
-      __builtin_amdgcn_raw_buffer_store_b128(b, dst_rsrc, (int)so1, 0, 2);
-    };
-
-    uint32_t cval[8], cmiss;  // the cache's answers for the step whose turn is next
-    fetch(first, ring[0]);
-    fetch(first + 1u, ring[1]);
-    fetch(first + 2u, ring[2]);
-#if TAG_EXP == 1
-    cmiss = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) cval[j] = j < 4 ? ring[0].p[j] : ring[0].q[j - 4];
-#else
-    cmiss = lookup(ring[0], cval, false);
-    // (the block's first step meets an empty cache: the waves share the bricks out between them through the notes, four each;
-    // what has not arrived when the step's turn comes goes to the table directly)
-    if (__builtin_amdgcn_ballot_w64(cmiss != 0u) != 0ull) request(ring[0], cmiss, 0u);
-    // Nothing in flight when the loop is entered: the compiler merges what is outstanding at the loop's entry with what is outstanding at its back edge, and with
-    // loads pending on this side it makes every third step wait for ALL memory operations (s_waitcnt vmcnt(0) in the loop).
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-#endif
-    auto iteration = [&](unsigned st, Slot &cur, Slot &next) {
-      uint32_t nval[8], nmiss;
-#if TAG_EXP == 1  // experiment: the walk alone (copy)
-      nmiss = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) nval[j] = j < 4 ? next.p[j] : next.q[j - 4];
-#else
-      install((st - first) & 0xffu);
-      nmiss = lookup(next, nval, false);
-      if (__builtin_amdgcn_ballot_w64(nmiss != 0u) != 0ull) request(next, nmiss, (st - first) & 0xffu);
-#endif
-      finalize(st, cur, cval, cmiss);
-      // the slot's next pixels travel while the other slots' steps are looked up
-      fetch(st + 3u, cur);
-#pragma unroll
-      for (int j = 0; j < 8; j++) cval[j] = nval[j];
-      cmiss = nmiss;
-    };
-    unsigned st = first;
-    for (; st + 3u <= last; st += 3u) {
-      iteration(st, ring[0], ring[1]);
-      iteration(st + 1u, ring[1], ring[2]);
-      iteration(st + 2u, ring[2], ring[0]);
-    }
-    if (st < last) iteration(st, ring[0], ring[1]);
-    if (st + 1u < last) iteration(st + 1u, ring[1], ring[2]);
-    n_px = (last - first) * 8u;
-  }
-  // diagnostics: {pixels looked up, pixels served past the cache, bricks installed}, spread over slots so that the waves
-  // of the chip do not queue up on one address
-  unsigned long long miss_w = n_miss;
-  for (int o = 32; o > 0; o >>= 1) miss_w += __shfl_xor(miss_w, o);
-  if (lane == 0 && counters) {
-    unsigned long long *c = counters + 3 * ((blockIdx.x * kWinWaves + wave) % kWinCounterSlots);
-    atomicAdd(c, (unsigned long long)n_px * 64ull);
-    atomicAdd(c + 1, miss_w);
-    atomicAdd(c + 2, (unsigned long long)n_fill);
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// colorlut_tilecache_kernel — the gather kernel's streaming (small blocks, one tile each, tiles in row-major order: what the
-// chip touches at any time is one band of the picture - tools/walk_bench.hip: a persistent block per CU streams 10-25 % slower
-// than that on most boxes, whatever it computes) with the self-tagged cache of colorlut_tagged_kernel in front of the
-// gathers, private to the block and filled by the gathers themselves: a tile of 256 x 32 pixels holds a few hundred distinct
-// colours, so after a wave's first rows most lookups are served by LDS (32 lanes per clock) instead of the texture-address
-// path (one lane per clock). No bricks, no requests: a missed pixel reads table[slot] and leaves {colour, value} behind.
-namespace {
-#ifndef TILE_EXP
-#define TILE_EXP 0
-#endif
-#ifndef TILE_FILLS
-#define TILE_FILLS 8
-#endif
-#ifndef TILE_ROUNDS
-#define TILE_ROUNDS 0
-#endif
-#ifndef TILE_WAVES
-#define TILE_WAVES 4
-#endif
-#ifndef TILE_WARM
-#define TILE_WARM 0
-#endif
-#ifndef TILE_SPLIT
-#define TILE_SPLIT 0
-#endif
-constexpr int kTileWaves = TILE_WAVES;
-constexpr int kTileRows = 8 * kTileWaves;   // rows per block: waves x 4 mini-steps x 2 rows
-template <int LOG2_SETS>
-__device__ __forceinline__ uint32_t tile_set_offset(uint32_t p) {
-  if constexpr (LOG2_SETS == 10) return ((p << 4) & 0xf0u) | (p & 0x700u) | ((p >> 5) & 0x3800u);        // r[3:0] g[2:0] b[2:0]
-  else if constexpr (LOG2_SETS == 11) return ((p << 4) & 0xf0u) | (p & 0xf00u) | ((p >> 4) & 0x7000u);   // r[3:0] g[3:0] b[2:0]
-  else return ((p << 4) & 0x1f0u) | ((p << 1) & 0x1e00u) | ((p >> 3) & 0xe000u);                         // r[4:0] g[3:0] b[2:0]
-}
-}  // namespace
-
-template <int LOG2_SETS>
-__global__ __launch_bounds__(64 * kTileWaves) void colorlut_tilecache_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
-                                                                 unsigned rows, unsigned dst_bytes, unsigned n_cols, const uint32_t *__restrict__ table,
-                                                                 unsigned long long *__restrict__ counters) {
-  // LDS: the cache at 0 (a set's offset IS its address), the Morton spread table, the notes {brick asked for} by brick & 127
-  constexpr uint32_t kSets = 1u << LOG2_SETS, kSpread = kSets * 16u, kNotes = kSpread + 1024u;
-  constexpr int F = TILE_FILLS;
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  {
-    const u4_t none = {kTagEmpty, 0u, kTagEmpty, 0u};
-#pragma unroll
-    for (unsigned i = threadIdx.x; i < kSets; i += 64u * kTileWaves) *(lds_u4 *)(lds_byte *)(uintptr_t)(16u * i) = none;
-    if (threadIdx.x < 256) lds_w32(kSpread + 4u * threadIdx.x, window_axis_entry(0, threadIdx.x));
-    if (threadIdx.x < 128) lds_w32(kNotes + 4u * threadIdx.x, 0xffffffffu);
-  }
-  __syncthreads();
-  const uint32_t lane_colour = (lane & 1u) | ((lane >> 2) & 2u) | ((lane & 2u) << 7) | ((lane & 16u) << 5) | ((lane & 4u) << 14) | ((lane & 32u) << 12);
-  const unsigned tx = blockIdx.x % n_cols, ty = blockIdx.x / n_cols;
-  const unsigned col = tx * 64u + lane, row0 = ty * kTileRows + wave * 8u;
-  const unsigned cc = col < w4 ? col : w4 - 1u;
-  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
-  const uint32_t two = 2u;
-  unsigned n_miss = 0, n_fill = 0;
-  auto morton_slot = [&](uint32_t p) {
-    return lds_r32(byte_times4<0>(p, two) + kSpread) + (lds_r32(byte_times4<1>(p, two) + kSpread) << 1) + (lds_r32(byte_times4<2>(p, two) + kSpread) << 2);
-  };
-  u4_t P[4], Q[4];
-#pragma unroll
-  for (int m = 0; m < 4; m++) {  // all of the wave's eight rows travel at once
-    const unsigned r0 = row0 + 2u * m, r1 = r0 + 1u;
-    const unsigned c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
-    P[m] = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
-    Q[m] = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
-  }
-  // val[j] = the cache's answer for pixel j; returns the mask of pixels it did not have
-  auto lookup = [&](const uint32_t (&px)[8], uint32_t (&val)[8], uint32_t only) -> uint32_t {
-    uint32_t miss = 0;
-#pragma unroll
-    for (int h = 0; h < 8; h += 4) {
-      u4_t e[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) e[j] = lds_r128v(tile_set_offset<LOG2_SETS>(px[h + j]));
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t tok = px[h + j] & 0x00ffffffu;
-        const bool ha = e[j].x == tok, hb = e[j].z == tok;
-        if (only & (1u << (h + j))) val[h + j] = hb ? e[j].w : e[j].y;
-        miss |= (ha | hb) ? 0u : (1u << (h + j));
-      }
-    }
-    return miss & only;
-  };
-  // A wave's rows go through the cache in TWO passes - its first two rows, then the other six together - so that a wave pays
-  // two gather round trips, not four: the first pass leaves the colours of two rows in the cache (of every wave of the block:
-  // rows 0-1, 8-9, 16-17, 24-25 of the tile), the second finds most of its pixels there.
-  // A pixel's register holds the pixel until it is served and the result from then on.
-  auto serve = [&](uint32_t (&x)[24], const int n, uint32_t stamp) {
-    uint32_t miss = 0;
-#pragma unroll
-    for (int h = 0; h < n; h += 4) {
-      u4_t e[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) e[j] = lds_r128v(tile_set_offset<LOG2_SETS>(x[h + j]));
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t tok = x[h + j] & 0x00ffffffu;
-        const bool ha = e[j].x == tok, hb = e[j].z == tok;
-        const uint32_t v = hb ? e[j].w : e[j].y;
-#if TILE_EXP == 2
-        x[h + j] = (v & 0x00ffffffu) | (x[h + j] & 0xff000000u);
-#elif TILE_EXP == 0
-        if (ha | hb) x[h + j] = (v & 0x00ffffffu) | (x[h + j] & 0xff000000u);
-        else miss |= 1u << (h + j);
-#endif
-      }
-    }
-    if (__builtin_amdgcn_ballot_w64(miss != 0u) != 0ull) {
-      uint32_t v[24];
-#pragma unroll
-      for (int j = 0; j < n; j++)
-        if (miss & (1u << j)) v[j] = table[morton_slot(x[j])];
-#pragma unroll
-      for (int j = 0; j < n; j++)
-        if (miss & (1u << j)) {
-          const uint32_t tok = x[j] & 0x00ffffffu, a = tile_set_offset<LOG2_SETS>(x[j]);
-          const u4_t cur = lds_r128v(a);
-          const u2_t pair = {tok, (v[j] & 0x00ffffffu) | (stamp << 24)};
-          lds_w64v(a + 8u * tag_victim(cur, tok, stamp), pair);
-          x[j] = (v[j] & 0x00ffffffu) | (x[j] & 0xff000000u);
-          n_miss++;
-        }
-    }
-  };
-  auto store = [&](int m, const u4_t a, const u4_t b) {
-    const unsigned r0 = row0 + 2u * m, r1 = r0 + 1u;
-    const uint32_t so0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
-    const uint32_t so1 = col < w4 && r1 < rows ? (r1 * dw4 + col) << 4 : 0x80000000u;
-    __builtin_amdgcn_raw_buffer_store_b128(a, dst_rsrc, (int)so0, 0, 2 /* nt */);
-    __builtin_amdgcn_raw_buffer_store_b128(b, dst_rsrc, (int)so1, 0, 2);
-  };
-  {
-    uint32_t x[24] = {P[0].x, P[0].y, P[0].z, P[0].w, Q[0].x, Q[0].y, Q[0].z, Q[0].w};
-    serve(x, 8, 0u);
-    const u4_t a = {x[0], x[1], x[2], x[3]}, b = {x[4], x[5], x[6], x[7]};
-    store(0, a, b);
-  }
-  {
-    uint32_t x[24] = {P[1].x, P[1].y, P[1].z, P[1].w, Q[1].x, Q[1].y, Q[1].z, Q[1].w, P[2].x, P[2].y, P[2].z, P[2].w, Q[2].x, Q[2].y, Q[2].z, Q[2].w,
-                      P[3].x, P[3].y, P[3].z, P[3].w, Q[3].x, Q[3].y, Q[3].z, Q[3].w};
-    serve(x, 24, 1u);
-#pragma unroll
-    for (int m = 1; m < 4; m++) {
-      const int o = 8 * (m - 1);
-      const u4_t a = {x[o], x[o + 1], x[o + 2], x[o + 3]}, b = {x[o + 4], x[o + 5], x[o + 6], x[o + 7]};
-      store(m, a, b);
-    }
-  }
-  unsigned long long miss_w = n_miss;
-  for (int o = 32; o > 0; o >>= 1) miss_w += __shfl_xor(miss_w, o);
-  if (lane == 0 && counters) {
-    unsigned long long *c = counters + 3 * ((blockIdx.x * kTileWaves + wave) % kWinCounterSlots);
-    atomicAdd(c, 32ull * 64ull);
-    atomicAdd(c + 1, miss_w);
-    atomicAdd(c + 2, (unsigned long long)n_fill);
-  }
-}
-
 bool window_applicable(const mi355_ctx *ctx, unsigned w4, unsigned dw4, size_t rows) {
   if (w4 < 1 || rows == 0 || rows >= (1u << 30)) return false;
   if (rows * dw4 * 16 > (1ull << 31)) return false;  // results are addressed by 32-bit byte offsets into one buffer descriptor
@@ -858,22 +366,7 @@ int launch_window_table(mi355_ctx *ctx, const uint32_t *table, const uint8_t *d_
   const unsigned total = n_strips * steps_per_strip;
   unsigned grid = (unsigned)ctx->n_cu;
   if (grid > total) grid = total;
-  if (ctx->window_kind == 2 || ctx->window_kind == 3) {
-    const unsigned tgrid = n_strips * (unsigned)((rows + kTileRows - 1) / kTileRows);
-    if (ctx->window_kind == 2)
-      hipLaunchKernelGGL(colorlut_tilecache_kernel<10>, dim3(tgrid), dim3(64 * kTileWaves), 16384 + 1024 + 512, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4, (unsigned)rows,
-                         (unsigned)(rows * dw4 * 16), n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
-    else
-      hipLaunchKernelGGL(colorlut_tilecache_kernel<11>, dim3(tgrid), dim3(64 * kTileWaves), 32768 + 1024 + 512, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4, (unsigned)rows,
-                         (unsigned)(rows * dw4 * 16), n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
-  } else if (ctx->window_kind == 1 && ctx->window_order == 1 && n_strips <= grid) {
-    const unsigned layers = grid / n_strips, per_layer = (steps_per_strip + layers - 1) / layers;
-    hipLaunchKernelGGL(colorlut_tagged_kernel<1>, dim3(n_strips * layers), dim3(64 * kWinWaves), kTagLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
-                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, per_layer, layers, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
-  } else if (ctx->window_kind == 1)
-    hipLaunchKernelGGL(colorlut_tagged_kernel<0>, dim3(grid), dim3(64 * kWinWaves), kTagLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
-                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, total / grid, total % grid, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
-  else if (ctx->window_order == 1 && n_strips <= grid) {
+  if (ctx->window_order == 1 && n_strips <= grid) {
     const unsigned layers = grid / n_strips, per_layer = (steps_per_strip + layers - 1) / layers;
     hipLaunchKernelGGL(colorlut_window_kernel, dim3(n_strips * layers), dim3(64 * kWinWaves), kWinLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
                        (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, per_layer, layers, n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);

@@ -194,7 +194,6 @@ int mi355_ctx_set_flag(mi355_ctx *ctx, int flag, int value) {
   if (flag == MI355_FLAG_HRTF_METHOD && value >= 0 && value <= 2) { ctx->hrtf_method = value; return MI355_OK; }
   if (flag == MI355_FLAG_BLOCKHASH_ANY_SIZE && (value == 0 || value == 1)) { ctx->blockhash_any_size = value; return MI355_OK; }
   if (flag == MI355_FLAG_HSV_NT && (value == 0 || value == 1)) { ctx->hsv_nt = value; return MI355_OK; }
-  if (flag == MI355_FLAG_WINDOW_KIND && value >= 0 && value <= 3) { ctx->window_kind = value; return MI355_OK; }
   if (flag == MI355_FLAG_WINDOW_ORDER && (value == 0 || value == 1)) { ctx->window_order = value; return MI355_OK; }
   if (flag == MI355_FLAG_WINDOW_STATS && (value == 0 || value == 1)) { ctx->window_stats_on = value != 0; return MI355_OK; }
   if (flag == MI355_FLAG_WINDOW_MIN_STEPS && value >= 0 && value <= 4096) { ctx->window_min_steps = value; return MI355_OK; }

@@ -111,8 +111,7 @@ struct mi355_ctx {
   int brick_sets = 0;           // MI355_FLAG_BRICK_SETS: 0 = content watch decides (default); 32 (4x4x2 sets, 16 waves per CU) or 64 (4x4x4 sets, 8 waves per CU) pinned
   int hrtf_method = 0;         // MI355_FLAG_HRTF_METHOD: 0 = by HRIR length, 1 = overlap-save FFT, 2 = time-domain FIR (takes effect at mi355_hrtf_setup)
   int window_min_steps = mi355::kWindowMinStepsPerBlock;  // MI355_FLAG_WINDOW_MIN_STEPS
-  int window_kind = 1;          // MI355_FLAG_WINDOW_KIND: 1 = colorlut_tagged_kernel, 0 = colorlut_window_kernel
-  int window_order = 0;         // MI355_FLAG_WINDOW_ORDER: how the blocks share the steps (0 contiguous shares, 1 aligned fronts)
+  int window_order = 1;         // MI355_FLAG_WINDOW_ORDER: how the blocks of colorlut_window_kernel share the steps (0 contiguous shares, 1 aligned fronts: default)
   bool window_stats_on = false; // MI355_FLAG_WINDOW_STATS: the LDS-cached kernels count {pixels, pixels past the cache, bricks installed} (three atomics per wave: off by default)
   unsigned long long *d_window_counters = nullptr;  // colorlut_window.hip: {pixels, pixels past the LDS cache, bricks installed} x 1024 slots
   int blockhash_any_size = 0;  // MI355_FLAG_BLOCKHASH_ANY_SIZE

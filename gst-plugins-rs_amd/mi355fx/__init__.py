@@ -37,7 +37,6 @@ FLAG_HRTF_METHOD = 12
 FLAG_WINDOW_MIN_STEPS = 13
 FLAG_HSV_NT = 14
 FLAG_BLOCKHASH_ANY_SIZE = 15
-FLAG_WINDOW_KIND = 16
 FLAG_WINDOW_ORDER = 17
 FLAG_WINDOW_STATS = 18
 

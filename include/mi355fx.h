@@ -107,8 +107,7 @@ typedef enum mi355_flag {
   MI355_FLAG_HRTF_METHOD = 12, /* hrtfrender convolution, read at mi355_hrtf_setup: 0 (default) = overlap-save FFT in LDS from 384-tap HRIRs on (the measured crossover), time-domain FIR below; 1 = FFT, 2 = FIR pinned (each only where it fits the LDS) */
   MI355_FLAG_BLOCKHASH_ANY_SIZE = 15, /* videocompare Blockhash on frames whose width or height is not a multiple of 8: 0 (default) = MI355_ERR_UNSUPPORTED, 1 = the crate's floating-point path (blockhash_slow: every pixel whole to block (floor(x / (w/8)), floor(y / (h/8))) in f32, block sums accumulated in pixel order - one lane per block, sequential by definition, 1-2 ms per 4K frame; restated from memory like the rest of the hash: parity unpinned) */
   MI355_FLAG_HSV_NT = 14, /* hsvfilter on packed 4-byte frames: 1 = loads and stores carry the non-temporal hint. The kernel alone is ~5 % faster, but its output then bypasses the Infinity Cache and the element behind it reads from HBM (bench.py's `hsvfilter_nontemporal_ab` leg measures exactly that); default 0 */
-  MI355_FLAG_WINDOW_KIND = 16, /* LDS-cached table kernel: 1 (default) = colorlut_tagged_kernel (self-tagged 8-byte entries, one ds_read_b128 per pixel), 0 = colorlut_window_kernel (round 4: brick tags + generations); A/B knob */
-  MI355_FLAG_WINDOW_ORDER = 17, /* colorlut_tagged_kernel: how its blocks share the picture: 0 = a contiguous share of the column-major step list each, 1 = aligned fronts (the blocks of a layer walk down side by side) */
+  MI355_FLAG_WINDOW_ORDER = 17, /* LDS-cached table kernel: how its blocks share the picture: 1 (default) = aligned fronts (block b takes strip b % n_strips, layer b / n_strips; the blocks of a layer walk down side by side, so the chip streams a few bands of full rows), 0 = a contiguous share of the column-major step list each (round 4); A/B knob */
   MI355_FLAG_WINDOW_STATS = 18, /* 1 = the LDS-cached table kernels count pixels / pixels served past the cache / bricks installed for mi355_colorlut_window_stats (three atomics per wave; default 0) */
   MI355_FLAG_WINDOW_MIN_STEPS = 13, /* LDS-cached table kernel (LUT variants 0 / 8): smallest launch it serves, in 256 x 32 pixel steps per CU (default 3; 0 = any size - its first step per block runs on a cold cache, so small launches are faster through the gather kernels) */
   MI355_FLAG_BRICK_SETS = 8 /* brick-cache kernels: 0 (default) = chosen by the content watch; pinned: 32 (16 waves per CU) or 64 (8 waves per CU) sets per WAVE cache, 512 = the block-shared cache of colorlut3d_shared_kernel (512 sets per CU, RGBA8 plain colorlut, launches of at least 3 steps of 256 x 32 pixels per CU; smaller ones take the 32-set kernel); two ways each */

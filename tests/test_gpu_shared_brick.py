@@ -261,7 +261,7 @@ def test_lds_cache_kernels_take_padded_rows(ctx, oracle, synth, which, w, h, n, 
             ctx.synchronize()
             ctx.d2h(got, d_dst)
             assert (got == exp).all(), (rep, _report(got, exp))
-        assert ctx.colorlut_kernel_name() == ("colorlut3d_shared_kernel" if which == "shared" else "colorlut_tagged_kernel"), ctx.colorlut_kernel_name()
+        assert ctx.colorlut_kernel_name() == ("colorlut3d_shared_kernel" if which == "shared" else "colorlut_window_kernel"), ctx.colorlut_kernel_name()
     finally:
         ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 0)
         ctx.set_flag(mi355fx.FLAG_BRICK_SETS, 0)

@@ -14,14 +14,14 @@ pytestmark = pytest.mark.gpu
 W4K, H4K = 3840, 2160
 
 
-@pytest.fixture(autouse=True, params=[1, 0, 2, 3], ids=["tagged", "bricktags", "tile10", "tile11"])
+@pytest.fixture(autouse=True, params=[1, 0], ids=["fronts", "shares"])
 def window_kind(request, ctx):
-    """Both LDS-cached kernels serve variant 8 (MI355_FLAG_WINDOW_KIND): colorlut_tagged_kernel (round 5, the default) and
-    colorlut_window_kernel (round 4). Returns the name the library must report."""
+    """Both ways the kernel's blocks share the picture (MI355_FLAG_WINDOW_ORDER: aligned fronts - the default - and round 4's
+    contiguous shares), with the diagnostic counters on. Returns the name the library must report."""
     import mi355fx
-    ctx.set_flag(mi355fx.FLAG_WINDOW_KIND, request.param)
+    ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, request.param)
     ctx.set_flag(mi355fx.FLAG_WINDOW_STATS, 1)
-    return ("colorlut_window_kernel", "colorlut_tagged_kernel", "colorlut_tilecache_kernel", "colorlut_tilecache_kernel")[request.param]
+    return "colorlut_window_kernel"
 
 
 def _load_cube(ctx, oracle, text):

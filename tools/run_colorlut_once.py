@@ -18,6 +18,8 @@ lut = parse_cube(synth.cube_text_3d(33))
 ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
 ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, variant)
 ctx.set_flag(mi355fx.FLAG_BRICK_SETS, sets)
+if os.environ.get("ORDER"):   # MI355_FLAG_WINDOW_ORDER of the LDS-cached table kernel (variant 8)
+    ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, int(os.environ["ORDER"]))
 if amp < 0:
     frames = np.stack([synth.noise_frame(W, H, seed=11 + i) for i in range(N)]).reshape(-1)
 else:

@@ -15,11 +15,10 @@ W, H, N = 3840, 2160, 8
 
 def main():
     amps = [int(a) for a in sys.argv[1:]] or [0, 4, 8, 16]
-    # "8:0" / "8:1": variant 8 through colorlut_window_kernel / colorlut_tagged_kernel (MI355_FLAG_WINDOW_KIND)
+    # "8:0" / "8:1": variant 8 (colorlut_window_kernel) with MI355_FLAG_WINDOW_ORDER 0 (contiguous shares) / 1 (aligned fronts)
     specs = os.environ.get("VARIANTS", "5,8:0,8:1,6").split(",")
     variants = list(range(len(specs)))
-    # third field: MI355_FLAG_WINDOW_ORDER (0 contiguous shares, 1 aligned fronts)
-    vk = [tuple(int(y) for y in (x.split(":") + ["1", "0"])[:3]) if ":" in x else (int(x), 1, 0) for x in specs]
+    vk = [(int(x.split(":")[0]), int(x.split(":")[1]) if ":" in x else 1) for x in specs]
     ctx = mi355fx.Context(0)
     lut = parse_cube(synth.cube_text_3d(33))
     rng = np.random.default_rng(2)
@@ -42,8 +41,7 @@ def main():
             for v in variants:
                 ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
                 ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, vk[v][0])
-                ctx.set_flag(mi355fx.FLAG_WINDOW_KIND, vk[v][1])
-                ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, vk[v][2])
+                ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, vk[v][1])
                 ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", 3)
                 res[v] = min(ctx.time_colorlut_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, "RGBA", 20) for _ in range(3))
                 if vk[v][0] == 8:
@@ -59,8 +57,7 @@ def main():
     for v in variants:
         ctx.colorlut_load(lut.is3d, lut.size, lut.table, lut.domain_scale, lut.domain_offset)
         ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, vk[v][0])
-        ctx.set_flag(mi355fx.FLAG_WINDOW_KIND, vk[v][1])
-        ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, vk[v][2])
+        ctx.set_flag(mi355fx.FLAG_WINDOW_ORDER, vk[v][1])
         for _ in range(3):
             ctx.hsv_colorlut_frames_device(d_src, H * W * 4, W * 4, d_dst, H * W * 4, W * 4, N, W, H, st)
         ctx.synchronize()
