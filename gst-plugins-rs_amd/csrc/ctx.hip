@@ -145,6 +145,7 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   loudnorm_release(ctx);
   loudnorm_batch_release(ctx);
   dssim_release(ctx);
+  roundedcorners_release(ctx);
   ebur128_release(ctx);
   hrtf_release(ctx);
   sofa_release(ctx);
@@ -218,6 +219,7 @@ int mi355_memcpy_h2d(mi355_ctx *ctx, void *dptr, const void *host, size_t bytes)
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
   int rc = check_hip(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
+  ctx->n_h2d++;
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -226,6 +228,7 @@ int mi355_memcpy_d2h(mi355_ctx *ctx, void *host, const void *dptr, size_t bytes)
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
   int rc = check_hip(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
+  ctx->n_d2h++;
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -268,10 +271,12 @@ int mi355_hsvfilter_frame_ip(mi355_ctx *ctx, uint8_t *data, size_t data_len, int
   if (rc) return rc;
   uint8_t *d = (uint8_t *)ctx->d_stage[0];
   rc = check_hip(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D frame)");
+  ctx->n_h2d++;
   if (rc) return rc;
   rc = launch_hsvfilter(ctx, d, 1, bytes, width, (int)rows, stride, fmt, *settings);
   if (rc) return rc;
   rc = check_hip(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H frame)");
+  ctx->n_d2h++;
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvfilter: stream synchronize");
 }
@@ -337,13 +342,16 @@ int mi355_hsvdetect_frame(mi355_ctx *ctx, const uint8_t *src, size_t src_len, in
   if (rc) return rc;
   uint8_t *ds = (uint8_t *)ctx->d_stage[0], *dd = (uint8_t *)ctx->d_stage[1];
   rc = check_hip(ctx, hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D src)");
+  ctx->n_h2d++;
   if (rc) return rc;
   // only out_line[..width*4] is written by the reference: bring the rest of dst over unchanged
   rc = check_hip(ctx, hipMemcpyAsync(dd, dst, db, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D dst)");
+  ctx->n_h2d++;
   if (rc) return rc;
   rc = launch_hsvdetect(ctx, ds, sb, src_stride, sfmt, dd, db, dst_stride, af, bgr, 1, width, (int)rows_in, *settings);
   if (rc) return rc;
   rc = check_hip(ctx, hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H dst)");
+  ctx->n_d2h++;
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvdetector: stream synchronize");
 }

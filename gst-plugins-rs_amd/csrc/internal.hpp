@@ -97,6 +97,10 @@ struct mi355_ctx {
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
   void *loudnorm_batch = nullptr;  // mi355::LoudNormBatch (loudnorm.hip): n streams in lock step
   void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
+  void *rounded = nullptr;     // mi355::RoundedMask (roundedcorners.hip): the element's alpha plane, device-resident
+  // host <-> device copies this context has enqueued through the library's own entry points and mi355_buf objects (tests assert
+  // that a chain of elements on device buffers costs ONE upload and ONE download: mi355_ctx_transfer_counts)
+  unsigned long long n_h2d = 0, n_d2h = 0;
   bool force_generic = false;
   int fused_variant = 0;  // MI355_FLAG_FUSED_VARIANT
   int lut_variant = 0;    // MI355_FLAG_LUT_VARIANT
@@ -201,6 +205,7 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
                          int channels, double *out);
 int dssim_cbrt_selftest(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 void dssim_release(mi355_ctx *ctx);
+void roundedcorners_release(mi355_ctx *ctx);
 int dssim_image_plane(mi355_ctx *ctx, const mi355_dssim_image *img, int scale, int channel, int kind, float *out, int *w, int *h);
 int hrtf_load_sphere(mi355_ctx *ctx, const unsigned char *bytes, size_t n, uint32_t device_rate);
 int hrtf_setup(mi355_ctx *ctx, int channels, int block_len, int steps);

@@ -1067,6 +1067,7 @@ static bool draw_rounded_mask(void **cairo_handle, uint8_t *alpha, size_t alpha_
 }
 
 bool RoundedCorners::generate_alpha_mask(uint32_t radius) {
+  device_mask_stale_ = true;
   return draw_rounded_mask(&cairo_, alpha_mem_.data(), alpha_mem_.size(), width_, height_, alpha_stride_, radius, last_error_);
 }
 
@@ -1093,9 +1094,27 @@ FlowReturn RoundedCorners::prepare_output_buffer(const uint8_t **alpha, size_t *
   return FlowReturn::Ok;
 }
 
+FlowReturn RoundedCorners::prepare_output_buffer_device(uint8_t *d_frames, size_t frame_pitch, size_t alpha_offset, int n_frames) {
+  const uint8_t *alpha = nullptr;
+  size_t size = 0;
+  int stride = 0;
+  const FlowReturn r = prepare_output_buffer(&alpha, &size, &stride);  // regenerates the plane if the radius changed (imp.rs:490-497)
+  if (r != FlowReturn::Ok || passthrough_) return r;
+  std::lock_guard<std::mutex> g(settings_mutex_);
+  if (!ctx_) { last_error_ = "roundedcorners: no device context"; return FlowReturn::Error; }
+  if (device_mask_stale_) {
+    const int rc = mi355_roundedcorners_set_mask(ctx_, alpha_mem_.data(), width_, height_, alpha_stride_);
+    if (rc) return flow_from_status(rc);
+    device_mask_stale_ = false;
+  }
+  return flow_from_status(mi355_roundedcorners_append_device(ctx_, d_frames, frame_pitch, alpha_offset, n_frames));
+}
+
 bool RoundedCorners::stop() {
   std::lock_guard<std::mutex> g(settings_mutex_);
   have_state_ = false;
+  device_mask_stale_ = true;
+  if (ctx_) (void)mi355_roundedcorners_set_mask(ctx_, nullptr, 0, 0, 0);
   alpha_mem_.clear();
   started_ = false;
   return true;
@@ -1501,6 +1520,12 @@ int mi355el_roundedcorners_prepare(mi355el *h, uint8_t *out, size_t capacity, si
   if (stride) *stride = st;
   if (a && out && n) std::memcpy(out, a, n < capacity ? n : capacity);
   return (int)r;
+}
+// device-resident A420 batch: plane 3 of every frame written by one launch on the element's context
+int mi355el_roundedcorners_prepare_device(mi355el *h, uint8_t *d_frames, size_t frame_pitch, size_t alpha_offset, int n_frames) {
+  auto *e = h ? dynamic_cast<RoundedCorners *>(h->e.get()) : nullptr;
+  if (!e) return (int)FlowReturn::Error;
+  return (int)e->prepare_output_buffer_device(d_frames, frame_pitch, alpha_offset, n_frames);
 }
 int mi355el_roundedcorners_src_formats(mi355el *h) {  // bit 0: I420 offered, bit 1: A420 offered
   auto *e = h ? dynamic_cast<RoundedCorners *>(h->e.get()) : nullptr;

@@ -317,7 +317,8 @@ class AudioLoudNorm final : public Element {
 // There is NO per-pixel work per buffer in the reference: an A8 alpha plane is rendered once per caps / radius
 // change with cairo (four arcs, antialiased fill + 1 px stroke, imp.rs:57-180) and the same memory is appended to every
 // output buffer (imp.rs:444-480, :482-559). The mask bytes are defined by cairo's rasteriser, so this mirror renders
-// them the same way — through the system libcairo, loaded at run time — and nothing runs on the device.
+// them the same way — through the system libcairo, loaded at run time. The device holds a copy of the plane for
+// device-resident streams (csrc/roundedcorners.hip): prepare_output_buffer_device.
 class RoundedCorners final : public Element {
  public:
   explicit RoundedCorners(int device);
@@ -337,6 +338,10 @@ class RoundedCorners final : public Element {
   // prepare_output_buffer (imp.rs:482-559): regenerates the mask when the radius changed, then hands out the shared
   // alpha plane that the element appends to the buffer (plane 3 of A420)
   FlowReturn prepare_output_buffer(const uint8_t **alpha, size_t *size, int *stride);
+  // the same for device-resident frames: the plane is kept in HBM (uploaded when it was regenerated) and written behind the
+  // I420 planes of n_frames frames (frame f's plane 3 at d_frames + f * frame_pitch + alpha_offset) by one launch
+  // (mi355_roundedcorners_set_mask / _append_device). Passthrough: nothing is written.
+  FlowReturn prepare_output_buffer_device(uint8_t *d_frames, size_t frame_pitch, size_t alpha_offset, int n_frames);
   bool stop() override;
 
  private:
@@ -347,6 +352,7 @@ class RoundedCorners final : public Element {
   bool generate_alpha_mask(uint32_t radius);
   uint32_t border_radius_px_ = 0;  // DEFAULT_BORDER_RADIUS (imp.rs:27)
   bool changed_ = false, have_state_ = false, passthrough_ = true;
+  bool device_mask_stale_ = true;  // the plane in HBM is not the one in alpha_mem_
   int width_ = 0, height_ = 0, alpha_stride_ = 0;
   std::vector<uint8_t> alpha_mem_;
   void *cairo_ = nullptr;  // dlopen handle

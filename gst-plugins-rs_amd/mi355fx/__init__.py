@@ -85,6 +85,19 @@ def load_library():
         "mi355_device_free": (i, [vp, vp]),
         "mi355_memcpy_h2d": (i, [vp, vp, vp, sz]),
         "mi355_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "mi355_buf_alloc": (vp, [vp, sz]),
+        "mi355_buf_ref": (vp, [vp]),
+        "mi355_buf_unref": (None, [vp]),
+        "mi355_buf_size": (sz, [vp]),
+        "mi355_buf_device_ptr": (vp, [vp, vp, i]),
+        "mi355_buf_commit": (i, [vp, vp]),
+        "mi355_buf_map_host": (vp, [vp, i]),
+        "mi355_buf_unmap_host": (i, [vp]),
+        "mi355_buf_state": (i, [vp]),
+        "mi355_ctx_transfer_counts": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "mi355_roundedcorners_set_mask": (i, [vp, u8p, i, i, i]),
+        "mi355_roundedcorners_mask_device": (i, [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]),
+        "mi355_roundedcorners_append_device": (i, [vp, u8p, sz, sz, i]),
         "mi355_hsvfilter_frame_ip": (i, [vp, u8p, sz, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_hsvfilter_frames_device": (i, [vp, u8p, i, sz, i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_hsvdetect_frame": (i, [vp, u8p, sz, i, i, u8p, sz, i, i, i, C.POINTER(HsvDetectSettings)]),
@@ -228,6 +241,58 @@ class StreamsRound:
             raise Mi355Error(rc, "mi355_issue_streams_round")
 
 
+MAP_READ, MAP_WRITE = 1, 2
+
+
+class DeviceBuffer:
+    """mi355_buf: HBM + lazily created pinned shadow + dirty tracking (include/mi355fx.h "device buffers")."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.L, self.h = ctx, ctx.L, handle
+
+    @property
+    def size(self):
+        return int(self.L.mi355_buf_size(self.h))
+
+    def device_ptr(self, ctx=None, flags=MAP_READ | MAP_WRITE):
+        c = ctx or self.ctx
+        p = self.L.mi355_buf_device_ptr(self.h, c.h, flags)
+        if not p:
+            raise Mi355Error(ERR_INVALID_ARG, (self.L.mi355_ctx_last_error(c.h) or b"").decode())
+        return p
+
+    def commit(self, ctx=None):
+        (ctx or self.ctx)._ck(self.L.mi355_buf_commit(self.h, (ctx or self.ctx).h))
+
+    def map(self, flags=MAP_READ):
+        """numpy view of the pinned shadow (valid until unmap)."""
+        p = self.L.mi355_buf_map_host(self.h, flags)
+        if not p:
+            raise Mi355Error(ERR_INVALID_ARG, (self.L.mi355_ctx_last_error(self.ctx.h) or b"").decode())
+        return np.ctypeslib.as_array((C.c_uint8 * self.size).from_address(p))
+
+    def unmap(self):
+        self.ctx._ck(self.L.mi355_buf_unmap_host(self.h))
+
+    def write(self, arr):
+        v = self.map(MAP_WRITE)
+        v[:] = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+        self.unmap()
+
+    def read(self):
+        v = self.map(MAP_READ).copy()
+        self.unmap()
+        return v
+
+    def state(self):
+        return self.L.mi355_buf_state(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.mi355_buf_unref(self.h)
+            self.h = None
+
+
 class Group:
     """Frames of many streams in few launches (mi355_group_*): submit_chain never blocks, wait(ticket) flushes if need be."""
 
@@ -354,6 +419,36 @@ class Context:
     def d2h(self, arr, dptr):
         assert arr.flags.c_contiguous
         self._ck(self.L.mi355_memcpy_d2h(self.h, arr.ctypes.data, dptr, arr.nbytes))
+
+    # ---- device buffers (what a device GstMemory wraps) and transfer accounting
+    def buf_alloc(self, nbytes):
+        b = self.L.mi355_buf_alloc(self.h, nbytes)
+        if not b:
+            raise Mi355Error(ERR_OOM, self.L.mi355_ctx_last_error(self.h).decode())
+        return DeviceBuffer(self, b)
+
+    def transfer_counts(self):
+        """(host->device, device->host) copies this context's buffers and copy entry points have enqueued so far."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.mi355_ctx_transfer_counts(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    # ---- roundedcorners: the host-rendered alpha plane kept in HBM
+    def roundedcorners_set_mask(self, mask, width, height, stride):
+        if mask is None:
+            self._ck(self.L.mi355_roundedcorners_set_mask(self.h, None, 0, 0, 0))
+        else:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.size >= stride * ((height + 1) & ~1)
+            self._ck(self.L.mi355_roundedcorners_set_mask(self.h, mask.ctypes.data, width, height, stride))
+
+    def roundedcorners_mask_device(self):
+        p, n, st = C.c_void_p(), C.c_size_t(0), C.c_int(0)
+        self._ck(self.L.mi355_roundedcorners_mask_device(self.h, C.byref(p), C.byref(n), C.byref(st)))
+        return p.value, int(n.value), int(st.value)
+
+    def roundedcorners_append_device(self, d_frames, frame_pitch, alpha_offset, n_frames):
+        self._ck(self.L.mi355_roundedcorners_append_device(self.h, d_frames, frame_pitch, alpha_offset, n_frames))
 
     # ---- hsvfilter
     def hsvfilter_frame_ip(self, data, width, stride, fmt, settings, data_len=None):

@@ -52,6 +52,7 @@ def _lib():
             "mi355el_roundedcorners_set_caps": (i, [vp, i, i, i]),
             "mi355el_roundedcorners_prepare": (i, [vp, vp, sz, C.POINTER(sz), C.POINTER(i), C.POINTER(i)]),
             "mi355el_roundedcorners_src_formats": (i, [vp]),
+            "mi355el_roundedcorners_prepare_device": (i, [vp, vp, sz, sz, i]),
             "mi355el_loudnorm_set_caps": (i, [vp, i, i]),
             "mi355el_loudnorm_chain": (i, [vp, vp, sz, i, vp, sz, C.POINTER(sz)]),
             "mi355el_loudnorm_drain": (i, [vp, i, vp, sz, C.POINTER(sz)]),
@@ -302,6 +303,10 @@ class Element:
     def roundedcorners_src_formats(self):
         m = self.L.mi355el_roundedcorners_src_formats(self.h)
         return [f for f, bit in (("I420", 1), ("A420", 2)) if m & bit]
+
+    def roundedcorners_prepare_device(self, d_frames, frame_pitch, alpha_offset, n_frames):
+        """prepare_output_buffer for a device-resident A420 batch: returns the flow value."""
+        return self.L.mi355el_roundedcorners_prepare_device(self.h, d_frames, frame_pitch, alpha_offset, n_frames)
 
     def roundedcorners_prepare(self):
         """-> (flow, passthrough, alpha plane as (rows, stride) uint8 array or None)"""

@@ -33,6 +33,7 @@ typedef struct {
   GstBuffer *inbuf, *outbuf;
   GstVideoFrame in, out; /* mapped for the duration of the job: the library borrows the pointers until the ticket is waited for */
   uint64_t ticket;
+  gboolean device; /* both buffers are device memory of ours: nothing mapped, nothing to wait for on the host */
 } ColorLutJob;
 
 struct _GstColorLut {
@@ -118,8 +119,10 @@ static gboolean gst_color_lut_start(GstBaseTransform *trans) {
 /* ---- the one-frame-deep queue */
 
 static void color_lut_job_free(ColorLutJob *job, gboolean keep_out) {
-  gst_video_frame_unmap(&job->in);
-  gst_video_frame_unmap(&job->out);
+  if (!job->device) {
+    gst_video_frame_unmap(&job->in);
+    gst_video_frame_unmap(&job->out);
+  }
   gst_buffer_unref(job->inbuf);
   if (!keep_out) gst_buffer_unref(job->outbuf);
   g_free(job);
@@ -130,7 +133,8 @@ static GstFlowReturn color_lut_finish_oldest(GstColorLut *self, GstBuffer **outb
   ColorLutJob *job = g_queue_pop_head(&self->jobs);
   *outbuf = NULL;
   if (!job) return GST_FLOW_OK;
-  const int rc = mi355_pipe_wait(self->pipe, job->ticket);
+  /* (a device job is ordered on the device: whoever maps or uses the output memory next is ordered behind the commit) */
+  const int rc = job->device ? MI355_OK : mi355_pipe_wait(self->pipe, job->ticket);
   if (rc != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_pipe_wait: %s", mi355_ctx_last_error(self->ctx));
     color_lut_job_free(job, FALSE);
@@ -184,6 +188,40 @@ static GstFlowReturn gst_color_lut_generate_output(GstBaseTransform *trans, GstB
       gst_buffer_unref(inbuf);
       g_free(job);
       return ret != GST_FLOW_OK ? ret : GST_FLOW_ERROR;
+    }
+    {
+      /* Frames in device memory of ours (an upstream mi355 element wrote them, or upstream took the pool offered in
+       * propose_allocation) and an output buffer from a device pool: the `_device` entry points on the buffers' device
+       * pointers, no map, no PCIe (the d3d12colorlut way: imp.rs:494-560 works on the GPU resource when the memory is its own). */
+      mi355_buf *bin = gst_mi355_buffer_peek_device(inbuf), *bout = gst_mi355_buffer_peek_device(job->outbuf);
+      const int dfmt = gst_mi355_format(GST_VIDEO_INFO_FORMAT(&filter->in_info));
+      if (bin && bout && dfmt >= 0) {
+        const GstVideoInfo *ii = &filter->in_info, *oi = &filter->out_info;
+        const GstMi355HsvMeta *dhsv = dfmt == MI355_FMT_RGBA ? gst_buffer_get_mi355_hsv_meta(inbuf) : NULL;
+        const uint8_t *d_src = mi355_buf_device_ptr(bin, self->ctx, MI355_MAP_READ);
+        uint8_t *d_dst = mi355_buf_device_ptr(bout, self->ctx, MI355_MAP_WRITE);
+        int drc = d_src && d_dst ? MI355_OK : MI355_ERR_HIP;
+        if (drc == MI355_OK && dhsv)
+          drc = mi355_hsv_colorlut_frames_device(self->ctx, d_src, GST_VIDEO_INFO_SIZE(ii), GST_VIDEO_INFO_PLANE_STRIDE(ii, 0), d_dst, GST_VIDEO_INFO_SIZE(oi),
+                                                 GST_VIDEO_INFO_PLANE_STRIDE(oi, 0), 1, GST_VIDEO_INFO_WIDTH(ii), GST_VIDEO_INFO_HEIGHT(ii), &dhsv->settings);
+        else if (drc == MI355_OK)
+          drc = mi355_colorlut_frames_device(self->ctx, d_src, GST_VIDEO_INFO_SIZE(ii), GST_VIDEO_INFO_PLANE_STRIDE(ii, 0), d_dst, GST_VIDEO_INFO_SIZE(oi),
+                                             GST_VIDEO_INFO_PLANE_STRIDE(oi, 0), 1, GST_VIDEO_INFO_WIDTH(ii), GST_VIDEO_INFO_HEIGHT(ii), dfmt);
+        if (drc == MI355_OK) drc = mi355_buf_commit(bin, self->ctx);
+        if (drc == MI355_OK) drc = mi355_buf_commit(bout, self->ctx);
+        if (drc != MI355_OK) {
+          GST_ERROR_OBJECT(self, "colorlut on device memory: %s", mi355_ctx_last_error(self->ctx));
+          gst_buffer_unref(inbuf); gst_buffer_unref(job->outbuf); g_free(job);
+          return GST_FLOW_ERROR;
+        }
+        if (dhsv) {
+          GstMeta *m = gst_buffer_get_meta(job->outbuf, GST_MI355_HSV_META_API_TYPE);
+          if (m) gst_buffer_remove_meta(job->outbuf, m);
+        }
+        job->device = TRUE;
+        g_queue_push_tail(&self->jobs, job);
+        return color_lut_finish_oldest(self, outbuf); /* no host work to overlap: the frame goes downstream at once, in order */
+      }
     }
     if (!gst_video_frame_map(&job->in, &filter->in_info, inbuf, GST_MAP_READ)) {
       gst_buffer_unref(inbuf); gst_buffer_unref(job->outbuf); g_free(job);
@@ -302,7 +340,10 @@ static gboolean gst_color_lut_stop(GstBaseTransform *trans) {
 static gboolean gst_color_lut_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query) {
   GstColorLut *self = GST_COLOR_LUT(trans);
   if (!GST_BASE_TRANSFORM_CLASS(gst_color_lut_parent_class)->propose_allocation(trans, decide_query, query)) return FALSE;
-  if (self->ctx) (void)gst_mi355_propose_pinned_pool(trans, query);
+  if (self->ctx) {
+    (void)gst_mi355_propose_device_pool(trans, query); /* first choice: frames stay in HBM between mi355 elements */
+    (void)gst_mi355_propose_pinned_pool(trans, query);
+  }
   return TRUE;
 }
 

@@ -106,8 +106,45 @@ static GstCaps *gst_hsv_detector_transform_caps(GstBaseTransform *trans, GstPadD
 static gboolean gst_hsv_detector_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query) {
   GstHsvDetector *self = GST_HSV_DETECTOR(trans);
   if (!GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->propose_allocation(trans, decide_query, query)) return FALSE;
-  if (self->ctx) (void)gst_mi355_propose_pinned_pool(trans, query);
+  if (self->ctx) {
+    (void)gst_mi355_propose_device_pool(trans, query); /* first choice: frames stay in HBM between mi355 elements */
+    (void)gst_mi355_propose_pinned_pool(trans, query);
+  }
   return TRUE;
+}
+
+static gboolean gst_hsv_detector_decide_allocation(GstBaseTransform *trans, GstQuery *query) {
+  if (!GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->decide_allocation(trans, query)) return FALSE;
+  return gst_mi355_decide_device_pool(trans, query);
+}
+
+/* GstBaseTransformClass::transform, in front of GstVideoFilter's (which maps both buffers): input and output in our device
+ * memory run mi355_hsvdetect_frames_device on them - no host copy; anything else goes the mapped way (transform_frame below). */
+static GstFlowReturn gst_hsv_detector_transform(GstBaseTransform *trans, GstBuffer *inbuf, GstBuffer *outbuf) {
+  GstHsvDetector *self = GST_HSV_DETECTOR(trans);
+  GstVideoFilter *vf = GST_VIDEO_FILTER(trans);
+  mi355_buf *bin = gst_mi355_buffer_peek_device(inbuf), *bout = gst_mi355_buffer_peek_device(outbuf);
+  if (!bin || !bout || !vf->negotiated) return GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->transform(trans, inbuf, outbuf);
+  mi355_hsvdetect_settings s;
+  g_mutex_lock(&self->lock);
+  s = self->settings;
+  g_mutex_unlock(&self->lock);
+  const GstVideoInfo *ii = &vf->in_info, *oi = &vf->out_info;
+  const int in_fmt = gst_mi355_format(GST_VIDEO_INFO_FORMAT(ii)), out_fmt = gst_mi355_format(GST_VIDEO_INFO_FORMAT(oi));
+  if (in_fmt < 0 || out_fmt < 0) return GST_FLOW_NOT_NEGOTIATED;
+  const uint8_t *d_src = mi355_buf_device_ptr(bin, self->ctx, MI355_MAP_READ);
+  uint8_t *d_dst = mi355_buf_device_ptr(bout, self->ctx, MI355_MAP_WRITE);
+  int rc = d_src && d_dst ? MI355_OK : MI355_ERR_HIP;
+  if (rc == MI355_OK)
+    rc = mi355_hsvdetect_frames_device(self->ctx, d_src, GST_VIDEO_INFO_SIZE(ii), GST_VIDEO_INFO_PLANE_STRIDE(ii, 0), in_fmt, d_dst, GST_VIDEO_INFO_SIZE(oi),
+                                       GST_VIDEO_INFO_PLANE_STRIDE(oi, 0), out_fmt, 1, GST_VIDEO_INFO_WIDTH(ii), GST_VIDEO_INFO_HEIGHT(ii), &s);
+  if (rc == MI355_OK) rc = mi355_buf_commit(bin, self->ctx);
+  if (rc == MI355_OK) rc = mi355_buf_commit(bout, self->ctx);
+  if (rc != MI355_OK) {
+    GST_ERROR_OBJECT(self, "mi355_hsvdetect_frames_device: %s", mi355_ctx_last_error(self->ctx));
+    return GST_FLOW_ERROR;
+  }
+  return GST_FLOW_OK;
 }
 
 /* VideoFilterImpl::transform_frame (imp.rs:423-707) */
@@ -165,6 +202,8 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass) {
   trans->stop = gst_hsv_detector_stop;
   trans->transform_caps = gst_hsv_detector_transform_caps;
   trans->propose_allocation = gst_hsv_detector_propose_allocation;
+  trans->decide_allocation = gst_hsv_detector_decide_allocation;
+  trans->transform = gst_hsv_detector_transform; /* GstVideoFilter's transform is reached by chaining up */
   trans->passthrough_on_same_caps = FALSE;     /* imp.rs:376 */
   trans->transform_ip_on_passthrough = FALSE;  /* imp.rs:377 */
   vfilter->transform_frame = gst_hsv_detector_transform_frame; /* only the non-ip slot == BaseTransformMode::NeverInPlace */

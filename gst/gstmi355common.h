@@ -32,6 +32,31 @@ gboolean gst_mi355_propose_pinned_pool(GstBaseTransform *trans, GstQuery *query)
 /* a pinned video pool for `caps`, configured (decide_allocation of an element that allocates its own output) */
 GstBufferPool *gst_mi355_pinned_pool_new(GstCaps *caps, const GstVideoInfo *info);
 
+/* ---- device memory: GstMemory over mi355_buf (include/mi355fx.h "device buffers"; csrc/buf.hip). Precedent:
+ * video/colorlut/src/d3d12colorlut/imp.rs:385-492 - propose_allocation offers upstream a pool of GPU memory, decide_allocation
+ * picks one for the output, and an element whose input memory is "ours" works on the GPU resource directly while anything else
+ * maps the memory and gets bytes. Here: mem_map = mi355_buf_map_host (the pinned shadow, downloaded only if the device side is
+ * newer), mem_unmap = mi355_buf_unmap_host (a WRITE map makes the host side newer: the next device use uploads it). The video
+ * shims look at their input / output buffers BEFORE GstVideoFilter maps them (they override GstBaseTransformClass::transform):
+ * two buffers of ours run the `_device` entry point on mi355_buf_device_ptr and are committed; anything else chains up and is
+ * mapped as before. `hsvdetector ! colorlut ! videocompare` then costs one upload and one download in total
+ * (tests/test_gpu_buf.py runs exactly that through the C ABI). NOTHING of this file has ever run inside GStreamer: this image
+ * has no GStreamer; `make -C gst syntax` compiles it against tests/gst_stub. */
+#define GST_MI355_DEVICE_MEMORY_TYPE "Mi355DeviceMemory"
+#define GST_CAPS_FEATURE_MEMORY_MI355 "memory:Mi355DeviceMemory"
+#define GST_TYPE_MI355_DEVICE_ALLOCATOR (gst_mi355_device_allocator_get_type())
+G_DECLARE_FINAL_TYPE(GstMi355DeviceAllocator, gst_mi355_device_allocator, GST, MI355_DEVICE_ALLOCATOR, GstAllocator)
+GstAllocator *gst_mi355_device_allocator_new(void);
+/* the mi355_buf behind `mem` (borrowed) if the memory is ours and covers its whole buffer object, else NULL */
+mi355_buf *gst_mi355_device_memory_get_buf(GstMemory *mem);
+/* the mi355_buf of a GstBuffer that consists of exactly one whole memory of ours, else NULL (the caller maps the buffer) */
+mi355_buf *gst_mi355_buffer_peek_device(GstBuffer *buffer);
+/* propose_allocation: the device allocator and (if asked for) a video pool over it are added IN FRONT of the pinned ones */
+gboolean gst_mi355_propose_device_pool(GstBaseTransform *trans, GstQuery *query);
+/* decide_allocation, after the parent class has run: if downstream offered no pool, the output comes from a device pool of
+ * ours (a downstream element that is not ours maps it: one lazy download) */
+gboolean gst_mi355_decide_device_pool(GstBaseTransform *trans, GstQuery *query);
+
 /* ---- hsvfilter -> colorlut fusion.
  * hsvfilter asks its downstream peer `mi355-fuse-hsv` (a custom query); this shim's colorlut answers it when it runs on
  * RGBA frames. From then on hsvfilter does NOT touch the pixels: it attaches a GstMi355HsvMeta with the settings snapshot

@@ -11,7 +11,7 @@
 #include <gst/gst.h>
 #include <gst/video/video.h>
 #include <gst/video/gstvideoaggregator.h>
-#include "../include/mi355fx.h"
+#include "gstmi355common.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_video_compare_debug);
 #define GST_CAT_DEFAULT gst_video_compare_debug
@@ -149,6 +149,22 @@ static GstFlowReturn gst_video_compare_update_src_caps(GstAggregator *agg, GstCa
 
 static int gst_video_compare_format(GstVideoFormat f) { return f == GST_VIDEO_FORMAT_RGB ? MI355_FMT_RGB : (f == GST_VIDEO_FORMAT_RGBA ? MI355_FMT_RGBA : -1); }
 
+/* HasherEngine::hash_image (hashed_image.rs:24-46) of one prepared frame. A frame whose buffer is device memory of ours (an
+ * upstream mi355 element wrote it) is hashed where it lies - the aggregator has mapped it for reading, which a mi355_buf allows
+ * next to a device READ - instead of being uploaded again from the mapped bytes. */
+static int gst_video_compare_hash(GstVideoCompare *self, GstVideoFrame *f, int w, int h, int fmt, int algo, uint64_t *hash) {
+  mi355_buf *buf = gst_mi355_buffer_peek_device(f->buffer);
+  if (buf) {
+    const uint8_t *d = mi355_buf_device_ptr(buf, self->ctx, MI355_MAP_READ);
+    if (d) {
+      int rc = mi355_videocompare_hash_frames_device(self->ctx, d, GST_VIDEO_INFO_SIZE(&f->info), GST_VIDEO_FRAME_PLANE_STRIDE(f, 0), 1, w, h, fmt, algo, hash);
+      if (rc == MI355_OK) rc = mi355_buf_commit(buf, self->ctx);
+      return rc;
+    }
+  }
+  return mi355_videocompare_hash_frame(self->ctx, GST_VIDEO_FRAME_PLANE_DATA(f, 0), GST_VIDEO_FRAME_PLANE_STRIDE(f, 0), w, h, fmt, algo, hash);
+}
+
 /* VideoAggregatorImpl::aggregate_frames (imp.rs:259-388) */
 static GstFlowReturn gst_video_compare_aggregate_frames(GstVideoAggregator *vagg, GstBuffer *outbuf) {
   GstVideoCompare *self = GST_VIDEO_COMPARE(vagg);
@@ -225,11 +241,10 @@ static GstFlowReturn gst_video_compare_aggregate_frames(GstVideoAggregator *vagg
     if (ref_img) mi355_dssim_free_image(self->ctx, ref_img);
   } else {
     uint64_t ref_hash = 0;
-    rc = mi355_videocompare_hash_frame(self->ctx, GST_VIDEO_FRAME_PLANE_DATA(ref, 0), GST_VIDEO_FRAME_PLANE_STRIDE(ref, 0), w, h, rfmt, algo, &ref_hash);
+    rc = gst_video_compare_hash(self, ref, w, h, rfmt, algo, &ref_hash);
     for (guint i = 0; i < n && rc == MI355_OK; i++) {
       uint64_t hash = 0;
-      rc = mi355_videocompare_hash_frame(self->ctx, GST_VIDEO_FRAME_PLANE_DATA(frames[i], 0), GST_VIDEO_FRAME_PLANE_STRIDE(frames[i], 0), w, h,
-                                         gst_video_compare_format(GST_VIDEO_FRAME_FORMAT(frames[i])), algo, &hash);
+      rc = gst_video_compare_hash(self, frames[i], w, h, gst_video_compare_format(GST_VIDEO_FRAME_FORMAT(frames[i])), algo, &hash);
       distances[i] = mi355_videocompare_distance(algo, ref_hash, hash);
     }
   }

@@ -541,6 +541,48 @@ int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_
                                uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
                                int width, int height, int format, int iters, float *ms_per_launch);
 
+/* ---------------------------------------------------------------- device buffers: what a device GstMemory wraps
+ * Precedent: video/colorlut/src/d3d12colorlut/imp.rs:385-492 (propose_allocation / decide_allocation offer a pool of GPU
+ * memory; an element whose input memory is "ours" works on the GPU resource, anything else maps it). A mi355_buf is `size`
+ * bytes of HBM with a lazily created pinned host shadow and three-state dirty tracking (in sync / host newer / device newer):
+ *   mi355_buf_device_ptr(buf, ctx, flags)  the pointer the *_device entry points take. MI355_MAP_READ uploads the shadow first
+ *       if it is newer (on ctx's stream); MI355_MAP_WRITE marks the device side newer; ctx's stream is ordered behind the last
+ *       commit of another context (hipStreamWaitEvent, no host wait). NULL on error (mi355_ctx_last_error(ctx)).
+ *   mi355_buf_commit(buf, ctx)             call after enqueuing the kernels that use the pointer: "ctx's stream now holds the
+ *       last use of this buffer".
+ *   mi355_buf_map_host / unmap_host        GstMemory mem_map / mem_unmap: the pinned shadow; downloaded first (and the calling
+ *       thread waits) only if the device side is newer; a WRITE map makes the host side newer at unmap.
+ *   mi355_buf_ref / unref                  GstMemory copies share the buffer; the last unref waits for the device and frees.
+ *   mi355_buf_state                        0 in sync, 1 host newer, 2 device newer (diagnostics).
+ * mi355_ctx_transfer_counts: host->device / device->host copies enqueued so far by this context's buffers and by its
+ * mi355_h2d / mi355_d2h / mask uploads (a chain of elements on device buffers costs ONE upload and ONE download:
+ * tests/test_gpu_buf.py). */
+enum { MI355_MAP_READ = 1, MI355_MAP_WRITE = 2 };
+typedef struct mi355_buf mi355_buf;
+mi355_buf *mi355_buf_alloc(mi355_ctx *ctx, size_t size);
+mi355_buf *mi355_buf_ref(mi355_buf *buf);
+void mi355_buf_unref(mi355_buf *buf);
+size_t mi355_buf_size(const mi355_buf *buf);
+void *mi355_buf_device_ptr(mi355_buf *buf, mi355_ctx *ctx, int flags);
+int mi355_buf_commit(mi355_buf *buf, mi355_ctx *ctx);
+void *mi355_buf_map_host(mi355_buf *buf, int flags);
+int mi355_buf_unmap_host(mi355_buf *buf);
+int mi355_buf_state(mi355_buf *buf);
+int mi355_ctx_transfer_counts(mi355_ctx *ctx, uint64_t *h2d, uint64_t *d2h);
+
+/* ---------------------------------------------------------------- roundedcorners on device-resident frames
+ * video/videofx/src/border/imp.rs: generate_alpha_mask (:57-180) renders ONE A8 plane per caps / radius change and
+ * prepare_output_buffer (:482-559) appends that one shared memory to every buffer as plane 3 of A420 (stride[3] x
+ * round_up_2(height) bytes, :469-470). The bytes are cairo's and are rendered on the host (mi355host_rounded_corners_mask);
+ *   mi355_roundedcorners_set_mask       keeps that plane in HBM (mask == NULL: passthrough, the plane is dropped);
+ *   mi355_roundedcorners_mask_device    the shared device plane - what a device GstMemory appended to every buffer wraps
+ *                                       (no bytes move per buffer, as in the reference);
+ *   mi355_roundedcorners_append_device  writes the plane behind the I420 planes of n_frames frames (frame f's plane 3 at
+ *                                       d_frames + f * frame_pitch + alpha_offset) for consumers that want A420 contiguous: one launch. */
+int mi355_roundedcorners_set_mask(mi355_ctx *ctx, const uint8_t *mask, int width, int height, int stride);
+int mi355_roundedcorners_mask_device(mi355_ctx *ctx, const uint8_t **d_mask, size_t *size, int *stride);
+int mi355_roundedcorners_append_device(mi355_ctx *ctx, uint8_t *d_frames, size_t frame_pitch, size_t alpha_offset, int n_frames);
+
 #ifdef __cplusplus
 }
 #endif

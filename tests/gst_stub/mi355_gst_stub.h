@@ -293,6 +293,7 @@ gsize gst_buffer_get_size(GstBuffer *buffer); void gst_buffer_set_size(GstBuffer
 gboolean gst_buffer_is_writable_stub(const GstBuffer *buf);
 #define gst_buffer_is_writable(b) gst_buffer_is_writable_stub(b)
 void gst_buffer_append_memory(GstBuffer *buffer, GstMemory *mem); void gst_buffer_remove_all_memory(GstBuffer *buffer);
+guint gst_buffer_n_memory(GstBuffer *buffer); GstMemory *gst_buffer_peek_memory(GstBuffer *buffer, guint idx); gboolean gst_memory_is_type(GstMemory *mem, const gchar *mem_type);
 gboolean gst_buffer_copy_into(GstBuffer *dest, GstBuffer *src, GstBufferCopyFlags flags, gsize offset, gsize size);
 GstMeta *gst_buffer_get_meta(GstBuffer *buffer, GType api); GstMeta *gst_buffer_add_meta(GstBuffer *buffer, const GstMetaInfo *info, gpointer params); gboolean gst_buffer_remove_meta(GstBuffer *buffer, GstMeta *meta);
 GType gst_meta_api_type_register(const gchar *api, const gchar **tags); const GstMetaInfo *gst_meta_get_info(const gchar *impl);
