@@ -146,6 +146,9 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   loudnorm_batch_release(ctx);
   dssim_release(ctx);
   roundedcorners_release(ctx);
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
   ebur128_release(ctx);
   hrtf_release(ctx);
   sofa_release(ctx);
@@ -805,6 +808,44 @@ int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *co
     if (rc) return rc;
   }
   return MI355_OK;
+}
+
+// hsvfilter (in place) then colorlut for n independent batches from ONE native call. lanes == 1: everything on the context's stream,
+// as n pairs of the two element calls would be. lanes == 2: odd batches go to a side stream that forks from the context's stream
+// after batch 0 (whose launches carry any one-off work - a table build - in stream order) and joins it at the end: the batches are
+// independent, and while one lane sits in the 3-6 us between two dependent launches the other lane's kernel has the chip.
+int mi355_hsv_colorlut_chain_batches_device(mi355_ctx *ctx, uint8_t *const *d_src, uint8_t *const *d_dst, int n_batches, int n_frames, size_t frame_pitch,
+                                            int stride, int width, int height, int format, const mi355_hsv_settings *settings, int lanes) {
+  REQUIRE_CTX(ctx);
+  if (!d_src || !d_dst || !settings || n_batches < 0 || lanes < 1 || lanes > 2) return set_error(ctx, MI355_ERR_INVALID_ARG, "chain batches: bad argument");
+  BIND_DEVICE(ctx);
+  int rc = MI355_OK;
+  hipStream_t main_stream = ctx->stream;
+  const bool fork = lanes == 2 && n_batches > 1;
+  if (fork && !ctx->side_stream) {
+    if ((rc = check_hip(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "hipStreamCreate(side lane)"))) return rc;
+    if ((rc = check_hip(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming), "hipEventCreate(side lane)"))) return rc;
+    if ((rc = check_hip(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming), "hipEventCreate(side lane)"))) return rc;
+  }
+  for (int k = 0; k < n_batches && !rc; k++) {
+    if (!d_src[k] || !d_dst[k]) { rc = set_error(ctx, MI355_ERR_INVALID_ARG, "chain batches: null batch"); break; }
+    const bool side = fork && (k & 1);
+    if (fork && k == 1) {  // the side lane starts behind batch 0 (and behind everything the stream held before this call)
+      if ((rc = check_hip(ctx, hipEventRecord(ctx->side_fork, main_stream), "hipEventRecord(side lane)"))) break;
+      if ((rc = check_hip(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0), "hipStreamWaitEvent(side lane)"))) break;
+    }
+    ctx->stream = side ? ctx->side_stream : main_stream;
+    rc = mi355_hsvfilter_frames_device(ctx, d_src[k], n_frames, frame_pitch, width, height, stride, format, settings);
+    if (!rc) rc = mi355_colorlut_frames_device(ctx, d_src[k], frame_pitch, stride, d_dst[k], frame_pitch, stride, n_frames, width, height, format);
+  }
+  ctx->stream = main_stream;
+  if (fork) {  // (also after an error: whatever the side lane holds is ordered before what the caller does next)
+    if (hipEventRecord(ctx->side_join, ctx->side_stream) != hipSuccess || hipStreamWaitEvent(main_stream, ctx->side_join, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(ctx->side_stream);
+    }
+  }
+  return rc;
 }
 
 int mi355_dssim_compare_frames_device(mi355_ctx *ctx, const mi355_dssim_image *original, const uint8_t *const *d_frames, int n_frames, int stride,

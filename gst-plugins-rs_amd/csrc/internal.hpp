@@ -97,6 +97,8 @@ struct mi355_ctx {
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
   void *loudnorm_batch = nullptr;  // mi355::LoudNormBatch (loudnorm.hip): n streams in lock step
   void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
+  hipStream_t side_stream = nullptr;  // mi355_hsv_colorlut_chain_batches_device with two lanes: the second lane and its fork / join events
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
   void *rounded = nullptr;     // mi355::RoundedMask (roundedcorners.hip): the element's alpha plane, device-resident
   // host <-> device copies this context has enqueued through the library's own entry points and mi355_buf objects (tests assert
   // that a chain of elements on device buffers costs ONE upload and ONE download: mi355_ctx_transfer_counts)

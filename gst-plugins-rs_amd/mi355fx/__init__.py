@@ -85,6 +85,7 @@ def load_library():
         "mi355_device_free": (i, [vp, vp]),
         "mi355_memcpy_h2d": (i, [vp, vp, vp, sz]),
         "mi355_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "mi355_hsv_colorlut_chain_batches_device": (i, [vp, vp, vp, i, i, sz, i, i, i, i, C.POINTER(HsvSettings), i]),
         "mi355_buf_alloc": (vp, [vp, sz]),
         "mi355_buf_ref": (vp, [vp]),
         "mi355_buf_unref": (None, [vp]),
@@ -419,6 +420,19 @@ class Context:
     def d2h(self, arr, dptr):
         assert arr.flags.c_contiguous
         self._ck(self.L.mi355_memcpy_d2h(self.h, arr.ctypes.data, dptr, arr.nbytes))
+
+    def chain_batches_device(self, src_ptrs, dst_ptrs, n_frames, frame_pitch, stride, width, height, fmt, settings, lanes=1):
+        """hsvfilter in place + colorlut for len(src_ptrs) independent batches from one native call (lanes: 1 or 2 streams)."""
+        key = (tuple(src_ptrs), tuple(dst_ptrs))
+        arr = self._chain_arrays.get(key) if hasattr(self, "_chain_arrays") else None
+        if arr is None:
+            if not hasattr(self, "_chain_arrays"):
+                self._chain_arrays = {}
+            n = len(src_ptrs)
+            arr = self._chain_arrays[key] = ((C.c_void_p * n)(*src_ptrs), (C.c_void_p * n)(*dst_ptrs))
+        hs = HsvSettings(*[float(v) for v in settings])
+        self._ck(self.L.mi355_hsv_colorlut_chain_batches_device(self.h, arr[0], arr[1], len(src_ptrs), n_frames, frame_pitch, stride, width, height,
+                                                                FMT[fmt], C.byref(hs), lanes))
 
     # ---- device buffers (what a device GstMemory wraps) and transfer accounting
     def buf_alloc(self, nbytes):

@@ -541,6 +541,15 @@ int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_
                                uint8_t *d_dst, size_t dst_pitch, int dst_stride, int n_frames,
                                int width, int height, int format, int iters, float *ms_per_launch);
 
+/* hsvfilter (in place on d_src[k]) then colorlut (d_src[k] -> d_dst[k]) for n_batches independent batches of n_frames packed frames
+ * each, issued from ONE native call - what n_batches pairs of mi355_hsvfilter_frames_device + mi355_colorlut_frames_device do
+ * (video/hsv/src/hsvfilter/imp.rs:323-376 then video/colorlut/src/colorlut/imp.rs:203-223 per buffer), same kernels, same bytes.
+ * lanes: 1 = all on the context's stream; 2 = odd batches on a side stream forked after batch 0 and joined before the call
+ * returns (independent batches: one lane's launch boundary is covered by the other lane's kernel). */
+int mi355_hsv_colorlut_chain_batches_device(mi355_ctx *ctx, uint8_t *const *d_src, uint8_t *const *d_dst, int n_batches, int n_frames,
+                                            size_t frame_pitch, int stride, int width, int height, int format,
+                                            const mi355_hsv_settings *settings, int lanes);
+
 /* ---------------------------------------------------------------- device buffers: what a device GstMemory wraps
  * Precedent: video/colorlut/src/d3d12colorlut/imp.rs:385-492 (propose_allocation / decide_allocation offer a pool of GPU
  * memory; an element whose input memory is "ours" works on the GPU resource, anything else maps it). A mi355_buf is `size`

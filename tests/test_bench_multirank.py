@@ -44,6 +44,9 @@ def test_two_ranks_aggregate_over_the_slowest_rank():
     # N > 1 keeps one secondary leg: rank 0 alone on the +-4-noise content (the scaling record then shows more than amp 0)
     amp4 = d["content_sweep"]["amp4"]
     assert amp4["auto"]["frames_per_s"] > 0 and "rank 0 alone" in amp4["measured_on"]
+    assert sorted(d["content_sweep"]) == ["amp4"]                # ... and only that one: the other legs are N = 1 business
+    for key in ("interpolating_kernel_only", "fused_chain", "other_content", "concurrent_streams", "config5"):
+        assert key not in d, key
 
 
 def test_single_process_stub_has_all_legs():
