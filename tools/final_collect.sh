@@ -2,7 +2,7 @@
 # tools/final_collect.sh <tag> — run ON THE GPU BOX: everything profiles/<tag>_* is made from, in one call (final state of a
 # round). Only gpurun_out/ travels back (<= 64 MiB): the summaries are made here, copied to gpurun_out/final_profiles/, and the
 # raw traces are deleted.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 F=gpurun_out/final_profiles
