@@ -36,10 +36,16 @@ struct AutoPolicy {
   bool table_unavailable = false;         // the table could not be allocated / built: compute kernel only
   // how much faster the kind not in use must measure to take over; samples of the kind in use averaged with the previous
   // one (smooth). The
-  // nested choice between the two table kernels sets 5 % + smoothing: behind hsvfilter they are within 5-10 % of each other,
+  // nested choice between the two table kernels sets 10 % + smoothing: behind hsvfilter they are within 5-10 % of each other,
   // single in-stream samples scatter by as much, and every flip costs 64 launches of probing at the short period
   double hysteresis = 0.03;
+  // ... and how much faster the kind in the "compute" role must measure to take the launches BACK from the table role (< 0: the
+  // same as `hysteresis`). The nested choice sets 0: the LDS-cached kernel keeps the launches only while it measures faster at all -
+  // a wrong turn towards it (behind hsvfilter the two are 5-10 % apart and single samples scatter by as much) is undone by the next
+  // sample instead of surviving until the gather kernel leads by the full margin.
+  double hysteresis_back = -1.0;
   bool smooth = false;
+  bool last_probe = false;                // the launch decided last was a learning / probe launch (auto_decide)
 };
 
 struct AutoDecision {
@@ -66,7 +72,8 @@ inline void auto_complete(AutoPolicy &A, double ms) {
     t = A.smooth && in_use && t > 0.0 ? 0.5 * (t + per_vec) : per_vec;
     if (A.t_compute > 0.0 && A.t_table > 0.0) {
       // hysteresis (3 % by default): measurements of near-equal kernels must not flip the choice back and forth
-      const bool table = A.t_table < A.t_compute * (A.table ? 1.0 + A.hysteresis : 1.0 - A.hysteresis);
+      const double back = A.hysteresis_back < 0.0 ? A.hysteresis : A.hysteresis_back;
+      const bool table = A.t_table < A.t_compute * (A.table ? 1.0 + back : 1.0 - A.hysteresis);
       if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
       else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
       A.table = table;
@@ -85,6 +92,7 @@ inline AutoDecision auto_decide(AutoPolicy &A, size_t n_vec) {
   }
   if (A.pending_kind < 0) A.vec = n_vec;
   AutoDecision D{0, false, false, false};
+  A.last_probe = A.learn < 4 || A.probe_second || (A.since_probe + 1 >= A.probe_period && A.pending_kind < 0);
   if (A.learn < 4) {
     D.kind = A.learn < 2 ? 0 : 1;
     D.discard = (A.learn & 1) == 0;

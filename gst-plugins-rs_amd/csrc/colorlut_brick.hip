@@ -653,6 +653,8 @@ __global__ __launch_bounds__(64 * brick_waves(ZN)) void colorlut3d_brick_kernel(
 #pragma unroll
           for (int i = 0; i < NP; i++) {
             if (i + 1 < NP) {
+              // (s_setprio 1 / 3 around these six reads, round 5: 0.1260 -> 0.1205 / 0.1267 ms at amp 0, 0.1492 -> 0.1577 / 0.1500 at
+              //  +-4 - noise; not kept)
 #pragma unroll
               for (int k = 0; k < 6; k++) f[(i + 1) & 1][k] = lds_r128(baddr[i + 1] + 16u * k);
             }

@@ -1752,7 +1752,10 @@ static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_
   };
   if (!window_ok) return gather();
   if (sub == kTableWindow || !pick) return window();
-  pick->hysteresis = 0.05;  // (autopick.hpp: the two table kernels are close behind hsvfilter, far apart from HBM)
+  // (autopick.hpp: the two table kernels are 5-10 % apart behind hsvfilter, 14-18 % from HBM: the LDS-cached kernel takes over
+  // with a 10 % lead and keeps the launches only while it measures faster at all)
+  pick->hysteresis = 0.10;
+  pick->hysteresis_back = 0.0;
   pick->smooth = true;
   return auto_launch(ctx, *pick, geo.n_vec, gather, []() { return (int)MI355_OK; }, window);
 }
@@ -1866,8 +1869,10 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   if (table_ok && table_variant(v))
     return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 4 ? 0 : 1, nullptr, table_variant_kernel(v));
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
+  // (the outer choice's own learning / probe launches read the table through the gather kernel: its sample of "the table" must not
+  // be whichever kernel the nested choice happens to be trying at that moment)
   return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
-                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr, kTableEither); });
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr, L.pick[0].last_probe ? kTableGather : kTableEither); });
 }
 
 // The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
@@ -1897,7 +1902,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
     L.pick[1].learn = 2;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
-                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, kTableEither); });
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, L.pick[1].last_probe ? kTableGather : kTableEither); });
 }
 
 // ---- frames of several streams in one launch (group.hip)
