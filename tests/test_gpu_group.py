@@ -308,3 +308,82 @@ def test_fused_frames_share_one_launch_and_leave_their_sources_alone(oracle, syn
             c.free(b)
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("max_batch", [16, 8])
+def test_settings_change_without_waiting_keeps_queued_frames_on_their_own_table(oracle, synth, mi355lib, max_batch):
+    """one stream, fused submits with settings A (enough for A's composed table), then - without waiting for anything -
+    with settings B until B's table is built. Frames of A are still queued (max_batch 16: never launched yet) or in flight (8)
+    when the context moves on to B: they hold a reference to A's table, so B gets a table of its own instead of a rebuild in place,
+    and every frame comes out with the settings it was submitted with."""
+    import mi355fx
+    (c, cube), = _ctxs(mi355fx, oracle, synth, 1)
+    g = mi355fx.Group(0, max_batch)
+    st_a, st_b = synth.HSV_SETTINGS["hue90"], synth.HSV_SETTINGS["mixed"]
+    w, h = 1280, 720
+    n_a, n_b = 12, 10
+    frames = [synth.smooth_frame(w, h, seed=700 + k).reshape(-1) for k in range(n_a + n_b)]
+    srcs, dsts, tickets = [], [], []
+    try:
+        for k, f in enumerate(frames):
+            srcs.append(c.alloc(f.nbytes)); dsts.append(c.alloc(f.nbytes))
+            c.h2d(srcs[k], f)
+        c.synchronize()
+        for k in range(n_a + n_b):   # no wait, no flush in between
+            tickets.append(g.submit_fused(c, srcs[k], dsts[k], w, h, w * 4, "RGBA", st_a if k < n_a else st_b))
+        g.wait_all()
+        tables = mi355fx.load_library().mi355_shared_table_count()
+        assert tables >= 1
+        for k, f in enumerate(frames):
+            g.wait(tickets[k])
+            got = np.zeros(f.nbytes, np.uint8)
+            c.d2h(got, dsts[k])
+            _, exp = _expect(oracle, cube, f, w, h, st_a if k < n_a else st_b)
+            assert (got == exp).all(), (max_batch, k, "A" if k < n_a else "B")
+    finally:
+        g.close()
+        for p in srcs + dsts:
+            c.free(p)
+        c.close()
+
+
+def test_pipeline_destroyed_while_its_frames_wait_in_the_group(oracle, synth, mi355lib):
+    """mi355_pipe_destroy in group mode. Two pipelines hand frames to a group that has not launched them yet
+    (max_batch 16, nobody waits); one pipeline is destroyed - its slot buffers are freed - before the group flushes. The destroy
+    makes the group finish that pipeline's frames first; the other pipeline's frames come out exact afterwards and nothing
+    touches freed memory (the run would fault or corrupt the survivor's output otherwise)."""
+    import mi355fx
+    w, h = 1280, 720
+    st = synth.HSV_SETTINGS["hue90"]
+    pairs = _ctxs(mi355fx, oracle, synth, 2)
+    (a, cube_a), (b, cube_b) = pairs
+    g = mi355fx.Group(0, 16)
+    pa, pb = a.pipe_create(4, w * h * 4), b.pipe_create(4, w * h * 4)
+    bufs = []
+    try:
+        a.pipe_set_group(pa, g); b.pipe_set_group(pb, g)
+        fa = [a.host_array(w * h * 4) for _ in range(3)]; oa = [a.host_array(w * h * 4) for _ in range(3)]
+        fb = [b.host_array(w * h * 4) for _ in range(3)]; ob = [b.host_array(w * h * 4) for _ in range(3)]
+        bufs = [(a, x) for x in fa + oa] + [(b, x) for x in fb + ob]
+        for k in range(3):
+            fa[k][:] = synth.smooth_frame(w, h, seed=800 + k).reshape(-1)
+            fb[k][:] = synth.smooth_frame(w, h, seed=810 + k).reshape(-1)
+        tb = []
+        for k in range(3):
+            a.pipe_submit_hsv_colorlut(pa, fa[k], w * 4, oa[k], w * 4, w, h, st)
+            tb.append(b.pipe_submit_hsv_colorlut(pb, fb[k], w * 4, ob[k], w * 4, w, h, st))
+        a.pipe_destroy(pa)          # frames of `a` are still with the group
+        pa = None
+        for k in range(3):
+            b.pipe_wait(pb, tb[k])
+            _, exp = _expect(oracle, cube_b, np.array(fb[k]), w, h, st)
+            assert (ob[k] == exp).all(), k
+        g.wait_all()
+    finally:
+        if pa is not None:
+            a.pipe_destroy(pa)
+        b.pipe_destroy(pb)
+        for c, x in bufs:
+            c.host_free(x)
+        g.close()
+        a.close(); b.close()
