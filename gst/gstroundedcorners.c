@@ -8,11 +8,16 @@
  * :565-572.
  * The reference has no per-buffer pixel loop here: the mask is drawn once per caps / radius change by cairo (four arcs,
  * antialiased fill + 1 px stroke, :57-180). The bytes are defined by cairo's rasteriser, so the mask comes from the same
- * library through mi355host_rounded_corners_mask; nothing runs on the device. */
+ * library through mi355host_rounded_corners_mask. The shared alpha memory is DEVICE memory of ours (GstMi355DeviceAllocator) when
+ * that allocator can be had: the mask is written once through a WRITE map (host side newer), the first mi355 element downstream
+ * that takes its device pointer uploads it once, and every buffer carries a reference to that one memory - as every buffer of the
+ * reference carries a reference to `alpha_mem` (:482-559). Anything that maps it gets the same bytes. (SURVEY.md §8 a8;
+ * contiguous A420 in HBM: mi355_roundedcorners_append_device, csrc/roundedcorners.hip.) */
 #include <gst/gst.h>
 #include <gst/base/gstbasetransform.h>
 #include <gst/video/video.h>
 #include "../gst-plugins-rs_amd/host/mi355fx_host.h"
+#include "gstmi355common.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_rounded_corners_debug);
 #define GST_CAT_DEFAULT gst_rounded_corners_debug
@@ -122,7 +127,14 @@ static gboolean gst_rounded_corners_set_caps(GstBaseTransform *trans, GstCaps *i
   const gsize alpha_mem_size = (gsize)GST_VIDEO_INFO_PLANE_STRIDE(&out_info, 3) * ru2_height;
   g_mutex_lock(&self->lock);
   if (self->alpha_mem) gst_memory_unref(self->alpha_mem);
-  self->alpha_mem = gst_allocator_alloc(NULL, alpha_mem_size, NULL);
+  {
+    GstAllocator *dev = gst_mi355_device_allocator_new(); /* NULL without an MI355X: plain system memory then, as the reference */
+    GstAllocationParams params;
+    gst_allocation_params_init(&params);
+    self->alpha_mem = dev ? gst_allocator_alloc(dev, alpha_mem_size, &params) : NULL;
+    if (dev) gst_object_unref(dev); /* the memory keeps its allocator alive */
+    if (!self->alpha_mem) self->alpha_mem = gst_allocator_alloc(NULL, alpha_mem_size, NULL);
+  }
   self->out_info = out_info;
   self->have_state = self->alpha_mem != NULL;
   self->changed = TRUE;
