@@ -130,6 +130,36 @@ __global__ __launch_bounds__(256) void hsvfilter_strided_kernel(uint8_t *__restr
   }
 }
 
+// The same for the common case of padded ROWS only (frame_pitch == stride * height: one tall picture of rows_total rows), without
+// the two 64-bit divisions per lane and iteration of the kernel above (~200 instructions next to the 146 of the four pixels): a
+// block is 64 lanes x 4 rows, blockIdx.x picks 64 groups of the row (1 KB contiguous per wave), blockIdx.y strides over the rows.
+// Round 5: 65 % -> see profiles/r05_configs_elements.txt.
+template <int VARIANT, int FIRST, bool BGR>
+__global__ __launch_bounds__(256) void hsvfilter_rowpad_kernel(uint8_t *__restrict__ data, unsigned rows_total, int width, int stride, HsvK k) {
+  constexpr int RPOS = FIRST + (BGR ? 2 : 0), GPOS = FIRST + 1, BPOS = FIRST + (BGR ? 0 : 2);
+  constexpr int NPOS = FIRST == 0 ? 3 : 0;
+  __shared__ HsvLds lds;
+  hsv_lds_fill<RPOS, GPOS, BPOS, NPOS>(&lds);
+  __syncthreads();
+  const uint32_t groups = ((uint32_t)width + 3u) >> 2;
+  const uint32_t g = blockIdx.x * 64u + (threadIdx.x & 63u);
+  if (g >= groups) return;
+  const int left = width - (int)(g * 4);  // pixels of this group inside the row
+  for (uint32_t r = blockIdx.y * 4u + (threadIdx.x >> 6); r < rows_total; r += gridDim.y * 4u) {
+    uint8_t *at = data + (size_t)r * (size_t)stride + (size_t)g * 16;
+    if (left >= 4) {
+      uint4 p = *(const uint4 *)at;
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(p.x, p.y, p.z, p.w, k, &lds);
+      *(uint4 *)at = p;
+    } else {
+      uint32_t px[4] = {0, 0, 0, 0};
+      for (int j = 0; j < left; j++) px[j] = ((const uint32_t *)at)[j];
+      hsvfilter_quad<VARIANT, RPOS, GPOS, BPOS, NPOS>(px[0], px[1], px[2], px[3], k, &lds);
+      for (int j = 0; j < left; j++) ((uint32_t *)at)[j] = px[j];
+    }
+  }
+}
+
 // 3-byte formats (RGB / BGR) on contiguous storage: one lane = 12 B = 4 pixels. The three dwords are
 // split into four pixel words with v_alignbit-style shifts, filtered by the same pair routine as the
 // 4-byte formats (byte 3 of each word is scratch) and re-packed.
@@ -281,6 +311,20 @@ static void launch_flat_multi(hipStream_t stream, const MultiFramePtrs &frames, 
 template <int VARIANT>
 static void launch_strided(mi355_ctx *ctx, uint8_t *d, int n_frames, size_t frame_pitch, int width, int height, int stride, const HsvK &k,
                            int first, int bgr, int grid) {
+  if ((n_frames == 1 || frame_pitch == (size_t)stride * (size_t)height) && (size_t)n_frames * (size_t)height < (1u << 31)) {
+    // padded rows only: the batch is one tall picture
+    const unsigned rows_total = (unsigned)n_frames * (unsigned)height, gx = ((unsigned)(width + 3) / 4 + 63) / 64;
+    unsigned gy = (rows_total + 3) / 4;
+    const unsigned cap = (unsigned)ctx->n_cu * (unsigned)ctx->hsv_blocks_per_cu / (gx ? gx : 1) + 1;
+    if (gy > cap) gy = cap;
+    if (gy > 65535) gy = 65535;
+    dim3 g2(gx, gy), b2(256);
+    if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_rowpad_kernel<VARIANT, 0, false>), g2, b2, 0, ctx->stream, d, rows_total, width, stride, k);
+    else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_rowpad_kernel<VARIANT, 0, true>), g2, b2, 0, ctx->stream, d, rows_total, width, stride, k);
+    else if (first == 1 && !bgr) hipLaunchKernelGGL((hsvfilter_rowpad_kernel<VARIANT, 1, false>), g2, b2, 0, ctx->stream, d, rows_total, width, stride, k);
+    else hipLaunchKernelGGL((hsvfilter_rowpad_kernel<VARIANT, 1, true>), g2, b2, 0, ctx->stream, d, rows_total, width, stride, k);
+    return;
+  }
   dim3 g(grid), b(256);
   if (first == 0 && !bgr) hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 0, false>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);
   else if (first == 0 && bgr) hipLaunchKernelGGL((hsvfilter_strided_kernel<VARIANT, 0, true>), g, b, 0, ctx->stream, d, n_frames, frame_pitch, width, height, stride, k);

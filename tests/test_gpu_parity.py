@@ -88,14 +88,16 @@ def test_hsvfilter_allcolors_wide_hue_shift(ctx, oracle, synth, st):
 @pytest.mark.parametrize("fmt,w,h,stride,n", [("RGBA", 1918, 9, 7680, 1), ("BGRx", 1921, 5, 7696, 3), ("xRGB", 637, 33, 2560, 2),
                                               ("ABGR", 4, 4, 64, 2), ("ARGB", 3, 2, 16, 1), ("RGBx", 3840, 17, 15424, 2)])
 @pytest.mark.parametrize("setting", ["hue90", "generic"])
-def test_hsvfilter_padded_rows_16_byte_aligned(ctx, oracle, synth, fmt, w, h, stride, n, setting):
+@pytest.mark.parametrize("gap", [48, 0])
+def test_hsvfilter_padded_rows_16_byte_aligned(ctx, oracle, synth, fmt, w, h, stride, n, setting, gap):
     """4-byte formats whose stride / frame pitch are padded to multiples of 16 (what aligned allocators negotiate) run
     the strided 16-B-per-lane kernel (round 3), not the one-pixel-per-lane rows kernel: widths that end inside a
-    4-pixel group, padding and inter-frame gaps untouched."""
+    4-pixel group, padding and inter-frame gaps untouched. gap 0 (frames back to back, rows padded: one tall picture) and single
+    frames take hsvfilter_rowpad_kernel (round 5: no divisions), frames with a gap between them hsvfilter_strided_kernel."""
     from mi355fx import FMT_LAYOUT
     ps, first, bgr = FMT_LAYOUT[fmt]
     st = synth.HSV_SETTINGS["hue90"] if setting == "hue90" else (float("inf"), 1.0, 0.0, 1.0, 0.0)
-    pitch = stride * h + 48
+    pitch = stride * h + gap
     rng = np.random.default_rng(5)
     frames = rng.integers(0, 256, size=pitch * n, dtype=np.uint8)
     exp = frames.copy()
