@@ -264,8 +264,11 @@ void mi355_group_destroy(mi355_group *g) {
     (void)wait_all_unlocking(g, L.lk);
   }
   (void)hipStreamSynchronize(g->stream);
+  for (Batch &b : g->batches) (void)hipEventDestroy(b.done);   // (normally none left: wait_all retired them)
+  for (Desc &d : g->pending)
+    if (d.ready) (void)hipEventDestroy(d.ready);
   g->pending.clear();
-  g->batches.clear();  // (their events are destroyed below; their table references go here, after the stream has drained)
+  g->batches.clear();  // their table references go here, after the stream has drained
   g->dead_refs.clear();
   for (hipEvent_t e : g->events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(g->stream);
