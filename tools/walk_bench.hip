@@ -28,7 +28,8 @@ __global__ __launch_bounds__(1024) void walk(const u4_t *__restrict__ src, u4_t 
   if (ORDER == 0) {
     first = blockIdx.x * share + (blockIdx.x < extra ? blockIdx.x : extra);
     last = first + share + (blockIdx.x < extra ? 1u : 0u);
-  } else if (ORDER == 1) {
+  } else if (ORDER == 1 || ORDER == 4 || ORDER == 6) {
+    // ORDER 4: aligned fronts, odd layers walk bottom-up; ORDER 6: every strip starts its share at another phase (diagonal fronts)
     const unsigned strip = blockIdx.x % n_strips, layer = blockIdx.x / n_strips;   // share = steps per layer, extra = layers
     first = strip * steps_per_strip + layer * share;
     last = first + share;
@@ -43,6 +44,8 @@ __global__ __launch_bounds__(1024) void walk(const u4_t *__restrict__ src, u4_t 
   Slot ring[DEPTH];
   auto fetch = [&](unsigned st_, Slot &S) {
     unsigned st = st_ < last ? st_ : last - 1u;
+    if (ORDER == 4 && ((blockIdx.x / n_strips) & 1u)) st = first + (last - 1u - st);
+    if (ORDER == 6) { const unsigned len = last - first, ph = ((blockIdx.x % n_strips) * len) / n_strips; st = first + ((st - first) + ph) % (len ? len : 1u); }
     unsigned strip, k;
     if (ORDER == 2) { st = st * gridDim.x + blockIdx.x; k = st / n_strips; strip = st - k * n_strips; }
     else {
@@ -295,7 +298,7 @@ static void run_walk(int blocks_per_cu_x1, int lds) {
   const unsigned n_strips = (W4 + 64 * SW - 1) / (64 * SW), sps = (ROWS + 32 / SW - 1) / (32 / SW), total = n_strips * sps;
   const unsigned grid = 256 * blocks_per_cu_x1;
   unsigned share = total / grid, extra = total % grid;
-  if (ORDER == 1) { extra = grid / n_strips; share = (sps + extra - 1) / extra; }
+  if (ORDER == 1 || ORDER == 4 || ORDER == 6) { extra = grid / n_strips; share = (sps + extra - 1) / extra; }
   const float ms = timeit([&](int k) {
     hipLaunchKernelGGL((walk<SW, DEPTH, NTL, NTS, FF, ORDER>), dim3(grid), dim3(1024), lds, 0, A[k], B[k], W4, ROWS, (unsigned)(ROWS * W4 * 16), sps, share, extra, (unsigned long long *)nullptr);
   });
@@ -388,19 +391,12 @@ int main() {
     printf("flat grid-stride copy (nt)  grid %6d : %.4f ms  %.0f GB/s\n", grid, ms, 2.0 * bytes / ms / 1e6);
   }
   const int L = 134144;
-  run_walk<1, 3, 1, 1, 0, 0>(1, L);
-  run_small<4, 3, 0>(1024, 33 * 1024);
-  run_small<4, 3, 0>(2048, 17 * 1024);
-  run_small<4, 2, 0>(2048, 17 * 1024);
-  run_small<4, 3, 2>(1024, 33 * 1024);
-  run_small<4, 3, 2>(2048, 17 * 1024);
-  run_small<4, 3, 0>(4096, 17 * 1024);
-  run_small<4, 3, 0>(8192, 17 * 1024);
-  run_small<4, 2, 0>(16384, 17 * 1024);
-  run_small<4, 1, 0>(32400, 17 * 1024);
-  run_small<8, 3, 0>(512, 65 * 1024);
-  run_small<8, 3, 0>(1024, 33 * 1024);
-  run_small<2, 3, 0>(4096, 9 * 1024);
-  run_small<1, 3, 0>(8192, 5 * 1024);
+  for (int rep = 0; rep < 2; rep++) {
+    run_walk<1, 3, 1, 1, 0, 0>(1, L);
+    run_walk<1, 3, 1, 1, 0, 1>(1, L);
+    run_walk<1, 3, 1, 1, 0, 4>(1, L);
+    run_walk<1, 3, 1, 1, 0, 6>(1, L);
+    run_walk<1, 3, 1, 1, 0, 2>(1, L);
+  }
   return 0;
 }
