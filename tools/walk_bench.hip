@@ -268,6 +268,76 @@ __global__ __launch_bounds__(NW * 64) void walk_small(const u4_t *__restrict__ s
     if (st + d < last) step(st + d, ring[d]);
 }
 
+// the flat copy as a PERSISTENT, software-pipelined loop: DEPTH loads in flight per lane, a store never waited for before the next load's
+// data is used (what the walk does, on the flat copy's linear addresses). Is it persistence or the 2D pattern that costs the walk 8-25 %?
+template <int DEPTH>
+__global__ __launch_bounds__(256) void flat_pipe(const u4_t *__restrict__ a, u4_t *__restrict__ b, size_t n) {
+  const size_t s = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u4_t v[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) v[d] = __builtin_nontemporal_load(a + (i + d * s < n ? i + d * s : n - 1));
+  for (; i + (DEPTH - 1) * s < n; i += DEPTH * s) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      u4_t x = v[d];
+      x.x ^= 1;
+      __builtin_nontemporal_store(x, b + i + d * s);
+      const size_t nx = i + (d + DEPTH) * s;
+      v[d] = __builtin_nontemporal_load(a + (nx < n ? nx : n - 1));
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+    if (i + d * s < n) { u4_t x = v[d]; x.x ^= 1; __builtin_nontemporal_store(x, b + i + d * s); }
+}
+
+// aligned fronts with NARROW strips: a row segment of a wave is 64 / NR lanes (1024 / NR bytes), a wave's load covers NR rows, a step
+// 32 * NR rows; strips = 15 * NR, layers = grid / strips: fewer, thicker bands of full rows (NR = 4: 60 strips x 4 layers of 128 rows)
+template <int NR, int DEPTH>
+__global__ __launch_bounds__(1024) void walk_narrow(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned rows, unsigned dst_bytes,
+                                                    unsigned steps_per_strip, unsigned share, unsigned layers) {
+  extern __shared__ unsigned char dyn[];
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (dyn[threadIdx.x] == 77 && rows == 1234567u) dst[0] = src[1];
+  constexpr unsigned LPR = 64 / NR, RPS = 32 * NR;  // lanes per row segment, rows per step
+  const unsigned n_strips = (w4 + LPR - 1u) / LPR;
+  const unsigned strip = blockIdx.x % n_strips, layer = blockIdx.x / n_strips;
+  unsigned first = layer * share, last = first + share;
+  if (last > steps_per_strip) last = steps_per_strip;
+  if (layer >= layers || first >= last) return;
+  const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
+  struct Slot { u4_t p, q; uint32_t o0, o1; };
+  Slot ring[DEPTH];
+  auto fetch = [&](unsigned st_, Slot &S) {
+    const unsigned k = st_ < last ? st_ : last - 1u;
+    const unsigned col = strip * LPR + (lane % LPR), r0 = k * RPS + wave * (2u * NR) + lane / LPR, r1 = r0 + NR;
+    const unsigned cc = col < w4 ? col : w4 - 1u, c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
+    S.o0 = col < w4 && r0 < rows ? (r0 * w4 + col) << 4 : 0x80000000u;
+    S.o1 = col < w4 && r1 < rows ? (r1 * w4 + col) << 4 : 0x80000000u;
+    S.p = __builtin_nontemporal_load(src + ((size_t)c0 * w4 + cc));
+    S.q = __builtin_nontemporal_load(src + ((size_t)c1 * w4 + cc));
+  };
+  auto step = [&](unsigned st, Slot &S) {
+    u4_t a = S.p, b = S.q;
+    const uint32_t so0 = S.o0, so1 = S.o1;
+    a.x ^= 1u; b.y ^= 1u;
+    __builtin_amdgcn_raw_buffer_store_b128(a, dst_rsrc, (int)so0, 0, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(b, dst_rsrc, (int)so1, 0, 2);
+    fetch(st + DEPTH, S);
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) fetch(first + d, ring[d]);
+  unsigned st = first;
+  for (; st + DEPTH <= last; st += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) step(st + d, ring[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; d++)
+    if (st + d < last) step(st + d, ring[d]);
+}
+
 __global__ __launch_bounds__(256) void flat(const u4_t *__restrict__ a, u4_t *__restrict__ b, size_t n) {
   const size_t s = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += s) { u4_t v = __builtin_nontemporal_load(a + i); v.x ^= 1; __builtin_nontemporal_store(v, b + i); }
@@ -381,6 +451,17 @@ static void run_small(unsigned grid, int lds) {
   fflush(stdout);
 }
 
+template <int NR, int DEPTH>
+static void run_narrow(int lds) {
+  const unsigned n_strips = (W4 + 64 / NR - 1) / (64 / NR), sps = (ROWS + 32 * NR - 1) / (32 * NR), layers = 256 / n_strips, share = (sps + layers - 1) / layers;
+  const float ms = timeit([&](int k) {
+    hipLaunchKernelGGL((walk_narrow<NR, DEPTH>), dim3(n_strips * layers), dim3(1024), lds, 0, A[k], B[k], W4, ROWS, (unsigned)(ROWS * W4 * 16), sps, share, layers);
+  });
+  printf("narrow strips: %3d px wide, %3d rows per step, %2u strips x %2u layers (%3u blocks)  depth %d : %.4f ms  %.0f GB/s\n", 256 / NR, 32 * NR, n_strips, layers, n_strips * layers, DEPTH, ms,
+         2.0 * ROWS * W4 * 16 / ms / 1e6);
+  fflush(stdout);
+}
+
 int main() {
   const size_t bytes = (size_t)ROWS * W4 * 16;
   for (int i = 0; i < 3; i++) { hipMalloc(&A[i], bytes); hipMalloc(&B[i], bytes); hipMemset(A[i], 1 + i, bytes); hipMemset(B[i], 0, bytes); }
@@ -390,12 +471,23 @@ int main() {
     const float ms = timeit([&](int k) { hipLaunchKernelGGL(flat, dim3(grid), dim3(256), 0, 0, A[k], B[k], bytes / 16); });
     printf("flat grid-stride copy (nt)  grid %6d : %.4f ms  %.0f GB/s\n", grid, ms, 2.0 * bytes / ms / 1e6);
   }
+  for (int grid : {1024, 2048, 4096, 8192}) {
+    const float m2 = timeit([&](int k) { hipLaunchKernelGGL(flat_pipe<2>, dim3(grid), dim3(256), 0, 0, A[k], B[k], bytes / 16); });
+    const float m3 = timeit([&](int k) { hipLaunchKernelGGL(flat_pipe<3>, dim3(grid), dim3(256), 0, 0, A[k], B[k], bytes / 16); });
+    const float m4 = timeit([&](int k) { hipLaunchKernelGGL(flat_pipe<4>, dim3(grid), dim3(256), 0, 0, A[k], B[k], bytes / 16); });
+    printf("flat persistent pipelined copy  grid %5d : depth 2 %.4f  depth 3 %.4f  depth 4 %.4f ms\n", grid, m2, m3, m4);
+  }
   const int L = 134144;
   for (int rep = 0; rep < 2; rep++) {
-    run_walk<1, 3, 1, 1, 0, 0>(1, L);
     run_walk<1, 3, 1, 1, 0, 1>(1, L);
-    run_walk<1, 3, 1, 1, 0, 4>(1, L);
-    run_walk<1, 3, 1, 1, 0, 6>(1, L);
+    run_walk<1, 2, 1, 1, 0, 1>(1, L);
+    run_narrow<1, 2>(L);
+    run_narrow<2, 2>(L);
+    run_narrow<4, 2>(L);
+    run_narrow<8, 2>(L);
+    run_narrow<16, 2>(L);
+    run_narrow<4, 1>(L);
+    run_narrow<4, 3>(L);
     run_walk<1, 3, 1, 1, 0, 2>(1, L);
   }
   return 0;
