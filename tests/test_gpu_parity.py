@@ -1283,3 +1283,30 @@ def test_colorlut_rgba64_1d_lds_kernel(ctx, oracle, synth, le, size, domain):
     oracle.colorlut_rgba64(cube, srcp.reshape(-1), ss, expp, ss, w, h, le=le)
     ctx.colorlut_frame(srcp.reshape(-1), ss, gotp, ss, w, h, fmt)
     assert (gotp == expp).all()
+
+
+@pytest.mark.parametrize("fmt", ["RGBA", "xBGR"])
+def test_hsvfilter_rowpad_kernel_4k_batch_equals_the_packed_kernel(ctx, synth, fmt):
+    """Full size: 3 x 4K frames with rows padded by 64 bytes (frames back to back: hsvfilter_rowpad_kernel, round 5) against the same
+    pixels packed (hsvfilter_flat_kernel): identical pixel bytes, padding untouched. (Both against the oracle at small sizes above.)"""
+    w, h, n, pad = 3840, 2160, 3, 64
+    st = synth.HSV_SETTINGS["mixed"]
+    rng = np.random.default_rng(77)
+    packed = np.concatenate([synth.smooth_frame(w, h, seed=60 + f).reshape(-1) if f != 1 else synth.noise_frame(w, h, seed=61).reshape(-1) for f in range(n)])
+    stride = w * 4 + pad
+    padded = rng.integers(0, 256, size=(n * h, stride), dtype=np.uint8)
+    padded[:, :w * 4] = packed.reshape(n * h, w * 4)
+    keep = padded.copy()
+    dp, dq = ctx.alloc(packed.nbytes), ctx.alloc(padded.nbytes)
+    try:
+        ctx.h2d(dp, packed); ctx.h2d(dq, padded.reshape(-1))
+        ctx.hsvfilter_frames_device(dp, n, w * h * 4, w, h, w * 4, fmt, st)
+        ctx.hsvfilter_frames_device(dq, n, stride * h, w, h, stride, fmt, st)
+        ctx.synchronize()
+        a, b = np.zeros_like(packed), np.zeros(padded.size, np.uint8)
+        ctx.d2h(a, dp); ctx.d2h(b, dq)
+    finally:
+        ctx.free(dp); ctx.free(dq)
+    b = b.reshape(n * h, stride)
+    assert (b[:, :w * 4] == a.reshape(n * h, w * 4)).all()
+    assert (b[:, w * 4:] == keep[:, w * 4:]).all()
