@@ -71,6 +71,16 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
     ap.add_argument("--shared-reference", action="store_true",
                     help="config 5: the streams are the non-reference pads of --workers videocompare elements (reference frame hashed once per aggregate)")
+    ap.add_argument("--no-group", action="store_true",
+                    help="config 5: the round-5 form (--workers contexts taking the streams in turn) instead of one element thread per stream\n"
+                         "submitting to the process's dispatcher (mi355_group_submit_compare)")
+    ap.add_argument("--hash-algo", default="dssim", choices=["dssim", "blockhash"],
+                    help="config 5: videocompare's hash-algorithm: dssim (BASELINE's 'SSIM', default) or blockhash (the element's own default)")
+    ap.add_argument("--rendezvous", type=int, default=0, help="config 5: pairs that make the dispatcher launch (0 = all streams of the rank: one launch sequence per interval)")
+    ap.add_argument("--compare-lanes", type=int, default=0, help="config 5: HIP streams of the dispatcher's compare queue (0 = library default, 8)")
+    ap.add_argument("--dssim-clock-ghz", type=float, default=2.4,
+                    help="config 5: shader clock of the VALU roofline's peak (default: the part's 2.4 GHz peak engine clock; under this load the\n"
+                         "SQ counters show less - SQ_BUSY_CYCLES / 32 SEs / kernel duration, profiles/r06_dssim_sq_counters.txt - so the fraction is conservative)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 --pmc child runs at the end (then it is quoted from\n"
                          "profiles/pmc_latest.json when that profile carries this code's fingerprint, else null)")
@@ -352,25 +362,101 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
+# Measured VALU cost of the Dssim kernels (profiles/r06_dssim_sq_counters.txt, 4K scale 0 launches, SQ_INSTS_VALU x 64 lanes / pixels):
+# dssim_scale_fused_kernel (the reference frame's hash) 522 and dssim_hash_compare_kernel (the other frame hashed + compared) 772
+# VALU instructions per pixel of the scale; the five scales together are 1 + 1/4 + ... = 1.332 scale-0 images. SQ_ACTIVE_INST_VALU x 4
+# / SQ_INSTS_VALU = 4.07 cycles per wave instruction (exact f32: unfused mul / add, IEEE division sequences, v_pk_* pairs).
+DSSIM_VALU_PER_PIXEL_PAIR = 522.0 + 772.0
+DSSIM_SCALE_SUM = 1.0 + 0.25 + 0.0625 + 0.015625 + 0.00390625
+DSSIM_CYCLES_PER_VALU = 4.07
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+
+
+def _valu_roofline(comps_per_gpu, clock_ghz):
+    """The Dssim pair against the VALU issue roofline: wave instructions per second the comparisons need / what 1024 SIMDs issue."""
+    wave_instr = DSSIM_VALU_PER_PIXEL_PAIR * DSSIM_SCALE_SUM * W * H / 64.0
+    achieved = comps_per_gpu * wave_instr / 1e9                 # G wave-instructions / s
+    peak = N_SIMD * clock_ghz / DSSIM_CYCLES_PER_VALU           # G wave-instructions / s
+    return {"bound": "valu", "kernel": "dssim_scale_fused_kernel + dssim_hash_compare_kernel", "instr_per_pixel": DSSIM_VALU_PER_PIXEL_PAIR,
+            "wave_instr_per_comparison": wave_instr, "cycles_per_instr": DSSIM_CYCLES_PER_VALU, "clock_ghz": clock_ghz,
+            "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
+            "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per launch, profiles/r06_dssim_sq_counters.txt; clock = SQ_BUSY_CYCLES / 32 SEs / kernel duration of the same pass"}
+
+
+def _install_stub_config5(mi355fx, rank):
+    """--stub for config 5: contexts and a dispatcher that sleep instead of launching (CPU test of the N > 1 control flow)."""
+    global W, H, FRAME_BYTES
+    W, H = 64, 16
+    FRAME_BYTES = W * H * 4
+    import itertools
+    import threading
+
+    class Ctx:
+        def __init__(self, device):
+            self.h = object()
+
+        def alloc(self, n): return 1
+        def h2d(self, *a): pass
+        def free(self, *a): pass
+        def close(self): pass
+        def videocompare_hash_frames_device(self, *a): time.sleep(0.0005 * (1 + rank)); return [0]
+        def videocompare_distance(self, *a): return 0.0
+        def dssim_create_image_device(self, *a): return 1
+        def dssim_free_image(self, *a): pass
+        def dssim_compare(self, *a): time.sleep(0.001 * (1 + rank)); return 0.25
+        def dssim_compare_frames_device(self, x, frames, *a): time.sleep(0.001 * (1 + rank) * len(frames)); return [0.25] * len(frames)
+
+    class Grp:
+        def __init__(self, device=0, max_batch=0):
+            self.tk, self.lock, self.n = itertools.count(1), threading.Lock(), 0
+
+        def set_rendezvous(self, *a): pass
+        def set_compare_lanes(self, *a): pass
+        def submit_compare(self, *a): return next(self.tk)
+
+        def wait_compare(self, t):
+            time.sleep(0.001 * (1 + rank))   # rank 1 is slower: the reported time must be the MAX over ranks
+            with self.lock:
+                self.n += 1
+            return 0.25, 0, 0
+
+        def compare_stats(self): return (self.n, self.n, 1)
+        def close(self): pass
+
+    mi355fx.Context, mi355fx.Group = Ctx, Grp
+
+
 def run_config5(args, rank, local_rank, world):
     """BASELINE config 5: 256 concurrent 4K streams through videocompare's SSIM engine = 32 streams per GPU. Every stream is a
     pair of resident 4K RGBA frames (the natural-like frame and the same frame + noise of sigma 2, SURVEY.md 8d synthetic (8));
     a step = one comparison per stream the way the element does it (hash_image of the reference frame; the other frame hashed and compared,
-    video/videofx/src/videocompare/hashed_image.rs:24-79). The streams are independent and sharded over the ranks; `--workers`
-    host threads per rank, each with its own context and HIP stream, take the rank's streams in turn (the calls release the
-    GIL and return a double, so a context is busy until its comparison is done). Timing: gloo barrier + MAX over ranks."""
+    video/videofx/src/videocompare/hashed_image.rs:24-79). The streams are independent and sharded over the ranks.
+    Default (round 6): every stream is its own two-pad element on its own host thread with its own context, submitting its pair to
+    the process's dispatcher and waiting for its score (mi355_group_submit_compare / _wait_compare: the interval's pairs are ONE
+    launch sequence). --no-group: the round-5 form, `--workers` host threads per rank, each with its own context and HIP stream,
+    taking the rank's streams in turn. Timing: gloo barrier + MAX over ranks."""
     import threading
-    import torch
     import mi355fx
     from mi355fx import sharding, synth
-    torch.cuda.set_device(local_rank)
+    stub = bool(getattr(args, "stub", False))
+    if stub:
+        _install_stub_config5(mi355fx, rank)
+        device_sync = lambda: None
+    else:
+        import torch
+        torch.cuda.set_device(local_rank)
+        device_sync = torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         dist = dist_mod
-    n_streams, n_workers = args.streams, max(1, min(args.workers, args.streams))
+    shared_ref = bool(getattr(args, "shared_reference", False))
+    two_step = bool(getattr(args, "dssim_two_step", False))   # round-2 form: create_image for every frame, then compare
+    use_group = not bool(getattr(args, "no_group", False)) and not shared_ref and not two_step
+    n_streams = args.streams
+    n_workers = n_streams if use_group else max(1, min(args.workers, args.streams))
     rng = np.random.default_rng(1234 + rank)
     base = synth.smooth_frame(W, H)
     noisy = base.reshape(H, W, 4).astype(np.int16)
@@ -387,13 +473,30 @@ def run_config5(args, rank, local_rank, world):
         c.h2d(da, a.reshape(-1)); c.h2d(db, b.reshape(-1))
         frames.append((da, db))
     results = [0.0] * n_streams
-
-    shared_ref = bool(getattr(args, "shared_reference", False))
-    two_step = bool(getattr(args, "dssim_two_step", False))   # round-2 form: create_image for every frame, then compare
+    algo_code = 4 if getattr(args, "hash_algo", "dssim") == "blockhash" else 5
+    group = None
+    if use_group:
+        group = mi355fx.Group(local_rank)
+        if getattr(args, "compare_lanes", 0):
+            group.set_compare_lanes(args.compare_lanes)
+        group.set_rendezvous(getattr(args, "rendezvous", 0) or n_streams, 5000)   # every element submits + waits at once; a straggler is waited for 5 ms at most
 
     def serve(w, steps):
         c = ctxs[w]
         for _ in range(steps):
+            if use_group:
+                # one two-pad videocompare element: aggregate() hands its pair to the dispatcher and waits for the score
+                da, db = frames[w]
+                results[w] = group.wait_compare(group.submit_compare(c, da, db, W * 4, W, H, "RGBA", algo_code))[0]
+                continue
+            if algo_code == 4:
+                # hash-algorithm=blockhash without the dispatcher: two hash calls (one synchronisation each) + the distance per stream
+                for s in range(w, n_streams, n_workers):
+                    da, db = frames[s]
+                    h0 = c.videocompare_hash_frames_device(da, FRAME_BYTES, W * 4, 1, W, H)[0]
+                    h1 = c.videocompare_hash_frames_device(db, FRAME_BYTES, W * 4, 1, W, H)[0]
+                    results[s] = c.videocompare_distance(h0, h1)
+                continue
             if shared_ref:
                 # one videocompare element per worker: its reference pad's frame is hashed ONCE per aggregate, every other pad's
                 # frame is hashed and compared with it (videocompare/imp.rs:316-345) - the worker's streams are those pads
@@ -429,37 +532,55 @@ def run_config5(args, rank, local_rank, world):
 
     t_end = time.perf_counter() + args.ramp_seconds
     while time.perf_counter() < t_end:
-        run(1)
+        run(2 if use_group else 1)
     run(max(1, args.warmup))
-    dt = sharding.timed_region(lambda: run(args.steps), dist=dist, device_sync=torch.cuda.synchronize)
+    dt = sharding.timed_region(lambda: run(args.steps), dist=dist, device_sync=device_sync)
     comps = sharding.aggregate_throughput(args.steps * n_streams, world, dt)
-    if getattr(args, "as_leg", False):
+    gstats = group.compare_stats() if group else None
+    form = ("one two-pad element per stream (own thread + context), the pairs of an interval through the process's dispatcher as ONE launch "
+            "sequence (mi355_group_submit_compare / _wait_compare, rendezvous of %d)" % n_streams) if use_group else (
+            "streams = non-reference pads of %d aggregators: reference hashed once per step, every pad hashed + compared" % n_workers if shared_ref else
+            "one two-pad element per stream, %d worker contexts taking the streams in turn: hash the reference frame, hash + compare the other" % n_workers)
+
+    def cleanup():
+        if group:
+            group.close()
         for s_, (da, db) in enumerate(frames):
             ctxs[s_ % n_workers].free(da)
             ctxs[s_ % n_workers].free(db)
         for c in ctxs:
             c.close()
-        return {"comparisons_per_s": comps, "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "steps": args.steps,
-                "seconds": dt, "real_time_need": 30 * n_streams, "frac_of_hbm_peak": comps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_comparison": 2 * FRAME_BYTES, "dssim_of_stream_0": results[0],
-                "what": ("BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA; %d aggregators, each hashing its reference pad's frame once per "
-                         "step and hashing + comparing the frames of its %d other pads (videocompare/imp.rs:316-345)" % (n_workers, n_streams // n_workers)) if shared_ref else
-                        "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA, one two-pad element per stream: hash the reference frame, hash + compare the other in one pass per stream and step"}
+
+    if getattr(args, "as_leg", False):
+        cleanup()
+        leg = {"comparisons_per_s": comps, "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "steps": args.steps,
+               "seconds": dt, "real_time_need": 30 * n_streams, "frac_of_hbm_peak": comps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_comparison": 2 * FRAME_BYTES, "dssim_of_stream_0": results[0],
+               "what": "BASELINE config 5 on this GPU: videocompare hash-algorithm=dssim, 3840x2160 RGBA; " + form}
+        if gstats:
+            leg["dispatcher"] = {"pairs": gstats[0], "launch_sequences": gstats[1], "pairs_in_the_largest": gstats[2]}
+        if not shared_ref and not two_step:
+            leg["roofline"] = _valu_roofline(comps, getattr(args, "dssim_clock_ghz", 2.4))
+        return leg
     if rank == 0:
         algo = 2 * FRAME_BYTES  # two 4K RGBA frames read per comparison
         out = {"metric": "videocompare SSIM comparisons/sec, 32 concurrent 4K streams per GPU (BASELINE config 5)", "value": comps, "unit": "comparisons/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "videocompare hash-algorithm=dssim, 3840x2160 RGBA, " + ("streams = non-reference pads of %d aggregators: reference hashed once per step, every pad hashed + compared" % n_workers
-                                                                                                 if shared_ref else "hash the reference frame, hash + compare the other per stream and step"),
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub" if stub else "synthetic",
+               "config": {"workload": "videocompare hash-algorithm=%s, 3840x2160 RGBA, " % getattr(args, "hash_algo", "dssim") + form,
                           "streams_per_gpu": n_streams, "worker_contexts_per_gpu": n_workers, "frames": "natural-like frame vs the same + N(0, 2) noise, resident",
                           "timing_group": "gloo (CPU) barrier + MAX; no RCCL" if world > 1 else "single process",
                           "real_time_need": "%d streams x 30 frames/s = %d comparisons/s per GPU" % (n_streams, 30 * n_streams)},
-               "roofline": {"bound": "hbm", "kernel": "dssim_* (create_image + compare_frames)", "achieved": comps / world * algo / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": comps / world * algo / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                            "algorithmic_bytes_per_comparison": algo},
+               "roofline": {"bound": "hbm", "kernel": "blockhash_rgba_kernel", "achieved": comps / world * algo / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": comps / world * algo / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_comparison": algo} if algo_code == 4 else
+                           dict(_valu_roofline(comps / world, getattr(args, "dssim_clock_ghz", 2.4)), traffic=None,
+                                hbm={"achieved_GBps": comps / world * algo / 1e9, "peak_GBps": HBM_PEAK_GBS, "frac": comps / world * algo / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_comparison": algo,
+                                     "note": "the HBM fraction is reported for completeness: the engine is VALU-bound (exact f32, ~1,300 instructions per pixel pair)"}),
                "dssim_of_stream_0": results[0]}
-        if not args.no_cpu_baseline:
+        if gstats:
+            out["dispatcher"] = {"pairs": gstats[0], "launch_sequences": gstats[1], "pairs_in_the_largest": gstats[2]}
+        if not args.no_cpu_baseline and not stub:
             from oracle import dssim_restate as R
             hw, hh = W // 2, H // 2
             fa = np.ascontiguousarray(base.reshape(H, W, 4)[:hh, :hw]).reshape(hh, hw * 4)
@@ -470,8 +591,7 @@ def run_config5(args, rank, local_rank, world):
             out["cpu_baseline"] = {"value": 1.0 / (4.0 * d1), "unit": "comparisons/s", "cores": 1, "kind": "port",
                                    "sample": "one 1920x1080 comparison by the numpy restatement (oracle/dssim_restate.py), scaled by 4 to 4K; dssim %.6f" % v}
         print(json.dumps(out), flush=True)
-    for c in ctxs:
-        c.close()
+    cleanup()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -861,6 +981,12 @@ def main():
         leg_args = argparse.Namespace(**vars(args))
         leg_args.as_leg, leg_args.streams, leg_args.workers, leg_args.steps, leg_args.warmup = True, 32, 8, 48, 4
         config5 = run_config5(leg_args, rank, local_rank, 1)
+        # the round-5 form of the same elements (no dispatcher: 8 worker contexts take the 32 streams in turn, one synchronisation each)
+        leg_args = argparse.Namespace(**vars(leg_args))
+        leg_args.no_group, leg_args.steps = True, 24
+        config5["without_the_dispatcher"] = run_config5(leg_args, rank, local_rank, 1)
+        leg_args = argparse.Namespace(**vars(leg_args))
+        leg_args.no_group, leg_args.steps = False, 48
         # the same 32 streams as the non-reference pads of 4 videocompare elements (8 pads + one reference pad each): the element
         # hashes its reference frame once per aggregate, so a comparison costs one hash + one compare (+ 1/8 of a hash)
         leg_args = argparse.Namespace(**vars(leg_args))

@@ -96,6 +96,7 @@ const char *mi355_status_string(int status) {
     case MI355_ERR_NOT_CONFIGURED: return "element not configured";
     case MI355_ERR_OUT_OF_MEMORY: return "out of device memory";
     case MI355_ERR_UNSUPPORTED: return "unsupported";
+    case MI355_ERR_TIMEOUT: return "timeout";
     default: return "unknown status";
   }
 }

@@ -1120,8 +1120,25 @@ int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_
 // videocompare's loop over the non-reference pads of one aggregate (imp.rs:316-345): frames[i] is hashed and compared against
 // `a` (the reference pad's image) in one pass per scale, nothing of frames[i] is kept. All frames are queued before the single
 // synchronisation that returns the values; the scratch (linear images, SSIM maps, partials) is shared in stream order.
-int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
-                         int channels, double *out) {
+// `d_refs` (optional): frame f is compared against the image of d_refs[f] instead of `a` - a PAIR per frame, what n independent
+// two-pad videocompare elements hand over in one interval (group.hip: mi355_group_submit_compare). The reference's image is
+// created right before the kernels that read it and released right behind them: one pool serves the whole call in stream order.
+// `h_slots` (optional, pinned, n_frames x 3 x kDssimScales doubles): the per-scale [sum, avg, dev] slots are copied there and the
+// call returns WITHOUT waiting (the caller owns an event behind it and finishes with dssim_scores_from_slots); otherwise the call
+// waits and writes the values to `out`.
+static int dssim_compare_frames_impl(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_refs, const uint8_t *const *d_frames, int n_frames,
+                                     int stride, int width, int height, int channels, double *out, double *h_slots) {
+  mi355_dssim_image geometry;   // scale sizes only (pairs: there is no image yet)
+  if (!a) {
+    int ns0 = 0;
+    for (int w = width, h = height; ns0 < kDssimScales; ) {
+      geometry.s[ns0].w = w; geometry.s[ns0].h = h; ns0++;
+      if (w < 8 || h < 8) break;
+      w /= 2; h /= 2;
+    }
+    geometry.n_scales = ns0;
+    a = &geometry;
+  }
   if (a->s[0].w != width || a->s[0].h != height) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: frame and image differ in size");
   const int ns = a->n_scales;
   if (n_frames > 64) return set_error(ctx, MI355_ERR_INVALID_ARG, "dssim: at most 64 frames per call");
@@ -1175,6 +1192,13 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
   float *d_lut = cache->d_lut;
   for (int f = 0; f < n_frames; f++) {
     const uint8_t *d_frame = d_frames[f];
+    mi355_dssim_image *own = nullptr;   // pairs: this frame's reference image (its scratch use - the linear images at the start of
+                                        // slot 1 - is what the loop below reuses right behind it, in stream order; never larger)
+    if (d_refs) {
+      if ((rc = dssim_create_image(ctx, d_refs[f], stride, width, height, channels, &own))) return rc;
+      if (ctx->d_stage[1] != scr) { dssim_free_image(ctx, own); return set_error(ctx, MI355_ERR_HIP, "dssim: scratch moved under a pair"); }
+    }
+    const mi355_dssim_image *orig = own ? own : a;
     for (int k = 1; k < ns; k++) {
       const unsigned g = dssim_grid(ctx, R.n[k]);
       if (k == 1) hipLaunchKernelGGL(dssim_downsample_u8_kernel, dim3(g), dim3(256), 0, ctx->stream, d_frame, stride, width, height, channels, (const float *)d_lut, lin[1]);
@@ -1182,7 +1206,7 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
     }
     auto job_of = [&](int k) {
       DssimFusedJob j;
-      const DssimScale &s = a->s[k];
+      const DssimScale &s = orig->s[k];
       if (k == 0) { j.S.u8 = d_frame; j.S.stride = stride; j.S.channels = channels; j.S.lut = d_lut; j.S.lin = nullptr; }
       else { j.S.u8 = nullptr; j.S.stride = 0; j.S.channels = 0; j.S.lut = nullptr; j.S.lin = lin[k]; }
       j.S.pattern = (channels == 4 && !ctx->dssim_translucent) ? 1 : 0;
@@ -1206,16 +1230,42 @@ int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8
       hipLaunchKernelGGL(dssim_hash_compare_kernel, dim3(total), dim3(kNt), 0, ctx->stream, J);
       k += count;
     }
+    if (own) dssim_free_image(ctx, own);   // back to the context's free list: the next pair's create_image takes it, behind these kernels
   }
   hipLaunchKernelGGL(dssim_avg_kernel, dim3(ns, n_frames), dim3(256), 0, ctx->stream, R);
   hipLaunchKernelGGL(dssim_absdev2_kernel, dim3(n_pb, n_frames), dim3(256), 0, ctx->stream, R);
   hipLaunchKernelGGL(dssim_sum_kernel, dim3(ns, n_frames), dim3(256), 0, ctx->stream, R);
   if ((rc = check_hip(ctx, hipGetLastError(), "dssim kernel launch"))) return rc;
+  if (h_slots) return check_hip(ctx, hipMemcpyAsync(h_slots, d_slots, (size_t)n_frames * 3 * kDssimScales * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H");
   std::vector<double> slots((size_t)n_frames * 3 * kDssimScales);
   if ((rc = check_hip(ctx, hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "dssim: scores D2H"))) return rc;
   if ((rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "dssim: sync"))) return rc;
   for (int f = 0; f < n_frames; f++) out[f] = dssim_value_of(a, slots.data() + (size_t)f * 3 * kDssimScales);
   return MI355_OK;
+}
+
+int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
+                         int channels, double *out) {
+  return dssim_compare_frames_impl(ctx, a, nullptr, d_frames, n_frames, stride, width, height, channels, out, nullptr);
+}
+
+// n (reference, frame) pairs of one geometry, enqueued on ctx->stream with their slots copied to `h_slots` (pinned); no host wait
+int dssim_compare_pairs_enqueue(mi355_ctx *ctx, const uint8_t *const *d_refs, const uint8_t *const *d_frames, int n_pairs, int stride, int width, int height,
+                                int channels, double *h_slots) {
+  return dssim_compare_frames_impl(ctx, nullptr, d_refs, d_frames, n_pairs, stride, width, height, channels, nullptr, h_slots);
+}
+
+// ... and the values once the copy has landed
+void dssim_scores_from_slots(int width, int height, const double *h_slots, int n_pairs, double *out) {
+  mi355_dssim_image g;
+  int ns = 0;
+  for (int w = width, h = height; ns < kDssimScales; ) {
+    g.s[ns].w = w; g.s[ns].h = h; ns++;
+    if (w < 8 || h < 8) break;
+    w /= 2; h /= 2;
+  }
+  g.n_scales = ns;
+  for (int f = 0; f < n_pairs; f++) out[f] = dssim_value_of(&g, h_slots + (size_t)f * 3 * kDssimScales);
 }
 
 // every f32 with bits in [lo_bits, hi_bits]: the cube root with the trimmed division, scalar and packed, against the one with the compiler's

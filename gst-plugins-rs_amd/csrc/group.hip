@@ -22,6 +22,9 @@
 // No persistent kernel: nothing here can hang the GPU waiting for the host, a launch is a launch.
 #include "internal.hpp"
 
+#include <chrono>
+#include <condition_variable>
+#include <algorithm>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -56,6 +59,29 @@ struct Batch {
   std::shared_ptr<void> table_ref;  // the table its launches read (see Desc)
 };
 
+// ---- videocompare across independent element instances (mi355_group_submit_compare): one (reference frame, frame) pair per submit
+struct CmpDesc {
+  mi355_ctx *ctx;
+  const uint8_t *ref, *frame;
+  int width, height, stride, format, algo, translucent;
+  uint64_t ticket;
+  hipEvent_t ready;  // recorded on ctx->stream at submit (nullptr: the stream held nothing)
+};
+struct CmpResult { int status; double distance; uint64_t hashes[2]; };
+struct CmpBatch {
+  uint64_t seq;
+  std::vector<uint64_t> tickets;
+  int algo, width, height;
+  int lane;        // which of the compare queue's streams carries it (batches of one lane finish in seq order)
+  hipEvent_t done;
+  int waiters;
+  void *h_block;  // pinned: Dssim [n][15] doubles / Blockhash [2 n] u64 (reference hashes, then frame hashes)
+  bool collected = false;  // its values are in cmp_results (the event and the block are recycled once nobody waits inside it)
+};
+constexpr int kCmpMaxBatch = 32;                      // pairs per launch set (a Dssim pair keeps 44 MB of maps until its batch is reduced)
+constexpr int kCmpMaxLanes = 16;                      // HIP streams the pairs of one launch set are dealt out to
+constexpr size_t kCmpBlockBytes = 64 * 15 * 8 + 1024; // one pinned result block
+
 }  // namespace
 
 struct mi355_group {
@@ -74,6 +100,24 @@ struct mi355_group {
   // table references of retired batches: dropping the last reference to a table frees 64 MiB behind a device-wide wait, which
   // does not belong under `mu` - the entry points empty this list into a local one that dies after they have unlocked (Locked)
   std::vector<std::shared_ptr<void>> dead_refs;
+  // ---- compare queue (videocompare's Dssim / Blockhash): its own context + stream, independent of the filter batches above
+  // The pairs of a launch set are dealt out to `n_lanes` contexts (streams): the Dssim kernels are VALU-bound at ~80 % busy when
+  // one runs alone, and a second stream's launches fill its tails and launch boundaries (32 4K pairs: 1.48 k comparisons/s on one
+  // stream, 1.84 k over eight) - what the dispatcher removes is the per-comparison host round trip, not the overlap.
+  mi355_ctx *alane[kCmpMaxLanes] = {nullptr};
+  int n_lanes = 8;
+  mi355_ctx *actx = nullptr;                 // = alane[0], created at the first compare submit
+  std::vector<CmpDesc> cmp_pending;
+  std::deque<CmpBatch> cmp_batches;          // launched, oldest first
+  std::unordered_map<uint64_t, uint64_t> cmp_where;      // ticket -> seq
+  std::unordered_map<uint64_t, CmpResult> cmp_results;   // finished, not yet collected by mi355_group_wait_compare
+  std::vector<void *> cmp_blocks;            // free pinned result blocks
+  uint32_t *d_hash_sums[kCmpMaxLanes] = {nullptr};   // Blockhash scratch per lane: [2 kCmpMaxBatch][64] u32 + [2 kCmpMaxBatch] u64
+  uint64_t next_cmp_seq = 1;
+  uint64_t n_cmp_pairs = 0, n_cmp_batches = 0, n_cmp_largest = 0;
+  int expected_streams = 0;                  // rendezvous: a waiter lingers until this many pairs are pending ...
+  unsigned linger_us = 0;                    // ... or this long (mi355_group_set_rendezvous)
+  std::condition_variable cv;                // "a compare batch has been launched"
 };
 
 namespace {
@@ -235,6 +279,156 @@ int wait_all_unlocking(mi355_group *g, std::unique_lock<std::mutex> &lk) {
   return MI355_OK;
 }
 
+// ------------------------------------------------------------------ compare queue
+
+void *cmp_take_block(mi355_group *g) {
+  if (!g->cmp_blocks.empty()) { void *b = g->cmp_blocks.back(); g->cmp_blocks.pop_back(); return b; }
+  void *b = nullptr;
+  if (hipHostMalloc(&b, kCmpBlockBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return b;
+}
+
+bool cmp_same_class(const CmpDesc &a, const CmpDesc &b) {
+  return a.algo == b.algo && a.width == b.width && a.height == b.height && a.stride == b.stride && a.format == b.format && a.translucent == b.translucent;
+}
+
+// a finished batch: values from its pinned block into cmp_results (once). g->mu held.
+void cmp_collect(mi355_group *g, CmpBatch &b) {
+  if (b.collected) return;
+  b.collected = true;
+  const int n = (int)b.tickets.size();
+  if (b.algo == MI355_HASH_DSSIM) {
+    std::vector<double> v((size_t)n);
+    dssim_scores_from_slots(b.width, b.height, (const double *)b.h_block, n, v.data());
+    for (int i = 0; i < n; i++) g->cmp_results[b.tickets[i]] = CmpResult{MI355_OK, v[i], {0, 0}};
+  } else {
+    const uint64_t *h = (const uint64_t *)b.h_block;
+    for (int i = 0; i < n; i++)
+      g->cmp_results[b.tickets[i]] = CmpResult{MI355_OK, mi355_videocompare_distance(MI355_HASH_BLOCKHASH, h[i], h[n + i]), {h[i], h[n + i]}};
+  }
+  for (uint64_t t : b.tickets) g->cmp_where.erase(t);
+}
+
+// collected batches nobody waits inside leave from the front: event and pinned block back to their free lists. g->mu held.
+void cmp_retire(mi355_group *g) {
+  for (auto it = g->cmp_batches.begin(); it != g->cmp_batches.end();) {
+    if (it->collected && it->waiters == 0) {
+      g->cmp_blocks.push_back(it->h_block);
+      g->events.push_back(it->done);
+      it = g->cmp_batches.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+// launches the pending pairs, class by class (all of them, or up to the batch that carries `until`): the pairs of a class are
+// dealt out to the lanes in contiguous shares (pairs that share a reference frame stay together). g->mu held.
+int cmp_flush_locked(mi355_group *g, uint64_t until = 0) {
+  bool reached = false;
+  int first_rc = MI355_OK;
+  while (!g->cmp_pending.empty() && !reached) {
+    std::vector<CmpDesc> all, keep;
+    const CmpDesc first = g->cmp_pending.front();
+    for (const CmpDesc &d : g->cmp_pending) {
+      if ((int)all.size() < kCmpMaxBatch && cmp_same_class(first, d)) all.push_back(d);
+      else keep.push_back(d);
+    }
+    g->cmp_pending.swap(keep);
+    // pairs that share a reference frame next to each other (videocompare with several pads: the reference is hashed once)
+    std::stable_sort(all.begin(), all.end(), [](const CmpDesc &a, const CmpDesc &b) { return (uintptr_t)a.ref < (uintptr_t)b.ref; });
+    const int total = (int)all.size();
+    const int lanes = total < g->n_lanes ? total : g->n_lanes;
+    PixFmt fmt;
+    (void)pixfmt_of(first.format, &fmt);
+    int begin = 0;
+    for (int lane = 0; lane < lanes; lane++) {
+      int end = (int)((long long)total * (lane + 1) / lanes);
+      // a reference frame is not split over two lanes
+      while (end < total && end > begin && all[end].ref == all[end - 1].ref) end++;
+      if (end <= begin) continue;
+      std::vector<CmpDesc> take(all.begin() + begin, all.begin() + end);
+      begin = end;
+      const int n = (int)take.size();
+      mi355_ctx *a = g->alane[lane];
+      int rc = MI355_OK;
+      hipEvent_t done = take_event(g);
+      void *block = cmp_take_block(g);
+      if (!done || !block) rc = MI355_ERR_HIP;
+      for (const CmpDesc &d : take)
+        if (!rc && d.ready && hipStreamWaitEvent(a->stream, d.ready, 0) != hipSuccess) rc = MI355_ERR_HIP;
+      std::vector<const uint8_t *> refs((size_t)n), frames((size_t)n);
+      for (int i = 0; i < n; i++) { refs[i] = take[i].ref; frames[i] = take[i].frame; }
+      if (!rc && first.algo == MI355_HASH_DSSIM) {
+        a->dssim_translucent = first.translucent;
+        rc = dssim_compare_pairs_enqueue(a, refs.data(), frames.data(), n, first.stride, first.width, first.height, fmt.pixel_stride, (double *)block);
+      } else if (!rc) {
+        std::vector<const uint8_t *> both(refs);
+        both.insert(both.end(), frames.begin(), frames.end());
+        unsigned long long *d_hashes = (unsigned long long *)(g->d_hash_sums[lane] + (size_t)2 * kCmpMaxBatch * 64);
+        rc = blockhash_enqueue(a, both.data(), 2 * n, first.stride, first.width, first.height, fmt.pixel_stride, g->d_hash_sums[lane], d_hashes);
+        if (!rc && hipMemcpyAsync(block, d_hashes, (size_t)2 * n * 8, hipMemcpyDeviceToHost, a->stream) != hipSuccess) rc = MI355_ERR_HIP;
+      }
+      if (!rc && hipEventRecord(done, a->stream) != hipSuccess) rc = MI355_ERR_HIP;
+      if (rc) {
+        (void)hipGetLastError();
+        if (done) g->events.push_back(done);
+        if (block) g->cmp_blocks.push_back(block);
+        g->last_error = a->last_error.empty() ? "group: compare launch failed" : a->last_error;
+        if (g->cmp_results.size() > 65536) g->cmp_results.clear();   // (results nobody ever collected)
+        for (const CmpDesc &d : take) g->cmp_results[d.ticket] = CmpResult{rc, 0.0, {0, 0}};   // told to the pair's own wait, once
+        if (!first_rc) first_rc = rc;
+        continue;
+      }
+      CmpBatch b{g->next_cmp_seq++, {}, first.algo, first.width, first.height, lane, done, 0, block};
+      for (const CmpDesc &d : take) { b.tickets.push_back(d.ticket); g->cmp_where[d.ticket] = b.seq; reached |= until != 0 && d.ticket == until; }
+      g->cmp_batches.push_back(std::move(b));
+    }
+    for (const CmpDesc &d : all)
+      if (d.ready) g->events.push_back(d.ready);
+    g->n_cmp_pairs += (uint64_t)total;
+    g->n_cmp_batches++;
+    if ((uint64_t)total > g->n_cmp_largest) g->n_cmp_largest = (uint64_t)total;
+  }
+  g->cv.notify_all();
+  return first_rc;
+}
+
+// finished batches are collected without a waiter (their results stay in cmp_results until asked for)
+void cmp_retire_done(mi355_group *g) {
+  for (CmpBatch &b : g->cmp_batches) {
+    if (b.collected) continue;
+    if (hipEventQuery(b.done) != hipSuccess) { (void)hipGetLastError(); continue; }   // (the lanes finish independently)
+    cmp_collect(g, b);
+  }
+  cmp_retire(g);
+}
+
+// host wait for the batch of `ticket`; `lk` owns g->mu on entry and on return, not while waiting
+int cmp_wait_unlocking(mi355_group *g, std::unique_lock<std::mutex> &lk, uint64_t ticket) {
+  auto it = g->cmp_where.find(ticket);
+  if (it == g->cmp_where.end()) return MI355_OK;  // collected already (or failed: cmp_results has it)
+  const uint64_t seq = it->second;
+  CmpBatch *mine = nullptr;
+  for (CmpBatch &b : g->cmp_batches)
+    if (b.seq == seq) { mine = &b; break; }
+  if (!mine) return MI355_OK;
+  const hipEvent_t ev = mine->done;
+  const int lane = mine->lane;
+  mine->waiters++;
+  lk.unlock();
+  const hipError_t e = hipEventSynchronize(ev);
+  lk.lock();
+  for (CmpBatch &b : g->cmp_batches)
+    if (b.seq == seq) { b.waiters--; break; }
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipEventSynchronize(group compare batch)"); }
+  // a lane's stream is in order: everything of that lane up to this batch is done
+  for (CmpBatch &b : g->cmp_batches)
+    if (b.lane == lane && b.seq <= seq) cmp_collect(g, b);
+  cmp_retire(g);
+  return MI355_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -264,6 +458,22 @@ void mi355_group_destroy(mi355_group *g) {
     (void)wait_all_unlocking(g, L.lk);
   }
   (void)hipStreamSynchronize(g->stream);
+  if (g->actx) {
+    // pairs still pending are launched and waited for: their frames belong to callers who may free them once this returns
+    {
+      Locked L(g);
+      (void)cmp_flush_locked(g);
+    }
+    for (int l = 0; l < kCmpMaxLanes; l++)
+      if (g->alane[l]) (void)hipStreamSynchronize(g->alane[l]->stream);
+    for (CmpBatch &b : g->cmp_batches) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.h_block); }
+    g->cmp_batches.clear();
+    for (void *b : g->cmp_blocks) (void)hipHostFree(b);
+    for (int l = 0; l < kCmpMaxLanes; l++) {
+      if (g->d_hash_sums[l]) (void)hipFree(g->d_hash_sums[l]);
+      if (g->alane[l]) mi355_ctx_destroy(g->alane[l]);
+    }
+  }
   for (Batch &b : g->batches) (void)hipEventDestroy(b.done);   // (normally none left: wait_all retired them)
   for (Desc &d : g->pending)
     if (d.ready) (void)hipEventDestroy(d.ready);
@@ -352,7 +562,120 @@ int mi355_group_flush(mi355_group *g) {
   if (!g) return MI355_ERR_INVALID_ARG;
   Locked L(g);
   if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
-  return flush_locked(g);
+  const int rc = flush_locked(g);
+  const int rc2 = g->actx ? cmp_flush_locked(g) : MI355_OK;
+  return rc ? rc : rc2;
+}
+
+// ---------------------------------------------------------------- videocompare pairs (Dssim / Blockhash) of independent elements
+
+int mi355_group_set_rendezvous(mi355_group *g, int expected_streams, unsigned linger_us) {
+  if (!g || expected_streams < 0) return MI355_ERR_INVALID_ARG;
+  Locked L(g);
+  g->expected_streams = expected_streams;
+  g->linger_us = linger_us;
+  return MI355_OK;
+}
+
+int mi355_group_set_compare_lanes(mi355_group *g, int lanes) {
+  if (!g || lanes < 1 || lanes > kCmpMaxLanes) return MI355_ERR_INVALID_ARG;
+  Locked L(g);
+  if (g->actx) return fail(g, MI355_ERR_INVALID_ARG, "group: the compare queue's streams exist already (set the lanes before the first submit_compare)");
+  g->n_lanes = lanes;
+  return MI355_OK;
+}
+
+int mi355_group_submit_compare(mi355_group *g, mi355_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_frame, int stride, int width, int height, int format,
+                               int algo, uint64_t *ticket) {
+  if (!g) return MI355_ERR_INVALID_ARG;
+  Locked L(g);
+  PixFmt fmt;
+  if (!ctx || !d_ref || !d_frame || width <= 0 || height <= 0 || !pixfmt_of(format, &fmt) || (format != MI355_FMT_RGB && format != MI355_FMT_RGBA) ||
+      (size_t)stride < (size_t)width * fmt.pixel_stride)
+    return fail(g, MI355_ERR_INVALID_ARG, "group: bad frame pair (videocompare's engines take packed RGB / RGBA)");
+  if (algo != MI355_HASH_DSSIM && algo != MI355_HASH_BLOCKHASH)
+    return fail(g, MI355_ERR_UNSUPPORTED, "group: pairs are batched for hash-algorithm dssim and blockhash; the resize hashes go through their context");
+  if (algo == MI355_HASH_BLOCKHASH && (width % 8 != 0 || height % 8 != 0))
+    return fail(g, MI355_ERR_UNSUPPORTED, "group: blockhash batches take frames of 8 x 8 whole blocks (the any-size path goes through its context)");
+  if (ctx->device != g->device) return fail(g, MI355_ERR_INVALID_ARG, "group: context of another device");
+  if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
+  if (!g->actx) {
+    int st = MI355_OK;
+    for (int l = 0; l < g->n_lanes && !st; l++) {
+      g->alane[l] = mi355_ctx_create(g->device, &st);
+      if (!g->alane[l] && !st) st = MI355_ERR_HIP;
+      if (!st && hipMalloc((void **)&g->d_hash_sums[l], (size_t)2 * kCmpMaxBatch * (64 * 4 + 8)) != hipSuccess) { (void)hipGetLastError(); st = MI355_ERR_OUT_OF_MEMORY; }
+    }
+    if (st) {
+      for (int l = 0; l < kCmpMaxLanes; l++) {
+        if (g->d_hash_sums[l]) (void)hipFree(g->d_hash_sums[l]);
+        if (g->alane[l]) mi355_ctx_destroy(g->alane[l]);
+        g->d_hash_sums[l] = nullptr; g->alane[l] = nullptr;
+      }
+      return fail(g, st, "group: no contexts for the compare queue");
+    }
+    g->actx = g->alane[0];
+  }
+  cmp_retire_done(g);
+  CmpDesc d{};
+  d.ctx = ctx; d.ref = d_ref; d.frame = d_frame; d.width = width; d.height = height; d.stride = stride; d.format = format; d.algo = algo;
+  d.translucent = ctx->dssim_translucent;
+  d.ready = nullptr;
+  if (hipStreamQuery(ctx->stream) != hipSuccess) {   // the pair starts after what the stream's own context holds now (an upload)
+    (void)hipGetLastError();
+    d.ready = take_event(g);
+    if (!d.ready || hipEventRecord(d.ready, ctx->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      if (d.ready) g->events.push_back(d.ready);
+      return fail(g, MI355_ERR_HIP, "group: hipEventRecord(ready)");
+    }
+  }
+  d.ticket = g->next_ticket++;
+  if (ticket) *ticket = d.ticket;
+  g->cmp_pending.push_back(d);
+  // everybody is here (rendezvous), or a launch set is full: go. The pair has been accepted whatever that launch does (a failure
+  // is told to the waits of the pairs it carried).
+  const int full = g->expected_streams > 0 && g->expected_streams < kCmpMaxBatch ? g->expected_streams : kCmpMaxBatch;
+  if ((int)g->cmp_pending.size() >= full) (void)cmp_flush_locked(g);
+  return MI355_OK;
+}
+
+int mi355_group_wait_compare(mi355_group *g, uint64_t ticket, double *distance, uint64_t hashes[2]) {
+  if (!g) return MI355_ERR_INVALID_ARG;
+  Locked L(g);
+  std::unique_lock<std::mutex> &lk = L.lk;
+  if (ticket == 0 || ticket >= g->next_ticket) return fail(g, MI355_ERR_INVALID_ARG, "group: unknown ticket");
+  if (hipSetDevice(g->device) != hipSuccess) { (void)hipGetLastError(); return fail(g, MI355_ERR_HIP, "hipSetDevice"); }
+  auto is_pending = [&]() { for (const CmpDesc &d : g->cmp_pending) if (d.ticket == ticket) return true; return false; };
+  if (is_pending()) {
+    // rendezvous: the other streams of this interval are about to submit - linger for them (bounded), then launch what is there
+    if (g->expected_streams > 0 && g->linger_us > 0) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(g->linger_us);
+      while (is_pending() && (int)g->cmp_pending.size() < g->expected_streams) {
+        if (g->cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+      }
+    }
+    if (is_pending()) (void)cmp_flush_locked(g, ticket);   // (a failure of this pair's own launch is in cmp_results)
+  }
+  int rc = cmp_wait_unlocking(g, lk, ticket);
+  if (rc) return rc;
+  auto r = g->cmp_results.find(ticket);
+  if (r == g->cmp_results.end()) return fail(g, MI355_ERR_INVALID_ARG, "group: this pair's result has been collected already (or the ticket is not a pair's)");
+  const CmpResult res = r->second;
+  g->cmp_results.erase(r);
+  if (res.status) return fail(g, res.status, "group: the launch that carried this pair failed");
+  if (distance) *distance = res.distance;
+  if (hashes) { hashes[0] = res.hashes[0]; hashes[1] = res.hashes[1]; }
+  return MI355_OK;
+}
+
+int mi355_group_compare_stats(mi355_group *g, uint64_t stats[3]) {
+  if (!g || !stats) return MI355_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  stats[0] = g->n_cmp_pairs;
+  stats[1] = g->n_cmp_batches;
+  stats[2] = g->n_cmp_largest;
+  return MI355_OK;
 }
 
 int mi355_group_wait(mi355_group *g, uint64_t ticket) {

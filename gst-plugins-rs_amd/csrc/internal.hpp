@@ -205,6 +205,12 @@ void dssim_free_image(mi355_ctx *ctx, mi355_dssim_image *img);
 int dssim_compare(mi355_ctx *ctx, const mi355_dssim_image *a, const mi355_dssim_image *b, double *out);
 int dssim_compare_frames(mi355_ctx *ctx, const mi355_dssim_image *a, const uint8_t *const *d_frames, int n_frames, int stride, int width, int height,
                          int channels, double *out);
+int dssim_compare_pairs_enqueue(mi355_ctx *ctx, const uint8_t *const *d_refs, const uint8_t *const *d_frames, int n_pairs, int stride, int width, int height,
+                                int channels, double *h_slots);
+void dssim_scores_from_slots(int width, int height, const double *h_slots, int n_pairs, double *out);
+constexpr int kDssimSlotDoubles = 15;  // per comparison: 5 scales x [sum, avg, dev]
+int blockhash_enqueue(mi355_ctx *ctx, const uint8_t *const *d_frames, int n, int stride, int width, int height, int channels, uint32_t *d_sums,
+                      unsigned long long *d_hashes);
 int dssim_cbrt_selftest(mi355_ctx *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *mismatches);
 void dssim_release(mi355_ctx *ctx);
 void roundedcorners_release(mi355_ctx *ctx);

@@ -291,6 +291,32 @@ int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "blockhash sync");
 }
 
+// group.hip (mi355_group_submit_compare with Blockhash): n SEPARATE frames (any pointers, one geometry, width and height multiples
+// of 8) hashed on ctx->stream into d_hashes[n] with NO host wait - one kernel per frame (a 4K frame is 33 MB: ~8 us of reads), one
+// finish launch for all of them. d_sums: n x 64 u32 of scratch. Same kernels, same bits as launch_blockhash.
+int blockhash_enqueue(mi355_ctx *ctx, const uint8_t *const *d_frames, int n, int stride, int width, int height, int channels, uint32_t *d_sums,
+                      unsigned long long *d_hashes) {
+  if (width % 8 != 0 || height % 8 != 0 || width < 8 || height < 8) return set_error(ctx, MI355_ERR_UNSUPPORTED, "videocompare: blockhash batches take frames of 8 x 8 whole blocks");
+  int rc = check_hip(ctx, hipMemsetAsync(d_sums, 0, (size_t)n * 64 * 4, ctx->stream), "hipMemset(blockhash sums)");
+  if (rc) return rc;
+  for (int f = 0; f < n; f++) {
+    const bool vec = channels == 4 && stride % 16 == 0 && ((uintptr_t)d_frames[f] % 16 == 0) && width >= 32;
+    const size_t seg_px = vec ? 1024 : 256;
+    const size_t rows = vec ? ((size_t)height + kRowGroup - 1) / kRowGroup : (size_t)height;
+    const size_t items = rows * (((size_t)width + seg_px - 1) / seg_px);
+    size_t grid = (size_t)ctx->n_cu * 8;
+    if (grid > items) grid = items;
+    if (grid < 1) grid = 1;
+    if (vec)
+      hipLaunchKernelGGL(blockhash_rgba_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_frames[f], (size_t)0, stride, 1, width, height, d_sums + (size_t)f * 64);
+    else
+      hipLaunchKernelGGL(blockhash_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_frames[f], (size_t)0, stride, 1, width, height, channels, d_sums + (size_t)f * 64);
+  }
+  const uint32_t cmp_factor = 765u * (uint32_t)((width / 8) * (height / 8)) / 2u;
+  hipLaunchKernelGGL(blockhash_finish_kernel, dim3(n), dim3(64), 0, ctx->stream, (const uint32_t *)d_sums, n, cmp_factor, d_hashes);
+  return check_hip(ctx, hipGetLastError(), "blockhash kernel launch");
+}
+
 
 // ------------------------------------------------------------------ resize-based hashes (Mean / Gradient / VertGradient / DoubleGradient)
 // image_hasher 3.1.1 with HasherConfig::new(): grayscale (integer luma), image::imageops::resize with Lanczos3 to

@@ -21,7 +21,7 @@ FMT = {"RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA":
 FMT_LAYOUT = {"RGBx": (4, 0, 0), "RGBA": (4, 0, 0), "RGB": (3, 0, 0), "xRGB": (4, 1, 0), "ARGB": (4, 1, 0),
               "BGRx": (4, 0, 1), "BGRA": (4, 0, 1), "BGR": (3, 0, 1), "xBGR": (4, 1, 1), "ABGR": (4, 1, 1)}
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_OOM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_OOM, ERR_UNSUPPORTED, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 FLAG_FORCE_GENERIC = 1
 FLAG_HSV_BLOCKS_PER_CU = 2
 FLAG_FUSED_VARIANT = 3
@@ -178,6 +178,27 @@ def load_library():
         "mi355_group_order_after": (i, [vp, vp, C.c_uint64]),
         "mi355_group_wait_all": (i, [vp]),
         "mi355_group_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "mi355_group_set_rendezvous": (i, [vp, i, C.c_uint]),
+        "mi355_group_set_compare_lanes": (i, [vp, i]),
+        "mi355_group_submit_compare": (i, [vp, vp, u8p, u8p, i, i, i, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_group_wait_compare": (i, [vp, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "mi355_group_compare_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_create_echo": (vp, [i, i, sz, C.POINTER(C.c_int)]),
+        "mi355_agroup_create_ebur128": (vp, [i, i, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mi355_agroup_create_loudnorm": (vp, [i, i, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]),
+        "mi355_agroup_destroy": (None, [vp]),
+        "mi355_agroup_last_error": (C.c_char_p, [vp]),
+        "mi355_agroup_set_linger": (i, [vp, C.c_uint, C.c_uint]),
+        "mi355_agroup_detach": (i, [vp, i]),
+        "mi355_agroup_submit_echo": (i, [vp, i, vp, sz, i, sz, C.c_double, C.c_double, i, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_submit_ebur128": (i, [vp, i, vp, sz, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_submit_loudnorm": (i, [vp, i, vp, sz, vp, sz, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_loudnorm_frame_size": (sz, [vp]),
+        "mi355_agroup_wait": (i, [vp, C.c_uint64, C.POINTER(sz)]),
+        "mi355_agroup_ebur128_loudness": (i, [vp, i, i, C.POINTER(C.c_double)]),
+        "mi355_agroup_ebur128_peak": (i, [vp, i, i, C.c_uint, C.POINTER(C.c_double)]),
+        "mi355_agroup_echo_get_state": (i, [vp, i, vp, sz, C.POINTER(sz)]),
+        "mi355_agroup_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "mi355_group_submit_round": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_group_submit_round_fused": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -352,9 +373,140 @@ class Group:
         self._ck(self.L.mi355_group_stats(self.h, c))
         return int(c[0]), int(c[1]), int(c[2])
 
+    # ---- videocompare pairs of independent elements (Dssim / Blockhash)
+    def set_rendezvous(self, expected_streams, linger_us):
+        self._ck(self.L.mi355_group_set_rendezvous(self.h, expected_streams, linger_us))
+
+    def set_compare_lanes(self, lanes):
+        self._ck(self.L.mi355_group_set_compare_lanes(self.h, lanes))
+
+    def submit_compare(self, ctx, d_ref, d_frame, stride, width, height, fmt="RGBA", algo=5):
+        """One (reference frame, frame) pair of stream `ctx`; algo 5 = Dssim, 4 = Blockhash (mi355_hash_algo)."""
+        t = C.c_uint64(0)
+        self._ck(self.L.mi355_group_submit_compare(self.h, ctx.h, d_ref, d_frame, stride, width, height, FMT[fmt], algo, C.byref(t)))
+        return t.value
+
+    def wait_compare(self, ticket):
+        """(distance, reference hash, frame hash): the dssim value / the Hamming distance and the two Blockhash hashes."""
+        d = C.c_double(0.0)
+        h = (C.c_uint64 * 2)()
+        self._ck(self.L.mi355_group_wait_compare(self.h, ticket, C.byref(d), h))
+        return d.value, int(h[0]), int(h[1])
+
+    def compare_stats(self):
+        """(pairs launched, launch sequences, pairs in the largest one)."""
+        c = (C.c_uint64 * 3)()
+        self._ck(self.L.mi355_group_compare_stats(self.h, c))
+        return int(c[0]), int(c[1]), int(c[2])
+
     def close(self):
         if self.h:
             self.L.mi355_group_destroy(self.h)
+            self.h = None
+
+
+class AudioGroup:
+    """Independent audio element instances of one kind and configuration sharing launches (mi355_agroup_*)."""
+
+    def __init__(self, kind, n_members, device=0, **kw):
+        self.L = load_library()
+        st = C.c_int(0)
+        self.kind, self.n = kind, n_members
+        self.channels = kw.get("channels", 1)
+        if kind == "echo":
+            self.h = self.L.mi355_agroup_create_echo(device, n_members, kw["ring_len"], C.byref(st))
+        elif kind == "ebur128":
+            cc = kw.get("channel_class")
+            arr = (C.c_int * len(cc))(*cc) if cc is not None else None
+            self.h = self.L.mi355_agroup_create_ebur128(device, n_members, kw["channels"], kw["rate"], kw["mode"], arr, C.byref(st))
+            self.channels = kw["channels"]
+        elif kind == "loudnorm":
+            self.h = self.L.mi355_agroup_create_loudnorm(device, n_members, kw["channels"], kw.get("loudness_target", -24.0), kw.get("loudness_range_target", 7.0),
+                                                         kw.get("max_true_peak", -2.0), kw.get("offset", 0.0), C.byref(st))
+            self.channels = kw["channels"]
+        else:
+            raise ValueError(kind)
+        if not self.h:
+            raise Mi355Error(st.value, "mi355_agroup_create_" + kind)
+        self._keep = {}
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise Mi355Error(rc, (self.L.mi355_agroup_last_error(self.h) or b"").decode())
+
+    def set_linger(self, linger_us=0, timeout_ms=0):
+        self._ck(self.L.mi355_agroup_set_linger(self.h, linger_us, timeout_ms))
+
+    def detach(self, member):
+        self._ck(self.L.mi355_agroup_detach(self.h, member))
+
+    def submit_echo(self, member, data, delay, intensity, feedback, n=None, is_f64=None):
+        """data: a numpy f32 / f64 array (host, processed in place and valid after wait) or a device pointer (then n, is_f64)."""
+        t = C.c_uint64(0)
+        if isinstance(data, np.ndarray):
+            assert data.flags.c_contiguous and data.dtype in (np.float32, np.float64)
+            self._keep[member] = data
+            self._ck(self.L.mi355_agroup_submit_echo(self.h, member, data.ctypes.data, data.size, int(data.dtype == np.float64), delay, intensity, feedback, 0, C.byref(t)))
+        else:
+            self._ck(self.L.mi355_agroup_submit_echo(self.h, member, data, n, int(bool(is_f64)), delay, intensity, feedback, 1, C.byref(t)))
+        return t.value
+
+    def submit_ebur128(self, member, data, frames=None, sample_format=None):
+        t = C.c_uint64(0)
+        if isinstance(data, np.ndarray):
+            fmt = {np.dtype(np.int16): 0, np.dtype(np.int32): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}[data.dtype]
+            assert data.flags.c_contiguous
+            self._keep[member] = data
+            self._ck(self.L.mi355_agroup_submit_ebur128(self.h, member, data.ctypes.data, data.size // self.channels, fmt, 0, C.byref(t)))
+        else:
+            self._ck(self.L.mi355_agroup_submit_ebur128(self.h, member, data, frames, sample_format, 1, C.byref(t)))
+        return t.value
+
+    def loudnorm_frame_size(self):
+        return int(self.L.mi355_agroup_loudnorm_frame_size(self.h))
+
+    def submit_loudnorm(self, member, data, out, final_frame=False, frames=None, out_capacity_frames=None):
+        """data / out: numpy f64 arrays [frames, channels] (host) or device pointers (then frames, out_capacity_frames)."""
+        t = C.c_uint64(0)
+        if isinstance(out, np.ndarray):
+            data = np.ascontiguousarray(data, dtype=np.float64)
+            assert out.flags.c_contiguous and out.dtype == np.float64
+            self._keep[member] = (data, out)
+            self._ck(self.L.mi355_agroup_submit_loudnorm(self.h, member, data.ctypes.data if data.size else None, data.size // self.channels, out.ctypes.data,
+                                                         out.size // self.channels, int(bool(final_frame)), 0, C.byref(t)))
+        else:
+            self._ck(self.L.mi355_agroup_submit_loudnorm(self.h, member, data, frames, out, out_capacity_frames, int(bool(final_frame)), 1, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        n = C.c_size_t(0)
+        self._ck(self.L.mi355_agroup_wait(self.h, ticket, C.byref(n)))
+        return int(n.value)
+
+    def loudness(self, member, what):
+        d = C.c_double(0.0)
+        self._ck(self.L.mi355_agroup_ebur128_loudness(self.h, member, what, C.byref(d)))
+        return d.value
+
+    def peak(self, member, channel, true_peak=False):
+        d = C.c_double(0.0)
+        self._ck(self.L.mi355_agroup_ebur128_peak(self.h, member, int(bool(true_peak)), channel, C.byref(d)))
+        return d.value
+
+    def echo_state(self, member, ring_len):
+        ring = np.zeros(ring_len, dtype=np.float64)
+        pos = C.c_size_t(0)
+        self._ck(self.L.mi355_agroup_echo_get_state(self.h, member, ring.ctypes.data, ring_len, C.byref(pos)))
+        return ring, int(pos.value)
+
+    def stats(self):
+        c = (C.c_uint64 * 3)()
+        self._ck(self.L.mi355_agroup_stats(self.h, c))
+        return int(c[0]), int(c[1]), int(c[2])
+
+    def close(self):
+        if self.h:
+            self.L.mi355_agroup_destroy(self.h)
             self.h = None
 
 

@@ -39,7 +39,8 @@ typedef enum mi355_status {
   MI355_ERR_NOT_CONFIGURED = -4,/* e.g. colorlut without a loaded LUT (colorlut/imp.rs:209-212),
                                    echo before setup (audioecho/imp.rs:210 NotNegotiated) */
   MI355_ERR_OUT_OF_MEMORY = -5,
-  MI355_ERR_UNSUPPORTED = -6
+  MI355_ERR_UNSUPPORTED = -6,
+  MI355_ERR_TIMEOUT = -7        /* mi355_agroup_wait: the other members of a lock-step group have not submitted (nothing dropped) */
 } mi355_status;
 
 /* Packed-RGB formats of the hot path. Values are stable ABI.
@@ -269,6 +270,81 @@ int mi355_group_submit_round(mi355_group *group, mi355_ctx *const *ctxs, int n_s
 int mi355_group_submit_round_fused(mi355_group *group, mi355_ctx *const *ctxs, int n_streams, uint8_t *const *d_src,
                                    uint8_t *const *d_dst, int width, int height, int stride, int format,
                                    const mi355_hsv_settings *settings);
+
+/* videocompare across independent element instances. The reference's aggregate() hashes the reference pad's frame, then hashes and
+ * compares every other pad's frame (video/videofx/src/videocompare/imp.rs:316-350 -> hashed_image.rs:24-79) - per element, one
+ * synchronous engine call per frame. N two-pad elements in one process are N such sequences on N streams, which on one device
+ * run SLOWER side by side than one after the other (32 4K Dssim streams over 8 contexts: 1.8 k comparisons/s; one context in
+ * sequence: 2.2 k). submit_compare queues one (reference frame, frame) pair of stream `ctx`; pairs of one geometry, format and
+ * algorithm run as ONE launch sequence on the group's compare stream - every pair's reference image is created right before the
+ * kernels that read it (one image pool for the whole batch), pairs with the same d_ref (videocompare with several pads) share
+ * it, the reductions and the copy of the scores happen once per batch - and wait_compare returns what
+ * mi355_dssim_create_image + mi355_dssim_compare_frames (algo MI355_HASH_DSSIM: *distance = the dssim value) or
+ * mi355_videocompare_hash_frame x 2 + mi355_videocompare_distance (MI355_HASH_BLOCKHASH: hashes[0] the reference's, hashes[1] the
+ * frame's) give for that pair, bit for bit. Other algorithms: MI355_ERR_UNSUPPORTED (they go through their context).
+ *   set_rendezvous : an element needs its result before it can return from aggregate(), so every stream submits and waits at
+ *           once. With expected_streams > 0 a launch goes out as soon as that many pairs are pending, and a waiter whose pair
+ *           has not been launched lingers up to linger_us for the others before it launches what is there (0 / 0 = a wait
+ *           launches at once, the behaviour of mi355_group_wait).
+ *   Frames are read until wait_compare for their ticket has returned. A result is collected once. Threads as for the group.
+ *   set_compare_lanes : the pairs of a launch sequence are dealt out to this many HIP streams (default 8, 1..16; before the first
+ *           submit_compare): the Dssim kernels are VALU-bound and ~80 % busy when one runs alone - a neighbour stream's launches
+ *           fill its tails (32 4K pairs: 1.48 k comparisons/s on one stream, 1.84 k+ over eight).
+ */
+int mi355_group_set_rendezvous(mi355_group *group, int expected_streams, unsigned linger_us);
+int mi355_group_set_compare_lanes(mi355_group *group, int lanes);
+int mi355_group_submit_compare(mi355_group *group, mi355_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_frame, int stride, int width, int height,
+                               int format, int algo, uint64_t *ticket);
+int mi355_group_wait_compare(mi355_group *group, uint64_t ticket, double *distance, uint64_t hashes[2]);
+/* {pairs launched, launch sequences, pairs in the largest one} */
+int mi355_group_compare_stats(mi355_group *group, uint64_t stats[3]);
+
+/* ---------------------------------------------------------------- many AUDIO element instances, few launches (csrc/agroup.hip)
+ * rsaudioecho (audio/audiofx/src/audioecho/imp.rs:205-227), ebur128level (audio/audiofx/src/ebur128level/imp.rs:682-745) and
+ * audioloudnorm (audio/audiofx/src/audioloudnorm/imp.rs:1545-1586) are one instance per stream and one buffer per call; the batch
+ * entry points above need ONE caller that owns all streams. An agroup is that caller for a process full of independent
+ * instances of one kind and configuration: `n_members` of them, each submitting its buffer of the interval from its own
+ * streaming thread and waiting for its ticket; the batch runs - one launch set for all - when every attached member has
+ * submitted (on the thread that completes the set). Per-member results are those of a single-instance context fed the same
+ * buffers, bit for bit.
+ *   create_echo     : members are fully independent (own ring of ring_len f64 and position; per submit its own buffer length,
+ *                     sample type, delay, intensity, feedback). A waiter lingers linger_us for the missing members, then launches
+ *                     whoever is there (linger 0 = at once).
+ *   create_ebur128 / create_loudnorm : members advance in LOCK STEP through the batch engines (one buffer size and format per
+ *                     interval; audioloudnorm: whole frames of mi355_agroup_loudnorm_frame_size(), or the shorter rest with
+ *                     final_frame = 1 - what drain_full_frames / drain hand to State::process). The rendezvous is strict, as an
+ *                     aggregator waits for all its pads: wait() blocks until the others have submitted, or returns
+ *                     MI355_ERR_TIMEOUT after timeout_ms (the submission stays pending - wait again - nothing is dropped or fed
+ *                     silence); a member that stops calls detach (its slot hears silence from then on).
+ *   submit_*        : device_data = 0: host buffers (copied through one pinned slab: one upload and one download per interval
+ *                     for all members); 1: device pointers. Buffers are borrowed until wait(ticket) returns.
+ *   wait            : *out_frames (optional) = frames produced (audioloudnorm), samples processed (echo), frames metered.
+ *   ebur128_loudness / _peak : the member's meter readings (what: 0 momentary, 1 short-term, 2 global, 3 relative threshold,
+ *                     4 loudness range), computed once per interval for all members.
+ *   stats           : {buffers, launch sets, buffers in the largest set}.
+ * Threads: every entry point from any thread; one lock per group, held while a launch set runs. */
+typedef struct mi355_agroup mi355_agroup;
+mi355_agroup *mi355_agroup_create_echo(int device, int n_members, size_t ring_len, int *status);
+mi355_agroup *mi355_agroup_create_ebur128(int device, int n_members, unsigned channels, unsigned rate, unsigned mode, const int *channel_class,
+                                          int *status);
+mi355_agroup *mi355_agroup_create_loudnorm(int device, int n_members, unsigned channels, double loudness_target, double loudness_range_target,
+                                           double max_true_peak, double offset, int *status);
+void mi355_agroup_destroy(mi355_agroup *group);
+const char *mi355_agroup_last_error(mi355_agroup *group);
+int mi355_agroup_set_linger(mi355_agroup *group, unsigned linger_us, unsigned timeout_ms);
+int mi355_agroup_detach(mi355_agroup *group, int member);
+int mi355_agroup_submit_echo(mi355_agroup *group, int member, void *data, size_t n, int is_f64, size_t delay_samples, double intensity,
+                             double feedback, int device_data, uint64_t *ticket);
+int mi355_agroup_submit_ebur128(mi355_agroup *group, int member, const void *data, size_t frames, int sample_format, int device_data,
+                                uint64_t *ticket);
+int mi355_agroup_submit_loudnorm(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
+                                 int final_frame, int device_data, uint64_t *ticket);
+size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *group);
+int mi355_agroup_wait(mi355_agroup *group, uint64_t ticket, size_t *out_frames);
+int mi355_agroup_ebur128_loudness(mi355_agroup *group, int member, int what, double *out);
+int mi355_agroup_ebur128_peak(mi355_agroup *group, int member, int true_peak, unsigned channel, double *out);
+int mi355_agroup_echo_get_state(mi355_agroup *group, int member, double *ring_out, size_t ring_len, size_t *pos_out);
+int mi355_agroup_stats(mi355_agroup *group, uint64_t stats[3]);
 
 /* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
  * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and

@@ -19,10 +19,10 @@ def _free_port():
     return p
 
 
-def _run(nproc, steps=6, warmup=2):
+def _run(nproc, steps=6, warmup=2, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", str(warmup),
-           "--stub", "--ramp-seconds", "0.02"]
+           "--stub", "--ramp-seconds", "0.02"] + list(extra)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -70,3 +70,28 @@ def test_single_process_stub_has_all_legs():
     for key in ("ramp_seconds", "rewarm_steps", "event_marker_ms"):   # everything untimed that precedes the bracket is declared
         assert key in d["config"], key
     assert sum(d["kernels"]["colorlut_kernels_served"].values()) == d["steps"] * d["config"]["launches_per_step"] // 2
+
+
+def test_config5_two_ranks_aggregate_over_the_slowest_rank():
+    """BASELINE config 5 is the config that names 8 GPUs: its own barrier / aggregation path (bench.py run_config5) as two real ranks
+    on the CPU. One JSON line from rank 0, n_gpus 2, value = both ranks' comparisons / the MAX-over-ranks time (rank 1's stub
+    dispatcher takes 2 ms per comparison, rank 0's 1 ms), gloo only."""
+    d = _run(2, steps=5, warmup=1, extra=("--config", "5", "--streams", "4"))
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["data"] == "stub" and d["scaling"] == "weak"
+    assert d["unit"] == "comparisons/s" and "config 5" in d["metric"]
+    assert "gloo" in d["config"]["timing_group"] and "RCCL" in d["config"]["timing_group"]
+    assert d["config"]["streams_per_gpu"] == 4 and "dispatcher" in d["config"]["workload"]
+    assert d["ms_per_step"] >= 2.0                                   # the slower rank's 2 ms per (concurrent) comparison
+    comps = d["steps"] * 4 * 2                                       # both ranks' comparisons
+    assert abs(d["value"] - comps / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["instr_per_pixel"] > 1000 and "hbm" in d["roofline"]
+    assert d["dispatcher"]["pairs"] >= 5 * 4
+
+
+def test_config5_single_process_stub_without_the_dispatcher():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--steps", "3", "--warmup", "1", "--stub", "--ramp-seconds", "0.02",
+                          "--streams", "4", "--workers", "2", "--no-group"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["worker_contexts_per_gpu"] == 2 and "dispatcher" not in d
