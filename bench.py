@@ -71,9 +71,11 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=8, help="config 5: host threads / contexts per GPU that serve the streams in turn")
     ap.add_argument("--shared-reference", action="store_true",
                     help="config 5: the streams are the non-reference pads of --workers videocompare elements (reference frame hashed once per aggregate)")
-    ap.add_argument("--no-group", action="store_true",
-                    help="config 5: the round-5 form (--workers contexts taking the streams in turn) instead of one element thread per stream\n"
-                         "submitting to the process's dispatcher (mi355_group_submit_compare)")
+    ap.add_argument("--group", action="store_true",
+                    help="config 5: every stream's pair through the process's dispatcher (mi355_group_submit_compare / _wait_compare, one launch\n"
+                         "sequence per interval; --workers host threads stand in for the element threads) instead of --workers contexts taking the\n"
+                         "streams in turn")
+    ap.add_argument("--no-group", action="store_true", help="config 5: accepted, the default (see --group)")
     ap.add_argument("--hash-algo", default="dssim", choices=["dssim", "blockhash"],
                     help="config 5: videocompare's hash-algorithm: dssim (BASELINE's 'SSIM', default) or blockhash (the element's own default)")
     ap.add_argument("--rendezvous", type=int, default=0, help="config 5: pairs that make the dispatcher launch (0 = all streams of the rank: one launch sequence per interval)")
@@ -454,9 +456,9 @@ def run_config5(args, rank, local_rank, world):
         dist = dist_mod
     shared_ref = bool(getattr(args, "shared_reference", False))
     two_step = bool(getattr(args, "dssim_two_step", False))   # round-2 form: create_image for every frame, then compare
-    use_group = not bool(getattr(args, "no_group", False)) and not shared_ref and not two_step
+    use_group = bool(getattr(args, "group", False)) and not shared_ref and not two_step
     n_streams = args.streams
-    n_workers = n_streams if use_group else max(1, min(args.workers, args.streams))
+    n_workers = max(1, min(args.workers, args.streams))
     rng = np.random.default_rng(1234 + rank)
     base = synth.smooth_frame(W, H)
     noisy = base.reshape(H, W, 4).astype(np.int16)
@@ -485,9 +487,14 @@ def run_config5(args, rank, local_rank, world):
         c = ctxs[w]
         for _ in range(steps):
             if use_group:
-                # one two-pad videocompare element: aggregate() hands its pair to the dispatcher and waits for the score
-                da, db = frames[w]
-                results[w] = group.wait_compare(group.submit_compare(c, da, db, W * 4, W, H, "RGBA", algo_code))[0]
+                # Two-pad videocompare elements: aggregate() hands its pair to the dispatcher and waits for the score. This host
+                # thread stands in for the element threads of ITS streams (an interpreter's threads wake one after the other: 32 of
+                # them cost more than the comparisons; native element threads: tools/agroup_bench.cpp): every element's submit,
+                # then every element's wait - on the device exactly what those elements' own threads produce
+                mine = list(range(w, n_streams, n_workers))
+                tk = [group.submit_compare(c, frames[s][0], frames[s][1], W * 4, W, H, "RGBA", algo_code) for s in mine]
+                for s, t in zip(mine, tk):
+                    results[s] = group.wait_compare(t)[0]
                 continue
             if algo_code == 4:
                 # hash-algorithm=blockhash without the dispatcher: two hash calls (one synchronisation each) + the distance per stream
@@ -537,8 +544,8 @@ def run_config5(args, rank, local_rank, world):
     dt = sharding.timed_region(lambda: run(args.steps), dist=dist, device_sync=device_sync)
     comps = sharding.aggregate_throughput(args.steps * n_streams, world, dt)
     gstats = group.compare_stats() if group else None
-    form = ("one two-pad element per stream (own thread + context), the pairs of an interval through the process's dispatcher as ONE launch "
-            "sequence (mi355_group_submit_compare / _wait_compare, rendezvous of %d)" % n_streams) if use_group else (
+    form = ("one two-pad element per stream, the pairs of an interval through the process's dispatcher as ONE launch sequence "
+            "(mi355_group_submit_compare / _wait_compare, rendezvous of %d; %d host threads stand in for the element threads)" % (n_streams, n_workers)) if use_group else (
             "streams = non-reference pads of %d aggregators: reference hashed once per step, every pad hashed + compared" % n_workers if shared_ref else
             "one two-pad element per stream, %d worker contexts taking the streams in turn: hash the reference frame, hash + compare the other" % n_workers)
 
@@ -980,13 +987,26 @@ def main():
         # BASELINE config 5 (32 concurrent 4K streams per GPU through the SSIM engine) as a short leg of the default line
         leg_args = argparse.Namespace(**vars(args))
         leg_args.as_leg, leg_args.streams, leg_args.workers, leg_args.steps, leg_args.warmup = True, 32, 8, 48, 4
-        config5 = run_config5(leg_args, rank, local_rank, 1)
-        # the round-5 form of the same elements (no dispatcher: 8 worker contexts take the 32 streams in turn, one synchronisation each)
+        leg_args.group = False
+        config5 = run_config5(leg_args, rank, local_rank, 1)     # 8 worker contexts take the 32 streams in turn (the form of rounds 3-5)
+        # the same elements through the process's dispatcher (8 host threads stand in for the 32 element threads) ...
         leg_args = argparse.Namespace(**vars(leg_args))
-        leg_args.no_group, leg_args.steps = True, 24
-        config5["without_the_dispatcher"] = run_config5(leg_args, rank, local_rank, 1)
+        leg_args.group, leg_args.steps = True, 24
+        config5["through_the_dispatcher"] = run_config5(leg_args, rank, local_rank, 1)
         leg_args = argparse.Namespace(**vars(leg_args))
-        leg_args.no_group, leg_args.steps = False, 48
+        leg_args.group, leg_args.steps = False, 48
+        # ... and as what BASELINE configures literally: 32 two-pad elements on 32 NATIVE threads, each with its own context, against
+        # the same threads handing their pairs to the dispatcher (tools/agroup_bench.cpp; an interpreter cannot host 32 streaming threads)
+        native = os.path.join(ROOT, "tools", "agroup_bench")
+        if os.path.exists(native):
+            import subprocess
+            try:
+                r_ = subprocess.run([native, "32", "dssim"], capture_output=True, text=True, timeout=300)
+                for l_ in r_.stdout.splitlines():
+                    if l_.startswith("{") and '"dssim"' in l_:
+                        config5["native_element_threads"] = json.loads(l_)
+            except Exception as e_:      # noqa: BLE001
+                config5["native_element_threads"] = {"error": str(e_)}
         # the same 32 streams as the non-reference pads of 4 videocompare elements (8 pads + one reference pad each): the element
         # hashes its reference frame once per aggregate, so a comparison costs one hash + one compare (+ 1/8 of a hash)
         leg_args = argparse.Namespace(**vars(leg_args))

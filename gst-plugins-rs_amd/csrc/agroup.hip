@@ -21,6 +21,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <utility>
@@ -150,6 +151,10 @@ struct mi355_agroup {
   std::vector<double> peak_cache[2];
   // ---- loudnorm
   size_t ln_out_frames = 0;
+  std::vector<std::vector<double>> adapter;   // mi355_agroup_loudnorm_push: what a member has pushed and not yet handed over as a whole frame
+  // ---- process-wide registry (mi355_agroup_shared_*): what the group was made from, members handed out, members released
+  std::string shared_key;
+  int handed_out = 0, released = 0;
 };
 
 namespace {
@@ -173,7 +178,8 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
   if (need > g->cap_bytes) {
     (void)hipStreamSynchronize(g->ctx->stream);
     size_t cap = 4096;
-    while (cap < need) cap *= 2;
+    while (cap < need && cap < ((size_t)1 << 20)) cap *= 2;
+    if (cap < need) cap = (need + 4095) & ~(size_t)4095;   // (large slots - a 3 s first frame - are sized exactly: they are pinned memory)
     char *h = nullptr, *d = nullptr;
     int rc = ahip(g, hipHostMalloc((void **)&h, cap * (size_t)g->n_members, hipHostMallocDefault), "hipHostMalloc(agroup staging)");
     if (rc) return rc;
@@ -188,7 +194,8 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
   if (out_need > g->out_cap_bytes) {
     (void)hipStreamSynchronize(g->ctx->stream);
     size_t cap = 4096;
-    while (cap < out_need) cap *= 2;
+    while (cap < out_need && cap < ((size_t)1 << 20)) cap *= 2;
+    if (cap < out_need) cap = (out_need + 4095) & ~(size_t)4095;
     if (g->h_out) (void)hipHostFree(g->h_out);
     if (g->d_out) (void)hipFree(g->d_out);
     g->h_out = nullptr; g->d_out = nullptr; g->out_cap_bytes = 0;
@@ -401,13 +408,15 @@ uint64_t ticket_of(const mi355_agroup *g, uint64_t interval, int member) { retur
 // first frames one after the other would be the longest thing in the interval), then the slot counts; run the interval if it is
 // complete. `lk` owns g->mu on entry and on return.
 void submitted(mi355_agroup *g, std::unique_lock<std::mutex> &lk, int member, uint64_t *ticket, void *dst, const void *src, size_t bytes) {
-  if (dst && bytes) {
+  if (dst && bytes > (size_t)65536) {
     g->copying++;
     lk.unlock();
     std::memcpy(dst, src, bytes);
     lk.lock();
     g->copying--;
     g->cv.notify_all();
+  } else if (dst && bytes) {
+    std::memcpy(dst, src, bytes);   // (a 10 ms audio buffer is a few KB: cheaper than giving the lock away and taking it again)
   }
   g->sub[member].have = true;
   g->sub[member].interval = g->interval;
@@ -458,7 +467,13 @@ mi355_agroup *mi355_agroup_create_loudnorm(int device, int n_members, unsigned c
   mi355_agroup *g = agroup_new(device, KIND_LOUDNORM, n_members, status);
   if (!g) return nullptr;
   g->channels = channels;
-  const int rc = loudnorm_setup_batch(g->ctx, (unsigned)n_members, channels, loudness_target, loudness_range_target, max_true_peak, offset);
+  int rc = loudnorm_setup_batch(g->ctx, (unsigned)n_members, channels, loudness_target, loudness_range_target, max_true_peak, offset);
+  if (!rc) {
+    // the slots for the largest frames State::process sees (the 3 s first frame in, 3 s out at drain) now, not inside the first interval
+    std::unique_lock<std::mutex> lk(g->mu);
+    if ((size_t)n_members * 576000 * channels * 8 <= ((size_t)2 << 30))   // (thousands of members: sized when the frames come)
+      rc = ensure_staging(g, lk, (size_t)576000 * channels * 8, (size_t)30 * 19200 * channels * 8);
+  }
   if (rc) { if (status) *status = rc; mi355_agroup_destroy(g); return nullptr; }
   if (status) *status = MI355_OK;
   return g;
@@ -700,6 +715,136 @@ int mi355_agroup_stats(mi355_agroup *g, uint64_t stats[3]) {
   stats[1] = g->n_batches;
   stats[2] = g->n_largest;
   return MI355_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- process-wide groups
+// Elements of independent pipelines cannot hand a group to each other; what they share is the process. mi355_agroup_shared_*
+// returns THE group of this configuration (kind, device, member count, parameters), creating it at first use, and the next free
+// member index; a group whose members have all been handed out is not offered again (the next element of that configuration
+// starts a new one). mi355_agroup_release = detach; the last member out destroys the group.
+namespace {
+std::mutex g_shared_mu;
+std::vector<mi355_agroup *> g_shared;
+
+template <typename Make>
+mi355_agroup *shared_get(const std::string &key, int n_members, int *member, int *status, Make make) {
+  std::lock_guard<std::mutex> lk(g_shared_mu);
+  for (mi355_agroup *g : g_shared)
+    if (g->shared_key == key && g->handed_out < g->n_members) {
+      if (member) *member = g->handed_out;
+      g->handed_out++;
+      if (status) *status = MI355_OK;
+      return g;
+    }
+  mi355_agroup *g = make();
+  if (!g) return nullptr;
+  g->shared_key = key;
+  g->handed_out = 1;
+  if (member) *member = 0;
+  g_shared.push_back(g);
+  (void)n_members;
+  return g;
+}
+
+std::string key_of(const char *kind, int device, int n_members, const double *v, int n) {
+  std::string k = std::string(kind) + ":" + std::to_string(device) + ":" + std::to_string(n_members);
+  for (int i = 0; i < n; i++) { char b[40]; std::snprintf(b, sizeof b, ":%.17g", v[i]); k += b; }
+  return k;
+}
+}  // namespace
+
+extern "C" {
+
+mi355_agroup *mi355_agroup_shared_echo(int device, int n_members, size_t ring_len, int *member, int *status) {
+  const double v[1] = {(double)ring_len};
+  return shared_get(key_of("echo", device, n_members, v, 1), n_members, member, status, [&] { return mi355_agroup_create_echo(device, n_members, ring_len, status); });
+}
+
+mi355_agroup *mi355_agroup_shared_ebur128(int device, int n_members, unsigned channels, unsigned rate, unsigned mode, const int *channel_class, int *member,
+                                          int *status) {
+  std::vector<double> v = {(double)channels, (double)rate, (double)mode};
+  for (unsigned c = 0; c < channels && c < 64; c++) v.push_back(channel_class ? (double)channel_class[c] : -1.0);
+  return shared_get(key_of("ebur128", device, n_members, v.data(), (int)v.size()), n_members, member, status,
+                    [&] { return mi355_agroup_create_ebur128(device, n_members, channels, rate, mode, channel_class, status); });
+}
+
+mi355_agroup *mi355_agroup_shared_loudnorm(int device, int n_members, unsigned channels, double loudness_target, double loudness_range_target,
+                                           double max_true_peak, double offset, int *member, int *status) {
+  const double v[5] = {(double)channels, loudness_target, loudness_range_target, max_true_peak, offset};
+  return shared_get(key_of("loudnorm", device, n_members, v, 5), n_members, member, status,
+                    [&] { return mi355_agroup_create_loudnorm(device, n_members, channels, loudness_target, loudness_range_target, max_true_peak, offset, status); });
+}
+
+// audioloudnorm's sink_chain / drain for a member (audioloudnorm/imp.rs:1545-1586 -> drain_full_frames :226-268, drain :270-310) with
+// the adapter on this side: what mi355_loudnorm_push / _drain are for a single-instance context. push appends the buffer and
+// hands every whole frame over in lock step with the other members (blocking like wait); drain hands over the rest as the final frame.
+int mi355_agroup_loudnorm_push(mi355_agroup *g, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames, size_t *out_frames) {
+  if (!g || !out_frames) return MI355_ERR_INVALID_ARG;
+  *out_frames = 0;
+  std::vector<double> *ad = nullptr;
+  size_t ch = 0;
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->kind != KIND_LOUDNORM || member < 0 || member >= g->n_members) return afail(g, MI355_ERR_INVALID_ARG, "agroup: not an audioloudnorm member");
+    if (frames && !data) return afail(g, MI355_ERR_INVALID_ARG, "agroup: null buffer");
+    if (g->adapter.empty()) g->adapter.resize((size_t)g->n_members);
+    ad = &g->adapter[(size_t)member];   // (only this member's thread touches its adapter)
+    ch = g->channels;
+  }
+  ad->insert(ad->end(), data, data + frames * ch);
+  for (;;) {
+    const size_t fs = mi355_agroup_loudnorm_frame_size(g);
+    if (fs == 0 || ad->size() / ch < fs) break;
+    uint64_t t = 0;
+    size_t n = 0;
+    int rc = mi355_agroup_submit_loudnorm(g, member, ad->data(), fs, out + *out_frames * ch, out_capacity_frames - *out_frames, 0, 0, &t);
+    if (!rc) rc = mi355_agroup_wait(g, t, &n);
+    if (rc) return rc;
+    ad->erase(ad->begin(), ad->begin() + (std::ptrdiff_t)(fs * ch));
+    *out_frames += n;
+  }
+  return MI355_OK;
+}
+
+int mi355_agroup_loudnorm_drain(mi355_agroup *g, int member, double *out, size_t out_capacity_frames, size_t *out_frames, int *eos) {
+  if (!g || !out_frames) return MI355_ERR_INVALID_ARG;
+  *out_frames = 0;
+  if (eos) *eos = 0;
+  std::vector<double> *ad = nullptr;
+  size_t ch = 0;
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->kind != KIND_LOUDNORM || member < 0 || member >= g->n_members) return afail(g, MI355_ERR_INVALID_ARG, "agroup: not an audioloudnorm member");
+    if (g->adapter.empty()) g->adapter.resize((size_t)g->n_members);
+    ad = &g->adapter[(size_t)member];
+    ch = g->channels;
+  }
+  const size_t rest = ad->size() / ch;
+  uint64_t t = 0;
+  int rc = mi355_agroup_submit_loudnorm(g, member, ad->data(), rest, out, out_capacity_frames, 1, 0, &t);
+  if (!rc) rc = mi355_agroup_wait(g, t, out_frames);
+  if (rc) return rc;
+  ad->clear();
+  if (eos && rest == 0 && *out_frames == 0) *eos = 1;   // nothing at all to drain: FlowError::Eos (imp.rs:289-293)
+  return MI355_OK;
+}
+
+void mi355_agroup_release(mi355_agroup *g, int member) {
+  if (!g) return;
+  (void)mi355_agroup_detach(g, member);
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> lk(g_shared_mu);
+    g->released++;
+    // members never handed out count as gone once everybody who came has left
+    last = g->released >= g->handed_out;
+    if (last)
+      for (size_t i = 0; i < g_shared.size(); i++)
+        if (g_shared[i] == g) { g_shared.erase(g_shared.begin() + (std::ptrdiff_t)i); break; }
+  }
+  if (last) mi355_agroup_destroy(g);
 }
 
 }  // extern "C"

@@ -14,13 +14,18 @@
 //     kind not in use keeps in the caches (the table's lines, the brick table) has been evicted by the launches in between,
 //     and a single cold launch of the table kernel measures 0.156 ms against 0.09-0.11 ms warm - enough to lose against the
 //     interpolating kernel for ever once a disturbance has flipped the choice (measured: 34 k frames/s instead of 41 k);
-//   * a change of launch size by more than 2x restarts the learning.
+//   * a decisive answer (the other kind at least twice as slow) sends its next probe straight to the longest period; a sample of
+//     the kind in use that differs from the previous one by more than 25 % (the content changed) brings the probe forward to now;
+//   * a change of launch size by more than 2x restarts the learning;
+//   * a LUT reload keeps what was learnt as the prior (lut_upload): the choice depends on the content, hardly on the LUT.
 #pragma once
 #include <cstddef>
 
 namespace mi355 {
 
 constexpr unsigned kProbeMin = 64, kProbeMax = 1024;
+constexpr double kDecisive = 2.0;       // the kind not in use measured this much slower: its next probe waits kProbeMax launches
+constexpr double kRegimeChange = 1.25;  // the kind in use changed by this factor between two samples: probe the other kind at once
 
 struct AutoPolicy {
   unsigned calls = 0, since_probe = 0, probe_period = kProbeMin;
@@ -69,13 +74,30 @@ inline void auto_complete(AutoPolicy &A, double ms) {
     //  are - averaged with a first, cold one they would take three probe periods to say what the second already said)
     double &t = A.pending_kind == 0 ? A.t_compute : A.t_table;
     const bool in_use = A.learn >= 4 && (A.pending_kind == 1) == A.table;
+    const double before = t;
+    const bool both_before = A.t_compute > 0.0 && A.t_table > 0.0;
     t = A.smooth && in_use && t > 0.0 ? 0.5 * (t + per_vec) : per_vec;
+    bool regime = false;
+    if (in_use && before > 0.0 && (per_vec > kRegimeChange * before || per_vec * kRegimeChange < before)) {
+      // The kind in use has just become much slower or much faster than it was: the content (or where the pixels come from) has
+      // changed, and what is known about the OTHER kind is as old as its last probe - ask it again now, not in up to 1024 launches.
+      A.probe_period = kProbeMin;
+      A.since_probe = kProbeMin;
+      regime = true;
+    }
     if (A.t_compute > 0.0 && A.t_table > 0.0) {
       // hysteresis (3 % by default): measurements of near-equal kernels must not flip the choice back and forth
       const double back = A.hysteresis_back < 0.0 ? A.hysteresis : A.hysteresis_back;
       const bool table = A.t_table < A.t_compute * (A.table ? 1.0 + back : 1.0 - A.hysteresis);
       if (table != A.table) { A.probe_period = kProbeMin; A.since_probe = 0; }
-      else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
+      else if ((A.pending_probe || !both_before) && !regime) {
+        // the answer stays: ask again later. A probe is two launches of the SLOWER kind (on uniform noise the table kernel takes three
+        // times the interpolating one: the five probes of the 64 ... 1024 ladder cost BENCH_r05's 32-launch uniform leg 10 %), so a
+        // decisive answer - the other kind at least twice as slow - goes straight to the longest period; a close one climbs the ladder.
+        const double mine = table ? A.t_table : A.t_compute, other = table ? A.t_compute : A.t_table;
+        if (other >= kDecisive * mine) A.probe_period = kProbeMax;
+        else if (A.pending_probe) A.probe_period = A.probe_period * 2 > kProbeMax ? kProbeMax : A.probe_period * 2;
+      }
       A.table = table;
     }
   }

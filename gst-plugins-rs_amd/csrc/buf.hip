@@ -18,21 +18,71 @@
 #include <atomic>
 #include <mutex>
 
+// Who still uses the buffer on the device: one entry per distinct stream since the last time everybody was waited for. Two
+// contexts may READ one buffer concurrently (a tee into two mi355 branches): a single "last commit" event would let the second
+// commit hide the first reader from a later writer or from the free.
+struct BufUse {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;   // ev marks the end of this stream's last committed use
+  bool writes = false;     // that use (or one since) wrote the buffer
+};
+constexpr int kBufUses = 4;
+
 struct mi355_buf {
   mi355_ctx *owner = nullptr;
   uint8_t *d = nullptr;
   uint8_t *h = nullptr;  // pinned shadow, allocated at the first host map
   size_t size = 0;
   enum State { kInSync = 0, kHostNewer = 1, kDeviceNewer = 2 } state = kInSync;
-  hipEvent_t committed = nullptr;   // last commit (any context)
-  hipStream_t committed_on = nullptr;
-  bool have_commit = false;
+  BufUse use[kBufUses];
   hipEvent_t uploaded = nullptr;    // last H2D from the shadow: a host WRITE map waits for it
   bool upload_pending = false;
   int map_flags = 0, map_count = 0;
   std::atomic<int> refs{1};
   std::mutex mu;
 };
+
+namespace {
+
+// a HIP call made on behalf of a buffer from a thread that may not be the owner context's: never writes owner->last_error
+bool buf_ok(hipError_t e) {
+  if (e == hipSuccess) return true;
+  (void)hipGetLastError();
+  return false;
+}
+
+// `stream` is ordered (on the device) behind the committed uses of the other streams: all of them before a write, the writers
+// before a read. b->mu held.
+bool order_behind(mi355_buf *b, hipStream_t stream, bool for_write) {
+  for (BufUse &u : b->use)
+    if (u.recorded && u.stream != stream && (for_write || u.writes) && !buf_ok(hipStreamWaitEvent(stream, u.ev, 0))) return false;
+  return true;
+}
+
+// the calling thread waits for the committed uses (all, or the writers only); entries that have been waited for are cleared
+bool host_wait(mi355_buf *b, bool all) {
+  for (BufUse &u : b->use)
+    if (u.recorded && (all || u.writes)) {
+      if (!buf_ok(hipEventSynchronize(u.ev))) return false;
+      u.recorded = false; u.writes = false; u.stream = nullptr;
+    }
+  return true;
+}
+
+BufUse *use_of(mi355_buf *b, hipStream_t stream) {
+  for (BufUse &u : b->use)
+    if (u.stream == stream) return &u;
+  for (BufUse &u : b->use)
+    if (!u.stream) { u.stream = stream; return &u; }
+  // more distinct streams than slots: the oldest entry is folded into this stream (it waits for that use, then takes the slot)
+  BufUse &u = b->use[0];
+  if (u.recorded && !buf_ok(hipStreamWaitEvent(stream, u.ev, 0))) return nullptr;
+  u.stream = stream; u.recorded = false;   // (writes stays: the chain behind this stream now includes that write)
+  return &u;
+}
+
+}  // namespace
 
 using namespace mi355;
 
@@ -44,11 +94,13 @@ mi355_buf *mi355_buf_alloc(mi355_ctx *ctx, size_t size) {
   mi355_buf *b = new mi355_buf();
   b->owner = ctx;
   b->size = size;
-  if (check_hip(ctx, hipMalloc((void **)&b->d, size ? (size + 15) & ~(size_t)15 : 16), "hipMalloc(mi355_buf)") ||
-      check_hip(ctx, hipEventCreateWithFlags(&b->committed, hipEventDisableTiming), "hipEventCreate(mi355_buf)") ||
-      check_hip(ctx, hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming), "hipEventCreate(mi355_buf)")) {
+  bool bad = check_hip(ctx, hipMalloc((void **)&b->d, size ? (size + 15) & ~(size_t)15 : 16), "hipMalloc(mi355_buf)") ||
+             check_hip(ctx, hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming), "hipEventCreate(mi355_buf)");
+  for (BufUse &u : b->use) bad = bad || check_hip(ctx, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming), "hipEventCreate(mi355_buf)");
+  if (bad) {
     if (b->d) (void)hipFree(b->d);
-    if (b->committed) (void)hipEventDestroy(b->committed);
+    if (b->uploaded) (void)hipEventDestroy(b->uploaded);
+    for (BufUse &u : b->use) if (u.ev) (void)hipEventDestroy(u.ev);
     delete b;
     return nullptr;
   }
@@ -63,11 +115,11 @@ mi355_buf *mi355_buf_ref(mi355_buf *b) {
 void mi355_buf_unref(mi355_buf *b) {
   if (!b || b->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   (void)hipSetDevice(b->owner->device);
-  if (b->have_commit) (void)hipEventSynchronize(b->committed);  // nothing reads or writes it any more
+  (void)host_wait(b, true);  // EVERY stream that used it has finished: nothing reads or writes it any more
   if (b->upload_pending) (void)hipEventSynchronize(b->uploaded);
   if (b->d) (void)hipFree(b->d);
   if (b->h) (void)hipHostFree(b->h);
-  (void)hipEventDestroy(b->committed);
+  for (BufUse &u : b->use) (void)hipEventDestroy(u.ev);
   (void)hipEventDestroy(b->uploaded);
   delete b;
 }
@@ -82,15 +134,21 @@ void *mi355_buf_device_ptr(mi355_buf *b, mi355_ctx *ctx, int flags) {
   // the element sees them; anything involving a write on either side is refused)
   if (b->map_count && ((b->map_flags | flags) & MI355_MAP_WRITE)) { set_error(ctx, MI355_ERR_INVALID_ARG, "mi355_buf: mapped on the host"); return nullptr; }
   if (check_hip(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
-  // behind whatever another context's stream still does with the buffer
-  if (b->have_commit && b->committed_on != ctx->stream && check_hip(ctx, hipStreamWaitEvent(ctx->stream, b->committed, 0), "hipStreamWaitEvent(mi355_buf)")) return nullptr;
+  // behind whatever the other contexts' streams still do with the buffer: behind all of them for a write (and for the upload
+  // below, which writes it), behind the writers for a read
+  const bool writes = (flags & MI355_MAP_WRITE) || (b->state == mi355_buf::kHostNewer && (flags & MI355_MAP_READ));
+  if (!order_behind(b, ctx->stream, writes)) { set_error(ctx, MI355_ERR_HIP, "hipStreamWaitEvent(mi355_buf)"); return nullptr; }
+  BufUse *mine = use_of(b, ctx->stream);
+  if (!mine) { set_error(ctx, MI355_ERR_HIP, "hipStreamWaitEvent(mi355_buf)"); return nullptr; }
+  if (writes) mine->writes = true;
   if (b->state == mi355_buf::kHostNewer) {
     // (a kernel that overwrites the whole buffer asks for WRITE alone and skips the upload)
     if (flags & MI355_MAP_READ) {
       if (check_hip(ctx, hipMemcpyAsync(b->d, b->h, b->size, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(mi355_buf H2D)")) return nullptr;
+      forget_written(ctx->device, b->d, b->size);
       if (check_hip(ctx, hipEventRecord(b->uploaded, ctx->stream), "hipEventRecord(mi355_buf)")) return nullptr;
       b->upload_pending = true;
-      b->owner->n_h2d++;
+      __atomic_fetch_add(&b->owner->n_h2d, 1ull, __ATOMIC_RELAXED);
     }
     b->state = mi355_buf::kInSync;
   }
@@ -103,32 +161,38 @@ int mi355_buf_commit(mi355_buf *b, mi355_ctx *ctx) {
   std::lock_guard<std::mutex> g(b->mu);
   int rc = check_hip(ctx, hipSetDevice(ctx->device), "hipSetDevice");
   if (rc) return rc;
-  if ((rc = check_hip(ctx, hipEventRecord(b->committed, ctx->stream), "hipEventRecord(mi355_buf commit)"))) return rc;
-  b->committed_on = ctx->stream;
-  b->have_commit = true;
+  BufUse *mine = use_of(b, ctx->stream);
+  if (!mine) return set_error(ctx, MI355_ERR_HIP, "hipStreamWaitEvent(mi355_buf)");
+  if ((rc = check_hip(ctx, hipEventRecord(mine->ev, ctx->stream), "hipEventRecord(mi355_buf commit)"))) return rc;
+  mine->recorded = true;
   return MI355_OK;
 }
 
 void *mi355_buf_map_host(mi355_buf *b, int flags) {
   if (!b || !(flags & (MI355_MAP_READ | MI355_MAP_WRITE))) return nullptr;
   std::lock_guard<std::mutex> g(b->mu);
+  // (any thread maps a GstMemory: nothing here writes the owner context's error string; the copy runs on the owner's stream, which
+  // HIP allows from any thread, and the counters are atomic)
   mi355_ctx *ctx = b->owner;
-  if (check_hip(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
-  if (!b->h && check_hip(ctx, hipHostMalloc((void **)&b->h, b->size ? b->size : 1, hipHostMallocDefault), "hipHostMalloc(mi355_buf)")) return nullptr;
+  if (!buf_ok(hipSetDevice(ctx->device))) return nullptr;
+  if (!b->h && !buf_ok(hipHostMalloc((void **)&b->h, b->size ? b->size : 1, hipHostMallocDefault))) return nullptr;
   if (b->upload_pending) {  // the shadow is still being read by an upload
-    if (check_hip(ctx, hipEventSynchronize(b->uploaded), "hipEventSynchronize(mi355_buf)")) return nullptr;
+    if (!buf_ok(hipEventSynchronize(b->uploaded))) return nullptr;
     b->upload_pending = false;
   }
   if (b->state == mi355_buf::kDeviceNewer) {
     // A WRITE-only map downloads too: the mapper may write part of the memory and the rest must stay what it was.
-    if (b->have_commit && check_hip(ctx, hipStreamWaitEvent(ctx->stream, b->committed, 0), "hipStreamWaitEvent(mi355_buf)")) return nullptr;
-    if (check_hip(ctx, hipMemcpyAsync(b->h, b->d, b->size, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(mi355_buf D2H)")) return nullptr;
-    if (check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize(mi355_buf)")) return nullptr;
-    ctx->n_d2h++;
+    if (!order_behind(b, ctx->stream, (flags & MI355_MAP_WRITE) != 0)) return nullptr;
+    if (!buf_ok(hipMemcpyAsync(b->h, b->d, b->size, hipMemcpyDeviceToHost, ctx->stream))) return nullptr;
+    if (!buf_ok(hipStreamSynchronize(ctx->stream))) return nullptr;
+    __atomic_fetch_add(&ctx->n_d2h, 1ull, __ATOMIC_RELAXED);
     b->state = mi355_buf::kInSync;
-  } else if (b->have_commit) {
+    if (flags & MI355_MAP_WRITE) {   // the owner's stream waited for everybody and has drained: nobody uses the buffer any more
+      for (BufUse &u : b->use) { u.recorded = false; u.writes = false; u.stream = nullptr; }
+    }
+  } else {
     // in sync or host newer: nothing to fetch, but device work that READS the buffer must not be overtaken by a host write
-    if ((flags & MI355_MAP_WRITE) && check_hip(ctx, hipEventSynchronize(b->committed), "hipEventSynchronize(mi355_buf)")) return nullptr;
+    if ((flags & MI355_MAP_WRITE) && !host_wait(b, true)) return nullptr;
   }
   b->map_count++;
   b->map_flags |= flags;
@@ -154,8 +218,8 @@ int mi355_buf_state(mi355_buf *b) {
 
 int mi355_ctx_transfer_counts(mi355_ctx *ctx, uint64_t *h2d, uint64_t *d2h) {
   if (!ctx) return MI355_ERR_INVALID_ARG;
-  if (h2d) *h2d = ctx->n_h2d;
-  if (d2h) *d2h = ctx->n_d2h;
+  if (h2d) *h2d = __atomic_load_n(&ctx->n_h2d, __ATOMIC_RELAXED);
+  if (d2h) *d2h = __atomic_load_n(&ctx->n_d2h, __ATOMIC_RELAXED);
   return MI355_OK;
 }
 

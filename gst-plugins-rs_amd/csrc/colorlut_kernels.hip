@@ -1055,8 +1055,6 @@ void lut_release(mi355_ctx *ctx) {
     shared_table_release(ctx, &ctx->lut.table_ref[i]);  // the shared table goes when its last user does
     if (ctx->lut.pick[i].ev0) (void)hipEventDestroy(ctx->lut.pick[i].ev0);
     if (ctx->lut.pick[i].ev1) (void)hipEventDestroy(ctx->lut.pick[i].ev1);
-    if (ctx->lut.pick_sub[i].ev0) (void)hipEventDestroy(ctx->lut.pick_sub[i].ev0);
-    if (ctx->lut.pick_sub[i].ev1) (void)hipEventDestroy(ctx->lut.pick_sub[i].ev1);
   }
   if (ctx->lut.d_cells) (void)hipFree(ctx->lut.d_cells);
   if (ctx->lut.d_planar) (void)hipFree(ctx->lut.d_planar);
@@ -1084,8 +1082,22 @@ static void axis_entry(int v, float scale, float offset, int S, float *t_out, in
 
 int lut_upload(mi355_ctx *ctx, int is3d, size_t size, const float *table, const float scale[3],
                const float offset[3]) {
+  // What the choice between the interpolating and the table kernels has learnt survives a reload as the PRIOR: which kind is
+  // faster depends on the content (colour locality) and hardly on the LUT (the table kernel does not see it at all). Without it a
+  // used context spends its first dozen launches after every reload re-learning through the slower kind
+  // (profiles/r05_configs_elements.txt: 17^3 at 0.134 ms next to 33^3 at 0.096). The other kind is probed again after kProbeMin launches.
+  AutoPolicy prior[2];
+  bool have_prior = ctx->lut.loaded && ctx->lut.is3d && is3d;
+  for (int i = 0; i < 2 && have_prior; i++) prior[i] = ctx->lut.pick[i];
   lut_release(ctx);
   LutDevice &L = ctx->lut;
+  for (int i = 0; i < 2 && have_prior; i++) {
+    if (prior[i].learn < 4 || prior[i].table_unavailable || !(prior[i].t_compute > 0.0 && prior[i].t_table > 0.0)) continue;
+    AutoPolicy &P = L.pick[i];
+    P.learn = 4; P.table = prior[i].table; P.t_compute = prior[i].t_compute; P.t_table = prior[i].t_table; P.vec = prior[i].vec;
+    P.calls = 1;   // (not a multiple of the sampling period: the first launch builds the table, the sampling starts behind it)
+    P.probe_period = kProbeMin; P.since_probe = 0; P.pending_kind = -1;
+  }
   L.is3d = is3d;
   L.size = (int)size;
   for (int c = 0; c < 3; c++) { L.scale[c] = scale[c]; L.offset[c] = offset[c]; }
@@ -1729,35 +1741,36 @@ template <class Compute, class Ensure, class Table>
 static int auto_launch(mi355_ctx *ctx, AutoPick &A, size_t n_vec, Compute &&compute, Ensure &&ensure, Table &&table);
 static int launch_table_gather(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton);
 static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
-                            TableKernel sub = kTableGather, AutoPick *pick = nullptr);
+                            TableKernel sub = kTableGather, int *last_sub = nullptr);
 static int launch_table(mi355_ctx *ctx, int which, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
                         const mi355_hsv_settings *hs, TableKernel sub = kTableGather) {
   int rc = table_ensure(ctx, which, morton, hs);
   if (rc) return rc;
-  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, geo, width, rows, morton, sub, &ctx->lut.pick_sub[which]);
+  return launch_table_raw(ctx, ctx->lut.d_table[which], d_src, d_dst, geo, width, rows, morton, sub, &ctx->lut.last_sub[which]);
 }
 
-// Both kernels read the same table and give the same bytes; which is faster depends on where the pixels come from and on
-// the content: the gather kernel wins when its input was just written by the previous element (Infinity Cache) and the
-// colours are few, the LDS-cached kernel when the frames come from HBM or the colours outgrow L1. With
-// kTableEither the choice is the same measured one as between the interpolating and the table kernels (autopick.hpp), with
-// its own state per entry point: role "compute" = gather kernel, role "table" = LDS-cached kernel.
+// Both kernels read the same table and give the same bytes; which is faster depends on WHERE THE PIXELS COME FROM: the gather
+// kernel wins when its input was just written by the previous launch and is still on-die (Infinity Cache; behind hsvfilter
+// 0.086-0.089 against 0.093-0.099 ms at amp 0, 0.114 against 0.142 at +-4), the LDS-cached kernel when the frames come from HBM
+// (0.096 against 0.117; 0.143 against 0.176; 0.171 against 0.231 at +-8 - every box of rounds 5 and 6). Rounds 4-5
+// decided this by a second, nested measured choice (autopick.hpp inside autopick.hpp): its samples of the kernel not in use
+// were up to 1024 launches old, so a choice made on input from HBM survived on on-die input and the other way round
+// (BENCH_r05 content_sweep.amp4: 35.3 k instead of 37.6 k). The provenance is known exactly (note_written / recently_written):
+// kTableEither is that rule now, with no state, no probes and nothing to settle.
 static int launch_table_raw(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton,
-                            TableKernel sub, AutoPick *pick) {
+                            TableKernel sub, int *last_sub) {
   const bool window_ok = morton && sub != kTableGather && width % 4 == 0 && window_applicable(ctx, (unsigned)width / 4, geo.dw4, rows);
-  auto gather = [&]() { return launch_table_gather(ctx, t, d_src, d_dst, geo, width, rows, morton); };
-  auto window = [&]() {
+  const size_t src_bytes = (size_t)geo.sw4 * 16 * rows;
+  const bool window = window_ok && (sub == kTableWindow || !recently_written(ctx->device, d_src, src_bytes));
+  if (last_sub) *last_sub = window ? 1 : 0;
+  int rc;
+  if (window) {
     ctx->lut.last_kernel = "colorlut_window_kernel";
-    return launch_window_table(ctx, t, d_src, d_dst, (unsigned)width / 4, geo.sw4, geo.dw4, rows);
-  };
-  if (!window_ok) return gather();
-  if (sub == kTableWindow || !pick) return window();
-  // (autopick.hpp: the two table kernels are 5-10 % apart behind hsvfilter, 14-18 % from HBM: the LDS-cached kernel takes over
-  // with a 10 % lead and keeps the launches only while it measures faster at all)
-  pick->hysteresis = 0.10;
-  pick->hysteresis_back = 0.0;
-  pick->smooth = true;
-  return auto_launch(ctx, *pick, geo.n_vec, gather, []() { return (int)MI355_OK; }, window);
+    rc = launch_window_table(ctx, t, d_src, d_dst, (unsigned)width / 4, geo.sw4, geo.dw4, rows);
+  } else {
+    rc = launch_table_gather(ctx, t, d_src, d_dst, geo, width, rows, morton);
+  }
+  return rc;
 }
 
 static int launch_table_gather(mi355_ctx *ctx, const uint32_t *t, const uint8_t *d_src, uint8_t *d_dst, const Rgba8Geom &geo, int width, size_t rows, int morton) {
@@ -1869,10 +1882,8 @@ int launch_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int 
   if (table_ok && table_variant(v))
     return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, v == 4 ? 0 : 1, nullptr, table_variant_kernel(v));
   if (!table_ok || v != 0 || n_vec < kAutoMinVec) return compute();
-  // (the outer choice's own learning / probe launches read the table through the gather kernel: its sample of "the table" must not
-  // be whichever kernel the nested choice happens to be trying at that moment)
   return auto_launch(ctx, L.pick[0], n_vec, compute, [&]() { return table_ensure(ctx, 0, 1, nullptr); },
-                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr, L.pick[0].last_probe ? kTableGather : kTableEither); });
+                     [&]() { return launch_table(ctx, 0, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, nullptr, kTableEither); });
 }
 
 // The fused entry point: hsvfilter -> colorlut is also a function of the colour alone, so the same memoisation applies
@@ -1902,7 +1913,7 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
     L.pick[1].learn = 2;
   }
   return auto_launch(ctx, L.pick[1], n_vec, compute, [&]() { return table_ensure(ctx, 1, 1, &hs); },
-                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, L.pick[1].last_probe ? kTableGather : kTableEither); });
+                     [&]() { return launch_table(ctx, 1, d_src, d_dst, geo, width, (size_t)n_frames * height, 1, &hs, kTableEither); });
 }
 
 // ---- frames of several streams in one launch (group.hip)
@@ -1961,8 +1972,6 @@ void hsv_table_release(mi355_ctx *ctx) {
   shared_table_release(ctx, &T.table_ref);
   if (T.pick.ev0) (void)hipEventDestroy(T.pick.ev0);
   if (T.pick.ev1) (void)hipEventDestroy(T.pick.ev1);
-  if (T.pick_sub.ev0) (void)hipEventDestroy(T.pick_sub.ev0);
-  if (T.pick_sub.ev1) (void)hipEventDestroy(T.pick_sub.ev1);
   T = HsvTable{};
 }
 
@@ -2002,7 +2011,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
   if (ctx->hsv_table_mode == 2) {
     int rc = hsv_table_ensure(ctx, fmt, hs);
     T.last_table = true;
-    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, &T.pick_sub);
+    return rc ? rc : launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, nullptr);
   }
   if (n_vec < kAutoMinVec) return compute();
   if (same_hs(hs, T.seen_hs) && fmt.bgr == T.seen_bgr) { if (T.seen_stable < kStableCalls) T.seen_stable++; }
@@ -2014,7 +2023,7 @@ int launch_hsvfilter(mi355_ctx *ctx, uint8_t *d_data, int n_frames, size_t frame
     T.pick.learn = 2;
   }
   return auto_launch(ctx, T.pick, n_vec, compute, [&]() { return hsv_table_ensure(ctx, fmt, hs); },
-                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, &T.pick_sub); });
+                     [&]() { T.last_table = true; return launch_table_raw(ctx, T.d_table, d_data, d_data, geo, width, rows, 1, kTableEither, nullptr); });
 }
 
 }  // namespace mi355

@@ -1,6 +1,7 @@
 // ctx.hip — the extern "C" layer of libmi355fx.so (declared in include/mi355fx.h): context
 // lifetime, staging of host buffers, argument validation, dispatch to the kernel launchers.
 #include "internal.hpp"
+#include <mutex>
 
 #include <cstdio>
 #include <cstring>
@@ -101,6 +102,47 @@ const char *mi355_status_string(int status) {
   }
 }
 
+}  // extern "C"
+
+namespace mi355 {
+namespace {
+// the last two launches per device that wrote frames: {begin, end}
+struct Written { uintptr_t lo = 0, hi = 0; };
+std::mutex g_written_mu;
+Written g_written[16][2];
+// An eight-frame 4K batch is 265 MB and the launch behind it still finds about half of it on-die (the gather kernel
+// then beats the LDS-cached one, 0.086-0.089 against 0.093-0.099 ms); twice that has been pushed out by its own tail.
+constexpr size_t kOnDieBytes = (size_t)320 << 20;
+}  // namespace
+
+void note_written(int device, const void *p, size_t bytes) {
+  if (device < 0 || device >= 16 || !p || !bytes) return;
+  std::lock_guard<std::mutex> lk(g_written_mu);
+  g_written[device][1] = g_written[device][0];
+  g_written[device][0].lo = (uintptr_t)p;
+  g_written[device][0].hi = (uintptr_t)p + bytes;
+}
+
+// a copy from the host has replaced [p, p + bytes): whatever a launch wrote there is no longer what a reader finds (and a DMA
+// upload lands in HBM, not in the cache)
+void forget_written(int device, const void *p, size_t bytes) {
+  if (device < 0 || device >= 16 || !p || !bytes) return;
+  std::lock_guard<std::mutex> lk(g_written_mu);
+  for (Written &w : g_written[device])
+    if (w.hi > w.lo && (uintptr_t)p < w.hi && (uintptr_t)p + bytes > w.lo) w = Written{};
+}
+
+bool recently_written(int device, const void *p, size_t bytes) {
+  if (device < 0 || device >= 16 || !p || !bytes || bytes > kOnDieBytes) return false;
+  std::lock_guard<std::mutex> lk(g_written_mu);
+  for (const Written &w : g_written[device])
+    if (w.hi > w.lo && (uintptr_t)p >= w.lo && (uintptr_t)p + bytes <= w.hi && w.hi - w.lo <= kOnDieBytes) return true;
+  return false;
+}
+}  // namespace mi355
+
+extern "C" {
+
 mi355_ctx *mi355_ctx_create(int device, int *status) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -147,9 +189,6 @@ void mi355_ctx_destroy(mi355_ctx *ctx) {
   loudnorm_batch_release(ctx);
   dssim_release(ctx);
   roundedcorners_release(ctx);
-  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
-  if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
   ebur128_release(ctx);
   hrtf_release(ctx);
   sofa_release(ctx);
@@ -223,7 +262,8 @@ int mi355_memcpy_h2d(mi355_ctx *ctx, void *dptr, const void *host, size_t bytes)
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
   int rc = check_hip(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
-  ctx->n_h2d++;
+  forget_written(ctx->device, dptr, bytes);
+  __atomic_fetch_add(&ctx->n_h2d, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -232,7 +272,7 @@ int mi355_memcpy_d2h(mi355_ctx *ctx, void *host, const void *dptr, size_t bytes)
   REQUIRE_CTX(ctx);
   BIND_DEVICE(ctx);
   int rc = check_hip(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
-  ctx->n_d2h++;
+  __atomic_fetch_add(&ctx->n_d2h, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -252,7 +292,9 @@ int mi355_hsvfilter_frames_device(mi355_ctx *ctx, uint8_t *d_data, int n_frames,
   if (n_frames > 1 && frame_pitch < (size_t)(height - 1) * (size_t)stride + (size_t)width * fmt.pixel_stride)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvfilter: frame_pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
-  return launch_hsvfilter(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, *settings);
+  const int rc = launch_hsvfilter(ctx, d_data, n_frames, frame_pitch, width, height, stride, fmt, *settings);
+  if (rc == MI355_OK) note_written(ctx->device, d_data, (size_t)(n_frames - 1) * frame_pitch + (size_t)stride * (size_t)height);   // what the element behind finds on-die
+  return rc;
 }
 
 int mi355_hsvfilter_frame_ip(mi355_ctx *ctx, uint8_t *data, size_t data_len, int width, int stride, int format,
@@ -275,12 +317,12 @@ int mi355_hsvfilter_frame_ip(mi355_ctx *ctx, uint8_t *data, size_t data_len, int
   if (rc) return rc;
   uint8_t *d = (uint8_t *)ctx->d_stage[0];
   rc = check_hip(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D frame)");
-  ctx->n_h2d++;
+  __atomic_fetch_add(&ctx->n_h2d, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   rc = launch_hsvfilter(ctx, d, 1, bytes, width, (int)rows, stride, fmt, *settings);
   if (rc) return rc;
   rc = check_hip(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H frame)");
-  ctx->n_d2h++;
+  __atomic_fetch_add(&ctx->n_d2h, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvfilter: stream synchronize");
 }
@@ -319,7 +361,9 @@ int mi355_hsvdetect_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t s
   if ((size_t)src_stride < (size_t)width * sfmt.pixel_stride || (size_t)dst_stride < (size_t)width * 4)
     return set_error(ctx, MI355_ERR_INVALID_ARG, "hsvdetector: line bytes exceed stride");
   BIND_DEVICE(ctx);
-  return launch_hsvdetect(ctx, d_src, src_pitch, src_stride, sfmt, d_dst, dst_pitch, dst_stride, af, bgr, n_frames, width, height, *settings);
+  const int rc = launch_hsvdetect(ctx, d_src, src_pitch, src_stride, sfmt, d_dst, dst_pitch, dst_stride, af, bgr, n_frames, width, height, *settings);
+  if (rc == MI355_OK) note_written(ctx->device, d_dst, (size_t)(n_frames - 1) * dst_pitch + (size_t)dst_stride * (size_t)height);
+  return rc;
 }
 
 int mi355_hsvdetect_frame(mi355_ctx *ctx, const uint8_t *src, size_t src_len, int src_stride, int src_format, uint8_t *dst,
@@ -346,16 +390,16 @@ int mi355_hsvdetect_frame(mi355_ctx *ctx, const uint8_t *src, size_t src_len, in
   if (rc) return rc;
   uint8_t *ds = (uint8_t *)ctx->d_stage[0], *dd = (uint8_t *)ctx->d_stage[1];
   rc = check_hip(ctx, hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D src)");
-  ctx->n_h2d++;
+  __atomic_fetch_add(&ctx->n_h2d, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   // only out_line[..width*4] is written by the reference: bring the rest of dst over unchanged
   rc = check_hip(ctx, hipMemcpyAsync(dd, dst, db, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D dst)");
-  ctx->n_h2d++;
+  __atomic_fetch_add(&ctx->n_h2d, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   rc = launch_hsvdetect(ctx, ds, sb, src_stride, sfmt, dd, db, dst_stride, af, bgr, 1, width, (int)rows_in, *settings);
   if (rc) return rc;
   rc = check_hip(ctx, hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H dst)");
-  ctx->n_d2h++;
+  __atomic_fetch_add(&ctx->n_d2h, 1ull, __ATOMIC_RELAXED);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hsvdetector: stream synchronize");
 }
@@ -385,11 +429,10 @@ int mi355_colorlut_unload(mi355_ctx *ctx) {
 
 int mi355_colorlut_kernel_choice(mi355_ctx *ctx, int fused, int *table_in_use, double *ms_per_mpx_compute, double *ms_per_mpx_table) {
   REQUIRE_CTX(ctx);
-  if (fused == 10 || fused == 11) {  // the table's own choice: gather kernel ("compute" role) against the LDS-cached kernel ("table" role)
-    const AutoPick &S = ctx->lut.pick_sub[fused - 10];
-    if (table_in_use) *table_in_use = S.t_table > 0.0 && S.table;
-    if (ms_per_mpx_compute) *ms_per_mpx_compute = S.t_compute * 250000.0;
-    if (ms_per_mpx_table) *ms_per_mpx_table = S.t_table * 250000.0;
+  if (fused == 10 || fused == 11) {  // inside the table path: which kernel read the table last (a rule on the input's provenance: no times)
+    if (table_in_use) *table_in_use = ctx->lut.last_sub[fused - 10];
+    if (ms_per_mpx_compute) *ms_per_mpx_compute = 0.0;
+    if (ms_per_mpx_table) *ms_per_mpx_table = 0.0;
     return MI355_OK;
   }
   const AutoPick &A = fused == 2 ? ctx->hsv_table.pick : ctx->lut.pick[fused ? 1 : 0];
@@ -451,7 +494,9 @@ int mi355_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t sr
                        dst_pitch < (size_t)(height - 1) * (size_t)dst_stride + (size_t)width * bpp))
     return set_error(ctx, MI355_ERR_INVALID_ARG, "colorlut: frame pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
-  return launch_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
+  const int rc = launch_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, format);
+  if (rc == MI355_OK) note_written(ctx->device, d_dst, (size_t)(n_frames - 1) * dst_pitch + (size_t)dst_stride * (size_t)height);
+  return rc;
 }
 
 int mi355_hsv_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride, uint8_t *d_dst,
@@ -469,7 +514,9 @@ int mi355_hsv_colorlut_frames_device(mi355_ctx *ctx, const uint8_t *d_src, size_
                        dst_pitch < (size_t)(height - 1) * (size_t)dst_stride + (size_t)width * 4))
     return set_error(ctx, MI355_ERR_INVALID_ARG, "hsv+colorlut: frame pitch smaller than one frame (frames would overlap)");
   BIND_DEVICE(ctx);
-  return launch_hsv_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, *settings);
+  const int rc = launch_hsv_colorlut(ctx, d_src, src_pitch, src_stride, d_dst, dst_pitch, dst_stride, n_frames, width, height, *settings);
+  if (rc == MI355_OK) note_written(ctx->device, d_dst, (size_t)(n_frames - 1) * dst_pitch + (size_t)dst_stride * (size_t)height);
+  return rc;
 }
 
 int mi355_colorlut_frame(mi355_ctx *ctx, const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width,
@@ -811,40 +858,22 @@ int mi355_issue_streams_round(mi355_ctx *const *ctxs, int n_streams, uint8_t *co
   return MI355_OK;
 }
 
-// hsvfilter (in place) then colorlut for n independent batches from ONE native call. lanes == 1: everything on the context's stream,
-// as n pairs of the two element calls would be. lanes == 2: odd batches go to a side stream that forks from the context's stream
-// after batch 0 (whose launches carry any one-off work - a table build - in stream order) and joins it at the end: the batches are
-// independent, and while one lane sits in the 3-6 us between two dependent launches the other lane's kernel has the chip.
+// hsvfilter (in place) then colorlut for n independent batches from ONE native call, on the context's stream, as n pairs of the two
+// element calls would be. `lanes`: 1; 2 is accepted and runs as 1. Round 5 put odd batches on a side stream (one lane's launch
+// boundary under the other lane's kernel): measured 12 % SLOWER (two memory-bound launches side by side push each other's
+// intermediate batch out of the Infinity Cache, profiles/r05_lanes_probe.txt) and not safe in auto mode - a table build that the
+// choice policy starts at batch k > 0 was enqueued on one lane and read by the other without an event in between.
+// Removed in round 6 rather than ordered: with every batch waiting for the other lane's builds there is nothing left to overlap.
 int mi355_hsv_colorlut_chain_batches_device(mi355_ctx *ctx, uint8_t *const *d_src, uint8_t *const *d_dst, int n_batches, int n_frames, size_t frame_pitch,
                                             int stride, int width, int height, int format, const mi355_hsv_settings *settings, int lanes) {
   REQUIRE_CTX(ctx);
   if (!d_src || !d_dst || !settings || n_batches < 0 || lanes < 1 || lanes > 2) return set_error(ctx, MI355_ERR_INVALID_ARG, "chain batches: bad argument");
   BIND_DEVICE(ctx);
   int rc = MI355_OK;
-  hipStream_t main_stream = ctx->stream;
-  const bool fork = lanes == 2 && n_batches > 1;
-  if (fork && !ctx->side_stream) {
-    if ((rc = check_hip(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking), "hipStreamCreate(side lane)"))) return rc;
-    if ((rc = check_hip(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming), "hipEventCreate(side lane)"))) return rc;
-    if ((rc = check_hip(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming), "hipEventCreate(side lane)"))) return rc;
-  }
   for (int k = 0; k < n_batches && !rc; k++) {
     if (!d_src[k] || !d_dst[k]) { rc = set_error(ctx, MI355_ERR_INVALID_ARG, "chain batches: null batch"); break; }
-    const bool side = fork && (k & 1);
-    if (fork && k == 1) {  // the side lane starts behind batch 0 (and behind everything the stream held before this call)
-      if ((rc = check_hip(ctx, hipEventRecord(ctx->side_fork, main_stream), "hipEventRecord(side lane)"))) break;
-      if ((rc = check_hip(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0), "hipStreamWaitEvent(side lane)"))) break;
-    }
-    ctx->stream = side ? ctx->side_stream : main_stream;
     rc = mi355_hsvfilter_frames_device(ctx, d_src[k], n_frames, frame_pitch, width, height, stride, format, settings);
     if (!rc) rc = mi355_colorlut_frames_device(ctx, d_src[k], frame_pitch, stride, d_dst[k], frame_pitch, stride, n_frames, width, height, format);
-  }
-  ctx->stream = main_stream;
-  if (fork) {  // (also after an error: whatever the side lane holds is ordered before what the caller does next)
-    if (hipEventRecord(ctx->side_join, ctx->side_stream) != hipSuccess || hipStreamWaitEvent(main_stream, ctx->side_join, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipStreamSynchronize(ctx->side_stream);
-    }
   }
   return rc;
 }

@@ -756,3 +756,40 @@ int mi355_group_stats(mi355_group *g, uint64_t stats[3]) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- the process's group per device
+// Elements of independent pipelines share nothing but the process: mi355_group_shared(device) is THE dispatcher of that device
+// (created at first use, reference-counted: every call is paired with one mi355_group_release; the last release destroys it).
+namespace {
+std::mutex g_pg_mu;
+struct ProcessGroup { int device; mi355_group *g; int refs; };
+std::vector<ProcessGroup> g_pg;
+}  // namespace
+
+extern "C" {
+
+mi355_group *mi355_group_shared(int device, int *status) {
+  std::lock_guard<std::mutex> lk(g_pg_mu);
+  for (ProcessGroup &p : g_pg)
+    if (p.device == device) { p.refs++; if (status) *status = MI355_OK; return p.g; }
+  mi355_group *g = mi355_group_create(device, 0, status);
+  if (g) g_pg.push_back(ProcessGroup{device, g, 1});
+  return g;
+}
+
+void mi355_group_release(mi355_group *g) {
+  if (!g) return;
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> lk(g_pg_mu);
+    for (size_t i = 0; i < g_pg.size(); i++)
+      if (g_pg[i].g == g) {
+        last = --g_pg[i].refs == 0;
+        if (last) g_pg.erase(g_pg.begin() + (std::ptrdiff_t)i);
+        break;
+      }
+  }
+  if (last) mi355_group_destroy(g);
+}
+
+}  // extern "C"

@@ -44,7 +44,7 @@ struct LutDevice {
   mi355_hsv_settings seen_hs{};    // settings of the previous fused call and for how many calls they have not changed
   unsigned seen_stable = 0;
   AutoPick pick[2];                // compute-kernel / table-kernel choice for the two entry points
-  AutoPick pick_sub[2];            // ... and, for the table, gather kernel / LDS-cached kernel (colorlut_window.hip)
+  int last_sub[2] = {0, 0};        // which kernel read the table last: 0 gather, 1 LDS-cached (colorlut_window.hip) - by provenance of the input
   BrickLut brick;                  // brick form of a 3D LUT for the brick-cache interpolating kernel (colorlut_brick.hip)
   bool building_table = false;     // launch_*_compute is being run over the all-colours frame by table_ensure
   const char *last_kernel = "";    // name of the kernel that served the last mi355_colorlut_* / mi355_hsv_colorlut_* launch
@@ -64,7 +64,6 @@ struct HsvTable {
   unsigned seen_stable = 0;
   bool last_table = false;       // the last launch_hsvfilter call ran the table kernel
   AutoPick pick;
-  AutoPick pick_sub;             // gather kernel / LDS-cached kernel for the table
 };
 
 struct EchoDevice {
@@ -97,8 +96,6 @@ struct mi355_ctx {
   void *loudnorm = nullptr;    // mi355::LoudNormState (loudnorm.hip)
   void *loudnorm_batch = nullptr;  // mi355::LoudNormBatch (loudnorm.hip): n streams in lock step
   void *dssim_cache = nullptr; // mi355::DssimCache (dssim_kernels.hip)
-  hipStream_t side_stream = nullptr;  // mi355_hsv_colorlut_chain_batches_device with two lanes: the second lane and its fork / join events
-  hipEvent_t side_fork = nullptr, side_join = nullptr;
   void *rounded = nullptr;     // mi355::RoundedMask (roundedcorners.hip): the element's alpha plane, device-resident
   // host <-> device copies this context has enqueued through the library's own entry points and mi355_buf objects (tests assert
   // that a chain of elements on device buffers costs ONE upload and ONE download: mi355_ctx_transfer_counts)
@@ -144,6 +141,12 @@ struct PixFmt {
 bool pixfmt_of(int format, PixFmt *out);
 
 int set_error(mi355_ctx *ctx, int status, const std::string &msg);
+// Where a launch's input comes from decides which of the two table kernels reads it (colorlut_kernels.hip: launch_table_raw):
+// note_written: a launch of this library that WRITES [p, p + bytes) has just been enqueued on `device`; recently_written: is
+// [p, p + bytes) inside what one of the last two such launches wrote, and small enough to still be on-die (Infinity Cache)?
+void note_written(int device, const void *p, size_t bytes);
+bool recently_written(int device, const void *p, size_t bytes);
+void forget_written(int device, const void *p, size_t bytes);   // a host copy has replaced that range
 int check_hip(mi355_ctx *ctx, hipError_t e, const char *what);
 
 // kernel launchers (asynchronous on ctx->stream)

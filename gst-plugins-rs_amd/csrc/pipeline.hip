@@ -88,6 +88,7 @@ static int pipe_take_slot(mi355_pipe *p, mi355_pipe::Slot **out) {
 // upload `rows` rows of `row_bytes` from a host plane with `stride` into the slot (tightly packed)
 static int pipe_upload(mi355_pipe *p, mi355_pipe::Slot *s, const uint8_t *src, size_t stride, size_t row_bytes, size_t rows) {
   int rc = check_hip(p->ctx, hipMemcpy2DAsync(s->d_in, row_bytes, src, stride, row_bytes, rows, hipMemcpyHostToDevice, p->s_up), "pipeline: H2D");
+  forget_written(p->ctx->device, s->d_in, row_bytes * rows);
   if (rc) return rc;
   rc = check_hip(p->ctx, hipEventRecord(s->uploaded, p->s_up), "pipeline: record upload");
   if (rc) return rc;

@@ -73,7 +73,7 @@ int mi355_roundedcorners_set_mask(mi355_ctx *ctx, const uint8_t *mask, int width
   m->width = width; m->height = height; m->stride = stride;
   // in stream order behind the launches that still read the previous mask; the caller's buffer is read before this returns
   if ((rc = check_hip(ctx, hipMemcpyAsync(m->d, mask, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(roundedcorners mask)"))) return rc;
-  ctx->n_h2d++;
+  __atomic_fetch_add(&ctx->n_h2d, 1ull, __ATOMIC_RELAXED);
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
 

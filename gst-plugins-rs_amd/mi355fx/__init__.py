@@ -199,6 +199,14 @@ def load_library():
         "mi355_agroup_ebur128_peak": (i, [vp, i, i, C.c_uint, C.POINTER(C.c_double)]),
         "mi355_agroup_echo_get_state": (i, [vp, i, vp, sz, C.POINTER(sz)]),
         "mi355_agroup_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_loudnorm_push": (i, [vp, i, vp, sz, vp, sz, C.POINTER(sz)]),
+        "mi355_agroup_loudnorm_drain": (i, [vp, i, vp, sz, C.POINTER(sz), C.POINTER(C.c_int)]),
+        "mi355_agroup_shared_echo": (vp, [i, i, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mi355_agroup_shared_ebur128": (vp, [i, i, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mi355_agroup_shared_loudnorm": (vp, [i, i, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mi355_agroup_release": (None, [vp, i]),
+        "mi355_group_shared": (vp, [i, C.POINTER(C.c_int)]),
+        "mi355_group_release": (None, [vp]),
         "mi355_group_submit_round": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_group_submit_round_fused": (i, [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp), i, i, i, i, C.POINTER(HsvSettings)]),
         "mi355_selftest_dssim_cbrt": (i, [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -408,11 +416,30 @@ class Group:
 class AudioGroup:
     """Independent audio element instances of one kind and configuration sharing launches (mi355_agroup_*)."""
 
-    def __init__(self, kind, n_members, device=0, **kw):
+    def __init__(self, kind, n_members, device=0, shared=False, **kw):
+        """shared=True: the process-wide group of this configuration (mi355_agroup_shared_*); self.member is the index handed out,
+        close() releases the membership (the last member out destroys the group)."""
         self.L = load_library()
         st = C.c_int(0)
         self.kind, self.n = kind, n_members
         self.channels = kw.get("channels", 1)
+        self.shared, self.member = shared, None
+        if shared:
+            m = C.c_int(-1)
+            if kind == "echo":
+                self.h = self.L.mi355_agroup_shared_echo(device, n_members, kw["ring_len"], C.byref(m), C.byref(st))
+            elif kind == "ebur128":
+                cc = kw.get("channel_class")
+                arr = (C.c_int * len(cc))(*cc) if cc is not None else None
+                self.h = self.L.mi355_agroup_shared_ebur128(device, n_members, kw["channels"], kw["rate"], kw["mode"], arr, C.byref(m), C.byref(st))
+            else:
+                self.h = self.L.mi355_agroup_shared_loudnorm(device, n_members, kw["channels"], kw.get("loudness_target", -24.0), kw.get("loudness_range_target", 7.0),
+                                                             kw.get("max_true_peak", -2.0), kw.get("offset", 0.0), C.byref(m), C.byref(st))
+            if not self.h:
+                raise Mi355Error(st.value, "mi355_agroup_shared_" + kind)
+            self.member = m.value
+            self._keep = {}
+            return
         if kind == "echo":
             self.h = self.L.mi355_agroup_create_echo(device, n_members, kw["ring_len"], C.byref(st))
         elif kind == "ebur128":
@@ -504,9 +531,29 @@ class AudioGroup:
         self._ck(self.L.mi355_agroup_stats(self.h, c))
         return int(c[0]), int(c[1]), int(c[2])
 
+    def loudnorm_push(self, member, data):
+        """mi355_agroup_loudnorm_push: the member's sink_chain (adapter on the library's side). -> output samples of the frames completed."""
+        a = np.ascontiguousarray(data, dtype=np.float64).reshape(-1)
+        frames = a.size // self.channels
+        cap = (frames // 19200 + 32) * 19200
+        out = np.zeros(cap * self.channels, np.float64)
+        n = C.c_size_t(0)
+        self._ck(self.L.mi355_agroup_loudnorm_push(self.h, member, a.ctypes.data, frames, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value * self.channels]
+
+    def loudnorm_drain(self, member):
+        cap = 31 * 19200 + 3 * 192000
+        out = np.zeros(cap * self.channels, np.float64)
+        n, eos = C.c_size_t(0), C.c_int(0)
+        self._ck(self.L.mi355_agroup_loudnorm_drain(self.h, member, out.ctypes.data, cap, C.byref(n), C.byref(eos)))
+        return None if eos.value else out[: n.value * self.channels]
+
     def close(self):
         if self.h:
-            self.L.mi355_agroup_destroy(self.h)
+            if self.shared:
+                self.L.mi355_agroup_release(self.h, self.member)
+            else:
+                self.L.mi355_agroup_destroy(self.h)
             self.h = None
 
 

@@ -8,6 +8,7 @@
  * _push / _drain: the element keeps the pads, the timestamps and the events, the library the adapter and the DSP. */
 #include <gst/gst.h>
 #include <gst/audio/audio.h>
+#include <stdlib.h>
 #include "../include/mi355fx.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_audio_loud_norm_debug);
@@ -30,6 +31,10 @@ struct _GstAudioLoudNorm {
   guint64 out_frames;    /* frames pushed downstream since then: the output timeline is continuous from base_pts */
   guint64 in_frames;     /* frames received and not yet accounted for by output (bounds the drain) */
   mi355_ctx *ctx;
+  /* MI355_GROUP_MEMBERS=n: the n audioloudnorm instances of this process (one configuration) advance in lock step through the
+   * process-wide mi355_agroup (include/mi355fx.h: mi355_agroup_shared_loudnorm): one launch set per 100 ms frame for all of them */
+  mi355_agroup *agroup;
+  int member;
 };
 
 G_DEFINE_TYPE(GstAudioLoudNorm, gst_audio_loud_norm, GST_TYPE_ELEMENT)
@@ -74,7 +79,15 @@ static gboolean gst_audio_loud_norm_new_state(GstAudioLoudNorm *self) {
   g_mutex_lock(&self->lock);
   const gdouble lt = self->loudness_target, lrt = self->loudness_range_target, tp = self->max_true_peak, off = self->offset;
   g_mutex_unlock(&self->lock);
-  if (mi355_loudnorm_setup(self->ctx, (unsigned)GST_AUDIO_INFO_CHANNELS(&self->info), lt, lrt, tp, off) != MI355_OK) {
+  const char *members = g_getenv("MI355_GROUP_MEMBERS");
+  if (self->agroup) mi355_agroup_release(self->agroup, self->member); /* a new State: a new membership */
+  self->agroup = NULL;
+  if (members && atoi(members) >= 2) {
+    int status = 0;
+    self->agroup = mi355_agroup_shared_loudnorm(0, atoi(members), (unsigned)GST_AUDIO_INFO_CHANNELS(&self->info), lt, lrt, tp, off, &self->member, &status);
+    if (!self->agroup) GST_WARNING_OBJECT(self, "no shared loudnorm group (%s): own launches", mi355_status_string(status));
+  }
+  if (!self->agroup && mi355_loudnorm_setup(self->ctx, (unsigned)GST_AUDIO_INFO_CHANNELS(&self->info), lt, lrt, tp, off) != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_loudnorm_setup: %s", mi355_ctx_last_error(self->ctx));
     self->have_state = FALSE;
     return FALSE;
@@ -102,7 +115,7 @@ static GstFlowReturn gst_audio_loud_norm_drain(GstAudioLoudNorm *self) {
   gdouble *out = g_new(gdouble, cap * (gsize)GST_AUDIO_INFO_CHANNELS(&self->info));
   size_t n = 0;
   int eos = 0;
-  if (mi355_loudnorm_drain(self->ctx, out, cap, &n, &eos) != MI355_OK) {
+  if ((self->agroup ? mi355_agroup_loudnorm_drain(self->agroup, self->member, out, cap, &n, &eos) : mi355_loudnorm_drain(self->ctx, out, cap, &n, &eos)) != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_loudnorm_drain: %s", mi355_ctx_last_error(self->ctx));
     g_free(out);
     return GST_FLOW_ERROR;
@@ -133,7 +146,8 @@ static GstFlowReturn gst_audio_loud_norm_chain(GstPad *pad, GstObject *parent, G
   const gsize cap = (gsize)self->in_frames + frames + 30 * (gsize)LOUDNORM_FRAME;
   gdouble *out = g_new(gdouble, cap * (gsize)GST_AUDIO_INFO_CHANNELS(&self->info));
   size_t n = 0;
-  const int rc = mi355_loudnorm_push(self->ctx, (const double *)map.data, frames, out, cap, &n);
+  const int rc = self->agroup ? mi355_agroup_loudnorm_push(self->agroup, self->member, (const double *)map.data, frames, out, cap, &n)
+                              : mi355_loudnorm_push(self->ctx, (const double *)map.data, frames, out, cap, &n);
   gst_buffer_unmap(buffer, &map);
   gst_buffer_unref(buffer);
   if (rc != MI355_OK) {
@@ -216,6 +230,8 @@ static GstStateChangeReturn gst_audio_loud_norm_change_state(GstElement *element
   const GstStateChangeReturn ret = GST_ELEMENT_CLASS(gst_audio_loud_norm_parent_class)->change_state(element, transition);
   if (transition == GST_STATE_CHANGE_PAUSED_TO_READY) { /* "Drop state" */
     self->have_state = FALSE;
+    if (self->agroup) mi355_agroup_release(self->agroup, self->member); /* the others go on without this member */
+    self->agroup = NULL;
     if (self->ctx) (void)mi355_loudnorm_teardown(self->ctx);
   }
   if (transition == GST_STATE_CHANGE_READY_TO_NULL && self->ctx) {

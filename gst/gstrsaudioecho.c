@@ -7,6 +7,7 @@
 #include <gst/gst.h>
 #include <gst/audio/audio.h>
 #include <gst/audio/gstaudiofilter.h>
+#include <stdlib.h>
 #include "../include/mi355fx.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_rs_audio_echo_debug);
@@ -24,6 +25,10 @@ struct _GstRsAudioEcho {
   gint rate, channels;
   gboolean f64;
   mi355_ctx *ctx;
+  /* MI355_GROUP_MEMBERS=n: this process hosts n pipelines of one shape; their rsaudioecho instances share launch sets through the
+   * process-wide mi355_agroup of their ring size (include/mi355fx.h: mi355_agroup_shared_echo) instead of three launches each */
+  mi355_agroup *agroup;
+  int member;
 };
 
 G_DEFINE_TYPE(GstRsAudioEcho, gst_rs_audio_echo, GST_TYPE_AUDIO_FILTER)
@@ -78,6 +83,8 @@ static gboolean gst_rs_audio_echo_stop(GstBaseTransform *trans) {
   g_mutex_lock(&self->lock);
   self->have_state = FALSE;
   g_mutex_unlock(&self->lock);
+  if (self->agroup) mi355_agroup_release(self->agroup, self->member);
+  self->agroup = NULL;
   if (self->ctx) mi355_ctx_destroy(self->ctx);
   self->ctx = NULL;
   return TRUE;
@@ -90,7 +97,16 @@ static gboolean gst_rs_audio_echo_setup(GstAudioFilter *filter, const GstAudioIn
   const guint64 max_delay = self->max_delay;
   g_mutex_unlock(&self->lock);
   const guint64 size = gst_util_uint64_scale(max_delay, (guint64)GST_AUDIO_INFO_RATE(info), GST_SECOND);
-  if (mi355_echo_setup(self->ctx, (size_t)size * (size_t)GST_AUDIO_INFO_CHANNELS(info)) != MI355_OK) {
+  const char *members = g_getenv("MI355_GROUP_MEMBERS");
+  if (self->agroup) mi355_agroup_release(self->agroup, self->member); /* renegotiation: a new ring, as RingBuffer::new does */
+  self->agroup = NULL;
+  if (members && atoi(members) >= 2) {
+    int status = 0;
+    self->agroup = mi355_agroup_shared_echo(0, atoi(members), (size_t)size * (size_t)GST_AUDIO_INFO_CHANNELS(info), &self->member, &status);
+    if (!self->agroup) GST_WARNING_OBJECT(self, "no shared echo group (%s): own launches", mi355_status_string(status));
+    else (void)mi355_agroup_set_linger(self->agroup, 2000, 0); /* a paused neighbour costs the others 2 ms, never a hang */
+  }
+  if (!self->agroup && mi355_echo_setup(self->ctx, (size_t)size * (size_t)GST_AUDIO_INFO_CHANNELS(info)) != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_echo_setup: %s", mi355_ctx_last_error(self->ctx));
     return FALSE;
   }
@@ -117,11 +133,19 @@ static GstFlowReturn gst_rs_audio_echo_transform_ip(GstBaseTransform *trans, Gst
   if (!gst_buffer_map(buf, &map, GST_MAP_READWRITE)) return GST_FLOW_ERROR; /* map_writable().map_err(Error) (imp.rs:212) */
   /* delay_frames = (delay * channels * rate).seconds() (imp.rs:74-77) */
   const size_t delay_samples = (size_t)gst_util_uint64_scale(delay, (guint64)channels * (guint64)rate, GST_SECOND);
-  const int rc = f64 ? mi355_echo_process_f64(self->ctx, (double *)map.data, map.size / sizeof(double), delay_samples, intensity, feedback)
-                     : mi355_echo_process_f32(self->ctx, (float *)map.data, map.size / sizeof(float), delay_samples, intensity, feedback);
+  int rc;
+  if (self->agroup) { /* this buffer joins the launch set of the interval; the call returns when it has run */
+    uint64_t ticket = 0;
+    rc = mi355_agroup_submit_echo(self->agroup, self->member, map.data, map.size / (f64 ? sizeof(double) : sizeof(float)), f64 ? 1 : 0, delay_samples, intensity,
+                                  feedback, 0, &ticket);
+    if (rc == MI355_OK) rc = mi355_agroup_wait(self->agroup, ticket, NULL);
+  } else {
+    rc = f64 ? mi355_echo_process_f64(self->ctx, (double *)map.data, map.size / sizeof(double), delay_samples, intensity, feedback)
+             : mi355_echo_process_f32(self->ctx, (float *)map.data, map.size / sizeof(float), delay_samples, intensity, feedback);
+  }
   gst_buffer_unmap(buf, &map);
   if (rc != MI355_OK) {
-    GST_ERROR_OBJECT(self, "mi355_echo_process: %s", mi355_ctx_last_error(self->ctx));
+    GST_ERROR_OBJECT(self, "mi355_echo_process: %s", self->agroup ? mi355_agroup_last_error(self->agroup) : mi355_ctx_last_error(self->ctx));
     return GST_FLOW_ERROR;
   }
   return GST_FLOW_OK;

@@ -11,6 +11,7 @@
 #include <gst/gst.h>
 #include <gst/video/video.h>
 #include <gst/video/gstvideoaggregator.h>
+#include <stdlib.h>
 #include "gstmi355common.h"
 
 GST_DEBUG_CATEGORY_STATIC(gst_video_compare_debug);
@@ -28,6 +29,9 @@ struct _GstVideoCompare {
   gdouble max_dist_threshold;
   GstPad *reference_pad; /* not owned: cleared in release_pad */
   mi355_ctx *ctx;
+  /* MI355_GROUP_MEMBERS=n: the n videocompare instances of this process hand their (reference, pad) pairs to the device's
+   * dispatcher (mi355_group_shared -> mi355_group_submit_compare): the pairs of an interval are ONE launch sequence */
+  mi355_group *group;
 };
 
 G_DEFINE_TYPE(GstVideoCompare, gst_video_compare, GST_TYPE_VIDEO_AGGREGATOR)
@@ -85,6 +89,9 @@ static gboolean gst_video_compare_start(GstAggregator *agg) {
     GST_ELEMENT_ERROR(self, LIBRARY, INIT, ("No MI355X context"), ("%s", mi355_status_string(status)));
     return FALSE;
   }
+  const char *members = g_getenv("MI355_GROUP_MEMBERS");
+  if (members && atoi(members) >= 2 && (self->group = mi355_group_shared(0, &status)))
+    (void)mi355_group_set_rendezvous(self->group, atoi(members), 2000); /* every instance submits + waits at once; a straggler is waited for 2 ms */
   /* The reference hashes frames of ANY size (hashed_image.rs:24-46 -> image_hasher's blockhash_slow for sizes that are not a
    * multiple of 8, e.g. 854x480); the library refuses those unless asked, because that path restates the crate's
    * floating-point code from memory (parity unpinned, include/mi355fx.h MI355_FLAG_BLOCKHASH_ANY_SIZE). An element that
@@ -96,6 +103,8 @@ static gboolean gst_video_compare_start(GstAggregator *agg) {
 static gboolean gst_video_compare_stop(GstAggregator *agg) {
   GstVideoCompare *self = GST_VIDEO_COMPARE(agg);
   const gboolean ret = GST_AGGREGATOR_CLASS(gst_video_compare_parent_class)->stop ? GST_AGGREGATOR_CLASS(gst_video_compare_parent_class)->stop(agg) : TRUE;
+  if (self->group) mi355_group_release(self->group);
+  self->group = NULL;
   if (self->ctx) mi355_ctx_destroy(self->ctx);
   self->ctx = NULL;
   return ret;
@@ -223,7 +232,28 @@ static GstFlowReturn gst_video_compare_aggregate_frames(GstVideoAggregator *vagg
     }
   }
   int rc = MI355_OK;
-  if (algo == MI355_HASH_DSSIM) {
+  /* the dispatcher takes device-resident pairs (frames an upstream mi355 element wrote) of its two batched algorithms */
+  gboolean grouped = self->group && (algo == MI355_HASH_DSSIM || (algo == MI355_HASH_BLOCKHASH && w % 8 == 0 && h % 8 == 0)) && gst_mi355_buffer_peek_device(ref->buffer);
+  for (guint i = 0; i < n && grouped; i++)
+    grouped = gst_mi355_buffer_peek_device(frames[i]->buffer) && gst_video_compare_format(GST_VIDEO_FRAME_FORMAT(frames[i])) == rfmt &&
+              GST_VIDEO_FRAME_PLANE_STRIDE(frames[i], 0) == GST_VIDEO_FRAME_PLANE_STRIDE(ref, 0);
+  if (grouped) {
+    uint64_t tickets[VIDEO_COMPARE_MAX_PADS];
+    mi355_buf *rbuf = gst_mi355_buffer_peek_device(ref->buffer);
+    const uint8_t *d_ref = mi355_buf_device_ptr(rbuf, self->ctx, MI355_MAP_READ);
+    guint submitted = 0;
+    for (guint i = 0; i < n && rc == MI355_OK && d_ref; i++) {
+      const uint8_t *d = mi355_buf_device_ptr(gst_mi355_buffer_peek_device(frames[i]->buffer), self->ctx, MI355_MAP_READ);
+      rc = d ? mi355_group_submit_compare(self->group, self->ctx, d_ref, d, GST_VIDEO_FRAME_PLANE_STRIDE(ref, 0), w, h, rfmt, algo, &tickets[i]) : MI355_ERR_HIP;
+      if (rc == MI355_OK) submitted++;
+    }
+    if (!d_ref) rc = MI355_ERR_HIP;
+    for (guint i = 0; i < submitted; i++) { /* every submitted pair is waited for: its frames are read until then */
+      const int wrc = mi355_group_wait_compare(self->group, tickets[i], &distances[i], NULL);
+      if (rc == MI355_OK) rc = wrc;
+    }
+    if (rc != MI355_OK) GST_ERROR_OBJECT(self, "grouped comparison failed: %s", mi355_group_last_error(self->group));
+  } else if (algo == MI355_HASH_DSSIM) {
     mi355_dssim_image *ref_img = NULL;
     rc = mi355_dssim_create_image(self->ctx, GST_VIDEO_FRAME_PLANE_DATA(ref, 0), GST_VIDEO_FRAME_PLANE_STRIDE(ref, 0), w, h, rfmt, &ref_img);
     /* frames that share format and stride go to the device together; anything else one by one */

@@ -340,11 +340,31 @@ int mi355_agroup_submit_ebur128(mi355_agroup *group, int member, const void *dat
 int mi355_agroup_submit_loudnorm(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
                                  int final_frame, int device_data, uint64_t *ticket);
 size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *group);
+/* audioloudnorm's sink_chain / drain for a member with the adapter on this side (what mi355_loudnorm_push / _drain are for a single
+ * context; audioloudnorm/imp.rs:1545-1586, :226-310): push appends the buffer and hands every whole frame over in lock step with
+ * the other members (it blocks like wait); drain hands over the rest as the final frame. Host buffers. */
+int mi355_agroup_loudnorm_push(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
+                               size_t *out_frames);
+int mi355_agroup_loudnorm_drain(mi355_agroup *group, int member, double *out, size_t out_capacity_frames, size_t *out_frames, int *eos);
 int mi355_agroup_wait(mi355_agroup *group, uint64_t ticket, size_t *out_frames);
 int mi355_agroup_ebur128_loudness(mi355_agroup *group, int member, int what, double *out);
 int mi355_agroup_ebur128_peak(mi355_agroup *group, int member, int true_peak, unsigned channel, double *out);
 int mi355_agroup_echo_get_state(mi355_agroup *group, int member, double *ring_out, size_t ring_len, size_t *pos_out);
 int mi355_agroup_stats(mi355_agroup *group, uint64_t stats[3]);
+/* Process-wide groups. Elements of independent pipelines cannot hand a group to each other; what they share is the process
+ * (gst/gstrsaudioecho.c, gstebur128level.c, gstaudioloudnorm.c, gstvideocompare.c with MI355_GROUP_MEMBERS=n in the environment).
+ *   mi355_agroup_shared_* : THE group of this configuration (kind, device, member count, parameters), created at first use, and
+ *           the next free member index in *member; a group whose members have all been handed out is not offered again.
+ *   mi355_agroup_release  : detach; the last member out destroys the group.
+ *   mi355_group_shared / _release : THE dispatcher of `device` (mi355_group_create(device, 0)), reference-counted. */
+mi355_agroup *mi355_agroup_shared_echo(int device, int n_members, size_t ring_len, int *member, int *status);
+mi355_agroup *mi355_agroup_shared_ebur128(int device, int n_members, unsigned channels, unsigned rate, unsigned mode, const int *channel_class,
+                                          int *member, int *status);
+mi355_agroup *mi355_agroup_shared_loudnorm(int device, int n_members, unsigned channels, double loudness_target, double loudness_range_target,
+                                           double max_true_peak, double offset, int *member, int *status);
+void mi355_agroup_release(mi355_agroup *group, int member);
+mi355_group *mi355_group_shared(int device, int *status);
+void mi355_group_release(mi355_group *group);
 
 /* ---------------------------------------------------------------- hsvfilter ! colorlut, fused
  * The chain `hsvfilter ! colorlut` on RGBA (the only format both elements accept, hsvfilter/imp.rs:252-266 and
@@ -620,8 +640,9 @@ int mi355_time_colorlut_device(mi355_ctx *ctx, const uint8_t *d_src, size_t src_
 /* hsvfilter (in place on d_src[k]) then colorlut (d_src[k] -> d_dst[k]) for n_batches independent batches of n_frames packed frames
  * each, issued from ONE native call - what n_batches pairs of mi355_hsvfilter_frames_device + mi355_colorlut_frames_device do
  * (video/hsv/src/hsvfilter/imp.rs:323-376 then video/colorlut/src/colorlut/imp.rs:203-223 per buffer), same kernels, same bytes.
- * lanes: 1 = all on the context's stream; 2 = odd batches on a side stream forked after batch 0 and joined before the call
- * returns (independent batches: one lane's launch boundary is covered by the other lane's kernel). */
+ * lanes: 1 = all on the context's stream; 2 is accepted and runs as 1 (round 5's side stream for odd batches measured 12 % slower -
+ * two memory-bound launches side by side evict each other's intermediate from the Infinity Cache - and did not order one-off
+ * table builds across the lanes; removed in round 6). */
 int mi355_hsv_colorlut_chain_batches_device(mi355_ctx *ctx, uint8_t *const *d_src, uint8_t *const *d_dst, int n_batches, int n_frames,
                                             size_t frame_pitch, int stride, int width, int height, int format,
                                             const mi355_hsv_settings *settings, int lanes);

@@ -62,10 +62,20 @@ def test_content_change_flips_within_a_sample_interval(mi355lib):
     first_compute = int(np.argmax(after == 0))
     assert after[first_compute] == 0 and first_compute <= 8 + 7 + 1   # next sample (every 8th launch) + read-back lag
     assert (after[first_compute:first_compute + 60] == 0).all()
-    # and back when the content becomes friendly again: only a probe can find that out
+    # and back when the content becomes friendly again. Noise that made the table kernel 10 x slower is a DECISIVE answer (round 6):
+    # its next probe is 1024 launches away - unless the kind in use says that the content has changed: the interpolating kernels
+    # get faster on friendly content too (uniform noise 0.40 ms, natural frames 0.13), and a sample of the kind in use that moves by
+    # more than 25 % brings the probe forward to now
     ms_t2 = ms_t + [0.12] * 400
-    kind2, _ = run(mi355lib, [NV] * (n + 400), [0.4] * (n + 400), ms_t2, lag=3)
-    assert kind2[-1] == 1
+    ms_c2 = [0.4] * n + [0.13] * 400
+    kind2, _ = run(mi355lib, [NV] * (n + 400), ms_c2, ms_t2, lag=3)
+    back = kind2[n:]
+    first_table = int(np.argmax(back == 1))
+    assert back[first_table] == 1 and first_table <= 32 + 3 + 2      # next sample of the kind in use + read-back lag + the probe's two launches
+    assert kind2[-1] == 1 and (back[first_table + 8:] == 1).sum() >= len(back) - first_table - 8 - 4
+    # a change the kind in use cannot see (its own time stays) is found by the long-period probe
+    kind3, _ = run(mi355lib, [NV] * (n + 1400), [0.4] * (n + 1400), ms_t + [0.12] * 1400, lag=3)
+    assert kind3[n + 300] == 0 and kind3[-1] == 1
 
 
 def test_a_cold_first_launch_does_not_bias_the_probe(mi355lib):
@@ -169,3 +179,22 @@ def test_property_steady_timings_pick_the_faster_kind(mi355lib):
         assert all(b - a >= 60 for a, b in zip([3 * (lag + 1)] + starts, starts)), starts[:5]
 
     prop()
+
+
+def test_a_decisive_answer_is_not_asked_again_for_1024_launches(mi355lib):
+    """Uniform noise: interpolating 0.40 ms, table 1.2 ms. Rounds 4-5 probed the table after 64, 128, 256, 512, 1024 launches - ten
+    launches at three times the cost in the first two thousand, 10 % of BENCH_r05's 32-launch uniform leg when two of them fell into
+    it (auto 14.6 k against 16.3 k pinned). A decisive answer now waits the longest period at once: at most one probe (two launches)
+    per 1024 launches after the learning phase, i.e. <= 0.2 % of the launches and <= 0.6 % of the time."""
+    n = 4300
+    kind, meas = run(mi355lib, [NV] * n, [0.40] * n, [1.2] * n, lag=2)
+    assert kind[0] == 0 and (kind[:16] == 1).sum() >= 2      # the learning phase (spread over more launches by the read-back lag)
+    table_launches = [i for i in range(16, n) if kind[i] == 1]
+    assert len(table_launches) <= 2 * 4 and len(table_launches) >= 2 * 3        # probes at ~1030, ~2055, ~3080, ~4105
+    assert table_launches[0] >= 1000
+    for w0 in range(16, n - 1024, 97):
+        assert sum(1 for i in table_launches if w0 <= i < w0 + 1024) <= 2
+    # ... and a close call (10 % apart) still climbs the 64, 128, ... ladder
+    kind, _ = run(mi355lib, [NV] * 600, [0.110] * 600, [0.100] * 600, lag=2)
+    probes = [i for i in range(16, 600) if kind[i] == 0][0::2]
+    assert 60 <= probes[0] <= 84 and len(probes) >= 3

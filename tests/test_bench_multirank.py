@@ -76,7 +76,7 @@ def test_config5_two_ranks_aggregate_over_the_slowest_rank():
     """BASELINE config 5 is the config that names 8 GPUs: its own barrier / aggregation path (bench.py run_config5) as two real ranks
     on the CPU. One JSON line from rank 0, n_gpus 2, value = both ranks' comparisons / the MAX-over-ranks time (rank 1's stub
     dispatcher takes 2 ms per comparison, rank 0's 1 ms), gloo only."""
-    d = _run(2, steps=5, warmup=1, extra=("--config", "5", "--streams", "4"))
+    d = _run(2, steps=5, warmup=1, extra=("--config", "5", "--streams", "4", "--group"))
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["data"] == "stub" and d["scaling"] == "weak"
     assert d["unit"] == "comparisons/s" and "config 5" in d["metric"]
     assert "gloo" in d["config"]["timing_group"] and "RCCL" in d["config"]["timing_group"]
@@ -91,7 +91,7 @@ def test_config5_two_ranks_aggregate_over_the_slowest_rank():
 def test_config5_single_process_stub_without_the_dispatcher():
     env = dict(os.environ, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--steps", "3", "--warmup", "1", "--stub", "--ramp-seconds", "0.02",
-                          "--streams", "4", "--workers", "2", "--no-group"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--streams", "4", "--workers", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["worker_contexts_per_gpu"] == 2 and "dispatcher" not in d

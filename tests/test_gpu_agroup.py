@@ -330,3 +330,54 @@ def test_loudnorm_members_equal_single_instances(mi355lib, seconds):
             g.submit_loudnorm(0, xs[0][:100], np.zeros((19200, ch)))     # not a whole frame
     finally:
         g.close()
+
+
+def test_loudnorm_push_and_drain_of_members_are_the_single_instance_calls(mi355lib):
+    """The shim's form (gst/gstaudioloudnorm.c with MI355_GROUP_MEMBERS): every element pushes whatever buffers arrive and drains at
+    EOS; the adapter lives behind mi355_agroup_loudnorm_push. Three members from three threads, odd buffer sizes, through the
+    PROCESS-WIDE group of their configuration: samples == mi355_loudnorm_push / _drain on own contexts."""
+    import mi355fx
+    n_m, ch, seconds = 3, 2, 3.9
+    xs = [_ln_signal(10 + k, seconds, ch) for k in range(n_m)]
+    chunks = [123457, 96000, 19200 * 7]
+    exp = []
+    for k, x in enumerate(xs):
+        c = mi355fx.Context(0)
+        c.loudnorm_setup(ch, loudness_target=-20.0)
+        parts = [c.loudnorm_push(x[i:i + chunks[k]]) for i in range(0, len(x), chunks[k])]
+        d = c.loudnorm_drain()
+        exp.append(np.concatenate(parts + ([d] if d is not None else [])))
+        c.close()
+    members = [mi355fx.AudioGroup("loudnorm", n_m, shared=True, channels=ch, loudness_target=-20.0) for _ in range(n_m)]
+    assert sorted(g.member for g in members) == [0, 1, 2] and len({g.h for g in members}) == 1     # one group, three memberships
+    other = mi355fx.AudioGroup("loudnorm", n_m, shared=True, channels=ch, loudness_target=-21.0)   # another configuration: another group
+    assert other.h != members[0].h and other.member == 0
+    other.close()
+    got = [None] * n_m
+    err = []
+
+    def element(k):
+        try:
+            g, x = members[k], xs[k]
+            parts = [g.loudnorm_push(g.member, x[i:i + chunks[k]]) for i in range(0, len(x), chunks[k])]
+            d = g.loudnorm_drain(g.member)
+            got[k] = np.concatenate(parts + ([d] if d is not None else []))
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+            members[k].detach(members[k].member)
+
+    ts = [threading.Thread(target=element, args=(k,)) for k in range(n_m)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    try:
+        assert not err, err
+        for k in range(n_m):
+            assert got[k].size == exp[k].size and (got[k] == exp[k]).all(), k
+    finally:
+        for g in members:
+            g.close()          # the last release destroys the group
+    again = mi355fx.AudioGroup("loudnorm", n_m, shared=True, channels=ch, loudness_target=-20.0)
+    assert again.member == 0   # a fresh group: the old one is gone
+    again.close()

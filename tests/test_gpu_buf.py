@@ -140,3 +140,48 @@ def test_two_contexts_are_ordered_through_commits(ctx, synth):
         assert ctx.transfer_counts() == (1, 1)
     finally:
         buf.close(); a.close(); b_ctx.close()
+
+
+def test_concurrent_readers_are_both_seen_by_a_later_writer(ctx, oracle, synth):
+    """A tee into two mi355 branches: two contexts READ one buffer concurrently (each commits), then a third context WRITES it in
+    place and the buffer is freed. The writer must start behind BOTH readers (round 5 kept only the last commit: the first
+    reader's kernels could still be reading when the writer started - ADVICE r05). 4K x 12 rounds so that the readers are in flight
+    when the writer is enqueued; every reader output is checked against the content it must have seen."""
+    import ctypes as C
+    import mi355fx
+    w, h = 3840, 2160
+    src = synth.smooth_frame(w, h, seed=5).reshape(-1)
+    st = synth.HSV_SETTINGS["hue90"]
+    ra, rb, wr = mi355fx.Context(0), mi355fx.Context(0), mi355fx.Context(0)
+    buf = ctx.buf_alloc(src.size)
+    out_a, out_b = ra.alloc(src.size), rb.alloc(src.size)
+    try:
+        buf.write(src)
+        exp_in = src.copy()
+        for rnd in range(12):
+            # reader A: hsvdetect of the buffer into out_a; reader B: the same with another target format byte order
+            ds = mi355fx.HsvDetectSettings(*DETECT)
+            ra._ck(ra.L.mi355_hsvdetect_frames_device(ra.h, buf.device_ptr(ra, mi355fx.MAP_READ), src.size, w * 4, mi355fx.FMT["RGBx"], out_a, src.size, w * 4,
+                                                      mi355fx.FMT["RGBA"], 1, w, h, C.byref(ds)))
+            buf.commit(ra)
+            rb._ck(rb.L.mi355_hsvdetect_frames_device(rb.h, buf.device_ptr(rb, mi355fx.MAP_READ), src.size, w * 4, mi355fx.FMT["RGBx"], out_b, src.size, w * 4,
+                                                      mi355fx.FMT["ARGB"], 1, w, h, C.byref(ds)))
+            buf.commit(rb)
+            # the writer: hsvfilter in place, enqueued at once (no host wait anywhere)
+            wr.hsvfilter_frames_device(buf.device_ptr(wr, mi355fx.MAP_READ | mi355fx.MAP_WRITE), 1, src.size, w, h, w * 4, "RGBA", st)
+            buf.commit(wr)
+            if rnd in (0, 11):
+                ga, gb = np.zeros_like(src), np.zeros_like(src)
+                ra.synchronize(); rb.synchronize()
+                ra.d2h(ga, out_a); rb.d2h(gb, out_b)
+                ea, eb = np.zeros_like(src), np.zeros_like(src)
+                oracle.hsvdetect(exp_in, w * 4, 4, 0, False, ea, w * 4, False, False, w, DETECT)
+                oracle.hsvdetect(exp_in, w * 4, 4, 0, False, eb, w * 4, True, False, w, DETECT)
+                assert (ga == ea).all() and (gb == eb).all(), rnd
+            oracle.hsvfilter(exp_in, w, w * 4, 4, 0, False, st)
+        assert (buf.read() == exp_in).all()
+    finally:
+        buf.close()      # waits for every stream that used it
+        ra.free(out_a); rb.free(out_b)
+        for c in (ra, rb, wr):
+            c.close()

@@ -201,3 +201,27 @@ def test_batch_and_single_entry_points_do_not_mix(ctx):
     ctx.ebur128_setup_batch(3, 2, 48000, 63)
     with pytest.raises(mi355fx.Mi355Error):
         ctx.ebur128_add_frames(np.zeros((480, 2), np.float32))
+
+
+# ---- EBU Tech 3341 / 3342 conformance on the device (tests/golden/ebu_tech_334x.json: published recipes, expected readings and
+# tolerances; the CPU oracle runs the same cases in tests/test_oracle_ebur128.py)
+from ebu_cases import check_case, load_cases  # noqa: E402
+
+_RATE, _CASES = load_cases()
+
+
+class _DeviceMeter:
+    def __init__(self, ctx, case, rate):
+        self.c = ctx
+        ctx.ebur128_setup(case["channels"], rate, 63, case.get("channel_class"))
+    add = lambda self, x: self.c.ebur128_add_frames(x)
+    momentary = lambda self: self.c.ebur128_loudness_momentary()
+    shortterm = lambda self: self.c.ebur128_loudness_shortterm()
+    integrated = lambda self: self.c.ebur128_loudness_global()
+    lra = lambda self: self.c.ebur128_loudness_range()
+    true_peak = lambda self, ch: self.c.ebur128_true_peak(ch)
+
+
+@pytest.mark.parametrize("case", _CASES, ids=[c["id"] for c in _CASES])
+def test_ebu_tech_334x_conformance_device(ctx, synth, case):
+    check_case(case, _RATE, _DeviceMeter(ctx, case, _RATE), synth)

@@ -210,28 +210,50 @@ def test_window_kernel_in_place(ctx, oracle, synth):
     assert (got == exp).all()
 
 
-def test_the_table_kernel_is_chosen_by_measurement(ctx, oracle, synth, window_kind):
-    """MI355_FLAG_LUT_VARIANT 9 (what auto does once it is on the table): ONE Morton table; on 4K batches the LDS-cached kernel
-    is timed against the gather kernel (both appear, results exact throughout); a 720p frame goes through the tiled gather
-    kernel on the same table."""
+def test_the_table_kernel_is_chosen_by_where_the_pixels_come_from(ctx, oracle, synth, window_kind):
+    """MI355_FLAG_LUT_VARIANT 9 (what auto does once it is on the table): ONE Morton table, read by the LDS-cached kernel when the
+    frames come from HBM and by the gather kernel when the launch before wrote them (they are on-die then: hsvfilter ! colorlut) -
+    a rule on the input's provenance (round 6; rounds 4-5 measured one kernel against the other with samples up to 1024 launches
+    old). Results exact either way; a 720p frame goes through the tiled gather kernel on the same table."""
     import mi355fx
     cube = _load_cube(ctx, oracle, synth.cube_text_3d(33))
     ctx.set_flag(mi355fx.FLAG_LUT_VARIANT, 9)
     src = _noisy(synth, 0, seed=70, n=2)
     exp = np.zeros(W4K * H4K * 4, np.uint8)
     oracle.colorlut_rgba8(cube, src[: exp.size], W4K * 4, exp, W4K * 4, W4K, H4K, nthreads=8)
+    st = synth.HSV_SETTINGS["hue90"]
+    mid = src[: exp.size].copy()
+    oracle.hsvfilter(mid, W4K, W4K * 4, 4, 0, False, st)
+    exp_chain = np.zeros_like(exp)
+    oracle.colorlut_rgba8(cube, mid, W4K * 4, exp_chain, W4K * 4, W4K, H4K, nthreads=8)
     d_s, d_o = ctx.alloc(src.nbytes), ctx.alloc(src.nbytes)
+    pitch = H4K * W4K * 4
     try:
-        ctx.h2d(d_s, src)
-        seen = set()
-        for _ in range(12):
-            ctx.colorlut_frames_device(d_s, H4K * W4K * 4, W4K * 4, d_o, H4K * W4K * 4, W4K * 4, 2, W4K, H4K, "RGBA")
-            ctx.synchronize()
-            seen.add(ctx.colorlut_kernel_name())
+        for _ in range(3):
+            # frames uploaded by a copy: from HBM -> the LDS-cached kernel, every time (nothing to settle, nothing to probe)
+            ctx.h2d(d_s, src)
+            for _ in range(3):
+                ctx.colorlut_frames_device(d_s, pitch, W4K * 4, d_o, pitch, W4K * 4, 2, W4K, H4K, "RGBA")
+                assert ctx.colorlut_kernel_name() == window_kind and ctx.colorlut_kernel_choice(fused=10)[0]
             out = np.zeros_like(src)
             ctx.d2h(out, d_o)
             assert (out[: exp.size] == exp).all()
-        assert seen == {window_kind, "colorlut_table_tiled_kernel"}, seen
+            # the same frames behind hsvfilter on this device: on-die -> the gather kernel
+            ctx.hsvfilter_frames_device(d_s, 2, pitch, W4K, H4K, W4K * 4, "RGBA", st)
+            ctx.colorlut_frames_device(d_s, pitch, W4K * 4, d_o, pitch, W4K * 4, 2, W4K, H4K, "RGBA")
+            assert ctx.colorlut_kernel_name() == "colorlut_table_tiled_kernel" and not ctx.colorlut_kernel_choice(fused=10)[0]
+            ctx.d2h(out, d_o)
+            assert (out[: exp.size] == exp_chain).all()
+            # ... also when ANOTHER context of the device wrote them (hsvfilter and colorlut are two elements, two contexts)
+            other = mi355fx.Context(0)
+            ctx.h2d(d_s, src)
+            other.hsvfilter_frames_device(d_s, 2, pitch, W4K, H4K, W4K * 4, "RGBA", st)
+            other.synchronize()
+            ctx.colorlut_frames_device(d_s, pitch, W4K * 4, d_o, pitch, W4K * 4, 2, W4K, H4K, "RGBA")
+            assert ctx.colorlut_kernel_name() == "colorlut_table_tiled_kernel"
+            other.close()
+            ctx.d2h(out, d_o)
+            assert (out[: exp.size] == exp_chain).all()
         tables = mi355fx.load_library().mi355_shared_table_count()
         small = synth.smooth_frame(1280, 720, seed=71).reshape(-1)
         got = _run(ctx, small, 1280, 720)

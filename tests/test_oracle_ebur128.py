@@ -73,3 +73,42 @@ def test_channel_weights_and_unused(oracle):
     mono = oracle.EbuR128(1, 48000, channel_classes=[3])                    # dual mono counts twice
     mono.add_frames(sine(-23, 5, ch=1))
     assert abs(mono.loudness_momentary() - (-23.0)) <= 0.1
+
+
+# ---- EBU Tech 3341 / 3342 as committed data (tests/golden/ebu_tech_334x.json): third-party conformance numbers for the BS.1770
+# chain that do not depend on anybody's memory of the ebur128 crate. The same cases run on the device (tests/test_gpu_ebur128.py).
+from ebu_cases import check_case, load_cases  # noqa: E402
+
+_RATE, _CASES = load_cases()
+
+
+class _OracleMeter:
+    def __init__(self, oracle, case, rate):
+        self.e = oracle.EbuR128(case["channels"], rate, 63, case.get("channel_class"))
+    add = lambda self, x: self.e.add_frames(x)
+    momentary = lambda self: self.e.loudness_momentary()
+    shortterm = lambda self: self.e.loudness_shortterm()
+    integrated = lambda self: self.e.loudness_global()
+    lra = lambda self: self.e.loudness_range()
+    true_peak = lambda self, c: self.e.true_peak(c)
+
+
+@pytest.mark.parametrize("case", _CASES, ids=[c["id"] for c in _CASES])
+def test_ebu_tech_334x_conformance_oracle(oracle, synth, case):
+    check_case(case, _RATE, _OracleMeter(oracle, case, _RATE), synth)
+
+
+def test_ebu_golden_file_is_complete_and_says_what_it_leaves_out():
+    import json
+    from ebu_cases import GOLDEN
+    doc = json.load(open(GOLDEN))
+    ids = [c["id"] for c in doc["cases"]]
+    assert ids == sorted(set(ids), key=ids.index) and len(ids) == 17
+    for c in doc["cases"]:
+        assert c["doc"].startswith("EBU Tech 334") and ("tolerance_lu" in c or "tolerance_db" in c)
+    # every case number of the two documents is either a recipe here or named with the reason it is not
+    left_out = " ".join(doc["not_included"])
+    for n in (7, 8, 10, 11, 13, 14, 20, 23):
+        assert "3341-%d" % n in left_out
+    for n in (5, 6):
+        assert "3342-%d" % n in left_out

@@ -1,4 +1,4 @@
-// tools/agroup_bench.cpp — N independent audio element instances as N NATIVE threads (what N GStreamer streaming threads are), each
+// tools/agroup_bench.cpp — N independent element instances (audio, then videocompare) as N NATIVE threads (what N GStreamer streaming threads are), each
 // handing one buffer per interval to (a) its own single-instance context (the shim's path until round 5) and (b) the process's
 // mi355_agroup (round 6). Prints one JSON line per element kind. Build: make -C tools agroup_bench (g++, links libmi355fx.so).
 // Run on the GPU box: tools/agroup_bench [instances]
@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -50,9 +51,11 @@ static double run_threads(int n, int iters, F body) {
 
 int main(int argc, char **argv) {
   const int S = argc > 1 ? std::atoi(argv[1]) : 32;
+  const std::string section = argc > 2 ? argv[2] : "all";   // all | audio | videocompare | dssim
+  const bool do_audio = section == "all" || section == "audio", do_video = section != "audio", dssim_only = section == "dssim";
   int st = 0;
   // ------------------------------------------------------------ rsaudioecho: 48 kHz stereo f32, 10 ms buffers, delay 250 ms, feedback 0.4
-  {
+  if (do_audio) {
     const size_t n = 960, ring = 96000;
     const int iters = 400;
     std::vector<mi355_ctx *> ctxs(S);
@@ -108,7 +111,7 @@ int main(int argc, char **argv) {
     for (int m = 0; m < S; m++) { mi355_device_free(ctxs[m], dev[m]); mi355_ctx_destroy(ctxs[m]); }
   }
   // ------------------------------------------------------------ ebur128level: 48 kHz stereo f32, 100 ms buffers, mode M | S | I | LRA | sample + true peak
-  {
+  if (do_audio) {
     const unsigned rate = 48000, ch = 2;
     const size_t frames = 4800;
     const int iters = 100;
@@ -145,7 +148,7 @@ int main(int argc, char **argv) {
     for (int m = 0; m < S; m++) mi355_ctx_destroy(ctxs[m]);
   }
   // ------------------------------------------------------------ audioloudnorm: 192 kHz stereo f64, 8 s per instance, whole frames
-  {
+  if (do_audio) {
     const unsigned ch = 2;
     const size_t rate = 192000, total = 8 * rate;
     std::vector<std::vector<double>> x(S, std::vector<double>(total * ch));
@@ -190,6 +193,64 @@ int main(int argc, char **argv) {
                 S, t_own, t_grp, S * 8.0 / t_own, S * 8.0 / t_grp);
     std::fflush(stdout);
     mi355_agroup_destroy(g);
+  }
+  // ------------------------------------------------------------ videocompare: N two-pad elements on N native threads, 4K RGBA, device-resident frames
+  if (do_video) {
+    const int W = 3840, H = 2160;
+    const size_t fb = (size_t)W * H * 4;
+    std::vector<mi355_ctx *> ctxs(S);
+    std::vector<uint8_t *> fa(S), fbuf(S);
+    std::vector<uint8_t> host(fb), host2(fb);
+    for (size_t i = 0; i < fb; i++) { host[i] = (uint8_t)((i * 2654435761u) >> 24); if ((i & 3) == 3) host[i] = 255; }
+    for (size_t i = 0; i < fb; i++) { host2[i] = (uint8_t)(host[i] ^ ((i >> 7) & 3)); if ((i & 3) == 3) host2[i] = 255; }
+    for (int m = 0; m < S; m++) {
+      ctxs[m] = mi355_ctx_create(0, &st);
+      fa[m] = (uint8_t *)mi355_device_alloc(ctxs[m], fb);
+      fbuf[m] = (uint8_t *)mi355_device_alloc(ctxs[m], fb);
+      CK(mi355_memcpy_h2d(ctxs[m], fa[m], host.data(), fb));
+      CK(mi355_memcpy_h2d(ctxs[m], fbuf[m], host2.data(), fb));
+    }
+    std::vector<double> own_v(S), grp_v(S);
+    for (int algo : {MI355_HASH_BLOCKHASH, MI355_HASH_DSSIM}) {
+      if (dssim_only && algo != MI355_HASH_DSSIM) continue;
+      const int iters = algo == MI355_HASH_DSSIM ? 12 : 200;
+      auto own = [&](int m, int) {
+        if (algo == MI355_HASH_DSSIM) {
+          mi355_dssim_image *img = nullptr;
+          const uint8_t *one[1] = {fbuf[m]};
+          CK(mi355_dssim_create_image_device(ctxs[m], fa[m], W * 4, W, H, MI355_FMT_RGBA, &img));
+          CK(mi355_dssim_compare_frames_device(ctxs[m], img, one, 1, W * 4, W, H, MI355_FMT_RGBA, &own_v[m]));
+          mi355_dssim_free_image(ctxs[m], img);
+        } else {
+          uint64_t h0 = 0, h1 = 0;
+          CK(mi355_videocompare_hash_frames_device(ctxs[m], fa[m], fb, W * 4, 1, W, H, MI355_FMT_RGBA, algo, &h0));
+          CK(mi355_videocompare_hash_frames_device(ctxs[m], fbuf[m], fb, W * 4, 1, W, H, MI355_FMT_RGBA, algo, &h1));
+          own_v[m] = mi355_videocompare_distance(algo, h0, h1);
+        }
+      };
+      run_threads(S, 3, own);
+      const double t_own = run_threads(S, iters, own) / iters;
+      mi355_group *g = mi355_group_create(0, 0, &st);
+      CK(mi355_group_set_rendezvous(g, S, 5000));
+      auto grp = [&](int m, int) {
+        uint64_t t = 0;
+        CK(mi355_group_submit_compare(g, ctxs[m], fa[m], fbuf[m], W * 4, W, H, MI355_FMT_RGBA, algo, &t));
+        CK(mi355_group_wait_compare(g, t, &grp_v[m], nullptr));
+      };
+      run_threads(S, 3, grp);
+      const double t_grp = run_threads(S, iters, grp) / iters;
+      uint64_t stats[3];
+      CK(mi355_group_compare_stats(g, stats));
+      bool same = true;
+      for (int m = 0; m < S; m++) same &= own_v[m] == grp_v[m];
+      std::printf("{\"element\": \"videocompare\", \"hash_algorithm\": \"%s\", \"instances\": %d, \"frames\": \"3840x2160 RGBA, device-resident, one two-pad element per native thread\", "
+                  "\"own_context_comparisons_per_s\": %.1f, \"dispatcher_comparisons_per_s\": %.1f, \"dispatcher_launch_sequences\": %llu, \"dispatcher_pairs\": %llu, "
+                  "\"results_identical\": %s}\n",
+                  algo == MI355_HASH_DSSIM ? "dssim" : "blockhash", S, S / t_own, S / t_grp, (unsigned long long)stats[1], (unsigned long long)stats[0], same ? "true" : "false");
+      std::fflush(stdout);
+      mi355_group_destroy(g);
+    }
+    for (int m = 0; m < S; m++) { mi355_device_free(ctxs[m], fa[m]); mi355_device_free(ctxs[m], fbuf[m]); mi355_ctx_destroy(ctxs[m]); }
   }
   return 0;
 }
