@@ -1937,7 +1937,7 @@ int colorlut_multi_fused_table(mi355_ctx *ctx, const mi355_hsv_settings *hs, con
   return MI355_OK;
 }
 int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
-                          int height) {
+                          int height, bool from_hbm) {
   if (n_frames < 1 || n_frames > kMultiFrames || width % 4 != 0 || width < 128 || height <= 0) return MI355_ERR_UNSUPPORTED;
   MultiFramePtrs s{}, d{};
   for (int f = 0; f < n_frames; f++) {
@@ -1946,6 +1946,13 @@ int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *ta
     d.p[f] = dsts[f];
   }
   const unsigned w4 = (unsigned)width / 4;
+  // the provenance rule of launch_table_raw: frames that come from HBM (the fused form: each stream's own source, uploaded or
+  // decoded, not written by a launch just before) go through the LDS-cached kernel where the launch is large enough for it
+  if (from_hbm && ctx->lut_variant == 0 && window_multi_applicable(ctx, w4, (size_t)height, n_frames)) {
+    ctx->lut.last_kernel = "colorlut_window_kernel";
+    return launch_window_table_multi(ctx, stream, table, srcs, dsts, n_frames, w4, (size_t)height);
+  }
+  ctx->lut.last_kernel = "colorlut_table_tiled_multi_kernel";
   const unsigned pad64 = (w4 + 63) / 64 * 64 - w4, pad32 = (w4 + 31) / 32 * 32 - w4;
   const unsigned tw4 = pad64 <= pad32 ? 64 : 32;
   const unsigned n_cols = (w4 + tw4 - 1) / tw4, rpb = 8 * (64 / tw4);

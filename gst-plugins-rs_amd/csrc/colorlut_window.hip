@@ -99,9 +99,15 @@ __device__ __forceinline__ uint32_t data_addr(uint32_t brick, uint32_t k, uint32
 
 // grid = blocks of 1024 lanes, one per CU; block b takes a contiguous share of the column-major list of 256 x 32 pixel
 // tiles (strip after strip, top to bottom).
+// MULTI: the rows are those of up to kMultiFrames SEPARATE packed frames of frame_rows rows each (group.hip: the frames of many
+// streams in one launch): row r belongs to frame r / frame_rows, whose base pointers travel in the kernel arguments; a wave's two
+// rows of a step are wave-uniform, so the frame of a load or a store is an SGPR matter. The walk, the cache and the results are
+// those of the one-buffer form.
+template <bool MULTI>
 __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__restrict__ src, u4_t *__restrict__ dst, unsigned w4, unsigned sw4, unsigned dw4,
-                                                               unsigned rows, unsigned dst_bytes, unsigned steps_per_strip, unsigned share, unsigned extra,
-                                                               unsigned fronts, const uint32_t *__restrict__ table, unsigned long long *__restrict__ counters) {
+                                                                 unsigned rows, unsigned dst_bytes, unsigned steps_per_strip, unsigned share, unsigned extra,
+                                                                 unsigned fronts, const uint32_t *__restrict__ table, unsigned long long *__restrict__ counters,
+                                                                 MultiFramePtrs srcs, MultiFramePtrs dsts, unsigned frame_rows) {
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x < 768) lds_w32(kWinAxis + 4u * threadIdx.x, window_axis_entry((int)(threadIdx.x >> 8), threadIdx.x & 255u));
   if (threadIdx.x < 256) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
     const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)dst_bytes, 0x00020000);
     // pixel groups in flight: WIN_DEPTH steps, each in its own registers (the loop below is unrolled WIN_DEPTH times so that
     // no loaded value is ever copied before its step: a copy would wait for the load)
-    struct Slot { u4_t p, q; uint32_t o0, o1; };  // o: byte offset of the results in dst, 0x80000000 (out of range: dropped) for lanes outside the picture
+    struct Slot { u4_t p, q; uint32_t o0, o1; unsigned f0, f1; };  // o: byte offset of the results in dst (MULTI: in the row's frame, f0 / f1), 0x80000000 (out of range: dropped) for lanes outside the picture
     Slot ring[WIN_DEPTH];
     // this lane's two pixel groups of step st (clamped into the picture: loads are unconditional)
     auto fetch = [&](unsigned st_, Slot &S) {
@@ -141,10 +147,23 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
       const unsigned strip = st / steps_per_strip, k = st - strip * steps_per_strip;
       const unsigned col = strip * 64u + lane, r0 = k * kWinRowsPerStep + 2u * wave, r1 = r0 + 1u;
       const unsigned cc = col < w4 ? col : w4 - 1u, c0 = r0 < rows ? r0 : rows - 1u, c1 = r1 < rows ? r1 : rows - 1u;
-      S.o0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
-      S.o1 = col < w4 && r1 < rows ? (r1 * dw4 + col) << 4 : 0x80000000u;
-      S.p = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
-      S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
+      if (MULTI) {
+        // (wave is made uniform for the compiler: the frame numbers, and with them the base pointers, live in SGPRs)
+        const unsigned uw = (unsigned)__builtin_amdgcn_readfirstlane((int)wave);
+        const unsigned u0 = k * kWinRowsPerStep + 2u * uw, u1 = u0 + 1u, v0 = u0 < rows ? u0 : rows - 1u, v1 = u1 < rows ? u1 : rows - 1u;
+        const unsigned f0 = v0 / frame_rows, f1 = v1 / frame_rows, y0 = v0 - f0 * frame_rows, y1 = v1 - f1 * frame_rows;
+        S.f0 = f0; S.f1 = f1;
+        S.o0 = col < w4 && r0 < rows ? (y0 * dw4 + col) << 4 : 0x80000000u;
+        S.o1 = col < w4 && r1 < rows ? (y1 * dw4 + col) << 4 : 0x80000000u;
+        S.p = __builtin_nontemporal_load((const u4_t *)srcs.p[f0] + ((size_t)y0 * sw4 + cc));
+        S.q = __builtin_nontemporal_load((const u4_t *)srcs.p[f1] + ((size_t)y1 * sw4 + cc));
+      } else {
+        S.f0 = 0; S.f1 = 0;
+        S.o0 = col < w4 && r0 < rows ? (r0 * dw4 + col) << 4 : 0x80000000u;
+        S.o1 = col < w4 && r1 < rows ? (r1 * dw4 + col) << 4 : 0x80000000u;
+        S.p = __builtin_nontemporal_load(src + ((size_t)c0 * sw4 + cc));
+        S.q = __builtin_nontemporal_load(src + ((size_t)c1 * sw4 + cc));
+      }
     };
 
 #if WIN_PACE
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
 #endif
       const uint32_t px[8] = {S.p.x, S.p.y, S.p.z, S.p.w, S.q.x, S.q.y, S.q.z, S.q.w};
       const uint32_t so0 = S.o0, so1 = S.o1;
+      const unsigned sf0 = S.f0, sf1 = S.f1;
 
       uint32_t val[8];
 #if WIN_EXP == 1  // experiment: the walk alone (copy)
@@ -314,8 +334,15 @@ __global__ __launch_bounds__(1024) void colorlut_window_kernel(const u4_t *__res
       b.w = (val[7] & 0x00ffffffu) | (px[7] & 0xff000000u);
       // unconditional buffer stores, range-checked by the hardware (a store inside a branch would make the number of
       // operations in flight unknown to the compiler, which then waits for ALL of them before the next step's pixels)
-      __builtin_amdgcn_raw_buffer_store_b128(a, dst_rsrc, (int)so0, 0, 2 /* nt */);
-      __builtin_amdgcn_raw_buffer_store_b128(b, dst_rsrc, (int)so1, 0, 2);
+      if (MULTI) {
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(dsts.p[sf0], 0, (int)dst_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(dsts.p[sf1], 0, (int)dst_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(a, r0, (int)so0, 0, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b128(b, r1, (int)so1, 0, 2);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(a, dst_rsrc, (int)so0, 0, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b128(b, dst_rsrc, (int)so1, 0, 2);
+      }
       // the slot's next pixels travel while the other slots' steps are looked up (issued last: a miss path's loads then do
       // not queue behind them)
       fetch(st + WIN_DEPTH, S);
@@ -368,12 +395,48 @@ int launch_window_table(mi355_ctx *ctx, const uint32_t *table, const uint8_t *d_
   if (grid > total) grid = total;
   if (ctx->window_order == 1 && n_strips <= grid) {
     const unsigned layers = grid / n_strips, per_layer = (steps_per_strip + layers - 1) / layers;
-    hipLaunchKernelGGL(colorlut_window_kernel, dim3(n_strips * layers), dim3(64 * kWinWaves), kWinLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
-                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, per_layer, layers, n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
+    hipLaunchKernelGGL(colorlut_window_kernel<false>, dim3(n_strips * layers), dim3(64 * kWinWaves), kWinLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
+                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, per_layer, layers, n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr,
+                       MultiFramePtrs{}, MultiFramePtrs{}, 1u);
   } else
-    hipLaunchKernelGGL(colorlut_window_kernel, dim3(grid), dim3(64 * kWinWaves), kWinLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
-                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, total / grid, total % grid, 0u, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr);
+    hipLaunchKernelGGL(colorlut_window_kernel<false>, dim3(grid), dim3(64 * kWinWaves), kWinLdsBytes, ctx->stream, (const u4_t *)d_src, (u4_t *)d_dst, w4, sw4, dw4,
+                       (unsigned)rows, (unsigned)(rows * dw4 * 16), steps_per_strip, total / grid, total % grid, 0u, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr,
+                       MultiFramePtrs{}, MultiFramePtrs{}, 1u);
   return check_hip(ctx, hipGetLastError(), "colorlut window kernel launch");
+}
+
+// n separate packed frames (w4 groups per row, frame_rows rows each, rows 16 B aligned and contiguous) in ONE launch on `stream`
+bool window_multi_applicable(const mi355_ctx *ctx, unsigned w4, size_t frame_rows, int n_frames) {
+  if (frame_rows == 0 || (size_t)frame_rows * w4 * 16 > (1ull << 31)) return false;
+  return window_applicable(ctx, w4, w4, frame_rows * (size_t)n_frames) || ((size_t)frame_rows * (size_t)n_frames < (1u << 30) && w4 >= 1 &&
+         (size_t)((w4 + 63) / 64) * ((frame_rows * (size_t)n_frames + kWinRowsPerStep - 1) / kWinRowsPerStep) >= (size_t)ctx->n_cu * (size_t)ctx->window_min_steps);
+}
+
+int launch_window_table_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, unsigned w4,
+                              size_t frame_rows) {
+  int rc;
+  if (!ctx->d_window_counters) {
+    if ((rc = check_hip(ctx, hipMalloc((void **)&ctx->d_window_counters, 3 * kWinCounterSlots * sizeof(unsigned long long)), "hipMalloc(window counters)"))) return rc;
+    if ((rc = check_hip(ctx, hipMemsetAsync(ctx->d_window_counters, 0, 3 * kWinCounterSlots * sizeof(unsigned long long), stream), "hipMemsetAsync(window counters)"))) return rc;
+  }
+  MultiFramePtrs s{}, d{};
+  for (int f = 0; f < kMultiFrames; f++) { s.p[f] = srcs[f < n_frames ? f : 0]; d.p[f] = dsts[f < n_frames ? f : 0]; }
+  const size_t rows = frame_rows * (size_t)n_frames;
+  const unsigned n_strips = (w4 + 63) / 64, steps_per_strip = (unsigned)((rows + kWinRowsPerStep - 1) / kWinRowsPerStep);
+  const unsigned total = n_strips * steps_per_strip;
+  unsigned grid = (unsigned)ctx->n_cu;
+  if (grid > total) grid = total;
+  const unsigned frame_bytes = (unsigned)(frame_rows * w4 * 16);
+  if (ctx->window_order == 1 && n_strips <= grid) {
+    const unsigned layers = grid / n_strips, per_layer = (steps_per_strip + layers - 1) / layers;
+    hipLaunchKernelGGL(colorlut_window_kernel<true>, dim3(n_strips * layers), dim3(64 * kWinWaves), kWinLdsBytes, stream, (const u4_t *)nullptr, (u4_t *)nullptr, w4, w4, w4,
+                       (unsigned)rows, frame_bytes, steps_per_strip, per_layer, layers, n_strips, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr, s, d,
+                       (unsigned)frame_rows);
+  } else
+    hipLaunchKernelGGL(colorlut_window_kernel<true>, dim3(grid), dim3(64 * kWinWaves), kWinLdsBytes, stream, (const u4_t *)nullptr, (u4_t *)nullptr, w4, w4, w4,
+                       (unsigned)rows, frame_bytes, steps_per_strip, total / grid, total % grid, 0u, table, ctx->window_stats_on ? ctx->d_window_counters : nullptr, s, d,
+                       (unsigned)frame_rows);
+  return check_hip(ctx, hipGetLastError(), "colorlut window kernel launch (multi-frame)");
 }
 
 int window_read_counters(mi355_ctx *ctx, unsigned long long out[3], bool reset) {

@@ -37,6 +37,10 @@ constexpr int kWindowMinStepsPerBlock = 3;
 // width % 4 == 0; anything else is the caller's business (colorlut_kernels.hip: launch_table_raw).
 bool window_applicable(const mi355_ctx *ctx, unsigned w4, unsigned dw4, size_t rows);
 int launch_window_table(mi355_ctx *ctx, const uint32_t *table, const uint8_t *d_src, uint8_t *d_dst, unsigned w4, unsigned sw4, unsigned dw4, size_t rows);
+// the same over n_frames SEPARATE packed frames (rows of w4 groups, frame_rows rows each) in one launch on `stream` (group.hip)
+bool window_multi_applicable(const mi355_ctx *ctx, unsigned w4, size_t frame_rows, int n_frames);
+int launch_window_table_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, unsigned w4,
+                              size_t frame_rows);
 // {pixels looked up, pixels served from the table in global memory, bricks installed} since the last reset (diagnostics; synchronous)
 int window_read_counters(mi355_ctx *ctx, unsigned long long out[3], bool reset);
 void window_release(mi355_ctx *ctx);

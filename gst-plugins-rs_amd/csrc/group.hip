@@ -202,7 +202,7 @@ int flush_locked(mi355_group *g, uint64_t until = 0) {
       }
       // (fused: `table` is the composed hsvfilter -> colorlut table of these settings: the gather IS the chain, one launch)
       if (!rc && !first.fused) rc = launch_hsvfilter_multi(first.ctx, g->stream, srcs, (int)take.size(), first.width, first.height, fmt, first.hs);
-      if (!rc) rc = launch_colorlut_multi(first.ctx, g->stream, first.table, srcs, dsts, (int)take.size(), first.width, first.height);
+      if (!rc) rc = launch_colorlut_multi(first.ctx, g->stream, first.table, srcs, dsts, (int)take.size(), first.width, first.height, first.fused);
       if (!rc && hipEventRecord(done, g->stream) != hipSuccess) rc = MI355_ERR_HIP;
       g->n_batched_launch_pairs++;
     } else {

@@ -163,7 +163,7 @@ int launch_hsvfilter_multi(mi355_ctx *ctx, hipStream_t stream, uint8_t *const *f
 int colorlut_multi_table(mi355_ctx *ctx, const uint32_t **table_out);
 int colorlut_multi_fused_table(mi355_ctx *ctx, const mi355_hsv_settings *hs, const uint32_t **table_out);
 int launch_colorlut_multi(mi355_ctx *ctx, hipStream_t stream, const uint32_t *table, uint8_t *const *srcs, uint8_t *const *dsts, int n_frames, int width,
-                          int height);
+                          int height, bool from_hbm = false);
 int launch_hsvdetect(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, int src_stride,
                      const PixFmt &sfmt, uint8_t *d_dst, size_t dst_pitch, int dst_stride,
                      int dst_alpha_first, int dst_bgr, int n_frames, int width, int height,

@@ -387,3 +387,77 @@ def test_pipeline_destroyed_while_its_frames_wait_in_the_group(oracle, synth, mi
             c.host_free(x)
         g.close()
         a.close(); b.close()
+
+
+def test_fused_batches_from_hbm_go_through_the_lds_cached_kernel(oracle, synth, mi355lib):
+    """Round 6: the fused pair of many streams in one launch reads frames that come from HBM (each stream's own source): the
+    multi-frame form of colorlut_window_kernel (rows of up to 16 separate frames, base pointers in the kernel arguments) serves
+    them where the launch is large enough - the provenance rule of the single-buffer entry points. Five 4K streams with odd
+    content (noise, two-colour bars, every stream different), twice (the second round on a warm cache), in and out of place:
+    every frame == the oracle chain; the two-launch form of the same streams keeps the gather kernel (its input is on-die)."""
+    import mi355fx
+    w, h, n = 3840, 2160, 5
+    pairs = _ctxs(mi355fx, oracle, synth, n, [synth.cube_text_3d(33)] * n)
+    ctxs, cube = [p[0] for p in pairs], pairs[0][1]
+    st = synth.HSV_SETTINGS["hue90"]
+    g = mi355fx.Group(0, 8)
+    rng = np.random.default_rng(12)
+    bufs = []
+    try:
+        frames = []
+        for i in range(n):
+            f = synth.smooth_frame(w, h, seed=300 + i).reshape(h, w * 4).copy()
+            if i == 1:
+                f[:, : w * 2] = rng.integers(0, 256, size=(h, w * 2), dtype=np.uint8)          # half noise: misses, installs, past-cache gathers
+            if i == 2:
+                f.reshape(h, w, 4)[:, ::2, :3] = (255, 0, 128)
+                f.reshape(h, w, 4)[:, 1::2, :3] = (127, 255, 0)                                # two colours 128 levels apart: one set, two ways
+            frames.append(f.reshape(-1))
+        exp = []
+        for f in frames:
+            mid = f.copy()
+            oracle.hsvfilter(mid, w, w * 4, 4, 0, False, st)
+            e = np.zeros_like(f)
+            oracle.colorlut_rgba8(cube, mid, w * 4, e, w * 4, w, h, nthreads=8)
+            exp.append(e)
+        srcs, dsts = [], []
+        for c, f in zip(ctxs, frames):
+            ds, dd = c.alloc(f.nbytes), c.alloc(f.nbytes)
+            bufs.extend([(c, ds), (c, dd)])
+            c.h2d(ds, f)
+            srcs.append(ds); dsts.append(dd)
+        for _ in range(8):      # settings that stay: the composed table is built (or found) at the eighth submit
+            for c, ds, dd in zip(ctxs, srcs, dsts):
+                g.submit_fused(c, ds, dd, w, h, w * 4, "RGBA", st)
+            g.wait_all()
+        for rnd in range(2):
+            for c, dd in zip(ctxs, dsts):
+                c.h2d(dd, np.full(w * h * 4, 0x11 + rnd, np.uint8))
+            tk = [g.submit_fused(c, ds, ds if (rnd == 1 and i == 4) else dd, w, h, w * 4, "RGBA", st) for i, (c, ds, dd) in enumerate(zip(ctxs, srcs, dsts))]
+            for t in tk:
+                g.wait(t)
+            assert ctxs[0].colorlut_kernel_name() == "colorlut_window_kernel"
+            for i, (c, ds, dd) in enumerate(zip(ctxs, srcs, dsts)):
+                out = np.zeros(w * h * 4, np.uint8)
+                c.d2h(out, ds if (rnd == 1 and i == 4) else dd)
+                assert (out == exp[i]).all(), (rnd, i)
+                if not (rnd == 1 and i == 4):
+                    c.d2h(out, ds)
+                    assert (out == frames[i]).all()          # the source is left alone
+        # the two-launch form of the same streams: hsvfilter's output is on-die -> the gather kernel
+        c4 = ctxs[4]
+        c4.h2d(srcs[4], frames[4])
+        tk = [g.submit_chain(c, ds, dd, w, h, w * 4, "RGBA", st) for c, ds, dd in zip(ctxs, srcs, dsts)]
+        for t in tk:
+            g.wait(t)
+        assert ctxs[0].colorlut_kernel_name() == "colorlut_table_tiled_multi_kernel"
+        for i, (c, dd) in enumerate(zip(ctxs, dsts)):
+            out = np.zeros(w * h * 4, np.uint8)
+            c.d2h(out, dd)
+            assert (out == exp[i]).all(), i
+    finally:
+        g.close()
+        for c, p in bufs:
+            c.free(p)
+        for c in ctxs:
+            c.close()

@@ -14,6 +14,10 @@ for t in bench_hrtf bench_videocompare bench_dssim bench_loudnorm bench_loudnorm
 done
 python3 "$R/tools/bench_hrtf.py" --taps 512 --no-cpu 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench_hrtf_512taps", /' >> "$OUT"
 python3 "$R/bench.py" --config 5 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 --group 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --group", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 --hash-algo blockhash 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --hash-algo blockhash", /' >> "$OUT"
+python3 "$R/bench.py" --config 5 --hash-algo blockhash --group 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --hash-algo blockhash --group", /' >> "$OUT"
+for n in 32 8 2; do "$R/tools/agroup_bench" $n 2>/dev/null | grep '^{' | sed "s/^{/{\"tool\": \"agroup_bench $n (native threads)\", /" >> "$OUT"; done
 python3 "$R/bench.py" --config 5 --shared-reference --workers 2 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --shared-reference --workers 2", /' >> "$OUT"
 python3 "$R/bench.py" --config 5 --shared-reference --workers 4 --dssim-two-step 2>/dev/null | grep '^{' | tail -1 | sed 's/^{/{"tool": "bench.py --config 5 --shared-reference --workers 4 --dssim-two-step", /' >> "$OUT"
 python3 "$R/tools/bench_rgba64.py" 2>/dev/null >> "$R/gpurun_out/configs_${TAG}_elements.txt"

@@ -21,8 +21,12 @@ python3 tools/summarize_profiles.py ${TAG}_window > gpurun_out/summarize_${TAG}_
 cp /tmp/pmc_keep.json profiles/pmc_latest.json     # pmc_latest stays the default command's
 python3 tools/window_probe.py 0 4 8 16 > $F/${TAG}_window_probe.txt 2>&1
 bash tools/prof_dssim.sh > $F/${TAG}_dssim_kernel_stats.txt 2>&1
+bash tools/pmc_dssim.sh > $F/${TAG}_dssim_sq_counters.txt 2>&1
+bash tools/pmc_brick.sh > $F/${TAG}_brick_sq_counters.txt 2>&1
+timeout 300 tools/walk_dma_bench > $F/${TAG}_walk_dma_bench_box.txt 2>&1
+timeout 300 python3 tools/stress_dispatch.py 25 > $F/${TAG}_stress_dispatch.txt 2>&1
 cp -n profiles/${TAG}_* $F/     # (what the steps above wrote into $F stays: -n)
-rm -rf gpurun_out/profiles_$TAG gpurun_out/profiles_${TAG}_interp gpurun_out/profiles_${TAG}_window gpurun_out/prof_dssim gpurun_out/pmc_dssim
+rm -rf gpurun_out/profiles_$TAG gpurun_out/profiles_${TAG}_interp gpurun_out/profiles_${TAG}_window gpurun_out/prof_dssim gpurun_out/pmc_dssim gpurun_out/pmc_brick
 bash tools/bench_all.sh $TAG > gpurun_out/bench_all_$TAG.log 2>&1
 cp gpurun_out/configs_$TAG.jsonl $F/${TAG}_configs.jsonl
 cp gpurun_out/configs_${TAG}_elements.txt $F/${TAG}_configs_elements.txt
