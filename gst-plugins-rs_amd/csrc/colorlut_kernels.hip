@@ -1907,6 +1907,9 @@ int launch_hsv_colorlut(mi355_ctx *ctx, const uint8_t *d_src, size_t src_pitch, 
   if (same_hs(hs, L.seen_hs)) { if (L.seen_stable < kStableCalls) L.seen_stable++; }
   else { L.seen_hs = hs; L.seen_stable = 0; }
   const bool have = L.table_ref[1] && L.table_morton[1] == 1 && same_hs(L.table_hs, hs);
+  // (Settings that change with every call - a hue shift animated by a controller - never settle and keep the arithmetic kernel. Round 6
+  // measured the alternative for large launches, a table built per call: 0.219 ms per 8 x 4K against 0.19 - the build is the fused
+  // arithmetic over ALL 2^24 colours, the one frame on which every cache of the arithmetic kernels misses: profiles/r06_fused_animated_probe.txt)
   if (!have && L.seen_stable < kStableCalls) return compute();
   if (!have && L.pick[1].learn > 2) {  // the table kernel's time belongs to the old table only loosely: measure it again
     L.pick[1].t_table = 0.0;

@@ -56,3 +56,4 @@ def test_reload_starts_on_the_kind_that_served_the_previous_lut(ctx, oracle, syn
     finally:
         ctx.free(d_s)
         ctx.free(d_o)
+
