@@ -10,11 +10,12 @@
 //   * members = element instances of ONE kind and configuration on one device (a transcoding farm's N identical pipelines);
 //   * each member submits its buffer of the interval from its own streaming thread and waits for its ticket;
 //   * the batch runs when every attached member has submitted (whoever completes the set runs it), ONE launch set for all;
-//   * rsaudioecho members are fully independent (own ring, position, buffer size and parameters per submit - a job table): a
-//     waiter that has lingered `linger_us` launches whoever is there; ebur128level / audioloudnorm members advance in LOCK STEP
-//     through the existing batch engines (ebur128_kernels.hip, loudnorm.hip: shared 100 ms phase and frame type), so their
-//     rendezvous is strict - like an aggregator that waits for all its pads - with an optional timeout that fails loudly
-//     (MI355_ERR_TIMEOUT: the submission stays pending, nothing is dropped or fed silence) and detach() for members that stop;
+//   * rsaudioecho and ebur128level members are fully independent - rsaudioecho: own ring, position, buffer size and parameters per
+//     submit (a job table); ebur128level: own buffer size, 100 ms phase and `reset` (per-stream rounds in ebur128_kernels.hip) - a
+//     waiter that has lingered `linger_us` launches whoever is there; audioloudnorm members advance in LOCK STEP through the batch
+//     engine (loudnorm.hip: shared 100 ms phase and frame type), so their rendezvous is strict - like an aggregator that waits for
+//     all its pads - with an optional timeout that fails loudly (MI355_ERR_TIMEOUT: the submission stays pending, nothing is
+//     dropped or fed silence) and detach() for members that stop;
 //   * per-member results are those of a single-instance context fed the same buffers, bit for bit (tests/test_gpu_agroup.py).
 // No persistent kernel, nothing on the device waits for the host.
 #include "internal.hpp"
@@ -186,7 +187,7 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
     if ((rc = ahip(g, hipMalloc((void **)&d, cap * (size_t)g->n_members), "hipMalloc(agroup staging)"))) { (void)hipHostFree(h); return rc; }
     // submissions already copied into the old slots move along
     for (int m = 0; m < g->n_members; m++)
-      if (g->kind == KIND_ECHO && g->h_in && g->sub[m].have && !g->sub[m].device) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
+      if (g->kind != KIND_LOUDNORM && g->h_in && g->sub[m].have && !g->sub[m].device) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
     if (g->h_in) (void)hipHostFree(g->h_in);
     if (g->d_in) (void)hipFree(g->d_in);
     g->h_in = h; g->d_in = d; g->cap_bytes = cap;
@@ -286,34 +287,39 @@ int run_echo(mi355_agroup *g) {
   return MI355_OK;
 }
 
-// ---- lock-step kinds: every attached member has submitted `frames` frames of one format; detached members are fed silence
+// ---- ebur128level: the members that have submitted advance, each by its own buffer size and with its own 100 ms phase (the engine
+// walks per-stream rounds, ebur128_kernels.hip); the others - late, detached, paused - do not move. One sample format per launch set.
 int run_ebur128(mi355_agroup *g) {
-  size_t frames = 0;
-  int fmt = -1;
-  for (int m = 0; m < g->n_members; m++)
-    if (g->attached[m] && g->sub[m].have) { frames = g->sub[m].n; fmt = g->sub[m].fmt; break; }
-  if (fmt < 0 || frames == 0) return MI355_OK;
   static const size_t esz[4] = {2, 4, 4, 8};
-  const size_t bytes = frames * g->channels * esz[fmt];
-  // host submissions were copied into the packed pinned slab at submit; device submissions come over with one D2D copy each;
-  // members that have left hear silence
+  std::vector<size_t> frames_per((size_t)g->n_members, 0);
+  int fmt = -1;
+  size_t max_host = 0;
   for (int m = 0; m < g->n_members; m++)
-    if (!(g->attached[m] && g->sub[m].have && !g->sub[m].device)) std::memset(g->h_in + (size_t)m * bytes, 0, bytes);
-  bool any_device = false;
-  for (int m = 0; m < g->n_members; m++)
-    if (g->attached[m] && g->sub[m].have && g->sub[m].device) any_device = true;
+    if (g->sub[m].have) {
+      fmt = g->sub[m].fmt;
+      frames_per[(size_t)m] = g->sub[m].n;
+      const size_t bytes = g->sub[m].n * g->channels * esz[fmt];
+      if (!g->sub[m].device && bytes > max_host) max_host = bytes;
+    }
+  if (fmt < 0) return MI355_OK;
   hipStream_t st = g->ctx->stream;
   int rc;
-  if (any_device) {
-    // everything on the device: the pinned slab goes over in one copy, then the device members' buffers on top of their slots
-    if ((rc = ahip(g, hipMemcpyAsync(g->d_in, g->h_in, bytes * (size_t)g->n_members, hipMemcpyHostToDevice, st), "agroup ebur128: upload"))) return rc;
-    for (int m = 0; m < g->n_members; m++)
-      if (g->attached[m] && g->sub[m].have && g->sub[m].device)
-        if ((rc = ahip(g, hipMemcpyAsync(g->d_in + (size_t)m * bytes, g->sub[m].data, bytes, hipMemcpyDeviceToDevice, st), "agroup ebur128: gather"))) return rc;
-    rc = ebur128_add_frames_batch(g->ctx, g->d_in, frames, fmt, 1);
-  } else {
-    rc = ebur128_add_frames_batch(g->ctx, g->h_in, frames, fmt, 0);
+  // host members: one strided copy per run of consecutive participating host members (never across the slot of a member that is
+  // not part of this launch set: it may be filling it for the next one); device members: one D2D copy each
+  std::vector<std::pair<int, int>> runs;
+  for (int m = 0; m < g->n_members; m++) {
+    if (!g->sub[m].have || g->sub[m].device) continue;
+    if (!runs.empty() && runs.back().second == m - 1) runs.back().second = m;
+    else runs.push_back({m, m});
   }
+  for (const auto &r : runs)
+    if ((rc = ahip(g, hipMemcpy2DAsync(g->d_in + (size_t)r.first * g->cap_bytes, g->cap_bytes, g->h_in + (size_t)r.first * g->cap_bytes, g->cap_bytes, max_host,
+                                       (size_t)(r.second - r.first + 1), hipMemcpyHostToDevice, st), "agroup ebur128: upload"))) return rc;
+  for (int m = 0; m < g->n_members; m++)
+    if (g->sub[m].have && g->sub[m].device)
+      if ((rc = ahip(g, hipMemcpyAsync(g->d_in + (size_t)m * g->cap_bytes, g->sub[m].data, g->sub[m].n * g->channels * esz[fmt], hipMemcpyDeviceToDevice, st),
+                     "agroup ebur128: gather"))) return rc;
+  rc = ebur128_add_frames_streams(g->ctx, g->d_in, g->cap_bytes / esz[fmt], frames_per.data(), fmt, 1);
   if (rc) g->last_error = g->ctx->last_error;
   return rc;
 }
@@ -554,19 +560,31 @@ int mi355_agroup_submit_ebur128(mi355_agroup *g, int member, const void *data, s
   int rc = check_member(g, KIND_EBUR128, member);
   if (rc) return rc;
   if (sample_format < 0 || sample_format > 3) return afail(g, MI355_ERR_INVALID_ARG, "ebur128: bad sample format");
-  if (frames == 0 || !data) return afail(g, MI355_ERR_INVALID_ARG, "agroup: empty buffer (a lock-step member submits frames every interval, or detaches)");
+  if (frames == 0 || !data) return afail(g, MI355_ERR_INVALID_ARG, "agroup: empty buffer");
   for (int m = 0; m < g->n_members; m++)
-    if (m != member && g->sub[m].have && (g->sub[m].n != frames || g->sub[m].fmt != sample_format))
-      return afail(g, MI355_ERR_INVALID_ARG, "agroup: lock-step members submit buffers of one size and format per interval");
+    if (m != member && g->sub[m].have && g->sub[m].fmt != sample_format)
+      return afail(g, MI355_ERR_INVALID_ARG, "agroup: the members of an ebur128level group submit one sample format");
   (void)hipSetDevice(g->device);
   static const size_t esz[4] = {2, 4, 4, 8};
   const size_t bytes = frames * g->channels * esz[sample_format];
   if ((rc = ensure_staging(g, lk, bytes, 0))) return rc;
-  // the batch engine reads n_members buffers back to back: the slab is PACKED at this interval's buffer size (detached members'
-  // slots are zeroed when the interval runs: they hear silence)
   Sub &s = g->sub[member];
   s.device = device_data != 0; s.data = (void *)data; s.n = frames; s.fmt = sample_format;
-  submitted(g, lk, member, ticket, s.device ? nullptr : g->h_in + (size_t)member * bytes, data, bytes);
+  submitted(g, lk, member, ticket, s.device ? nullptr : g->h_in + (size_t)member * g->cap_bytes, data, bytes);
+  return MI355_OK;
+}
+
+// the `reset` action of one ebur128level instance (imp.rs:124-139, :320-333): this member's meter back to the state of a new one -
+// history, histograms, peaks and its 100 ms phase; the other members are not touched. Not while this member has a buffer pending.
+int mi355_agroup_ebur128_reset(mi355_agroup *g, int member) {
+  if (!g) return MI355_ERR_INVALID_ARG;
+  std::unique_lock<std::mutex> lk(g->mu);
+  int rc = check_member(g, KIND_EBUR128, member);
+  if (rc) return rc;
+  (void)hipSetDevice(g->device);
+  if ((rc = ebur128_reset_stream(g->ctx, (unsigned)member))) { g->last_error = g->ctx->last_error; return rc; }
+  for (int k = 0; k < 5; k++) g->query_interval[k] = ~(uint64_t)0;   // cached answers are stale
+  g->peak_interval[0] = g->peak_interval[1] = ~(uint64_t)0;
   return MI355_OK;
 }
 
@@ -618,8 +636,8 @@ int mi355_agroup_wait(mi355_agroup *g, uint64_t ticket, size_t *out_frames) {
   while (g->interval <= interval) {
     if (!g->attached[member]) return afail(g, MI355_ERR_INVALID_ARG, "agroup: destroyed or detached while waiting");
     if (everybody_here(g)) { run_interval(g); continue; }
-    if (g->kind == KIND_ECHO) {
-      // independent members: linger for the others, then launch whoever is there
+    if (g->kind != KIND_LOUDNORM) {
+      // independent members (rsaudioecho, ebur128level): linger for the others, then launch whoever is there
       if (g->linger_us == 0 || g->cv.wait_until(lk, t0 + std::chrono::microseconds(g->linger_us)) == std::cv_status::timeout) {
         if (g->interval <= interval) run_interval(g);
       }

@@ -35,6 +35,17 @@ struct EbFilterK {
   double b[5], a[5];
 };
 
+// Streams of a batch are independent meters: each has its own 100 ms phase (a member of an audio group resets, joins late or
+// submits another buffer size). One launch covers one ROUND - the next segment of every stream - and reads what that is for its
+// stream from a table in device memory: a stream with nothing to do in a round has n == 0 (segment) or slot < 0 (energy).
+struct EbSeg {
+  unsigned long long src0, n, ring0;   // first source frame, frames, first ring frame of this stream's segment
+};
+struct EbEv {
+  unsigned long long end_frame;        // the window ends before this ring frame
+  long long slot;                      // energy slot of this stream the result goes to, < 0: nothing for this stream
+};
+
 template <typename T>
 __device__ __forceinline__ double eb_to_double(T v);
 template <> __device__ __forceinline__ double eb_to_double<int16_t>(int16_t v) { return (double)v / 32768.0; }
@@ -56,12 +67,15 @@ template <> __device__ __forceinline__ double eb_to_double<double>(double v) { r
 // src element (i,c) at src[i*stride_f + c*stride_c].
 constexpr int kEbChunk = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
-                                                        double *__restrict__ ring, size_t ring_frame0, unsigned channels,
+__global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ src, const EbSeg *__restrict__ segs, size_t stride_f, size_t stride_c,
+                                                        double *__restrict__ ring, unsigned channels,
                                                         const int *__restrict__ channel_class, double *__restrict__ vstate,
                                                         unsigned long long *__restrict__ peak, EbFilterK k, size_t src_ss, size_t ring_ss) {
   // batch of independent streams: block y works on stream y (src_ss / ring_ss = elements between consecutive streams)
-  src += (size_t)blockIdx.y * src_ss;
+  const EbSeg seg = segs[blockIdx.y];
+  const size_t n = (size_t)seg.n, ring_frame0 = (size_t)seg.ring0;
+  if (n == 0) return;   // (block-uniform)
+  src += (size_t)blockIdx.y * src_ss + (size_t)seg.src0 * stride_f;
   ring += (size_t)blockIdx.y * ring_ss;
   vstate += (size_t)blockIdx.y * channels * 4;
   if (peak) peak += (size_t)blockIdx.y * 2 * channels;
@@ -154,9 +168,13 @@ __global__ __launch_bounds__(256) void eb_filter_kernel(const T *__restrict__ sr
 // eb_energy_partial_kernel: grid of kEbEnergyBlocks blocks, block b sums its slice per channel -> partial[slot][b][c];
 // eb_energy_final_kernel: fixed-order sum over the blocks, channel weights, division -> out[slot] (deterministic).
 constexpr unsigned kEbEnergyBlocks = 32;
-__global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *__restrict__ ring, size_t ring_frames, size_t end_frame,
-                                                                  size_t frames, unsigned channels, double *__restrict__ partial, unsigned slot,
+__global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *__restrict__ ring, size_t ring_frames, const EbEv *__restrict__ evs,
+                                                                  size_t frames, unsigned channels, double *__restrict__ partial,
                                                                   size_t ring_ss, unsigned slots_per_stream) {
+  const EbEv ev = evs[blockIdx.y];
+  if (ev.slot < 0) return;   // (block-uniform)
+  const size_t end_frame = (size_t)ev.end_frame;
+  const unsigned slot = (unsigned)ev.slot;
   ring += (size_t)blockIdx.y * ring_ss;
   partial += (size_t)blockIdx.y * slots_per_stream * gridDim.x * channels;
   __shared__ double wave_sum[kEbNT / 64];
@@ -183,8 +201,10 @@ __global__ __launch_bounds__(kEbNT) void eb_energy_partial_kernel(const double *
 }
 
 __global__ __launch_bounds__(64) void eb_energy_final_kernel(const double *__restrict__ partial, unsigned blocks, size_t frames, unsigned channels,
-                                                             const int *__restrict__ channel_class, double *__restrict__ out, unsigned slot,
+                                                             const int *__restrict__ channel_class, double *__restrict__ out, const EbEv *__restrict__ evs,
                                                              unsigned slots_per_stream) {
+  if (evs[blockIdx.x].slot < 0) return;
+  const unsigned slot = (unsigned)evs[blockIdx.x].slot;
   partial += (size_t)blockIdx.x * slots_per_stream * blocks * channels;
   out += (size_t)blockIdx.x * slots_per_stream;
   if (threadIdx.x != 0) return;
@@ -210,11 +230,14 @@ struct EbInterpK {
 };
 
 template <typename T>
-__global__ __launch_bounds__(kEbNT) void eb_truepeak_kernel(const T *__restrict__ src, size_t n, size_t stride_f, size_t stride_c,
+__global__ __launch_bounds__(kEbNT) void eb_truepeak_kernel(const T *__restrict__ src, const EbSeg *__restrict__ segs, size_t stride_f, size_t stride_c,
                                                             float *__restrict__ tail, unsigned long long *__restrict__ peak,
                                                             EbInterpK ik, size_t src_ss, unsigned channels) {
   const unsigned c = blockIdx.x;
-  src += (size_t)blockIdx.y * src_ss;
+  const EbSeg seg = segs[blockIdx.y];
+  const size_t n = (size_t)seg.n;
+  if (n == 0) return;   // (block-uniform)
+  src += (size_t)blockIdx.y * src_ss + (size_t)seg.src0 * stride_f;
   tail += (size_t)blockIdx.y * channels * ik.delay;
   peak += (size_t)blockIdx.y * 2 * channels;
   const T *sp = src + (size_t)c * stride_c;
@@ -265,7 +288,8 @@ struct Ebur128State {
   EbFilterK fk{};
   EbInterpK ik{};
   bool have_interp = false;
-  size_t samples_in_100ms = 0, ring_frames = 0, index_frames = 0, needed_frames = 0, st_counter = 0;
+  size_t samples_in_100ms = 0, ring_frames = 0;
+  std::vector<size_t> index_frames, needed_frames, st_counter;   // [n_streams]: every stream has its own 100 ms phase
   std::vector<unsigned long> block_hist, st_hist;  // [n_streams][kHistBins]
   std::vector<double> sample_peak, true_peak;      // [n_streams][channels]
   // device
@@ -276,6 +300,9 @@ struct Ebur128State {
   void *d_in = nullptr;
   size_t d_in_bytes = 0;
   size_t energy_cap = 0;
+  // the rounds of one call: [rounds][n_streams] segments, then [rounds][2][n_streams] energy events (pinned + device copy)
+  char *h_tab = nullptr, *d_tab = nullptr;
+  size_t tab_bytes = 0;
 };
 
 static double g_hist_energy[kHistBins], g_hist_bound[kHistBins + 1];
@@ -354,20 +381,31 @@ void ebur128_release(mi355_ctx *ctx) {
   if (st->d_peak) (void)hipFree(st->d_peak);
   if (st->d_tail) (void)hipFree(st->d_tail);
   if (st->d_in) (void)hipFree(st->d_in);
+  if (st->h_tab) (void)hipHostFree(st->h_tab);
+  if (st->d_tab) (void)hipFree(st->d_tab);
   delete st;
   ctx->ebur128 = nullptr;
 }
 
-static int eb_reset_device(mi355_ctx *ctx, Ebur128State *st) {
-  const size_t S = st->n_streams;
-  int rc = check_hip(ctx, hipMemsetAsync(st->d_ring, 0, S * st->ring_frames * st->channels * sizeof(double), ctx->stream), "hipMemset(ebur128 ring)");
+// streams [s0, s0 + S) back to the state of a new meter
+static int eb_reset_device(mi355_ctx *ctx, Ebur128State *st, size_t s0, size_t S) {
+  const size_t C = st->channels;
+  int rc = check_hip(ctx, hipMemsetAsync(st->d_ring + s0 * st->ring_frames * C, 0, S * st->ring_frames * C * sizeof(double), ctx->stream), "hipMemset(ebur128 ring)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMemsetAsync(st->d_vstate, 0, S * st->channels * 4 * sizeof(double), ctx->stream), "hipMemset(ebur128 state)");
+  rc = check_hip(ctx, hipMemsetAsync(st->d_vstate + s0 * C * 4, 0, S * C * 4 * sizeof(double), ctx->stream), "hipMemset(ebur128 state)");
   if (rc) return rc;
-  rc = check_hip(ctx, hipMemsetAsync(st->d_peak, 0, S * 2 * st->channels * sizeof(unsigned long long), ctx->stream), "hipMemset(ebur128 peaks)");
+  rc = check_hip(ctx, hipMemsetAsync(st->d_peak + s0 * 2 * C, 0, S * 2 * C * sizeof(unsigned long long), ctx->stream), "hipMemset(ebur128 peaks)");
   if (rc) return rc;
-  if (st->d_tail) rc = check_hip(ctx, hipMemsetAsync(st->d_tail, 0, S * st->channels * st->ik.delay * sizeof(float), ctx->stream), "hipMemset(ebur128 tail)");
+  if (st->d_tail) rc = check_hip(ctx, hipMemsetAsync(st->d_tail + s0 * C * st->ik.delay, 0, S * C * st->ik.delay * sizeof(float), ctx->stream), "hipMemset(ebur128 tail)");
   return rc;
+}
+static void eb_reset_host(Ebur128State *st, size_t s0, size_t S) {
+  const size_t C = st->channels;
+  std::fill(st->block_hist.begin() + s0 * kHistBins, st->block_hist.begin() + (s0 + S) * kHistBins, 0ul);
+  std::fill(st->st_hist.begin() + s0 * kHistBins, st->st_hist.begin() + (s0 + S) * kHistBins, 0ul);
+  std::fill(st->sample_peak.begin() + s0 * C, st->sample_peak.begin() + (s0 + S) * C, 0.0);
+  std::fill(st->true_peak.begin() + s0 * C, st->true_peak.begin() + (s0 + S) * C, 0.0);
+  for (size_t s = s0; s < s0 + S; s++) { st->index_frames[s] = 0; st->needed_frames[s] = st->samples_in_100ms * 4; st->st_counter[s] = 0; }
 }
 
 // n_streams independent meters of one configuration that are fed in lock step (ebur128_setup = one stream)
@@ -395,8 +433,10 @@ int ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, u
   const size_t window = (mode & EB_S) ? 3000 : 400;
   st->ring_frames = (size_t)rate * window / 1000;
   if (st->ring_frames % st->samples_in_100ms) st->ring_frames += st->samples_in_100ms - st->ring_frames % st->samples_in_100ms;
-  st->needed_frames = st->samples_in_100ms * 4;
   const size_t S = n_streams;
+  st->index_frames.assign(S, 0);
+  st->needed_frames.assign(S, st->samples_in_100ms * 4);
+  st->st_counter.assign(S, 0);
   st->block_hist.assign(S * kHistBins, 0ul);
   st->st_hist.assign(S * kHistBins, 0ul);
   st->sample_peak.assign(S * channels, 0.0);
@@ -420,7 +460,7 @@ int ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, u
   rc = check_hip(ctx, hipMemcpyAsync(st->d_class, st->channel_class.data(), channels * sizeof(int), hipMemcpyHostToDevice, ctx->stream),
                  "hipMemcpy(ebur128 classes)");
   if (rc) return rc;
-  rc = eb_reset_device(ctx, st);
+  rc = eb_reset_device(ctx, st, 0, S);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
@@ -432,37 +472,60 @@ int ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsigned mod
 int ebur128_reset(mi355_ctx *ctx) {
   Ebur128State *st = (Ebur128State *)ctx->ebur128;
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
-  std::fill(st->block_hist.begin(), st->block_hist.end(), 0ul);
-  std::fill(st->st_hist.begin(), st->st_hist.end(), 0ul);
-  st->index_frames = 0; st->needed_frames = st->samples_in_100ms * 4; st->st_counter = 0;
-  std::fill(st->sample_peak.begin(), st->sample_peak.end(), 0.0);
-  std::fill(st->true_peak.begin(), st->true_peak.end(), 0.0);
-  int rc = eb_reset_device(ctx, st);
+  eb_reset_host(st, 0, st->n_streams);
+  int rc = eb_reset_device(ctx, st, 0, st->n_streams);
   if (rc) return rc;
   return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
 
-// energy of the last `frames` ring frames of every stream -> d_energy[stream][slot]
-static void eb_launch_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, unsigned slot) {
-  const size_t ring_ss = st->ring_frames * st->channels;
-  hipLaunchKernelGGL(eb_energy_partial_kernel, dim3(kEbEnergyBlocks, st->n_streams), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring,
-                     st->ring_frames, st->index_frames, frames, st->channels, st->d_partial, slot, ring_ss, (unsigned)st->energy_cap);
-  hipLaunchKernelGGL(eb_energy_final_kernel, dim3(st->n_streams), dim3(64), 0, ctx->stream, (const double *)st->d_partial, kEbEnergyBlocks, frames,
-                     st->channels, (const int *)st->d_class, st->d_energy, slot, (unsigned)st->energy_cap);
+// one stream of a batch back to the state of a new meter (the `reset` action of one ebur128level instance, imp.rs:320-333); the
+// other streams keep their history and their phase
+int ebur128_reset_stream(mi355_ctx *ctx, unsigned stream) {
+  Ebur128State *st = (Ebur128State *)ctx->ebur128;
+  if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (stream >= st->n_streams) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: no such stream");
+  eb_reset_host(st, stream, 1);
+  int rc = eb_reset_device(ctx, st, stream, 1);
+  if (rc) return rc;
+  return check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
 }
 
-// src_ss: elements between the buffers of consecutive streams
+// room for `bytes` of round tables (pinned + device); the previous call's tables are dead: every call ends with a stream synchronize
+static int eb_table_capacity(mi355_ctx *ctx, Ebur128State *st, size_t bytes) {
+  if (st->tab_bytes >= bytes) return MI355_OK;
+  if (st->h_tab) (void)hipHostFree(st->h_tab);
+  if (st->d_tab) (void)hipFree(st->d_tab);
+  st->h_tab = nullptr; st->d_tab = nullptr; st->tab_bytes = 0;
+  size_t cap = 4096;
+  while (cap < bytes) cap *= 2;
+  int rc = check_hip(ctx, hipHostMalloc((void **)&st->h_tab, cap, hipHostMallocDefault), "hipHostMalloc(ebur128 round tables)");
+  if (rc) return rc;
+  rc = check_hip(ctx, hipMalloc((void **)&st->d_tab, cap), "hipMalloc(ebur128 round tables)");
+  if (rc) return rc;
+  st->tab_bytes = cap;
+  return MI355_OK;
+}
+
+// energy of the `frames` ring frames before evs[stream].end_frame of every stream that has an event -> d_energy[stream][slot]
+static void eb_launch_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, const EbEv *d_evs) {
+  const size_t ring_ss = st->ring_frames * st->channels;
+  hipLaunchKernelGGL(eb_energy_partial_kernel, dim3(kEbEnergyBlocks, st->n_streams), dim3(kEbNT), 0, ctx->stream, (const double *)st->d_ring,
+                     st->ring_frames, d_evs, frames, st->channels, st->d_partial, ring_ss, (unsigned)st->energy_cap);
+  hipLaunchKernelGGL(eb_energy_final_kernel, dim3(st->n_streams), dim3(64), 0, ctx->stream, (const double *)st->d_partial, kEbEnergyBlocks, frames,
+                     st->channels, (const int *)st->d_class, st->d_energy, d_evs, (unsigned)st->energy_cap);
+}
+
+// one round: the segment d_segs[stream] of every stream. src_ss: elements between the buffers of consecutive streams
 template <typename T>
-static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, size_t frame0, size_t n, size_t stride_f, size_t stride_c, size_t src_ss) {
-  const T *p = d_src + frame0 * stride_f;
+static void eb_launch_segment(mi355_ctx *ctx, Ebur128State *st, const T *d_src, const EbSeg *d_segs, size_t stride_f, size_t stride_c, size_t src_ss) {
   unsigned long long *speak = (st->mode & EB_SAMPLE_PEAK) ? st->d_peak : nullptr;
   if (st->have_interp)
-    hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels, st->n_streams), dim3(kEbNT), 0, ctx->stream, p, n, stride_f, stride_c, st->d_tail,
+    hipLaunchKernelGGL((eb_truepeak_kernel<T>), dim3(st->channels, st->n_streams), dim3(kEbNT), 0, ctx->stream, d_src, d_segs, stride_f, stride_c, st->d_tail,
                        st->d_peak + st->channels, st->ik, src_ss, st->channels);
   const size_t filter_lds = (size_t)st->channels * (kEbChunk + 4) * sizeof(double);
   (void)hipFuncSetAttribute((const void *)eb_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds);
-  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1, st->n_streams), dim3(256), filter_lds, ctx->stream, p, n, stride_f, stride_c, st->d_ring,
-                     st->index_frames, st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk, src_ss, st->ring_frames * st->channels);
+  hipLaunchKernelGGL((eb_filter_kernel<T>), dim3(1, st->n_streams), dim3(256), filter_lds, ctx->stream, d_src, d_segs, stride_f, stride_c, st->d_ring,
+                     st->channels, (const int *)st->d_class, st->d_vstate, speak, st->fk, src_ss, st->ring_frames * st->channels);
 }
 
 static int eb_energy_capacity(mi355_ctx *ctx, Ebur128State *st, size_t events) {
@@ -479,13 +542,16 @@ static int eb_energy_capacity(mi355_ctx *ctx, Ebur128State *st, size_t events) {
 }
 
 // fmt: 0 s16, 1 s32, 2 f32, 3 f64. `planes`: nullptr for interleaved `data`, else `channels` plane pointers (one stream only).
-// Batch: `data` holds n_streams buffers of frames x channels interleaved samples back to back.
+// Batch: `data` holds n_streams slots of `slot_elems` samples each; stream s takes frames_per[s] frames (x channels interleaved
+// samples) from the start of its slot - none is allowed.
 template <typename T>
-static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, const T *const *planes, size_t frames, bool device_data) {
-  if (frames == 0) return MI355_OK;
+static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, const T *const *planes, const size_t *frames_per, size_t slot_elems, bool device_data) {
   const unsigned C = st->channels;
   const size_t S = st->n_streams;
-  const size_t bytes = S * frames * C * sizeof(T);
+  size_t frames = 0;   // the longest buffer of this call
+  for (size_t s = 0; s < S; s++) frames = frames_per[s] > frames ? frames_per[s] : frames;
+  if (frames == 0) return MI355_OK;
+  const size_t bytes = S * slot_elems * sizeof(T);
   const T *d_src = data;
   size_t stride_f, stride_c;
   if (device_data) {
@@ -512,46 +578,82 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
     }
     d_src = (const T *)st->d_in;
   }
-  const size_t src_ss = frames * C;
+  const size_t src_ss = slot_elems;
   // worst case one gating block + one short-term block per 100 ms
   int rc = eb_energy_capacity(ctx, st, 2 * (frames / st->samples_in_100ms + 2));
   if (rc) return rc;
-  std::vector<int> event_kind;  // 0 = gating block (I), 1 = short-term block (LRA), in stream order
-  // ---- the add_frames loop of libebur128 (filter up to the next 100 ms boundary, then gate); identical for every stream
-  size_t src_index = 0, left = frames;
-  while (left > 0) {
-    if (left >= st->needed_frames) {
-      eb_launch_segment<T>(ctx, st, d_src, src_index, st->needed_frames, stride_f, stride_c, src_ss);
-      src_index += st->needed_frames;
-      left -= st->needed_frames;
-      st->index_frames += st->needed_frames;
-      if (st->mode & EB_I) {
-        eb_launch_energy(ctx, st, st->samples_in_100ms * 4, (unsigned)event_kind.size());
-        event_kind.push_back(0);
-      }
-      if (st->mode & EB_LRA) {
-        st->st_counter += st->needed_frames;
-        if (st->st_counter == st->samples_in_100ms * 30) {
-          eb_launch_energy(ctx, st, st->samples_in_100ms * 30, (unsigned)event_kind.size());
-          event_kind.push_back(1);
-          st->st_counter = st->samples_in_100ms * 20;
+  // ---- the add_frames loop of libebur128 (filter up to the next 100 ms boundary, then gate), walked per stream: round r of a
+  // stream is its r-th segment and the blocks that segment completes
+  struct Round { EbSeg seg; EbEv ev[2]; };
+  std::vector<std::vector<Round>> rounds(S);
+  std::vector<std::vector<int>> event_kind(S);  // per stream: 0 = gating block (I), 1 = short-term block (LRA), in stream order
+  size_t R = 0;
+  for (size_t s = 0; s < S; s++) {
+    size_t src_index = 0, left = frames_per[s];
+    size_t &index = st->index_frames[s], &needed = st->needed_frames[s], &stc = st->st_counter[s];
+    while (left > 0) {
+      Round rd;
+      rd.ev[0].slot = rd.ev[1].slot = -1;
+      rd.ev[0].end_frame = rd.ev[1].end_frame = 0;
+      if (left >= needed) {
+        rd.seg = EbSeg{src_index, needed, index};
+        src_index += needed;
+        left -= needed;
+        index += needed;
+        if (st->mode & EB_I) {
+          rd.ev[0] = EbEv{index, (long long)event_kind[s].size()};
+          event_kind[s].push_back(0);
         }
+        if (st->mode & EB_LRA) {
+          stc += needed;
+          if (stc == st->samples_in_100ms * 30) {
+            rd.ev[1] = EbEv{index, (long long)event_kind[s].size()};
+            event_kind[s].push_back(1);
+            stc = st->samples_in_100ms * 20;
+          }
+        }
+        needed = st->samples_in_100ms;
+        if (index == st->ring_frames) index = 0;
+      } else {
+        rd.seg = EbSeg{src_index, left, index};
+        index += left;
+        if (st->mode & EB_LRA) stc += left;
+        needed -= left;
+        left = 0;
       }
-      st->needed_frames = st->samples_in_100ms;
-      if (st->index_frames == st->ring_frames) st->index_frames = 0;
-    } else {
-      eb_launch_segment<T>(ctx, st, d_src, src_index, left, stride_f, stride_c, src_ss);
-      st->index_frames += left;
-      if (st->mode & EB_LRA) st->st_counter += left;
-      st->needed_frames -= left;
-      left = 0;
+      rounds[s].push_back(rd);
     }
+    R = rounds[s].size() > R ? rounds[s].size() : R;
+  }
+  const size_t seg_bytes = R * S * sizeof(EbSeg), ev_bytes = R * 2 * S * sizeof(EbEv);
+  if ((rc = eb_table_capacity(ctx, st, seg_bytes + ev_bytes))) return rc;
+  EbSeg *h_segs = (EbSeg *)st->h_tab;
+  EbEv *h_evs = (EbEv *)(st->h_tab + seg_bytes);
+  std::vector<char> any_ev(R * 2, 0);
+  for (size_t r = 0; r < R; r++)
+    for (size_t s = 0; s < S; s++) {
+      const bool have = r < rounds[s].size();
+      h_segs[r * S + s] = have ? rounds[s][r].seg : EbSeg{0, 0, 0};
+      for (int k = 0; k < 2; k++) {
+        h_evs[(r * 2 + k) * S + s] = have ? rounds[s][r].ev[k] : EbEv{0, -1};
+        if (have && rounds[s][r].ev[k].slot >= 0) any_ev[r * 2 + k] = 1;
+      }
+    }
+  rc = check_hip(ctx, hipMemcpyAsync(st->d_tab, st->h_tab, seg_bytes + ev_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(ebur128 round tables)");
+  if (rc) return rc;
+  const EbSeg *d_segs = (const EbSeg *)st->d_tab;
+  const EbEv *d_evs = (const EbEv *)(st->d_tab + seg_bytes);
+  bool any_event = false;
+  for (size_t r = 0; r < R; r++) {
+    eb_launch_segment<T>(ctx, st, d_src, d_segs + r * S, stride_f, stride_c, src_ss);
+    if (any_ev[r * 2 + 0]) { eb_launch_energy(ctx, st, st->samples_in_100ms * 4, d_evs + (r * 2 + 0) * S); any_event = true; }
+    if (any_ev[r * 2 + 1]) { eb_launch_energy(ctx, st, st->samples_in_100ms * 30, d_evs + (r * 2 + 1) * S); any_event = true; }
   }
   rc = check_hip(ctx, hipGetLastError(), "ebur128 kernel launch");
   if (rc) return rc;
   std::vector<double> energies(S * st->energy_cap);
   std::vector<unsigned long long> peaks(S * 2 * C);
-  if (!event_kind.empty()) {
+  if (any_event) {
     rc = check_hip(ctx, hipMemcpyAsync(energies.data(), st->d_energy, energies.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream),
                    "hipMemcpyAsync(ebur128 energies)");
     if (rc) return rc;
@@ -562,10 +664,10 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
   rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "ebur128: stream synchronize");
   if (rc) return rc;
   for (size_t s = 0; s < S; s++) {
-    for (size_t k = 0; k < event_kind.size(); k++) {
+    for (size_t k = 0; k < event_kind[s].size(); k++) {
       const double e = energies[s * st->energy_cap + k];
       if (e >= g_hist_bound[0]) {
-        if (event_kind[k] == 0) st->block_hist[s * kHistBins + hist_index(e)]++;
+        if (event_kind[s][k] == 0) st->block_hist[s * kHistBins + hist_index(e)]++;
         else st->st_hist[s * kHistBins + hist_index(e)]++;
       }
     }
@@ -580,12 +682,13 @@ static int eb_add_frames_t(mi355_ctx *ctx, Ebur128State *st, const T *data, cons
   return MI355_OK;
 }
 
-static int eb_add_dispatch(mi355_ctx *ctx, Ebur128State *st, const void *data, const void *const *planes, size_t frames, int fmt, bool device_data) {
+static int eb_add_dispatch(mi355_ctx *ctx, Ebur128State *st, const void *data, const void *const *planes, const size_t *frames_per, size_t slot_elems, int fmt,
+                           bool device_data) {
   switch (fmt) {
-    case 0: return eb_add_frames_t<int16_t>(ctx, st, (const int16_t *)data, (const int16_t *const *)planes, frames, device_data);
-    case 1: return eb_add_frames_t<int32_t>(ctx, st, (const int32_t *)data, (const int32_t *const *)planes, frames, device_data);
-    case 2: return eb_add_frames_t<float>(ctx, st, (const float *)data, (const float *const *)planes, frames, device_data);
-    case 3: return eb_add_frames_t<double>(ctx, st, (const double *)data, (const double *const *)planes, frames, device_data);
+    case 0: return eb_add_frames_t<int16_t>(ctx, st, (const int16_t *)data, (const int16_t *const *)planes, frames_per, slot_elems, device_data);
+    case 1: return eb_add_frames_t<int32_t>(ctx, st, (const int32_t *)data, (const int32_t *const *)planes, frames_per, slot_elems, device_data);
+    case 2: return eb_add_frames_t<float>(ctx, st, (const float *)data, (const float *const *)planes, frames_per, slot_elems, device_data);
+    case 3: return eb_add_frames_t<double>(ctx, st, (const double *)data, (const double *const *)planes, frames_per, slot_elems, device_data);
     default: return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: bad sample format");
   }
 }
@@ -595,14 +698,26 @@ int ebur128_add_frames(mi355_ctx *ctx, const void *data, const void *const *plan
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
   if (st->n_streams != 1) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: this meter is a batch, use the batch entry points");
   if (frames && !data && !planes) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null data");
-  return eb_add_dispatch(ctx, st, data, planes, frames, fmt, false);
+  return eb_add_dispatch(ctx, st, data, planes, &frames, frames * st->channels, fmt, false);
 }
 
 int ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int fmt, int device_data) {
   Ebur128State *st = (Ebur128State *)ctx->ebur128;
   if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
   if (frames && !data) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null data");
-  return eb_add_dispatch(ctx, st, data, nullptr, frames, fmt, device_data != 0);
+  const std::vector<size_t> per(st->n_streams, frames);
+  return eb_add_dispatch(ctx, st, data, nullptr, per.data(), frames * st->channels, fmt, device_data != 0);
+}
+
+// the streams of a batch fed independently: stream s takes frames_per[s] frames (none is allowed) from slot s of `data`, the slots
+// `slot_elems` samples apart - every stream keeps its own 100 ms phase, so buffer sizes may differ between streams and calls
+int ebur128_add_frames_streams(mi355_ctx *ctx, const void *data, size_t slot_elems, const size_t *frames_per, int fmt, int device_data) {
+  Ebur128State *st = (Ebur128State *)ctx->ebur128;
+  if (!st) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "ebur128: Have no state yet");
+  if (!data || !frames_per) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: null data");
+  for (size_t s = 0; s < st->n_streams; s++)
+    if (frames_per[s] * st->channels > slot_elems) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: a stream's buffer is larger than its slot");
+  return eb_add_dispatch(ctx, st, data, nullptr, frames_per, slot_elems, fmt, device_data != 0);
 }
 
 // window energy of every stream -> out[n_streams]
@@ -610,7 +725,12 @@ static int eb_window_energy(mi355_ctx *ctx, Ebur128State *st, size_t frames, std
   if (frames > st->ring_frames) return set_error(ctx, MI355_ERR_INVALID_ARG, "ebur128: interval larger than the history window");
   int rc = eb_energy_capacity(ctx, st, 16);
   if (rc) return rc;
-  eb_launch_energy(ctx, st, frames, 0u);
+  if ((rc = eb_table_capacity(ctx, st, st->n_streams * sizeof(EbEv)))) return rc;
+  EbEv *h_evs = (EbEv *)st->h_tab;
+  for (size_t s = 0; s < st->n_streams; s++) h_evs[s] = EbEv{st->index_frames[s], 0};   // every stream's window ends at its own write position
+  rc = check_hip(ctx, hipMemcpyAsync(st->d_tab, st->h_tab, st->n_streams * sizeof(EbEv), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(ebur128 query table)");
+  if (rc) return rc;
+  eb_launch_energy(ctx, st, frames, (const EbEv *)st->d_tab);
   std::vector<double> all(st->n_streams * st->energy_cap);
   rc = check_hip(ctx, hipMemcpyAsync(all.data(), st->d_energy, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(ebur128 energy)");
   if (rc) return rc;

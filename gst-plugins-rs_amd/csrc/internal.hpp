@@ -189,6 +189,8 @@ int ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, in
 int ebur128_query_batch(mi355_ctx *ctx, int what, double *out);
 int ebur128_peak_batch(mi355_ctx *ctx, int true_peak, double *out);
 int ebur128_reset(mi355_ctx *ctx);
+int ebur128_reset_stream(mi355_ctx *ctx, unsigned stream);
+int ebur128_add_frames_streams(mi355_ctx *ctx, const void *data, size_t slot_elems, const size_t *frames_per, int fmt, int device_data);
 void ebur128_release(mi355_ctx *ctx);
 int launch_blockhash(mi355_ctx *ctx, const uint8_t *d_frames, size_t frame_pitch, int stride, int n_frames, int width, int height,
                      int channels, unsigned long long *hashes);

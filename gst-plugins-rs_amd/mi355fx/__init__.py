@@ -192,6 +192,7 @@ def load_library():
         "mi355_agroup_detach": (i, [vp, i]),
         "mi355_agroup_submit_echo": (i, [vp, i, vp, sz, i, sz, C.c_double, C.c_double, i, C.POINTER(C.c_uint64)]),
         "mi355_agroup_submit_ebur128": (i, [vp, i, vp, sz, i, i, C.POINTER(C.c_uint64)]),
+        "mi355_agroup_ebur128_reset": (i, [vp, i]),
         "mi355_agroup_submit_loudnorm": (i, [vp, i, vp, sz, vp, sz, i, i, C.POINTER(C.c_uint64)]),
         "mi355_agroup_loudnorm_frame_size": (sz, [vp]),
         "mi355_agroup_wait": (i, [vp, C.c_uint64, C.POINTER(sz)]),
@@ -488,6 +489,10 @@ class AudioGroup:
         else:
             self._ck(self.L.mi355_agroup_submit_ebur128(self.h, member, data, frames, sample_format, 1, C.byref(t)))
         return t.value
+
+    def ebur128_reset(self, member):
+        """the `reset` action of one ebur128level instance: this member's meter starts over, the others are not touched"""
+        self._ck(self.L.mi355_agroup_ebur128_reset(self.h, member))
 
     def loudnorm_frame_size(self):
         return int(self.L.mi355_agroup_loudnorm_frame_size(self.h))

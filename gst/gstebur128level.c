@@ -6,6 +6,7 @@
  * weights :520-595, interval in frames :597-601), transform_ip_passthrough :296-486: the buffer is cut at interval
  * boundaries, each piece goes to mi355_ebur128_add_frames[_planar] (the K-weighting biquads, gating blocks, true-peak FIR
  * of the `ebur128` crate run on the GPU) and every full interval posts one "ebur128-level" element message :371-470. */
+#include <stdlib.h>
 #include <gst/gst.h>
 #include <gst/audio/audio.h>
 #include <gst/audio/gstaudiofilter.h>
@@ -31,6 +32,11 @@ struct _GstEbuR128Level {
   gint sample_format; /* 0 S16, 1 S32, 2 F32, 3 F64 */
   guint64 num_frames, interval_frames, interval_frames_remaining;
   mi355_ctx *ctx;
+  /* MI355_GROUP_MEMBERS=n: this process hosts n pipelines of one shape; their ebur128level instances (interleaved caps) are members
+   * of the process-wide mi355_agroup of their configuration (include/mi355fx.h: mi355_agroup_shared_ebur128) - independent meters,
+   * each with its own 100 ms phase and `reset`, that share the launches of every interval */
+  mi355_agroup *agroup;
+  int member;
 };
 
 G_DEFINE_TYPE(GstEbuR128Level, gst_ebur128_level, GST_TYPE_AUDIO_FILTER)
@@ -102,6 +108,8 @@ static gboolean gst_ebur128_level_start(GstBaseTransform *trans) {
 static gboolean gst_ebur128_level_stop(GstBaseTransform *trans) {
   GstEbuR128Level *self = GST_EBUR128_LEVEL(trans);
   self->have_state = FALSE;
+  if (self->agroup) mi355_agroup_release(self->agroup, self->member);
+  self->agroup = NULL;
   if (self->ctx) {
     (void)mi355_ebur128_teardown(self->ctx);
     mi355_ctx_destroy(self->ctx);
@@ -143,7 +151,16 @@ static gboolean gst_ebur128_level_setup(GstAudioFilter *filter, const GstAudioIn
   int klass[64];
   for (gint c = 0; c < channels && c < 64; c++) /* unpositioned: every channel weighted like Center (imp.rs:589-595) */
     klass[c] = GST_AUDIO_INFO_IS_UNPOSITIONED(info) ? 1 : gst_ebur128_level_channel_class(GST_AUDIO_INFO_POSITION(info, c));
-  if (mi355_ebur128_setup(self->ctx, (unsigned)channels, (unsigned)GST_AUDIO_INFO_RATE(info), mode, klass) != MI355_OK) {
+  if (self->agroup) mi355_agroup_release(self->agroup, self->member); /* renegotiation: a new meter, as EbuR128::new does */
+  self->agroup = NULL;
+  const char *members = g_getenv("MI355_GROUP_MEMBERS");
+  if (members && atoi(members) > 1 && GST_AUDIO_INFO_LAYOUT(info) == GST_AUDIO_LAYOUT_INTERLEAVED) {
+    int status = 0;
+    self->agroup = mi355_agroup_shared_ebur128(0, atoi(members), (unsigned)channels, (unsigned)GST_AUDIO_INFO_RATE(info), mode, klass, &self->member, &status);
+    if (!self->agroup) GST_WARNING_OBJECT(self, "no shared ebur128level group (%s): own launches", mi355_status_string(status));
+    else (void)mi355_agroup_set_linger(self->agroup, 2000, 0); /* a paused neighbour costs the others 2 ms, never a hang */
+  }
+  if (!self->agroup && mi355_ebur128_setup(self->ctx, (unsigned)channels, (unsigned)GST_AUDIO_INFO_RATE(info), mode, klass) != MI355_OK) {
     GST_ERROR_OBJECT(self, "Failed to create EBU R128: %s", mi355_ctx_last_error(self->ctx));
     return FALSE;
   }
@@ -171,23 +188,26 @@ static void gst_ebur128_level_post(GstEbuR128Level *self, GstBaseTransform *tran
                                       gst_segment_to_stream_time(segment, GST_FORMAT_TIME, timestamp), NULL);
   double v = 0.0;
   const unsigned mode = self->state_mode;
+  mi355_agroup *ag = self->agroup;
+  const int me = self->member;
+#define EB_ERR() (ag ? mi355_agroup_last_error(ag) : mi355_ctx_last_error(self->ctx))
   if (mode & MI355_EBUR128_MOMENTARY) {
-    if (mi355_ebur128_loudness_momentary(self->ctx, &v) == MI355_OK) gst_structure_set(s, "momentary-loudness", G_TYPE_DOUBLE, v, NULL);
-    else GST_ERROR_OBJECT(self, "Failed to get momentary loudness: %s", mi355_ctx_last_error(self->ctx));
+    if ((ag ? mi355_agroup_ebur128_loudness(ag, me, 0, &v) : mi355_ebur128_loudness_momentary(self->ctx, &v)) == MI355_OK) gst_structure_set(s, "momentary-loudness", G_TYPE_DOUBLE, v, NULL);
+    else GST_ERROR_OBJECT(self, "Failed to get momentary loudness: %s", EB_ERR());
   }
   if (mode & MI355_EBUR128_SHORT_TERM) {
-    if (mi355_ebur128_loudness_shortterm(self->ctx, &v) == MI355_OK) gst_structure_set(s, "shortterm-loudness", G_TYPE_DOUBLE, v, NULL);
-    else GST_ERROR_OBJECT(self, "Failed to get shortterm loudness: %s", mi355_ctx_last_error(self->ctx));
+    if ((ag ? mi355_agroup_ebur128_loudness(ag, me, 1, &v) : mi355_ebur128_loudness_shortterm(self->ctx, &v)) == MI355_OK) gst_structure_set(s, "shortterm-loudness", G_TYPE_DOUBLE, v, NULL);
+    else GST_ERROR_OBJECT(self, "Failed to get shortterm loudness: %s", EB_ERR());
   }
   if (mode & MI355_EBUR128_GLOBAL) {
-    if (mi355_ebur128_loudness_global(self->ctx, &v) == MI355_OK) gst_structure_set(s, "global-loudness", G_TYPE_DOUBLE, v, NULL);
-    else GST_ERROR_OBJECT(self, "Failed to get global loudness: %s", mi355_ctx_last_error(self->ctx));
-    if (mi355_ebur128_relative_threshold(self->ctx, &v) == MI355_OK) gst_structure_set(s, "relative-threshold", G_TYPE_DOUBLE, v, NULL);
-    else GST_ERROR_OBJECT(self, "Failed to get relative threshold: %s", mi355_ctx_last_error(self->ctx));
+    if ((ag ? mi355_agroup_ebur128_loudness(ag, me, 2, &v) : mi355_ebur128_loudness_global(self->ctx, &v)) == MI355_OK) gst_structure_set(s, "global-loudness", G_TYPE_DOUBLE, v, NULL);
+    else GST_ERROR_OBJECT(self, "Failed to get global loudness: %s", EB_ERR());
+    if ((ag ? mi355_agroup_ebur128_loudness(ag, me, 3, &v) : mi355_ebur128_relative_threshold(self->ctx, &v)) == MI355_OK) gst_structure_set(s, "relative-threshold", G_TYPE_DOUBLE, v, NULL);
+    else GST_ERROR_OBJECT(self, "Failed to get relative threshold: %s", EB_ERR());
   }
   if (mode & MI355_EBUR128_LOUDNESS_RANGE) {
-    if (mi355_ebur128_loudness_range(self->ctx, &v) == MI355_OK) gst_structure_set(s, "loudness-range", G_TYPE_DOUBLE, v, NULL);
-    else GST_ERROR_OBJECT(self, "Failed to get loudness range: %s", mi355_ctx_last_error(self->ctx));
+    if ((ag ? mi355_agroup_ebur128_loudness(ag, me, 4, &v) : mi355_ebur128_loudness_range(self->ctx, &v)) == MI355_OK) gst_structure_set(s, "loudness-range", G_TYPE_DOUBLE, v, NULL);
+    else GST_ERROR_OBJECT(self, "Failed to get loudness range: %s", EB_ERR());
   }
   for (int peak = 0; peak < 2; peak++) {
     if (!(mode & (peak ? MI355_EBUR128_TRUE_PEAK : MI355_EBUR128_SAMPLE_PEAK))) continue;
@@ -195,7 +215,8 @@ static void gst_ebur128_level_post(GstEbuR128Level *self, GstBaseTransform *tran
     g_value_init(&arr, GST_TYPE_ARRAY);
     gboolean ok = TRUE;
     for (gint c = 0; c < GST_AUDIO_INFO_CHANNELS(&self->info) && ok; c++) {
-      ok = (peak ? mi355_ebur128_true_peak(self->ctx, (unsigned)c, &v) : mi355_ebur128_sample_peak(self->ctx, (unsigned)c, &v)) == MI355_OK;
+      ok = (ag ? mi355_agroup_ebur128_peak(ag, me, peak, (unsigned)c, &v)
+                : (peak ? mi355_ebur128_true_peak(self->ctx, (unsigned)c, &v) : mi355_ebur128_sample_peak(self->ctx, (unsigned)c, &v))) == MI355_OK;
       if (ok) {
         GValue d = G_VALUE_INIT;
         g_value_init(&d, G_TYPE_DOUBLE);
@@ -204,11 +225,12 @@ static void gst_ebur128_level_post(GstEbuR128Level *self, GstBaseTransform *tran
       }
     }
     if (ok) gst_structure_set_value(s, peak ? "true-peak" : "sample-peak", &arr);
-    else GST_ERROR_OBJECT(self, "Failed to get %s peaks: %s", peak ? "true" : "sample", mi355_ctx_last_error(self->ctx));
+    else GST_ERROR_OBJECT(self, "Failed to get %s peaks: %s", peak ? "true" : "sample", EB_ERR());
     g_value_unset(&arr);
   }
   (void)gst_element_post_message(GST_ELEMENT(self), gst_message_new_element(GST_OBJECT(self), s));
 }
+#undef EB_ERR
 
 /* BaseTransformImpl::transform_ip_passthrough (imp.rs:296-486) */
 static GstFlowReturn gst_ebur128_level_transform_ip(GstBaseTransform *trans, GstBuffer *buf) {
@@ -234,7 +256,7 @@ static GstFlowReturn gst_ebur128_level_transform_ip(GstBaseTransform *trans, Gst
   GstFlowReturn ret = GST_FLOW_OK;
   while (frames - done > 0) {
     if (g_atomic_int_compare_and_exchange(&self->reset, TRUE, FALSE)) { /* imp.rs:320-333 */
-      if (mi355_ebur128_reset(self->ctx) != MI355_OK) { ret = GST_FLOW_ERROR; break; }
+      if ((self->agroup ? mi355_agroup_ebur128_reset(self->agroup, self->member) : mi355_ebur128_reset(self->ctx)) != MI355_OK) { ret = GST_FLOW_ERROR; break; }
       self->interval_frames_remaining = self->interval_frames;
       self->num_frames = 0;
     }
@@ -245,11 +267,16 @@ static GstFlowReturn gst_ebur128_level_transform_ip(GstBaseTransform *trans, Gst
       const void *planes[64];
       for (gint c = 0; c < channels && c < 64; c++) planes[c] = (const guint8 *)abuf.planes[c] + done * sb;
       rc = mi355_ebur128_add_frames_planar(self->ctx, planes, (size_t)to_process, self->sample_format);
+    } else if (self->agroup) { /* this piece joins the launch set of the interval; the call returns when it has run */
+      uint64_t ticket = 0;
+      rc = mi355_agroup_submit_ebur128(self->agroup, self->member, (const guint8 *)abuf.planes[0] + done * sb * (size_t)channels, (size_t)to_process,
+                                       self->sample_format, 0, &ticket);
+      if (rc == MI355_OK) rc = mi355_agroup_wait(self->agroup, ticket, NULL);
     } else {
       rc = mi355_ebur128_add_frames(self->ctx, (const guint8 *)abuf.planes[0] + done * sb * (size_t)channels, (size_t)to_process, self->sample_format);
     }
     if (rc != MI355_OK) {
-      GST_ELEMENT_ERROR(self, RESOURCE, READ, ("Failed to process buffer: %s", mi355_ctx_last_error(self->ctx)), (NULL));
+      GST_ELEMENT_ERROR(self, RESOURCE, READ, ("Failed to process buffer: %s", self->agroup ? mi355_agroup_last_error(self->agroup) : mi355_ctx_last_error(self->ctx)), (NULL));
       ret = GST_FLOW_ERROR;
       break;
     }

@@ -40,7 +40,7 @@ typedef enum mi355_status {
                                    echo before setup (audioecho/imp.rs:210 NotNegotiated) */
   MI355_ERR_OUT_OF_MEMORY = -5,
   MI355_ERR_UNSUPPORTED = -6,
-  MI355_ERR_TIMEOUT = -7        /* mi355_agroup_wait: the other members of a lock-step group have not submitted (nothing dropped) */
+  MI355_ERR_TIMEOUT = -7        /* mi355_agroup_wait: the other members of a lock-step (audioloudnorm) group have not submitted (nothing dropped) */
 } mi355_status;
 
 /* Packed-RGB formats of the hot path. Values are stable ABI.
@@ -310,12 +310,16 @@ int mi355_group_compare_stats(mi355_group *group, uint64_t stats[3]);
  *   create_echo     : members are fully independent (own ring of ring_len f64 and position; per submit its own buffer length,
  *                     sample type, delay, intensity, feedback). A waiter lingers linger_us for the missing members, then launches
  *                     whoever is there (linger 0 = at once).
- *   create_ebur128 / create_loudnorm : members advance in LOCK STEP through the batch engines (one buffer size and format per
- *                     interval; audioloudnorm: whole frames of mi355_agroup_loudnorm_frame_size(), or the shorter rest with
- *                     final_frame = 1 - what drain_full_frames / drain hand to State::process). The rendezvous is strict, as an
- *                     aggregator waits for all its pads: wait() blocks until the others have submitted, or returns
- *                     MI355_ERR_TIMEOUT after timeout_ms (the submission stays pending - wait again - nothing is dropped or fed
- *                     silence); a member that stops calls detach (its slot hears silence from then on).
+ *   create_ebur128  : members are independent meters of one configuration: per submit its own buffer length, each with its own
+ *                     100 ms phase, and ebur128_reset (the element's `reset` action, ebur128level/imp.rs:124-139) for one member
+ *                     alone; one sample format per launch set. Linger as for create_echo: a member that is late, paused or
+ *                     detached simply does not advance.
+ *   create_loudnorm : members advance in LOCK STEP through the batch engine (whole frames of
+ *                     mi355_agroup_loudnorm_frame_size(), or the shorter rest with final_frame = 1 - what drain_full_frames /
+ *                     drain hand to State::process). The rendezvous is strict, as an aggregator waits for all its pads: wait()
+ *                     blocks until the others have submitted, or returns MI355_ERR_TIMEOUT after timeout_ms (the submission
+ *                     stays pending - wait again - nothing is dropped or fed silence); a member that stops calls detach (its
+ *                     slot hears silence from then on).
  *   submit_*        : device_data = 0: host buffers (copied through one pinned slab: one upload and one download per interval
  *                     for all members); 1: device pointers. Buffers are borrowed until wait(ticket) returns.
  *   wait            : *out_frames (optional) = frames produced (audioloudnorm), samples processed (echo), frames metered.
@@ -337,6 +341,7 @@ int mi355_agroup_submit_echo(mi355_agroup *group, int member, void *data, size_t
                              double feedback, int device_data, uint64_t *ticket);
 int mi355_agroup_submit_ebur128(mi355_agroup *group, int member, const void *data, size_t frames, int sample_format, int device_data,
                                 uint64_t *ticket);
+int mi355_agroup_ebur128_reset(mi355_agroup *group, int member);
 int mi355_agroup_submit_loudnorm(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
                                  int final_frame, int device_data, uint64_t *ticket);
 size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *group);

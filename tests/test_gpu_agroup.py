@@ -223,32 +223,128 @@ def test_ebur128_members_equal_single_meters(mi355lib, rate, ch, dtype):
             c.close()
 
 
-def test_lockstep_rendezvous_is_strict_times_out_loudly_and_detach_releases(mi355lib):
+def test_ebur128_members_are_independent_meters(mi355lib):
+    """Every member has its own 100 ms phase: buffer sizes differ between members of one launch set, members sit intervals out
+    (the waiter lingers, then whoever is there runs), one member is reset (ebur128level's `reset` action, imp.rs:124-139) while
+    the others keep their history. Every reading of every member == a single-instance meter that was fed / reset the same way."""
+    import mi355fx
+    rate, ch, n_m = 48000, 2, 6
+    rng = np.random.default_rng(77)
+    g = mi355fx.AudioGroup("ebur128", n_m, channels=ch, rate=rate, mode=63)
+    singles = [mi355fx.Context(0) for _ in range(n_m)]
+    for c in singles:
+        c.ebur128_setup(ch, rate, 63)
+    fed = [0] * n_m
+    try:
+        g.set_linger(0, 0)      # whoever is there runs as soon as somebody waits
+        sizes = [4800, 1000, 4801, 9600, 333, 14400, 48000, 2400, 7, 4799]
+        for it in range(40):
+            who = [m for m in range(n_m) if rng.random() < 0.7] or [int(rng.integers(n_m))]
+            tk = {}
+            for m in who:
+                frames = int(sizes[int(rng.integers(len(sizes)))])
+                tt = (fed[m] + np.arange(frames)) / rate
+                x = np.stack([0.03 * (m + 1) * np.sin(2 * np.pi * (200.0 + 40 * m + 9 * c) * tt) * (1 + 0.6 * np.sin(2 * np.pi * 0.9 * tt)) for c in range(ch)], 1)
+                x = np.ascontiguousarray((x + 1e-3 * rng.standard_normal((frames, ch))).astype(np.float32))
+                fed[m] += frames
+                singles[m].ebur128_add_frames(x.reshape(-1))
+                tk[m] = (g.submit_ebur128(m, x.reshape(-1)), frames)
+            for m in who:
+                assert g.wait(tk[m][0]) == tk[m][1]
+            if it in (11, 23):      # one member starts over; nobody else notices
+                victim = it % n_m
+                g.ebur128_reset(victim)
+                singles[victim].ebur128_reset()
+                fed[victim] = 0
+            for m in range(n_m):
+                s = singles[m]
+                own = [s.ebur128_loudness_momentary(), s.ebur128_loudness_shortterm(), s.ebur128_loudness_global(), s.ebur128_relative_threshold(), s.ebur128_loudness_range()]
+                got = [g.loudness(m, k) for k in range(5)]
+                assert got == own, (it, m, got, own)
+                for c in range(ch):
+                    assert g.peak(m, c) == s.ebur128_sample_peak(c) and g.peak(m, c, True) == s.ebur128_true_peak(c)
+        with pytest.raises(mi355fx.Mi355Error):
+            t = g.submit_ebur128(0, np.zeros(4800 * ch, np.float32))
+            try:
+                g.ebur128_reset(0)          # not with a buffer pending
+            finally:
+                g.wait(t)
+        with pytest.raises(mi355fx.Mi355Error):
+            t = g.submit_ebur128(0, np.zeros(4800 * ch, np.float32))
+            try:
+                g.submit_ebur128(1, np.zeros(4800 * ch, np.int16))     # another sample format in the same launch set
+            finally:
+                g.wait(t)
+    finally:
+        g.close()
+        for c in singles:
+            c.close()
+
+
+def test_ebur128_linger_collects_the_members_that_come_in_time(mi355lib):
+    """Three of four members submit from their own threads within the linger; the fourth is paused: one launch set of three, and the
+    paused member's meter has not moved (no silence is fed to it)."""
     import mi355fx
     rate, ch = 48000, 2
-    g = mi355fx.AudioGroup("ebur128", 3, channels=ch, rate=rate, mode=63)
+    g = mi355fx.AudioGroup("ebur128", 4, channels=ch, rate=rate, mode=63)
     single = mi355fx.Context(0)
     single.ebur128_setup(ch, rate, 63)
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(5)
+    try:
+        g.set_linger(200000, 0)
+        x = (0.1 * rng.standard_normal((3, 19200, ch))).astype(np.float32)
+        done = [None] * 3
+
+        def element(m):
+            done[m] = g.wait(g.submit_ebur128(m, x[m].reshape(-1)))
+
+        ts = [threading.Thread(target=element, args=(m,)) for m in range(3)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=30)
+        assert done == [19200] * 3
+        assert g.stats() == (3, 1, 3)
+        single.ebur128_add_frames(x[1].reshape(-1))
+        assert g.loudness(1, 0) == single.ebur128_loudness_momentary()
+        assert g.loudness(3, 0) == -np.inf and g.peak(3, 0) == 0.0      # the paused member: a meter that has heard nothing
+    finally:
+        g.close()
+        single.close()
+
+
+def test_lockstep_rendezvous_is_strict_times_out_loudly_and_detach_releases(mi355lib):
+    """audioloudnorm members advance in lock step: a missing member makes wait() time out loudly (nothing dropped, nothing fed
+    silence), a wrong frame size is refused, and detach releases the ones already waiting."""
+    import mi355fx
+    ch = 1
+    g = mi355fx.AudioGroup("loudnorm", 3, channels=ch)
+    single = mi355fx.Context(0)
+    single.loudnorm_setup(ch)
     try:
         g.set_linger(0, 30)
-        x = (0.1 * rng.standard_normal((4800, ch))).astype(np.float32)
-        t0 = g.submit_ebur128(0, x.reshape(-1))
-        t1 = g.submit_ebur128(1, x.reshape(-1))
+        fs = g.loudnorm_frame_size()
+        assert fs == 3 * 192000
+        x = _ln_signal(3, 3.2, ch)
+        outs = [np.zeros((19200, ch)) for _ in range(3)]
+        t0 = g.submit_loudnorm(0, x[:fs], outs[0])
+        t1 = g.submit_loudnorm(1, x[:fs], outs[1])
         with pytest.raises(mi355fx.Mi355Error) as e:
             g.wait(t0)                                   # member 2 has not come
         assert e.value.status == mi355fx.ERR_TIMEOUT
         with pytest.raises(mi355fx.Mi355Error):
-            g.submit_ebur128(2, x.reshape(-1)[: 100 * ch])      # another buffer size in the same interval
-        t2 = g.submit_ebur128(2, x.reshape(-1))          # ... now it comes: the pending submissions were kept
+            g.submit_loudnorm(2, x[:100], outs[2])       # not the frame the others submitted
+        t2 = g.submit_loudnorm(2, x[:fs], outs[2])       # ... now it comes: the pending submissions were kept
         for t in (t0, t1, t2):
-            assert g.wait(t) == 4800
-        single.ebur128_add_frames(x.reshape(-1))
-        assert g.loudness(1, 0) == single.ebur128_loudness_momentary()
+            assert g.wait(t) == 19200
+        exp = single.loudnorm_push(x[:fs])
+        assert (outs[1].reshape(-1) == exp).all() and (outs[2].reshape(-1) == exp).all()
         # member 2 stops: the others are complete without it, from a thread that was already waiting
-        y = (0.1 * rng.standard_normal((4800, ch))).astype(np.float32)
         g.set_linger(0, 0)
-        ta, tb = g.submit_ebur128(0, y.reshape(-1)), g.submit_ebur128(1, y.reshape(-1))
+        fs = g.loudnorm_frame_size()
+        assert fs == 19200
+        y = x[3 * 192000:3 * 192000 + fs]
+        ta, tb = g.submit_loudnorm(0, y, outs[0]), g.submit_loudnorm(1, y, outs[1])
         done = []
         th = threading.Thread(target=lambda: done.append(g.wait(ta)))
         th.start()
@@ -256,9 +352,9 @@ def test_lockstep_rendezvous_is_strict_times_out_loudly_and_detach_releases(mi35
         assert not done
         g.detach(2)
         th.join(timeout=10)
-        assert done == [4800] and g.wait(tb) == 4800
-        single.ebur128_add_frames(y.reshape(-1))
-        assert g.loudness(0, 0) == single.ebur128_loudness_momentary()
+        assert done == [19200] and g.wait(tb) == 19200
+        exp = single.loudnorm_push(y)
+        assert (outs[0].reshape(-1) == exp).all() and (outs[1].reshape(-1) == exp).all()
     finally:
         g.close()
         single.close()

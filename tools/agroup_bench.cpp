@@ -131,6 +131,7 @@ int main(int argc, char **argv) {
     const double t_own = run_threads(S, iters, own) / iters;
     mi355_agroup *g = mi355_agroup_create_ebur128(0, S, ch, rate, 63, nullptr, &st);
     if (!g) { std::fprintf(stderr, "no agroup: %d\n", st); return 1; }
+    CK(mi355_agroup_set_linger(g, 2000, 0));   // independent meters: what gst/gstebur128level.c sets
     auto grp = [&](int m, int) {
       uint64_t t = 0;
       double v;
