@@ -51,8 +51,8 @@ constexpr uint32_t kWinData = 8192;           // 16 K entries (slot & 0x3fff) x 
 constexpr uint32_t kWinLdsBytes = kWinData + 16384 * 8;  // 139,264 B: one block per CU
 constexpr int kWinWaves = 16;
 constexpr unsigned kWinRowsPerStep = 2 * kWinWaves;
-#ifndef WIN_FILLS
-#define WIN_FILLS 8
+#ifndef WIN_FILLS  // bricks a wave installs per step at most. Round 6: 4 (8 before): every election round and every brick in flight is paid by
+#define WIN_FILLS 4  // all the waves that miss, and what a step misses is mostly the same few new bricks in all sixteen (tools/r06_miss_probe.sh)
 #endif
 #ifndef WIN_DEPTH
 #define WIN_DEPTH 2
