@@ -12,6 +12,7 @@ from mi355fx.cube import parse_cube
 
 W, H, N = 3840, 2160, 8
 FB = W * H * 4
+B_FIRST = os.environ.get("B_FIRST", "0") == "1"   # enqueue the interpolating kernel's launch before the table kernel's
 
 
 def main():
@@ -29,9 +30,11 @@ def main():
     def run(k, iters=20):
         """k frames through the table kernel (context a), N - k through the interpolating kernel (context b)"""
         def once():
+            if k < N and B_FIRST:
+                b.colorlut_frames_device(d_src + k * FB, FB, W * 4, d_dst + k * FB, FB, W * 4, N - k, W, H, "RGBA")
             if k:
                 a.colorlut_frames_device(d_src, FB, W * 4, d_dst, FB, W * 4, k, W, H, "RGBA")
-            if k < N:
+            if k < N and not B_FIRST:
                 b.colorlut_frames_device(d_src + k * FB, FB, W * 4, d_dst + k * FB, FB, W * 4, N - k, W, H, "RGBA")
         for _ in range(3):
             once()
