@@ -114,8 +114,10 @@ static gboolean gst_hsv_detector_propose_allocation(GstBaseTransform *trans, Gst
 }
 
 static gboolean gst_hsv_detector_decide_allocation(GstBaseTransform *trans, GstQuery *query) {
-  if (!GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->decide_allocation(trans, query)) return FALSE;
-  return gst_mi355_decide_device_pool(trans, query);
+  /* BEFORE chaining up (as gst_color_lut_decide_allocation does for its pinned pool): the parent class adds a system-memory video pool
+   * of its own when the query has none, after which "downstream offered no pool" can no longer be seen */
+  if (!gst_mi355_decide_device_pool(trans, query)) return FALSE;
+  return GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->decide_allocation(trans, query);
 }
 
 /* GstBaseTransformClass::transform, in front of GstVideoFilter's (which maps both buffers): input and output in our device

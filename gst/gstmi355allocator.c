@@ -181,16 +181,29 @@ static void gst_mi355_device_allocator_init(GstMi355DeviceAllocator *self) {
   GST_OBJECT_FLAG_SET(self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 
+/* ONE device allocator - one mi355_ctx with its stream - per process: allocation params, pools and roundedcorners' plane all hold a
+ * reference to the same object; the last unref destroys it, the next caller makes a new one. (Statically allocated: a zero-filled GMutex
+ * and GWeakRef are valid. g_weak_ref_get hands out a strong reference or NULL, never an object that is being finalized.) */
+static GMutex gst_mi355_device_allocator_lock;
+static GWeakRef gst_mi355_device_allocator_ref;
+
 GstAllocator *gst_mi355_device_allocator_new(void) {
-  GstMi355DeviceAllocator *self = g_object_new(GST_TYPE_MI355_DEVICE_ALLOCATOR, NULL);
-  int status = 0;
-  self->ctx = mi355_ctx_create(0, &status);
-  gst_object_ref_sink(self);
-  if (!self->ctx) {
-    gst_object_unref(self);
-    return NULL;
+  g_mutex_lock(&gst_mi355_device_allocator_lock);
+  GstAllocator *alloc = (GstAllocator *)g_weak_ref_get(&gst_mi355_device_allocator_ref);
+  if (!alloc) {
+    GstMi355DeviceAllocator *self = g_object_new(GST_TYPE_MI355_DEVICE_ALLOCATOR, NULL);
+    int status = 0;
+    self->ctx = mi355_ctx_create(0, &status);
+    gst_object_ref_sink(self);
+    if (!self->ctx) {
+      gst_object_unref(self);
+    } else {
+      g_weak_ref_set(&gst_mi355_device_allocator_ref, self);
+      alloc = GST_ALLOCATOR_CAST(self);
+    }
   }
-  return GST_ALLOCATOR_CAST(self);
+  g_mutex_unlock(&gst_mi355_device_allocator_lock);
+  return alloc;
 }
 
 mi355_buf *gst_mi355_device_memory_get_buf(GstMemory *mem) {

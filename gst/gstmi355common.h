@@ -53,8 +53,9 @@ mi355_buf *gst_mi355_device_memory_get_buf(GstMemory *mem);
 mi355_buf *gst_mi355_buffer_peek_device(GstBuffer *buffer);
 /* propose_allocation: the device allocator and (if asked for) a video pool over it are added IN FRONT of the pinned ones */
 gboolean gst_mi355_propose_device_pool(GstBaseTransform *trans, GstQuery *query);
-/* decide_allocation, after the parent class has run: if downstream offered no pool, the output comes from a device pool of
- * ours (a downstream element that is not ours maps it: one lazy download) */
+/* decide_allocation, BEFORE chaining up to the parent class (which adds a system-memory pool of its own to a query without one): if
+ * downstream offered no pool, the output comes from a device pool of ours (a downstream element that is not ours maps it: one lazy
+ * download) */
 gboolean gst_mi355_decide_device_pool(GstBaseTransform *trans, GstQuery *query);
 
 /* ---- hsvfilter -> colorlut fusion.

@@ -72,6 +72,8 @@ GType g_bytes_get_type(void);
 void g_object_warn_invalid_property_id_stub(gpointer object, guint id, GParamSpec *pspec);
 #define G_OBJECT_WARN_INVALID_PROPERTY_ID(o, id, p) g_object_warn_invalid_property_id_stub((o), (id), (p))
 void g_mutex_init(GMutex *m); void g_mutex_clear(GMutex *m); void g_mutex_lock(GMutex *m); void g_mutex_unlock(GMutex *m);
+typedef struct { union { gpointer p; } priv; } GWeakRef;   /* (gobject.h) */
+void g_weak_ref_set(GWeakRef *weak_ref, gpointer object); gpointer g_weak_ref_get(GWeakRef *weak_ref);
 gint g_atomic_int_get_stub(const volatile gint *p); void g_atomic_int_set_stub(volatile gint *p, gint v); gboolean g_atomic_int_cas_stub(volatile gint *p, gint o, gint n);
 #define g_atomic_int_get(p) g_atomic_int_get_stub(p)
 #define g_atomic_int_set(p, v) g_atomic_int_set_stub((p), (v))
