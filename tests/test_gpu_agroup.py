@@ -291,7 +291,7 @@ def test_ebur128_linger_collects_the_members_that_come_in_time(mi355lib):
     single.ebur128_setup(ch, rate, 63)
     rng = np.random.default_rng(5)
     try:
-        g.set_linger(200000, 0)
+        g.set_linger(1000000, 0)     # (the fourth member never comes: the first waiter lingers its full second for the other two)
         x = (0.1 * rng.standard_normal((3, 19200, ch))).astype(np.float32)
         done = [None] * 3
 
