@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kEbNT) void eb_truepeak_kernel(const T *__restrict_
 // ---------------------------------------------------------------- host side state machine
 
 struct Ebur128State {
-  unsigned n_streams = 1;  // independent streams of identical configuration advancing in lock step (batch entry points)
+  unsigned n_streams = 1;  // independent streams of identical configuration (batch entry points): fed together or one by one, each with its own phase
   unsigned channels = 0, rate = 0, mode = 0;
   std::vector<int> channel_class;
   EbFilterK fk{};
@@ -408,7 +408,8 @@ static void eb_reset_host(Ebur128State *st, size_t s0, size_t S) {
   for (size_t s = s0; s < s0 + S; s++) { st->index_frames[s] = 0; st->needed_frames[s] = st->samples_in_100ms * 4; st->st_counter[s] = 0; }
 }
 
-// n_streams independent meters of one configuration that are fed in lock step (ebur128_setup = one stream)
+// n_streams independent meters of one configuration (ebur128_setup = one stream): mi355_ebur128_add_frames_batch feeds them the same
+// number of frames each, ebur128_add_frames_streams (the audio groups) any number per stream
 int ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class) {
   hist_tables();
   ebur128_release(ctx);

@@ -435,7 +435,9 @@ int mi355_ebur128_setup(mi355_ctx *ctx, unsigned channels, unsigned rate, unsign
  * back to back (host pointer; _device: device pointer, asynchronous up to the read-back of the gating energies).
  * loudness_batch: what = 0 momentary, 1 short-term, 2 global, 3 relative threshold, 4 loudness range -> out[n_streams];
  * peak_batch -> out[n_streams][channels]. mi355_ebur128_reset / _teardown apply to the batch as a whole. Per-stream results
- * are identical to n_streams separate single-stream meters (tests/test_gpu_ebur128.py). */
+ * are identical to n_streams separate single-stream meters (tests/test_gpu_ebur128.py). Meters that are fed independently - other
+ * buffer sizes, late or paused members, a reset of one of them - are members of an audio group (mi355_agroup_create_ebur128 above):
+ * the engine underneath keeps a 100 ms phase per stream. */
 int mi355_ebur128_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, unsigned rate, unsigned mode, const int *channel_class);
 int mi355_ebur128_add_frames_batch(mi355_ctx *ctx, const void *data, size_t frames, int sample_format);
 int mi355_ebur128_add_frames_batch_device(mi355_ctx *ctx, const void *d_data, size_t frames, int sample_format);
