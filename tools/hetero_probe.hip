@@ -35,7 +35,7 @@ __global__ void fill_table(uint32_t *t) {
 // roles: wave w of a block is an arithmetic wave if w < n_arith, else a gather wave. queue[0] = tiles claimed, [1] = taken from the
 // front, [2] = taken from the back.
 __global__ __launch_bounds__(256) void hetero(const u4_t *__restrict__ src, u4_t *__restrict__ dst, const uint32_t *__restrict__ table, unsigned tiles_g,
-                                              unsigned n_arith, unsigned long long *__restrict__ taken) {
+                                              unsigned n_arith, unsigned long long *__restrict__ taken, int other_role) {
   __shared__ uint32_t s_spread[256];
   __shared__ uint32_t s_strip[4][512];
   __shared__ float s_lut[1024];
@@ -74,6 +74,28 @@ __global__ __launch_bounds__(256) void hetero(const u4_t *__restrict__ src, u4_t
       a = *(u4_t *)(x + lane * 4);
       b = *(u4_t *)(x + 256 + lane * 4);
       wave_sync();
+    } else if (other_role == 1) {
+      // role S: the same table lookups through the SCALAR memory path: lane by lane, v_readlane -> s_buffer_load_dword -> v_writelane,
+      // sixteen loads in flight per wave (what the texture-address path does for the gather waves, the scalar cache does here)
+      const uint32_t px[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+      uint32_t o[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t idx4 = (s_spread[px[j] & 0xffu] | (s_spread[(px[j] >> 8) & 0xffu] << 1) | (s_spread[(px[j] >> 16) & 0xffu] << 2)) << 2;
+        uint32_t oj = 0;
+#define HP_LOAD(K) { const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)idx4, (K)); asm volatile("s_load_dword %0, %1, %2" : "=s"(r[(K) & 15]) : "s"(table), "s"(off)); }
+#define HP_PUT(K) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(oj) : "s"(r[(K) & 15]), "n"(K));
+#define HP_GROUP(L0) { uint32_t r[16]; \
+          HP_LOAD(L0 + 0) HP_LOAD(L0 + 1) HP_LOAD(L0 + 2) HP_LOAD(L0 + 3) HP_LOAD(L0 + 4) HP_LOAD(L0 + 5) HP_LOAD(L0 + 6) HP_LOAD(L0 + 7) \
+          HP_LOAD(L0 + 8) HP_LOAD(L0 + 9) HP_LOAD(L0 + 10) HP_LOAD(L0 + 11) HP_LOAD(L0 + 12) HP_LOAD(L0 + 13) HP_LOAD(L0 + 14) HP_LOAD(L0 + 15) \
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+          HP_PUT(L0 + 0) HP_PUT(L0 + 1) HP_PUT(L0 + 2) HP_PUT(L0 + 3) HP_PUT(L0 + 4) HP_PUT(L0 + 5) HP_PUT(L0 + 6) HP_PUT(L0 + 7) \
+          HP_PUT(L0 + 8) HP_PUT(L0 + 9) HP_PUT(L0 + 10) HP_PUT(L0 + 11) HP_PUT(L0 + 12) HP_PUT(L0 + 13) HP_PUT(L0 + 14) HP_PUT(L0 + 15) }
+        HP_GROUP(0) HP_GROUP(16) HP_GROUP(32) HP_GROUP(48)
+        o[j] = (oj & 0x00ffffffu) | (px[j] & 0xff000000u);
+      }
+      a.x = o[0]; a.y = o[1]; a.z = o[2]; a.w = o[3];
+      b.x = o[4]; b.y = o[5]; b.z = o[6]; b.w = o[7];
     } else {
       const uint32_t px[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
       uint32_t o[8];
@@ -116,7 +138,7 @@ int main(int argc, char **argv) {
   unsigned long long *taken;
   CK(hipMalloc(&src, n4 * 16)); CK(hipMalloc(&dst, n4 * 16)); CK(hipMalloc(&table, (size_t)(1u << 24) * 4)); CK(hipMalloc(&taken, 16));
   hipLaunchKernelGGL(fill_table, dim3((1u << 24) / 256), dim3(256), 0, 0, table);
-  std::vector<uint32_t> h((size_t)W * ROWS);
+  std::vector<uint32_t> h((size_t)W * ROWS), ref_g, ref_s;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int blocks_per_cu = argc > 1 ? std::atoi(argv[1]) : 8;
@@ -134,9 +156,10 @@ int main(int argc, char **argv) {
         h[(size_t)y * W + xx] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | 0xff000000u;
       }
     CK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    std::printf("amp %d, %d blocks of 4 waves per CU:", amp, blocks_per_cu);
+    for (int other_role = 0; other_role < 2; other_role++) {
+    std::printf("amp %d, %d blocks of 4 waves per CU, other role = %s:", amp, blocks_per_cu, other_role ? "S (scalar-path gather)" : "A (arithmetic stand-in)");
     struct Mix { unsigned n_arith; double share_a; };
-    for (Mix m : {Mix{0u, 0.0}, Mix{4u, 1.0}, Mix{2u, 0.3}, Mix{2u, 0.4}, Mix{2u, 0.5}, Mix{2u, 0.6}, Mix{1u, 0.2}, Mix{1u, 0.3}, Mix{3u, 0.6}, Mix{3u, 0.7}}) {
+    for (Mix m : {Mix{0u, 0.0}, Mix{4u, 1.0}, Mix{2u, 0.3}, Mix{2u, 0.4}, Mix{2u, 0.5}, Mix{2u, 0.6}, Mix{1u, 0.08}, Mix{1u, 0.12}, Mix{1u, 0.16}, Mix{1u, 0.2}, Mix{1u, 0.3}, Mix{3u, 0.6}, Mix{3u, 0.7}}) {
       const unsigned n_arith = m.n_arith;
       const unsigned tiles_g = (unsigned)((1.0 - m.share_a) * TILES);
       float best = 1e9f;
@@ -144,7 +167,7 @@ int main(int argc, char **argv) {
       for (int rep = 0; rep < 6; rep++) {
         CK(hipMemsetAsync(taken, 0, 16, 0));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(hetero, dim3(256 * blocks_per_cu), dim3(256), 0, 0, src, dst, table, tiles_g, n_arith, taken);
+        hipLaunchKernelGGL(hetero, dim3(256 * blocks_per_cu), dim3(256), 0, 0, src, dst, table, tiles_g, n_arith, taken, other_role);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -152,10 +175,17 @@ int main(int argc, char **argv) {
         if (rep >= 1 && ms < best) best = ms;
         CK(hipMemcpy(tk, taken, 16, hipMemcpyDeviceToHost));
       }
-      std::printf("  G:A %u:%u %.4f ms (A took %.0f %%)", 4 - n_arith, n_arith, best, 100.0 * (double)tk[1] / (double)(tk[0] + tk[1] ? tk[0] + tk[1] : 1));
+      std::printf("  G:%s %u:%u %.4f ms (%s took %.0f %%)", other_role ? "S" : "A", 4 - n_arith, n_arith, best, other_role ? "S" : "A", 100.0 * (double)tk[1] / (double)(tk[0] + tk[1] ? tk[0] + tk[1] : 1));
+      if (other_role == 1 && (n_arith == 0u || n_arith == 4u)) {   // the scalar path must give what the gather path gives
+        std::vector<uint32_t> &keep = n_arith == 0u ? ref_g : ref_s;
+        keep.resize(h.size());
+        CK(hipMemcpy(keep.data(), dst, h.size() * 4, hipMemcpyDeviceToHost));
+        if (n_arith == 4u) std::printf(" [S == G: %s]", ref_g == ref_s ? "ok" : "WRONG");
+      }
     }
     std::printf("\n");
     std::fflush(stdout);
+    }
   }
   return 0;
 }
