@@ -10,12 +10,11 @@
 //   * members = element instances of ONE kind and configuration on one device (a transcoding farm's N identical pipelines);
 //   * each member submits its buffer of the interval from its own streaming thread and waits for its ticket;
 //   * the batch runs when every attached member has submitted (whoever completes the set runs it), ONE launch set for all;
-//   * rsaudioecho and ebur128level members are fully independent - rsaudioecho: own ring, position, buffer size and parameters per
-//     submit (a job table); ebur128level: own buffer size, 100 ms phase and `reset` (per-stream rounds in ebur128_kernels.hip) - a
-//     waiter that has lingered `linger_us` launches whoever is there; audioloudnorm members advance in LOCK STEP through the batch
-//     engine (loudnorm.hip: shared 100 ms phase and frame type), so their rendezvous is strict - like an aggregator that waits for
-//     all its pads - with an optional timeout that fails loudly (MI355_ERR_TIMEOUT: the submission stays pending, nothing is
-//     dropped or fed silence) and detach() for members that stop;
+//   * members are independent: rsaudioecho - own ring, position, buffer size and parameters per submit (a job table);
+//     ebur128level - own buffer size, 100 ms phase and `reset` (per-stream rounds in ebur128_kernels.hip); audioloudnorm - own frame
+//     type and ring positions (loudnorm.hip: a launch sequence per CLASS of members that stand at the same frame type and size:
+//     streams that started together are one class). A waiter that has lingered `linger_us` launches whoever is there: a member that
+//     is late, paused or gone costs the others one linger, never a hang, and is never fed silence;
 //   * per-member results are those of a single-instance context fed the same buffers, bit for bit (tests/test_gpu_agroup.py).
 // No persistent kernel, nothing on the device waits for the host.
 #include "internal.hpp"
@@ -127,7 +126,7 @@ struct mi355_agroup {
   std::vector<Sub> sub;
   uint64_t interval = 1;      // the interval being collected; intervals < this one are complete
   unsigned linger_us = 0;     // echo: how long a waiter lingers for the missing members before it launches without them
-  unsigned timeout_ms = 0;    // strict kinds: 0 = wait for the others as long as it takes
+  unsigned timeout_ms = 0;    // (accepted and ignored since every kind's members are independent: nobody waits for a member that does not come)
   // results of each member's last completed interval
   std::vector<int> res_status;
   std::vector<size_t> res_frames;
@@ -151,7 +150,7 @@ struct mi355_agroup {
   uint64_t peak_interval[2] = {0, 0};
   std::vector<double> peak_cache[2];
   // ---- loudnorm
-  size_t ln_out_frames = 0;
+  std::vector<size_t> ln_out;                 // [member]: frames the member's last frame produced
   std::vector<std::vector<double>> adapter;   // mi355_agroup_loudnorm_push: what a member has pushed and not yet handed over as a whole frame
   // ---- process-wide registry (mi355_agroup_shared_*): what the group was made from, members handed out, members released
   std::string shared_key;
@@ -187,7 +186,7 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
     if ((rc = ahip(g, hipMalloc((void **)&d, cap * (size_t)g->n_members), "hipMalloc(agroup staging)"))) { (void)hipHostFree(h); return rc; }
     // submissions already copied into the old slots move along
     for (int m = 0; m < g->n_members; m++)
-      if (g->kind != KIND_LOUDNORM && g->h_in && g->sub[m].have && !g->sub[m].device) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
+      if (g->h_in && g->sub[m].have && !g->sub[m].device) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
     if (g->h_in) (void)hipHostFree(g->h_in);
     if (g->d_in) (void)hipFree(g->d_in);
     g->h_in = h; g->d_in = d; g->cap_bytes = cap;
@@ -324,38 +323,59 @@ int run_ebur128(mi355_agroup *g) {
   return rc;
 }
 
+// ---- audioloudnorm: the members that have submitted advance, class by class - a class = the members that stand at the same frame
+// type and hand over the same number of frames (streams that started together; a late starter is a class of its own until it has
+// caught up with the 100 ms frames of the others). One launch sequence per class (loudnorm.hip: loudnorm_process_members), the
+// other members do not move.
 int run_loudnorm(mi355_agroup *g) {
-  size_t frames = 0;
-  int final_frame = 0;
-  bool any = false;
-  for (int m = 0; m < g->n_members; m++)
-    if (g->attached[m] && g->sub[m].have) { frames = g->sub[m].n; final_frame = g->sub[m].final_frame; any = true; break; }
-  if (!any) return MI355_OK;
-  const size_t ch = g->channels, bytes = frames * ch * 8;
+  const size_t ch = g->channels, N = (size_t)g->n_members;
   hipStream_t st = g->ctx->stream;
+  std::vector<char> todo(N, 0);
+  bool any = false;
+  for (size_t m = 0; m < N; m++) if (g->sub[m].have) { todo[m] = 1; any = true; }
+  if (!any) return MI355_OK;
+  const size_t in_stride = g->cap_bytes / 8, cap_frames = g->out_cap_bytes / (ch * 8);
+  size_t max_out = 0;
   int rc;
-  if (bytes) {
-    for (int m = 0; m < g->n_members; m++)
-      if (!(g->attached[m] && g->sub[m].have && !g->sub[m].device)) std::memset(g->h_in + (size_t)m * bytes, 0, bytes);
-    if ((rc = ahip(g, hipMemcpyAsync(g->d_in, g->h_in, bytes * (size_t)g->n_members, hipMemcpyHostToDevice, st), "agroup loudnorm: upload"))) return rc;
-    for (int m = 0; m < g->n_members; m++)
-      if (g->attached[m] && g->sub[m].have && g->sub[m].device)
-        if ((rc = ahip(g, hipMemcpyAsync(g->d_in + (size_t)m * bytes, g->sub[m].data, bytes, hipMemcpyDeviceToDevice, st), "agroup loudnorm: gather"))) return rc;
+  for (size_t m0 = 0; m0 < N; m0++) {
+    if (!todo[m0]) continue;
+    // the class of member m0
+    const size_t frames = g->sub[m0].n;
+    const int final_frame = g->sub[m0].final_frame, ft = loudnorm_member_frame_type(g->ctx, (unsigned)m0);
+    const size_t fs = loudnorm_member_frame_size(g->ctx, (unsigned)m0);
+    std::vector<unsigned char> cls(N, 0);
+    for (size_t m = m0; m < N; m++)
+      if (todo[m] && g->sub[m].n == frames && g->sub[m].final_frame == final_frame && loudnorm_member_frame_type(g->ctx, (unsigned)m) == ft &&
+          loudnorm_member_frame_size(g->ctx, (unsigned)m) == fs) { cls[m] = 1; todo[m] = 0; }
+    const size_t bytes = frames * ch * 8;
+    if (bytes) {
+      // host members of the class: one strided copy per run of consecutive ones; device members: one D2D copy each
+      for (size_t m = 0; m < N;) {
+        if (!(cls[m] && !g->sub[m].device)) { m++; continue; }
+        size_t e = m;
+        while (e + 1 < N && cls[e + 1] && !g->sub[e + 1].device) e++;
+        if ((rc = ahip(g, hipMemcpy2DAsync(g->d_in + m * g->cap_bytes, g->cap_bytes, g->h_in + m * g->cap_bytes, g->cap_bytes, bytes, e - m + 1, hipMemcpyHostToDevice, st),
+                       "agroup loudnorm: upload"))) return rc;
+        m = e + 1;
+      }
+      for (size_t m = 0; m < N; m++)
+        if (cls[m] && g->sub[m].device)
+          if ((rc = ahip(g, hipMemcpyAsync(g->d_in + m * g->cap_bytes, g->sub[m].data, bytes, hipMemcpyDeviceToDevice, st), "agroup loudnorm: gather"))) return rc;
+    }
+    size_t out_frames = 0;
+    rc = loudnorm_process_members(g->ctx, cls.data(), (const double *)g->d_in, in_stride, frames, (double *)g->d_out, cap_frames * ch, cap_frames, &out_frames, 1, final_frame);
+    if (rc) { g->last_error = g->ctx->last_error; return rc; }
+    for (size_t m = 0; m < N; m++) if (cls[m]) g->ln_out[m] = out_frames;
+    if (out_frames > max_out) max_out = out_frames;
+    if (out_frames)
+      for (size_t m = 0; m < N; m++)
+        if (cls[m] && g->sub[m].device && g->sub[m].out)
+          if ((rc = ahip(g, hipMemcpyAsync(g->sub[m].out, g->d_out + m * cap_frames * ch * 8, out_frames * ch * 8, hipMemcpyDeviceToDevice, st), "agroup loudnorm: scatter"))) return rc;
   }
-  // output: packed [member][out_frames * ch] in the device slab, then one copy to the pinned slab (host members) and one D2D per
-  // device member
-  size_t cap_frames = g->out_cap_bytes / (ch * 8);
-  size_t out_frames = 0;
-  rc = loudnorm_process_batch(g->ctx, (const double *)g->d_in, frames * ch, frames, (double *)g->d_out, cap_frames * ch, cap_frames, &out_frames, 1, final_frame);
-  if (rc) { g->last_error = g->ctx->last_error; return rc; }
-  g->ln_out_frames = out_frames;
-  if (out_frames) {
-    if ((rc = ahip(g, hipMemcpy2DAsync(g->h_out, cap_frames * ch * 8, g->d_out, cap_frames * ch * 8, out_frames * ch * 8, (size_t)g->n_members, hipMemcpyDeviceToHost, st),
-                   "agroup loudnorm: download"))) return rc;
-    for (int m = 0; m < g->n_members; m++)
-      if (g->attached[m] && g->sub[m].have && g->sub[m].device && g->sub[m].out)
-        if ((rc = ahip(g, hipMemcpyAsync(g->sub[m].out, g->d_out + (size_t)m * cap_frames * ch * 8, out_frames * ch * 8, hipMemcpyDeviceToDevice, st), "agroup loudnorm: scatter"))) return rc;
-  }
+  // output: packed [member][cap frames] in the device slab -> one copy to the pinned slab for the host members (rows of members that
+  // did not take part are copied along and never read)
+  if (max_out)
+    if ((rc = ahip(g, hipMemcpy2DAsync(g->h_out, cap_frames * ch * 8, g->d_out, cap_frames * ch * 8, max_out * ch * 8, N, hipMemcpyDeviceToHost, st), "agroup loudnorm: download"))) return rc;
   return ahip(g, hipStreamSynchronize(st), "agroup loudnorm: sync");
 }
 
@@ -372,7 +392,7 @@ void run_interval(mi355_agroup *g) {
     if (!s.have) continue;
     carried++;
     g->res_status[m] = rc;
-    g->res_frames[m] = g->kind == KIND_LOUDNORM ? g->ln_out_frames : s.n;
+    g->res_frames[m] = g->kind == KIND_LOUDNORM ? g->ln_out[(size_t)m] : s.n;
     g->res_interval[m] = s.interval;
     s.have = false;   // (data / out stay: wait copies the member's result out)
   }
@@ -405,6 +425,7 @@ mi355_agroup *agroup_new(int device, int kind, int n_members, int *status) {
   g->res_status.assign((size_t)n_members, MI355_OK);
   g->res_frames.assign((size_t)n_members, 0);
   g->res_interval.assign((size_t)n_members, 0);
+  g->ln_out.assign((size_t)n_members, 0);
   return g;
 }
 
@@ -595,17 +616,15 @@ int mi355_agroup_submit_loudnorm(mi355_agroup *g, int member, const double *data
   int rc = check_member(g, KIND_LOUDNORM, member);
   if (rc) return rc;
   if (frames && !data) return afail(g, MI355_ERR_INVALID_ARG, "agroup: null buffer");
-  for (int m = 0; m < g->n_members; m++)
-    if (m != member && g->sub[m].have && (g->sub[m].n != frames || g->sub[m].final_frame != (final_frame ? 1 : 0)))
-      return afail(g, MI355_ERR_INVALID_ARG, "agroup: lock-step members submit frames of one size per interval (mi355_agroup_loudnorm_frame_size)");
   (void)hipSetDevice(g->device);
   const size_t ch = g->channels, bytes = frames * ch * 8;
   {
     // the output capacity is checked BEFORE anything changes (as mi355_loudnorm_process_batch does): a first or inner frame answers
     // 100 ms, the final frame what is still inside (imp.rs:270-310), a stream that ends inside its first 3 s its own length
-    const size_t cur = loudnorm_batch_frame_size(g->ctx);
+    const size_t cur = loudnorm_member_frame_size(g->ctx, (unsigned)member);
     const size_t need = final_frame ? (cur == 19200 ? (size_t)30 * 19200 - (19200 - (frames < 19200 ? frames : 19200)) : frames) : (size_t)19200;
-    if (!final_frame && frames != cur) return afail(g, MI355_ERR_INVALID_ARG, "audioloudnorm: a batch takes whole frames (mi355_agroup_loudnorm_frame_size)");
+    if (!final_frame && frames != cur) return afail(g, MI355_ERR_INVALID_ARG, "audioloudnorm: a member hands over whole frames (mi355_agroup_loudnorm_frame_size)");
+    if (final_frame && frames >= cur && frames != 0) return afail(g, MI355_ERR_INVALID_ARG, "audioloudnorm: the final frame is shorter than a full one");
     if (need > out_capacity_frames || (need && !out)) return afail(g, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
   }
   // what State::process can hand back for this frame: the first frame answers 100 ms, the final one up to 3 s (imp.rs:226-310)
@@ -613,14 +632,15 @@ int mi355_agroup_submit_loudnorm(mi355_agroup *g, int member, const double *data
   if ((rc = ensure_staging(g, lk, bytes ? bytes : 8, worst * ch * 8))) return rc;
   Sub &s = g->sub[member];
   s.device = device_data != 0; s.data = (void *)data; s.out = out; s.n = frames; s.out_cap = out_capacity_frames; s.final_frame = final_frame ? 1 : 0;
-  submitted(g, lk, member, ticket, s.device ? nullptr : g->h_in + (size_t)member * bytes, data, bytes);
+  submitted(g, lk, member, ticket, s.device ? nullptr : g->h_in + (size_t)member * g->cap_bytes, data, bytes);
   return MI355_OK;
 }
 
-size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *g) {
-  if (!g || g->kind != KIND_LOUDNORM) return 0;
+// the frame member `member` hands over next: its first 3 s (576,000 frames at 192 kHz), then 100 ms (19,200)
+size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *g, int member) {
+  if (!g || g->kind != KIND_LOUDNORM || member < 0 || member >= g->n_members) return 0;
   std::lock_guard<std::mutex> lk(g->mu);
-  return loudnorm_batch_frame_size(g->ctx);
+  return loudnorm_member_frame_size(g->ctx, (unsigned)member);
 }
 
 // Waits until the member's interval has run; copies a host member's result back to its buffer. *out_frames (optional): frames
@@ -636,16 +656,9 @@ int mi355_agroup_wait(mi355_agroup *g, uint64_t ticket, size_t *out_frames) {
   while (g->interval <= interval) {
     if (!g->attached[member]) return afail(g, MI355_ERR_INVALID_ARG, "agroup: destroyed or detached while waiting");
     if (everybody_here(g)) { run_interval(g); continue; }
-    if (g->kind != KIND_LOUDNORM) {
-      // independent members (rsaudioecho, ebur128level): linger for the others, then launch whoever is there
-      if (g->linger_us == 0 || g->cv.wait_until(lk, t0 + std::chrono::microseconds(g->linger_us)) == std::cv_status::timeout) {
-        if (g->interval <= interval) run_interval(g);
-      }
-    } else if (g->timeout_ms) {
-      if (g->cv.wait_until(lk, t0 + std::chrono::milliseconds(g->timeout_ms)) == std::cv_status::timeout && g->interval <= interval)
-        return afail(g, MI355_ERR_TIMEOUT, "agroup: the other members of this lock-step group have not submitted their buffers (still pending: wait again, or detach the members that stopped)");
-    } else {
-      g->cv.wait(lk);
+    // independent members: linger for the others, then launch whoever is there
+    if (g->linger_us == 0 || g->cv.wait_until(lk, t0 + std::chrono::microseconds(g->linger_us)) == std::cv_status::timeout) {
+      if (g->interval <= interval) run_interval(g);
     }
   }
   if (g->res_interval[member] != interval) return afail(g, MI355_ERR_INVALID_ARG, "agroup: this ticket has been waited for already");
@@ -813,7 +826,7 @@ int mi355_agroup_loudnorm_push(mi355_agroup *g, int member, const double *data, 
   }
   ad->insert(ad->end(), data, data + frames * ch);
   for (;;) {
-    const size_t fs = mi355_agroup_loudnorm_frame_size(g);
+    const size_t fs = mi355_agroup_loudnorm_frame_size(g, member);
     if (fs == 0 || ad->size() / ch < fs) break;
     uint64_t t = 0;
     size_t n = 0;

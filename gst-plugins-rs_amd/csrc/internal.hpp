@@ -202,6 +202,10 @@ int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *o
 void loudnorm_release(mi355_ctx *ctx);
 int loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, double loudness_target, double loudness_range_target, double max_true_peak, double offset_db);
 size_t loudnorm_batch_frame_size(mi355_ctx *ctx);
+size_t loudnorm_member_frame_size(mi355_ctx *ctx, unsigned stream);
+int loudnorm_member_frame_type(mi355_ctx *ctx, unsigned stream);
+int loudnorm_process_members(mi355_ctx *ctx, const unsigned char *members, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride,
+                             size_t out_cap_frames, size_t *out_frames, int device_data, int final_frame);
 int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride, size_t out_cap_frames,
                            size_t *out_frames, int device_data, int final_frame);
 void loudnorm_batch_release(mi355_ctx *ctx);

@@ -649,8 +649,9 @@ int loudnorm_drain(mi355_ctx *ctx, double *out, size_t out_cap_frames, size_t *o
 
 
 // ================================================================== batches of streams (round 3)
-// n_streams instances of the element in LOCK STEP: every stream gets the same number of frames per call, so frame types,
-// ring indices and launch shapes are shared and only values differ per stream. What kept round 2 from batching - the
+// n_streams instances of the element, advanced TOGETHER by one call: the streams a call advances (all of them, or the members
+// loudnorm_process_members names) get the same number of frames of the same frame type, so the launch shapes are shared; ring
+// positions, gain indices and values are per stream (round 6: a stream that started later, or sat calls out, keeps its own). What kept round 2 from batching - the
 // limiter's state machines of different streams take different transitions - is solved by running the state machine ON THE
 // DEVICE: one 1024-lane block per stream executes true_peak_limiter (imp.rs:1374-1430) for the whole frame: every lane
 // carries an identical copy of the state and takes the transitions together (they are scalar f64 expressions, the host
@@ -666,18 +667,26 @@ struct LnbLimiter {  // per stream, device
   unsigned long long env_cnt, sustain_cnt;
   double gr0, gr1;
 };
-struct LnbGain { double gain, gain_next, offset; };  // per stream and fill launch
+// per stream and launch: the fill's gains and where the stream's rings stand (the values of a launch are snapshotted right before it)
+struct LnbGain {
+  double gain, gain_next, offset;
+  unsigned long long lidx, bidx, pidx;   // limiter ring index, buf read index, buf write index
+  int active, pad;                        // not a member of this call: the stream's blocks return at once
+};
 
 struct LoudNormBatch {
   size_t S = 0, channels = 0;
-  size_t current_samples_per_frame = GAIN_LOOKAHEAD;
+  std::vector<size_t> current_samples_per_frame;   // [S]: GAIN_LOOKAHEAD until the first frame has been taken, FRAME_SIZE afterwards
   double target_i = 0, target_lra = 0, target_tp = 0;
   double weights[21];
-  size_t index = 1;  // shared: every stream advances it once per inner frame
+  std::vector<size_t> index;                       // [S]: advanced once per inner frame of the stream
   std::vector<double> delta, prev_delta, offset;  // [S][30], [S], [S]
   std::vector<char> above_threshold;              // [S]
-  size_t buf_len = 0, buf_index = 0, prev_buf_index = 0, limiter_len = 0, limiter_buf_index = 0;
-  int frame_type = FT_FIRST;
+  size_t buf_len = 0, limiter_len = 0;
+  std::vector<size_t> buf_index, prev_buf_index, limiter_buf_index;   // [S]
+  std::vector<int> frame_type;                     // [S]
+  std::vector<char> active;                        // [S]: the streams the call in progress advances
+  size_t adv = 0;                                  // how far the members' limiter rings have moved since the last upload of the table
   double *d_buf = nullptr, *d_limiter = nullptr, *d_src = nullptr, *d_dst = nullptr;  // [S][...]
   LnbLimiter *d_lim = nullptr;
   LnbGain *d_gain = nullptr, *h_gain = nullptr;
@@ -688,14 +697,17 @@ struct LoudNormBatch {
 __global__ __launch_bounds__(256) void lnb_scale_kernel(double *__restrict__ limiter, size_t llen, const double *__restrict__ buf, size_t blen,
                                                         const LnbGain *__restrict__ g) {
   const size_t s = blockIdx.y, gs = (size_t)gridDim.x * 256;
+  if (!g[s].active) return;
   const double pd = g[s].gain, off = g[s].offset;  // gain = prev_delta here
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < llen; i += gs) limiter[s * llen + i] = buf[s * blen + i] * pd * off;
 }
 
-__global__ __launch_bounds__(256) void lnb_fill_kernel(double *__restrict__ limiter, size_t llen, size_t lidx, double *__restrict__ buf, size_t blen,
-                                                       size_t bidx, size_t pidx, const double *__restrict__ src, size_t src_stride, size_t ch, size_t n0, size_t n1,
+__global__ __launch_bounds__(256) void lnb_fill_kernel(double *__restrict__ limiter, size_t llen, double *__restrict__ buf, size_t blen,
+                                                       const double *__restrict__ src, size_t src_stride, size_t ch, size_t n0, size_t n1,
                                                        double denom, const LnbGain *__restrict__ g) {
   const size_t s = blockIdx.y, total = (n1 - n0) * ch, gs = (size_t)gridDim.x * 256;
+  if (!g[s].active) return;
+  const size_t lidx = (size_t)g[s].lidx, bidx = (size_t)g[s].bidx, pidx = (size_t)g[s].pidx;
   const double gain = g[s].gain, gain_next = g[s].gain_next, offset = g[s].offset;
   double *lim = limiter + s * llen, *b = buf + s * blen;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gs) {
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(256) void lnb_fill_kernel(double *__restrict__ limi
 __global__ __launch_bounds__(256) void lnb_linear_kernel(double *__restrict__ dst, size_t dst_stride, const double *__restrict__ src, size_t src_stride, size_t n,
                                                          const LnbGain *__restrict__ g) {
   const size_t s = blockIdx.y, gs = (size_t)gridDim.x * 256;
+  if (!g[s].active) return;
   const double off = g[s].offset;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gs) dst[s * dst_stride + i] = src[s * src_stride + i] * off;
 }
@@ -776,11 +789,14 @@ __device__ __forceinline__ void lnb_envelope(double *lim, size_t llen, size_t li
 // true_peak_limiter (imp.rs:1374-1430) of stream blockIdx.x over `nb` frames, then the output copy with the hard clamp.
 // Every lane keeps the same copy of the limiter state; the transitions below are limiter_out / _attack / _sustain /
 // _release of the host path, line for line.
-__global__ __launch_bounds__(1024) void lnb_limiter_kernel(double *__restrict__ limiter, size_t llen, size_t lidx, size_t ch, size_t nb, double target_tp,
-                                                           int first_frame, LnbLimiter *__restrict__ state, double *__restrict__ dst, size_t dst_stride) {
+__global__ __launch_bounds__(1024) void lnb_limiter_kernel(double *__restrict__ limiter, size_t llen, const LnbGain *__restrict__ g, size_t lidx_add, size_t ch, size_t nb,
+                                                           double target_tp, int first_frame, LnbLimiter *__restrict__ state, double *__restrict__ dst, size_t dst_stride) {
   __shared__ unsigned long long s_min;
   __shared__ double s_val;
   const size_t s = blockIdx.x;
+  if (!g[s].active) return;   // (block-uniform)
+  // the table is the snapshot of the call's last upload; the members' rings have all moved on by lidx_add since
+  const size_t lidx = ((size_t)g[s].lidx + lidx_add) % llen;
   double *lim = limiter + s * llen;
   LnbLimiter L = state[s];
   if (first_frame) {  // limiter_first_frame: the serial scan with the reference's quirk (`max` keeps the SIGNED sample, imp.rs:1339-1342)
@@ -968,6 +984,13 @@ int loudnorm_setup_batch(mi355_ctx *ctx, unsigned n_streams, unsigned channels, 
   b->delta.assign(S * 30, 0.0);
   b->prev_delta.assign(S, 0.0);
   b->above_threshold.assign(S, 0);
+  b->current_samples_per_frame.assign(S, (size_t)GAIN_LOOKAHEAD);
+  b->index.assign(S, 1);
+  b->buf_index.assign(S, 0);
+  b->prev_buf_index.assign(S, 0);
+  b->limiter_buf_index.assign(S, 0);
+  b->frame_type.assign(S, FT_FIRST);
+  b->active.assign(S, 1);
   {  // init_gaussian_filter (imp.rs:1893-1914)
     double total = 0.0;
     const double sigma = 3.5, c1 = 1.0 / (sigma * std::sqrt(2.0 * M_PI)), c2 = 2.0 * std::pow(sigma, 2.0);
@@ -988,26 +1011,49 @@ static double lnb_gaussian(const LoudNormBatch *b, size_t s, size_t index) {
   return result;
 }
 
-// per-stream {gain, gain_next, offset} of the next fill launch -> device, in stream order
+// per-stream {gains, ring positions, member or not} of the next launch -> device, in stream order: a snapshot taken right before
+// every launch that reads it (the positions move between the launches of a call)
 static int lnb_upload_gains(mi355_ctx *ctx, LoudNormBatch *b, bool scale_first) {
   int rc = check_hip(ctx, hipEventSynchronize(b->gain_ev), "hipEventSynchronize(loudnorm gains)");  // the previous upload has been consumed
   if (rc) return rc;
   for (size_t s = 0; s < b->S; s++) {
-    if (scale_first) b->h_gain[s] = LnbGain{b->prev_delta[s], 0.0, b->offset[s]};
-    else b->h_gain[s] = LnbGain{lnb_gaussian(b, s, b->index + 10 < 30 ? b->index + 10 : b->index + 10 - 30),
-                                lnb_gaussian(b, s, b->index + 11 < 30 ? b->index + 11 : b->index + 11 - 30), b->offset[s]};
+    LnbGain &g = b->h_gain[s];
+    const size_t ix = b->index[s];
+    if (scale_first) { g.gain = b->prev_delta[s]; g.gain_next = 0.0; }
+    else { g.gain = lnb_gaussian(b, s, ix + 10 < 30 ? ix + 10 : ix + 10 - 30); g.gain_next = lnb_gaussian(b, s, ix + 11 < 30 ? ix + 11 : ix + 11 - 30); }
+    g.offset = b->offset[s];
+    g.lidx = b->limiter_buf_index[s]; g.bidx = b->buf_index[s]; g.pidx = b->prev_buf_index[s];
+    g.active = b->active[s] ? 1 : 0; g.pad = 0;
   }
+  b->adv = 0;
   if ((rc = check_hip(ctx, hipMemcpyAsync(b->d_gain, b->h_gain, b->S * sizeof(LnbGain), hipMemcpyHostToDevice, ctx->stream), "loudnorm: gains H2D"))) return rc;
   return check_hip(ctx, hipEventRecord(b->gain_ev, ctx->stream), "hipEventRecord(loudnorm gains)");
 }
 
-static int lnb_meter_add(mi355_ctx *ctx, void *m, const double *d_data, size_t frames) {
+// `frames` frames of every member of the call (none of the others) from the packed device buffer d_data [S][frames * channels]
+static int lnb_meter_add(mi355_ctx *ctx, LoudNormBatch *b, void *m, const double *d_data, size_t frames) {
   MeterSwap sw(ctx, m);
-  return ebur128_add_frames_batch(ctx, d_data, frames, 3, 1);
+  std::vector<size_t> per(b->S);
+  for (size_t s = 0; s < b->S; s++) per[s] = b->active[s] ? frames : 0;
+  return ebur128_add_frames_streams(ctx, d_data, frames * b->channels, per.data(), 3, 1);
 }
 static int lnb_meter_query(mi355_ctx *ctx, void *m, int what, std::vector<double> &out) {
   MeterSwap sw(ctx, m);
   return ebur128_query_batch(ctx, what, out.data());
+}
+
+// f(first, count) for every run of consecutive members of the call
+template <typename F>
+static int lnb_for_runs(const LoudNormBatch *b, F f) {
+  for (size_t s = 0; s < b->S;) {
+    if (!b->active[s]) { s++; continue; }
+    size_t e = s;
+    while (e + 1 < b->S && b->active[e + 1]) e++;
+    const int rc = f(s, e - s + 1);
+    if (rc) return rc;
+    s = e + 1;
+  }
+  return MI355_OK;
 }
 
 static int lnb_fill(mi355_ctx *ctx, LoudNormBatch *b, const double *d_src, size_t n0, size_t n1, double denom) {
@@ -1016,34 +1062,41 @@ static int lnb_fill(mi355_ctx *ctx, LoudNormBatch *b, const double *d_src, size_
   if (rc) return rc;
   const size_t ch = b->channels, frames = n1 - n0;
   hipLaunchKernelGGL(lnb_fill_kernel, dim3(ln_blocks(frames * ch, ctx->n_cu / 4 + 1), (unsigned)b->S), dim3(256), 0, ctx->stream, b->d_limiter, b->limiter_len,
-                     b->limiter_buf_index, b->d_buf, b->buf_len, b->buf_index, b->prev_buf_index, d_src, frames * ch, ch, n0, n1, denom, (const LnbGain *)b->d_gain);
-  advance(&b->limiter_buf_index, frames * ch, b->limiter_len);
-  if (d_src) advance(&b->prev_buf_index, frames * ch, b->buf_len);
-  advance(&b->buf_index, frames * ch, b->buf_len);
+                     b->d_buf, b->buf_len, d_src, frames * ch, ch, n0, n1, denom, (const LnbGain *)b->d_gain);
+  for (size_t s = 0; s < b->S; s++) {
+    if (!b->active[s]) continue;
+    advance(&b->limiter_buf_index[s], frames * ch, b->limiter_len);
+    if (d_src) advance(&b->prev_buf_index[s], frames * ch, b->buf_len);
+    advance(&b->buf_index[s], frames * ch, b->buf_len);
+  }
+  b->adv += frames * ch;
   return MI355_OK;
 }
 
-static int lnb_limit(mi355_ctx *ctx, LoudNormBatch *b, double *d_dst, size_t dst_stride, size_t nb) {
-  hipLaunchKernelGGL(lnb_limiter_kernel, dim3((unsigned)b->S), dim3(1024), 0, ctx->stream, b->d_limiter, b->limiter_len, b->limiter_buf_index, b->channels, nb,
-                     b->target_tp, b->frame_type == FT_FIRST ? 1 : 0, b->d_lim, d_dst, dst_stride);
+// (every call uploads the table - its members, where their rings stand - before its first limiter launch: the fill's or the first
+// frame's upload; the limiter only needs to know how far the rings have moved since)
+static int lnb_limit(mi355_ctx *ctx, LoudNormBatch *b, double *d_dst, size_t dst_stride, size_t nb, bool first_frame) {
+  hipLaunchKernelGGL(lnb_limiter_kernel, dim3((unsigned)b->S), dim3(1024), 0, ctx->stream, b->d_limiter, b->limiter_len, (const LnbGain *)b->d_gain, b->adv % b->limiter_len,
+                     b->channels, nb, b->target_tp, first_frame ? 1 : 0, b->d_lim, d_dst, dst_stride);
   return check_hip(ctx, hipGetLastError(), "loudnorm batch kernel launch");
 }
 
-// process_update_gain_inner_frame (imp.rs:526-608) for every stream
+// process_update_gain_inner_frame (imp.rs:526-608) for every member of the call
 static int lnb_update_gain(mi355_ctx *ctx, LoudNormBatch *b) {
   const size_t S = b->S;
   std::vector<double> global(S), shortterm(S), rel(S), shortterm_out(S);
   int rc;
   if ((rc = lnb_meter_query(ctx, b->r128_in, 2, global)) || (rc = lnb_meter_query(ctx, b->r128_in, 1, shortterm)) || (rc = lnb_meter_query(ctx, b->r128_in, 3, rel))) return rc;
   bool need_out = false;
-  for (size_t s = 0; s < S; s++) need_out |= !b->above_threshold[s];
+  for (size_t s = 0; s < S; s++) need_out |= b->active[s] && !b->above_threshold[s];
   if (need_out && (rc = lnb_meter_query(ctx, b->r128_out, 1, shortterm_out))) return rc;
   for (size_t s = 0; s < S; s++) {
+    if (!b->active[s]) continue;
     if (!b->above_threshold[s]) {
       if (shortterm[s] > -70.0) b->prev_delta[s] *= 1.0058;
       if (shortterm_out[s] >= b->target_i) b->above_threshold[s] = 1;
     }
-    double &d = b->delta[s * 30 + b->index];
+    double &d = b->delta[s * 30 + b->index[s]];
     if (shortterm[s] < rel[s] || shortterm[s] <= -70.0 || !b->above_threshold[s]) {
       d = b->prev_delta[s];
     } else {
@@ -1055,16 +1108,26 @@ static int lnb_update_gain(mi355_ctx *ctx, LoudNormBatch *b) {
       d = std::pow(10.0, (env_global + env_shortterm) / 20.0);
     }
     b->prev_delta[s] = d;
+    b->index[s] += 1;
+    if (b->index[s] >= 30) b->index[s] -= 30;
   }
-  b->index += 1;
-  if (b->index >= 30) b->index -= 30;
   return MI355_OK;
 }
 
-size_t loudnorm_batch_frame_size(mi355_ctx *ctx) {
+// the frame the next call must hand over for stream `stream` (its first 3 s, then 100 ms); streams of a uniform batch agree
+size_t loudnorm_member_frame_size(mi355_ctx *ctx, unsigned stream) {
   LoudNormBatch *b = lnb_of(ctx);
-  return b ? b->current_samples_per_frame : 0;
+  return b && stream < b->S ? b->current_samples_per_frame[stream] : 0;
 }
+size_t loudnorm_batch_frame_size(mi355_ctx *ctx) { return loudnorm_member_frame_size(ctx, 0); }
+// where stream `stream` stands: its frame type (FT_*) - members of one call must agree in it and in their frame size
+int loudnorm_member_frame_type(mi355_ctx *ctx, unsigned stream) {
+  LoudNormBatch *b = lnb_of(ctx);
+  return b && stream < b->S ? b->frame_type[stream] : -1;
+}
+
+static int lnb_process(mi355_ctx *ctx, LoudNormBatch *b, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride, size_t out_cap_frames,
+                       size_t *out_frames, int device_data, int final_frame);
 
 // State::process (imp.rs:800-828) for the batch. `data`: stream s at data + s * stream_stride, `frames` frames each; full frames
 // (frames == current_samples_per_frame) or, with `final_frame`, the shorter tail at drain. Output likewise.
@@ -1072,81 +1135,118 @@ int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_str
                            size_t *out_frames, int device_data, int final_frame) {
   LoudNormBatch *b = lnb_of(ctx);
   if (!b) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "audioloudnorm: not negotiated (setup_batch not called)");
+  std::fill(b->active.begin(), b->active.end(), (char)1);
+  return lnb_process(ctx, b, data, stream_stride, frames, out, out_stride, out_cap_frames, out_frames, device_data, final_frame);
+}
+
+// The same for the streams with members[s] != 0 only - they must stand at the same frame type and frame size (streams that started
+// together do; the audio groups call this once per such class) -; the other streams do not move and their rows of `data` / `out`
+// are neither read nor written.
+int loudnorm_process_members(mi355_ctx *ctx, const unsigned char *members, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride,
+                             size_t out_cap_frames, size_t *out_frames, int device_data, int final_frame) {
+  LoudNormBatch *b = lnb_of(ctx);
+  if (!b) return set_error(ctx, MI355_ERR_NOT_CONFIGURED, "audioloudnorm: not negotiated (setup_batch not called)");
+  if (!members) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: null member list");
+  bool any = false;
+  for (size_t s = 0; s < b->S; s++) { b->active[s] = members[s] ? 1 : 0; any |= members[s] != 0; }
+  if (!any) { *out_frames = 0; return MI355_OK; }
+  return lnb_process(ctx, b, data, stream_stride, frames, out, out_stride, out_cap_frames, out_frames, device_data, final_frame);
+}
+
+static int lnb_process(mi355_ctx *ctx, LoudNormBatch *b, const double *data, size_t stream_stride, size_t frames, double *out, size_t out_stride, size_t out_cap_frames,
+                       size_t *out_frames, int device_data, int final_frame) {
   *out_frames = 0;
   const size_t ch = b->channels, S = b->S;
-  if (!final_frame && frames != b->current_samples_per_frame) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: a batch takes whole frames (mi355_loudnorm_batch_frame_size)");
-  if (final_frame && frames >= b->current_samples_per_frame && !(frames == 0)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: the final frame is shorter than a full one");
+  // the members of the call stand at ONE frame type and frame size (the class): taken from the first, checked for the rest
+  size_t first = S;
+  for (size_t s = 0; s < S; s++) if (b->active[s]) { first = s; break; }
+  if (first == S) return MI355_OK;
+  const size_t cspf = b->current_samples_per_frame[first];
+  int ft = b->frame_type[first];
+  for (size_t s = first; s < S; s++)
+    if (b->active[s] && (b->current_samples_per_frame[s] != cspf || b->frame_type[s] != ft))
+      return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: the streams of one call stand at one frame type and size");
+  if (!final_frame && frames != cspf) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: a batch takes whole frames (mi355_loudnorm_batch_frame_size)");
+  if (final_frame && frames >= cspf && !(frames == 0)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: the final frame is shorter than a full one");
   if (frames && (!data || stream_stride < frames * ch)) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: bad input / stream stride");
-  if (final_frame && b->current_samples_per_frame != FRAME_SIZE && frames == 0) return MI355_OK;  // nothing at all: the element answers FlowError::Eos (imp.rs:289-293)
+  if (final_frame && cspf != FRAME_SIZE && frames == 0) return MI355_OK;  // nothing at all: the element answers FlowError::Eos (imp.rs:289-293)
   {
     // The output capacity is checked BEFORE anything changes: the meter has not seen the frame, frame_type has not moved. A
     // caller told "output buffer too small" can come back with a larger one and gets what State::process gives.
-    int ft = b->frame_type;
-    if (final_frame && b->current_samples_per_frame == FRAME_SIZE) ft = FT_FINAL;
-    if (ft == FT_FIRST && frames < b->current_samples_per_frame) ft = FT_LINEAR;  // process_first_frame_is_last
-    const size_t need = ft == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames)
-                        : (ft == FT_LINEAR ? frames : (ft == FT_FIRST ? FRAME_SIZE : b->current_samples_per_frame));
+    int f2 = ft;
+    if (final_frame && cspf == FRAME_SIZE) f2 = FT_FINAL;
+    if (f2 == FT_FIRST && frames < cspf) f2 = FT_LINEAR;  // process_first_frame_is_last
+    const size_t need = f2 == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames) : (f2 == FT_LINEAR ? frames : (f2 == FT_FIRST ? FRAME_SIZE : cspf));
     if (need > out_cap_frames || (need && (!out || out_stride < need * ch))) return set_error(ctx, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
   }
-  if (final_frame && b->current_samples_per_frame == FRAME_SIZE) b->frame_type = FT_FINAL;
+  auto set_type = [&](int t) { for (size_t s = 0; s < S; s++) if (b->active[s]) b->frame_type[s] = t; };
+  if (final_frame && cspf == FRAME_SIZE) { ft = FT_FINAL; set_type(ft); }
   int rc;
-  // the frame on the device, packed [S][frames * ch]
+  // the frame on the device, packed [S][frames * ch] (the members' rows only)
   const double *d_in = b->d_src;
   if (frames) {
     if (device_data && stream_stride == frames * ch) d_in = data;
-    else if ((rc = check_hip(ctx, hipMemcpy2DAsync(b->d_src, frames * ch * 8, data, stream_stride * 8, frames * ch * 8, S, device_data ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                                   ctx->stream), "loudnorm: input copy"))) return rc;
-    if ((rc = lnb_meter_add(ctx, b->r128_in, d_in, frames))) return rc;
+    else if ((rc = lnb_for_runs(b, [&](size_t s0, size_t n) {
+               return check_hip(ctx, hipMemcpy2DAsync(b->d_src + s0 * frames * ch, frames * ch * 8, data + s0 * stream_stride, stream_stride * 8, frames * ch * 8, n,
+                                                      device_data ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream), "loudnorm: input copy");
+             }))) return rc;
+    if ((rc = lnb_meter_add(ctx, b, b->r128_in, d_in, frames))) return rc;
   }
-  if (b->frame_type == FT_FIRST && frames < b->current_samples_per_frame) {  // process_first_frame_is_last (imp.rs:334-366)
+  if (ft == FT_FIRST && frames < cspf) {  // process_first_frame_is_last (imp.rs:334-366)
     std::vector<double> global(S), peaks(S * ch);
     if ((rc = lnb_meter_query(ctx, b->r128_in, 2, global))) return rc;
     { MeterSwap sw(ctx, b->r128_in); if ((rc = ebur128_peak_batch(ctx, 0, peaks.data()))) return rc; }
     for (size_t s = 0; s < S; s++) {
+      if (!b->active[s]) continue;
       double true_peak = 0.0;
       for (size_t c = 0; c < ch; c++) if (c == 0 || peaks[s * ch + c] > true_peak) true_peak = peaks[s * ch + c];
       const double offset = std::pow(10.0, (b->target_i - global[s]) / 20.0);
       const double offset_tp = true_peak * offset;
       b->offset[s] = offset_tp < b->target_tp ? offset : b->target_tp / true_peak;
     }
-    b->frame_type = FT_LINEAR;
+    ft = FT_LINEAR; set_type(ft);
   }
-  const size_t need = b->frame_type == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames)
-                      : (b->frame_type == FT_LINEAR ? frames : (b->frame_type == FT_FIRST ? FRAME_SIZE : b->current_samples_per_frame));
-  // a sub-frame of `n` frames from d_dst (packed [S][n * ch]) to the caller's buffer at frame offset `at`
+  const size_t need = ft == FT_FINAL ? 30 * FRAME_SIZE - (FRAME_SIZE - frames) : (ft == FT_LINEAR ? frames : (ft == FT_FIRST ? FRAME_SIZE : cspf));
+  // a sub-frame of `n` frames from d_dst (packed [S][n * ch]) to the caller's buffer at frame offset `at`: the members' rows
   auto deliver = [&](size_t at, size_t n) -> int {
-    return check_hip(ctx, hipMemcpy2DAsync(out + at * ch, out_stride * 8, b->d_dst, n * ch * 8, n * ch * 8, S, device_data ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream),
-                     "loudnorm: output copy");
+    return lnb_for_runs(b, [&](size_t s0, size_t cnt) {
+      return check_hip(ctx, hipMemcpy2DAsync(out + s0 * out_stride + at * ch, out_stride * 8, b->d_dst + s0 * n * ch, n * ch * 8, n * ch * 8, cnt,
+                                             device_data ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream), "loudnorm: output copy");
+    });
   };
-  switch (b->frame_type) {
+  switch (ft) {
     case FT_FIRST: {
-      if ((rc = check_hip(ctx, hipMemcpyAsync(b->d_buf, d_in, S * b->buf_len * 8, hipMemcpyDeviceToDevice, ctx->stream), "loudnorm: buf fill"))) return rc;
+      if ((rc = lnb_for_runs(b, [&](size_t s0, size_t n) {
+             return check_hip(ctx, hipMemcpyAsync(b->d_buf + s0 * b->buf_len, d_in + s0 * b->buf_len, n * b->buf_len * 8, hipMemcpyDeviceToDevice, ctx->stream), "loudnorm: buf fill");
+           }))) return rc;
       std::vector<double> shortterm(S);
       if ((rc = lnb_meter_query(ctx, b->r128_in, 1, shortterm))) return rc;
       for (size_t s = 0; s < S; s++) {
+        if (!b->active[s]) continue;
         double env_shortterm;
         if (shortterm[s] < -70.0) { b->above_threshold[s] = 0; env_shortterm = 0.0; }
         else { b->above_threshold[s] = 1; env_shortterm = b->target_i - shortterm[s]; }
         for (int i = 0; i < 30; i++) b->delta[s * 30 + i] = std::pow(10.0, env_shortterm / 20.0);
-        b->prev_delta[s] = b->delta[s * 30 + b->index];
+        b->prev_delta[s] = b->delta[s * 30 + b->index[s]];
       }
       if ((rc = lnb_upload_gains(ctx, b, true))) return rc;
       hipLaunchKernelGGL(lnb_scale_kernel, dim3(ln_blocks(b->limiter_len, ctx->n_cu / 4 + 1), (unsigned)S), dim3(256), 0, ctx->stream, b->d_limiter, b->limiter_len,
                          (const double *)b->d_buf, b->buf_len, (const LnbGain *)b->d_gain);
-      b->buf_index = b->limiter_len;
-      b->limiter_buf_index = 0;
-      if ((rc = lnb_limit(ctx, b, b->d_dst, FRAME_SIZE * ch, FRAME_SIZE))) return rc;
-      if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, FRAME_SIZE))) return rc;
+      for (size_t s = 0; s < S; s++)
+        if (b->active[s]) { b->buf_index[s] = b->limiter_len; b->limiter_buf_index[s] = 0; }   // (the snapshot just uploaded says 0 as well: a first frame's rings have not moved)
+      if ((rc = lnb_limit(ctx, b, b->d_dst, FRAME_SIZE * ch, FRAME_SIZE, true))) return rc;
+      if ((rc = lnb_meter_add(ctx, b, b->r128_out, b->d_dst, FRAME_SIZE))) return rc;
       if ((rc = deliver(0, FRAME_SIZE))) return rc;
-      b->current_samples_per_frame = FRAME_SIZE;
-      b->frame_type = FT_INNER;
+      for (size_t s = 0; s < S; s++)
+        if (b->active[s]) b->current_samples_per_frame[s] = FRAME_SIZE;
+      set_type(FT_INNER);
       *out_frames = FRAME_SIZE;
       break;
     }
     case FT_INNER: {
       if ((rc = lnb_fill(ctx, b, d_in, 0, frames, (double)FRAME_SIZE))) return rc;
-      if ((rc = lnb_limit(ctx, b, b->d_dst, frames * ch, frames))) return rc;
-      if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frames))) return rc;
+      if ((rc = lnb_limit(ctx, b, b->d_dst, frames * ch, frames, false))) return rc;
+      if ((rc = lnb_meter_add(ctx, b, b->r128_out, b->d_dst, frames))) return rc;
       if ((rc = deliver(0, frames))) return rc;
       if ((rc = lnb_update_gain(ctx, b))) return rc;
       *out_frames = frames;
@@ -1159,15 +1259,18 @@ int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_str
       size_t smp_cnt = 0;
       while (smp_cnt < need) {
         const size_t frame_size = need - smp_cnt < FRAME_SIZE ? need - smp_cnt : FRAME_SIZE;
-        if ((rc = lnb_limit(ctx, b, b->d_dst, frame_size * ch, frame_size))) return rc;
+        if ((rc = lnb_limit(ctx, b, b->d_dst, frame_size * ch, frame_size, false))) return rc;
         if ((rc = deliver(smp_cnt, frame_size))) return rc;
         smp_cnt += frame_size;
         if (smp_cnt == need) break;
-        if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frame_size))) return rc;
+        if ((rc = lnb_meter_add(ctx, b, b->r128_out, b->d_dst, frame_size))) return rc;
         if ((rc = lnb_update_gain(ctx, b))) return rc;
         const size_t next_frame_size = need - smp_cnt < FRAME_SIZE ? need - smp_cnt : FRAME_SIZE;
         if ((rc = lnb_fill(ctx, b, nullptr, 0, next_frame_size, (double)next_frame_size))) return rc;
-        if (next_frame_size < FRAME_SIZE) advance(&b->limiter_buf_index, FRAME_SIZE - next_frame_size, b->limiter_len);  // sic (imp.rs:763)
+        if (next_frame_size < FRAME_SIZE)
+          for (size_t s = 0; s < S; s++)
+            if (b->active[s]) advance(&b->limiter_buf_index[s], FRAME_SIZE - next_frame_size, b->limiter_len);  // sic (imp.rs:763)
+        if (next_frame_size < FRAME_SIZE) b->adv += FRAME_SIZE - next_frame_size;
       }
       *out_frames = need;
       break;
@@ -1177,7 +1280,7 @@ int loudnorm_process_batch(mi355_ctx *ctx, const double *data, size_t stream_str
         if ((rc = lnb_upload_gains(ctx, b, true))) return rc;
         hipLaunchKernelGGL(lnb_linear_kernel, dim3(ln_blocks(frames * ch, ctx->n_cu / 4 + 1), (unsigned)S), dim3(256), 0, ctx->stream, b->d_dst, frames * ch, d_in, frames * ch,
                            frames * ch, (const LnbGain *)b->d_gain);
-        if ((rc = lnb_meter_add(ctx, b->r128_out, b->d_dst, frames))) return rc;
+        if ((rc = lnb_meter_add(ctx, b, b->r128_out, b->d_dst, frames))) return rc;
         if ((rc = deliver(0, frames))) return rc;
       }
       *out_frames = frames;

@@ -194,7 +194,7 @@ def load_library():
         "mi355_agroup_submit_ebur128": (i, [vp, i, vp, sz, i, i, C.POINTER(C.c_uint64)]),
         "mi355_agroup_ebur128_reset": (i, [vp, i]),
         "mi355_agroup_submit_loudnorm": (i, [vp, i, vp, sz, vp, sz, i, i, C.POINTER(C.c_uint64)]),
-        "mi355_agroup_loudnorm_frame_size": (sz, [vp]),
+        "mi355_agroup_loudnorm_frame_size": (sz, [vp, i]),
         "mi355_agroup_wait": (i, [vp, C.c_uint64, C.POINTER(sz)]),
         "mi355_agroup_ebur128_loudness": (i, [vp, i, i, C.POINTER(C.c_double)]),
         "mi355_agroup_ebur128_peak": (i, [vp, i, i, C.c_uint, C.POINTER(C.c_double)]),
@@ -494,8 +494,9 @@ class AudioGroup:
         """the `reset` action of one ebur128level instance: this member's meter starts over, the others are not touched"""
         self._ck(self.L.mi355_agroup_ebur128_reset(self.h, member))
 
-    def loudnorm_frame_size(self):
-        return int(self.L.mi355_agroup_loudnorm_frame_size(self.h))
+    def loudnorm_frame_size(self, member=0):
+        """the frame `member` hands over next: its first 3 s, then 100 ms"""
+        return int(self.L.mi355_agroup_loudnorm_frame_size(self.h, member))
 
     def submit_loudnorm(self, member, data, out, final_frame=False, frames=None, out_capacity_frames=None):
         """data / out: numpy f64 arrays [frames, channels] (host) or device pointers (then frames, out_capacity_frames)."""

@@ -86,9 +86,8 @@ static gboolean gst_audio_loud_norm_new_state(GstAudioLoudNorm *self) {
     int status = 0;
     self->agroup = mi355_agroup_shared_loudnorm(0, atoi(members), (unsigned)GST_AUDIO_INFO_CHANNELS(&self->info), lt, lrt, tp, off, &self->member, &status);
     if (!self->agroup) GST_WARNING_OBJECT(self, "no shared loudnorm group (%s): own launches", mi355_status_string(status));
-    /* lock step: the first frame runs when all MI355_GROUP_MEMBERS instances have handed theirs over. A count that does not match
-     * the instances that actually run must fail loudly, not hang: a wait gives up after 10 s with MI355_ERR_TIMEOUT -> GST_FLOW_ERROR */
-    else (void)mi355_agroup_set_linger(self->agroup, 0, 10000);
+    /* independent members: an instance that starts later, pauses or ends costs the others 2 ms per interval, never a hang */
+    else (void)mi355_agroup_set_linger(self->agroup, g_getenv("MI355_GROUP_LINGER_US") ? (unsigned)atoi(g_getenv("MI355_GROUP_LINGER_US")) : 2000u, 0);
   }
   if (!self->agroup && mi355_loudnorm_setup(self->ctx, (unsigned)GST_AUDIO_INFO_CHANNELS(&self->info), lt, lrt, tp, off) != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_loudnorm_setup: %s", mi355_ctx_last_error(self->ctx));

@@ -158,7 +158,7 @@ static gboolean gst_ebur128_level_setup(GstAudioFilter *filter, const GstAudioIn
     int status = 0;
     self->agroup = mi355_agroup_shared_ebur128(0, atoi(members), (unsigned)channels, (unsigned)GST_AUDIO_INFO_RATE(info), mode, klass, &self->member, &status);
     if (!self->agroup) GST_WARNING_OBJECT(self, "no shared ebur128level group (%s): own launches", mi355_status_string(status));
-    else (void)mi355_agroup_set_linger(self->agroup, 2000, 0); /* a paused neighbour costs the others 2 ms, never a hang */
+    else (void)mi355_agroup_set_linger(self->agroup, g_getenv("MI355_GROUP_LINGER_US") ? (unsigned)atoi(g_getenv("MI355_GROUP_LINGER_US")) : 2000u, 0); /* a paused neighbour costs the others 2 ms, never a hang */
   }
   if (!self->agroup && mi355_ebur128_setup(self->ctx, (unsigned)channels, (unsigned)GST_AUDIO_INFO_RATE(info), mode, klass) != MI355_OK) {
     GST_ERROR_OBJECT(self, "Failed to create EBU R128: %s", mi355_ctx_last_error(self->ctx));

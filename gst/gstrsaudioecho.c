@@ -104,7 +104,7 @@ static gboolean gst_rs_audio_echo_setup(GstAudioFilter *filter, const GstAudioIn
     int status = 0;
     self->agroup = mi355_agroup_shared_echo(0, atoi(members), (size_t)size * (size_t)GST_AUDIO_INFO_CHANNELS(info), &self->member, &status);
     if (!self->agroup) GST_WARNING_OBJECT(self, "no shared echo group (%s): own launches", mi355_status_string(status));
-    else (void)mi355_agroup_set_linger(self->agroup, 2000, 0); /* a paused neighbour costs the others 2 ms, never a hang */
+    else (void)mi355_agroup_set_linger(self->agroup, g_getenv("MI355_GROUP_LINGER_US") ? (unsigned)atoi(g_getenv("MI355_GROUP_LINGER_US")) : 2000u, 0); /* a paused neighbour costs the others 2 ms, never a hang */
   }
   if (!self->agroup && mi355_echo_setup(self->ctx, (size_t)size * (size_t)GST_AUDIO_INFO_CHANNELS(info)) != MI355_OK) {
     GST_ERROR_OBJECT(self, "mi355_echo_setup: %s", mi355_ctx_last_error(self->ctx));

@@ -40,7 +40,7 @@ typedef enum mi355_status {
                                    echo before setup (audioecho/imp.rs:210 NotNegotiated) */
   MI355_ERR_OUT_OF_MEMORY = -5,
   MI355_ERR_UNSUPPORTED = -6,
-  MI355_ERR_TIMEOUT = -7        /* mi355_agroup_wait: the other members of a lock-step (audioloudnorm) group have not submitted (nothing dropped) */
+  MI355_ERR_TIMEOUT = -7        /* (reserved: mi355_agroup_wait of a lock-step group returned it; the members of every audio group are independent now) */
 } mi355_status;
 
 /* Packed-RGB formats of the hot path. Values are stable ABI.
@@ -314,12 +314,12 @@ int mi355_group_compare_stats(mi355_group *group, uint64_t stats[3]);
  *                     100 ms phase, and ebur128_reset (the element's `reset` action, ebur128level/imp.rs:124-139) for one member
  *                     alone; one sample format per launch set. Linger as for create_echo: a member that is late, paused or
  *                     detached simply does not advance.
- *   create_loudnorm : members advance in LOCK STEP through the batch engine (whole frames of
- *                     mi355_agroup_loudnorm_frame_size(), or the shorter rest with final_frame = 1 - what drain_full_frames /
- *                     drain hand to State::process). The rendezvous is strict, as an aggregator waits for all its pads: wait()
- *                     blocks until the others have submitted, or returns MI355_ERR_TIMEOUT after timeout_ms (the submission
- *                     stays pending - wait again - nothing is dropped or fed silence); a member that stops calls detach (its
- *                     slot hears silence from then on).
+ *   create_loudnorm : members are independent too: each stands at its own frame type (its first 3 s frame, 100 ms frames, the final
+ *                     rest) and hands over whole frames of mi355_agroup_loudnorm_frame_size(group, member), or the shorter rest with
+ *                     final_frame = 1 - what drain_full_frames / drain hand to State::process. A launch set runs one launch
+ *                     sequence per class of members that stand at the same frame type and size (streams that started together);
+ *                     linger as for create_echo. (timeout_ms of set_linger is accepted and ignored; MI355_ERR_TIMEOUT is not
+ *                     returned any more: nobody waits for a member that does not come.)
  *   submit_*        : device_data = 0: host buffers (copied through one pinned slab: one upload and one download per interval
  *                     for all members); 1: device pointers. Buffers are borrowed until wait(ticket) returns.
  *   wait            : *out_frames (optional) = frames produced (audioloudnorm), samples processed (echo), frames metered.
@@ -344,9 +344,9 @@ int mi355_agroup_submit_ebur128(mi355_agroup *group, int member, const void *dat
 int mi355_agroup_ebur128_reset(mi355_agroup *group, int member);
 int mi355_agroup_submit_loudnorm(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
                                  int final_frame, int device_data, uint64_t *ticket);
-size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *group);
+size_t mi355_agroup_loudnorm_frame_size(mi355_agroup *group, int member);
 /* audioloudnorm's sink_chain / drain for a member with the adapter on this side (what mi355_loudnorm_push / _drain are for a single
- * context; audioloudnorm/imp.rs:1545-1586, :226-310): push appends the buffer and hands every whole frame over in lock step with
+ * context; audioloudnorm/imp.rs:1545-1586, :226-310): push appends the buffer and hands every whole frame over together with
  * the other members (it blocks like wait); drain hands over the rest as the final frame. Host buffers. */
 int mi355_agroup_loudnorm_push(mi355_agroup *group, int member, const double *data, size_t frames, double *out, size_t out_capacity_frames,
                                size_t *out_frames);

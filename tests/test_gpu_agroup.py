@@ -313,51 +313,63 @@ def test_ebur128_linger_collects_the_members_that_come_in_time(mi355lib):
         single.close()
 
 
-def test_lockstep_rendezvous_is_strict_times_out_loudly_and_detach_releases(mi355lib):
-    """audioloudnorm members advance in lock step: a missing member makes wait() time out loudly (nothing dropped, nothing fed
-    silence), a wrong frame size is refused, and detach releases the ones already waiting."""
+def test_loudnorm_members_are_independent(mi355lib):
+    """audioloudnorm members stand at their own frame type: one starts three seconds into the others' streams (its 3 s first frame
+    while they hand over 100 ms frames), one pauses, one ends early; a member that does not come holds nobody (linger). A launch
+    set runs one launch sequence per class of members at the same frame type and size. Samples == single-instance contexts."""
     import mi355fx
-    ch = 1
-    g = mi355fx.AudioGroup("loudnorm", 3, channels=ch)
-    single = mi355fx.Context(0)
-    single.loudnorm_setup(ch)
+    ch, n_m = 1, 4
+    lengths = [4.3, 3.9, 3.5, 3.2]                     # seconds of 192 kHz audio per member
+    xs = [_ln_signal(20 + k, lengths[k], ch) for k in range(n_m)]
+    exp = []
+    for x in xs:
+        c = mi355fx.Context(0)
+        c.loudnorm_setup(ch)
+        parts = [c.loudnorm_push(x)]
+        d = c.loudnorm_drain()
+        exp.append(np.concatenate(parts + ([d] if d is not None else [])))
+        c.close()
+    g = mi355fx.AudioGroup("loudnorm", n_m, channels=ch)
     try:
-        g.set_linger(0, 30)
-        fs = g.loudnorm_frame_size()
-        assert fs == 3 * 192000
-        x = _ln_signal(3, 3.2, ch)
-        outs = [np.zeros((19200, ch)) for _ in range(3)]
-        t0 = g.submit_loudnorm(0, x[:fs], outs[0])
-        t1 = g.submit_loudnorm(1, x[:fs], outs[1])
-        with pytest.raises(mi355fx.Mi355Error) as e:
-            g.wait(t0)                                   # member 2 has not come
-        assert e.value.status == mi355fx.ERR_TIMEOUT
-        with pytest.raises(mi355fx.Mi355Error):
-            g.submit_loudnorm(2, x[:100], outs[2])       # not the frame the others submitted
-        t2 = g.submit_loudnorm(2, x[:fs], outs[2])       # ... now it comes: the pending submissions were kept
-        for t in (t0, t1, t2):
-            assert g.wait(t) == 19200
-        exp = single.loudnorm_push(x[:fs])
-        assert (outs[1].reshape(-1) == exp).all() and (outs[2].reshape(-1) == exp).all()
-        # member 2 stops: the others are complete without it, from a thread that was already waiting
         g.set_linger(0, 0)
-        fs = g.loudnorm_frame_size()
-        assert fs == 19200
-        y = x[3 * 192000:3 * 192000 + fs]
-        ta, tb = g.submit_loudnorm(0, y, outs[0]), g.submit_loudnorm(1, y, outs[1])
-        done = []
-        th = threading.Thread(target=lambda: done.append(g.wait(ta)))
-        th.start()
-        time.sleep(0.05)
-        assert not done
-        g.detach(2)
-        th.join(timeout=10)
-        assert done == [19200] and g.wait(tb) == 19200
-        exp = single.loudnorm_push(y)
-        assert (outs[0].reshape(-1) == exp).all() and (outs[1].reshape(-1) == exp).all()
+        pos, outs, done = [0] * n_m, [[] for _ in range(n_m)], [False] * n_m
+
+        def step(members):
+            """every listed member hands over its next frame (or its final rest) in ONE launch set"""
+            tk = {}
+            for m in members:
+                fs = g.loudnorm_frame_size(m)
+                x = xs[m]
+                if len(x) - pos[m] >= fs:
+                    out = np.zeros((max(fs, 19200), ch))
+                    tk[m] = (g.submit_loudnorm(m, x[pos[m]:pos[m] + fs], out), out, fs)
+                else:
+                    out = np.zeros((31 * 19200, ch))
+                    tk[m] = (g.submit_loudnorm(m, x[pos[m]:], out, final_frame=True), out, None)
+            for m, (t, out, fs) in tk.items():
+                n = g.wait(t)
+                outs[m].append(out[:n].reshape(-1).copy())
+                if fs is None:
+                    done[m] = True
+                else:
+                    pos[m] += fs
+
+        step([0, 1])                  # members 0 and 1 start together: their 3 s first frames, one class
+        for _ in range(3):
+            step([0, 1])              # 100 ms frames
+        step([0, 1, 2])               # member 2 starts late: its first frame beside the others' inner frames (two classes in one set)
+        step([0, 2])                  # member 1 pauses
+        step([0, 1, 2, 3])            # member 3 starts, member 1 is back
+        while not all(done):
+            step([m for m in range(n_m) if not done[m]])      # to the end: the final rests come at different times
+        for m in range(n_m):
+            got = np.concatenate(outs[m])
+            assert got.size == exp[m].size, (m, got.size, exp[m].size)
+            assert (got == exp[m]).all(), m
+        with pytest.raises(mi355fx.Mi355Error):
+            g.submit_loudnorm(0, xs[0][:100], np.zeros((19200, ch)))     # not a whole frame
     finally:
         g.close()
-        single.close()
 
 
 # ---------------------------------------------------------------- audioloudnorm
@@ -397,7 +409,7 @@ def test_loudnorm_members_equal_single_instances(mi355lib, seconds):
         try:
             x, outs, pos = xs[m], [], 0
             while True:
-                fs = g.loudnorm_frame_size()
+                fs = g.loudnorm_frame_size(m)
                 if len(x) - pos < fs:
                     break
                 out = np.zeros((max(fs, 19200), ch))

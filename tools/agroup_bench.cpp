@@ -176,11 +176,15 @@ int main(int argc, char **argv) {
     // (b) the group
     mi355_agroup *g = mi355_agroup_create_loudnorm(0, S, ch, -24.0, 7.0, -2.0, 0.0, &st);
     if (!g) { std::fprintf(stderr, "no agroup: %d\n", st); return 1; }
+    // independent members. A run that goes as fast as it can (a file transcode, this bench) lingers long enough for the slowest thread of
+    // an interval - 100 ms: a straggler then joins the set instead of opening one of its own; a live pipeline (100 ms frames every
+    // 100 ms) takes the shim's 2 ms (MI355_GROUP_LINGER_US)
+    CK(mi355_agroup_set_linger(g, 100000, 0));
     const double t_grp = run_threads(S, 1, [&](int m, int) {
       size_t pos = 0, n_out = 0;
       uint64_t t = 0;
       for (;;) {
-        const size_t fs = mi355_agroup_loudnorm_frame_size(g);
+        const size_t fs = mi355_agroup_loudnorm_frame_size(g, m);
         if (total - pos < fs) break;
         CK(mi355_agroup_submit_loudnorm(g, m, x[m].data() + pos * ch, fs, out[m].data(), out[m].size() / ch, 0, 0, &t));
         CK(mi355_agroup_wait(g, t, &n_out));
