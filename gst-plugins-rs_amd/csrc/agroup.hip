@@ -132,7 +132,8 @@ struct mi355_agroup {
   std::vector<size_t> res_frames;
   std::vector<uint64_t> res_interval;
   uint64_t n_batches = 0, n_buffers = 0, n_largest = 0;
-  int copying = 0;            // members that are copying their buffer into their staging slot right now (outside the lock)
+  int copying = 0;            // members that are copying between their buffer and their staging slot right now (outside the lock)
+  std::vector<char> res_pending;   // [member]: a host member's result of a launch set that ran sits in the slabs and has not been collected
   // staging: per-member slots of `cap_bytes` bytes, pinned host + device (input and, for loudnorm, output)
   size_t cap_bytes = 0, out_cap_bytes = 0;
   char *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr;
@@ -171,8 +172,8 @@ int ahip(mi355_agroup *g, hipError_t e, const char *what) {
   return e == hipErrorOutOfMemory ? MI355_ERR_OUT_OF_MEMORY : MI355_ERR_HIP;
 }
 
-// staging slots of at least `need` bytes per member (and `out_need` for the output side). Grows only while nothing is in flight
-// (the callers run it right before a launch set, after the previous one has been waited for).
+// staging slots of at least `need` bytes per member (and `out_need` for the output side). A slab is replaced while no copy runs on it and
+// no launch is in flight; what it holds of members' business - submissions copied in, results not collected yet - moves along.
 int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t need, size_t out_need) {
   if (need > g->cap_bytes || out_need > g->out_cap_bytes) g->cv.wait(lk, [g] { return g->copying == 0; });   // nobody is writing into the old slots
   if (need > g->cap_bytes) {
@@ -184,9 +185,10 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
     int rc = ahip(g, hipHostMalloc((void **)&h, cap * (size_t)g->n_members, hipHostMallocDefault), "hipHostMalloc(agroup staging)");
     if (rc) return rc;
     if ((rc = ahip(g, hipMalloc((void **)&d, cap * (size_t)g->n_members), "hipMalloc(agroup staging)"))) { (void)hipHostFree(h); return rc; }
-    // submissions already copied into the old slots move along
+    // submissions already copied into the old slots move along, and so do results that their members have not collected yet
+    // (rsaudioecho works in place: the result of a member sits in its input slot)
     for (int m = 0; m < g->n_members; m++)
-      if (g->h_in && g->sub[m].have && !g->sub[m].device) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
+      if (g->h_in && ((g->sub[m].have && !g->sub[m].device) || g->res_pending[(size_t)m])) std::memcpy(h + (size_t)m * cap, g->h_in + (size_t)m * g->cap_bytes, g->cap_bytes);
     if (g->h_in) (void)hipHostFree(g->h_in);
     if (g->d_in) (void)hipFree(g->d_in);
     g->h_in = h; g->d_in = d; g->cap_bytes = cap;
@@ -196,13 +198,20 @@ int ensure_staging(mi355_agroup *g, std::unique_lock<std::mutex> &lk, size_t nee
     size_t cap = 4096;
     while (cap < out_need && cap < ((size_t)1 << 20)) cap *= 2;
     if (cap < out_need) cap = (out_need + 4095) & ~(size_t)4095;
+    char *h = nullptr, *d = nullptr;
+    int rc = ahip(g, hipHostMalloc((void **)&h, cap * (size_t)g->n_members, hipHostMallocDefault), "hipHostMalloc(agroup output staging)");
+    if (rc) return rc;
+    if ((rc = ahip(g, hipMalloc((void **)&d, cap * (size_t)g->n_members), "hipMalloc(agroup output staging)"))) { (void)hipHostFree(h); return rc; }
+    // results that their members have not collected yet move along (a row of the output slab is out_cap_bytes wide, rounded down to
+    // whole frames: wait() computes the row the same way)
+    if (g->h_out && g->channels) {
+      const size_t fb = (size_t)g->channels * 8, old_row = g->out_cap_bytes / fb * fb, new_row = cap / fb * fb;
+      for (int m = 0; m < g->n_members; m++)
+        if (g->res_pending[(size_t)m]) std::memcpy(h + (size_t)m * new_row, g->h_out + (size_t)m * old_row, old_row);
+    }
     if (g->h_out) (void)hipHostFree(g->h_out);
     if (g->d_out) (void)hipFree(g->d_out);
-    g->h_out = nullptr; g->d_out = nullptr; g->out_cap_bytes = 0;
-    int rc = ahip(g, hipHostMalloc((void **)&g->h_out, cap * (size_t)g->n_members, hipHostMallocDefault), "hipHostMalloc(agroup output staging)");
-    if (rc) return rc;
-    if ((rc = ahip(g, hipMalloc((void **)&g->d_out, cap * (size_t)g->n_members), "hipMalloc(agroup output staging)"))) return rc;
-    g->out_cap_bytes = cap;
+    g->h_out = h; g->d_out = d; g->out_cap_bytes = cap;
   }
   return MI355_OK;
 }
@@ -394,6 +403,7 @@ void run_interval(mi355_agroup *g) {
     g->res_status[m] = rc;
     g->res_frames[m] = g->kind == KIND_LOUDNORM ? g->ln_out[(size_t)m] : s.n;
     g->res_interval[m] = s.interval;
+    g->res_pending[(size_t)m] = !s.device && rc == MI355_OK && g->kind != KIND_EBUR128;
     s.have = false;   // (data / out stay: wait copies the member's result out)
   }
   g->n_batches++;
@@ -426,6 +436,7 @@ mi355_agroup *agroup_new(int device, int kind, int n_members, int *status) {
   g->res_frames.assign((size_t)n_members, 0);
   g->res_interval.assign((size_t)n_members, 0);
   g->ln_out.assign((size_t)n_members, 0);
+  g->res_pending.assign((size_t)n_members, 0);
   return g;
 }
 
@@ -668,24 +679,35 @@ int mi355_agroup_wait(mi355_agroup *g, uint64_t ticket, size_t *out_frames) {
   const size_t frames = g->res_frames[member];
   if (out_frames) *out_frames = frames;
   // copy-out happens under the lock only for its pointer arithmetic: the member's slot is not written again before this member
-  // submits again
+  // submits again, and the slab is not reallocated while a copy is counted (a member that grows the slots waits in ensure_staging:
+  // round 6's stress run caught a result read from a slab another member's larger buffer had just replaced)
   if (g->kind == KIND_ECHO) {
     if (!s.device && s.n) {
       const char *src = g->h_in + (size_t)member * g->cap_bytes;
       void *dst = s.data;
       const size_t bytes = s.n * (s.fmt ? 8 : 4);
+      g->copying++;   // (the slab must not be reallocated under this copy: ensure_staging waits for copies in either direction)
       lk.unlock();
       std::memcpy(dst, src, bytes);
+      lk.lock();
+      g->copying--;
+      g->cv.notify_all();
     }
+    g->res_pending[(size_t)member] = 0;
   } else if (g->kind == KIND_LOUDNORM) {
     if (frames > s.out_cap) return afail(g, MI355_ERR_INVALID_ARG, "audioloudnorm: output buffer too small");
     if (!s.device && frames && s.out) {
       const size_t ch = g->channels, cap_frames = g->out_cap_bytes / (ch * 8);
       const char *src = g->h_out + (size_t)member * cap_frames * ch * 8;
       void *dst = s.out;
+      g->copying++;
       lk.unlock();
       std::memcpy(dst, src, frames * ch * 8);
+      lk.lock();
+      g->copying--;
+      g->cv.notify_all();
     }
+    g->res_pending[(size_t)member] = 0;
   }
   return MI355_OK;
 }

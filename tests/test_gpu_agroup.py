@@ -164,6 +164,41 @@ def test_echo_errors(mi355lib):
         mi355fx.AudioGroup("echo", 0, ring_len=100)
 
 
+def test_echo_results_survive_a_growing_slab(mi355lib):
+    """A member's result waits in the staging slab until the member collects it. Another member's larger buffer replaces the slab in
+    between: what has not been collected moves along (round 6's stress run caught a result read from the slab that had just been
+    replaced - one thread is enough to show it)."""
+    import mi355fx
+    ring = 4096
+    g = mi355fx.AudioGroup("echo", 3, ring_len=ring)
+    singles = [mi355fx.Context(0) for _ in range(3)]
+    for c in singles:
+        c.echo_setup(ring)
+    rng = np.random.default_rng(3)
+    try:
+        g.set_linger(0)
+        n_big = 600
+        for rnd in range(6):
+            small = [rng.standard_normal(500).astype(np.float32) for _ in range(2)]
+            exp = [singles[m].echo_process(small[m].copy(), 1000, 0.5, 0.3) for m in range(2)]
+            t1 = g.submit_echo(1, small[1], 1000, 0.5, 0.3)
+            t0 = g.submit_echo(0, small[0], 1000, 0.5, 0.3)
+            g.wait(t0)                                   # the launch set of {0, 1} runs; member 1 has not collected its result
+            assert (small[0] == exp[0]).all()
+            n_big *= 4                                   # ... and member 2's buffer needs larger slots every round
+            big = rng.standard_normal(n_big).astype(np.float64)
+            exp_big = singles[2].echo_process(big.copy(), 777, 0.25, 0.0)
+            t2 = g.submit_echo(2, big, 777, 0.25, 0.0)
+            g.wait(t1)
+            assert (small[1] == exp[1]).all(), rnd
+            g.wait(t2)
+            assert (big == exp_big).all(), rnd
+    finally:
+        g.close()
+        for c in singles:
+            c.close()
+
+
 # ---------------------------------------------------------------- ebur128level
 
 @pytest.mark.parametrize("rate,ch,dtype", [(48000, 2, np.float32), (44100, 1, np.int16), (96000, 6, np.float64)])
