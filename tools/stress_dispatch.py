@@ -3,7 +3,11 @@
      sizes x RGB / RGBA x Dssim / Blockhash), random pauses, a random rendezvous setting changed while they run, a thread that
      flushes at random - every result == the element's own entry points on a second context;
  (b) the echo group (mi355_agroup_*): T members with random buffer sizes / sample types / parameters per interval, random pauses
-     longer than the linger (partial launch sets), host and device buffers - every buffer == the member's own single-instance context.
+     longer than the linger (partial launch sets), host and device buffers - every buffer == the member's own single-instance context;
+ (c) an ebur128level group: T meters fed ragged buffer sizes from their own threads with pauses and resets of single members - every
+     reading == the member's own single meter;
+ (d) audioloudnorm groups: rounds of 6 streams of random length that start at random times and pause (members at different frame types
+     in one launch set), through push / drain - every sample == the stream's own single-instance context.
 Prints one line per part: cases, mismatches."""
 import os, sys, threading, time
 import numpy as np
@@ -123,5 +127,99 @@ def part_echo():
     return bad[0]
 
 
+def part_ebur128():
+    rate, ch = 48000, 2
+    g = mi355fx.AudioGroup("ebur128", T, channels=ch, rate=rate, mode=63)
+    g.set_linger(300)
+    stop = time.time() + SECONDS / 2
+    bad, done, lock = [0], [0], threading.Lock()
+
+    def member(m):
+        rng = np.random.default_rng(900 + m)
+        single = mi355fx.Context(0)
+        single.ebur128_setup(ch, rate, 63)
+        t = 0
+        while time.time() < stop:
+            n = int(rng.integers(1, 20000))
+            tt = (t + np.arange(n)) / rate
+            t += n
+            x = np.stack([0.05 * (m + 1) * np.sin(2 * np.pi * (250.0 + 31 * m + 5 * c) * tt) for c in range(ch)], 1) + 2e-3 * rng.standard_normal((n, ch))
+            x = np.ascontiguousarray(x.astype(np.float32))
+            single.ebur128_add_frames(x.reshape(-1))
+            assert g.wait(g.submit_ebur128(m, x.reshape(-1))) == n
+            got = [g.loudness(m, k) for k in range(5)] + [g.peak(m, c) for c in range(ch)] + [g.peak(m, c, True) for c in range(ch)]
+            own = [single.ebur128_loudness_momentary(), single.ebur128_loudness_shortterm(), single.ebur128_loudness_global(), single.ebur128_relative_threshold(),
+                   single.ebur128_loudness_range()] + [single.ebur128_sample_peak(c) for c in range(ch)] + [single.ebur128_true_peak(c) for c in range(ch)]
+            if rng.integers(0, 40) == 0:
+                g.ebur128_reset(m); single.ebur128_reset(); t = 0
+            if rng.integers(0, 6) == 0:
+                time.sleep(float(rng.uniform(0, 0.002)))
+            with lock:
+                done[0] += 1
+                bad[0] += 0 if got == own else 1
+        g.detach(m)
+        single.close()
+
+    ts = [threading.Thread(target=member, args=(m,)) for m in range(T)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    st = g.stats()
+    g.close()
+    print("ebur128level group: %d buffers through %d launch sets (largest %d), %d buffers with a reading that differs" % (done[0], st[1], st[2], bad[0]), flush=True)
+    return bad[0]
+
+
+def part_loudnorm():
+    n_m, ch = 6, 1
+    stop = time.time() + SECONDS / 2
+    bad, done, sets = 0, 0, 0
+    rnd = 0
+    while time.time() < stop:
+        rnd += 1
+        rng = np.random.default_rng(7000 + rnd)
+        xs = []
+        for k in range(n_m):
+            n = int(rng.uniform(0.4, 3.9) * 192000)
+            tt = np.arange(n) / 192000
+            x = 0.05 * np.sin(2 * np.pi * (300 + 17 * k) * tt) * (1 + 0.5 * np.sin(2 * np.pi * 0.3 * tt))
+            for s0 in rng.uniform(0.1 * n, 0.9 * n, 4):
+                x[int(s0):int(s0) + int(rng.integers(10, 2000))] *= rng.uniform(8, 20)
+            xs.append(x.reshape(-1, ch))
+        g = mi355fx.AudioGroup("loudnorm", n_m, channels=ch)
+        g.set_linger(500)
+        got = [None] * n_m
+
+        def element(k):
+            r2 = np.random.default_rng(rnd * 100 + k)
+            time.sleep(float(r2.uniform(0, 0.03)))          # streams start at different times
+            x, parts, i = xs[k], [], 0
+            while i < len(x):
+                c = int(r2.integers(1000, 200000))
+                parts.append(g.loudnorm_push(k, x[i:i + c]))
+                i += c
+                if r2.integers(0, 5) == 0:
+                    time.sleep(float(r2.uniform(0, 0.003)))
+            d = g.loudnorm_drain(k)
+            got[k] = np.concatenate(parts + ([d] if d is not None else []))
+            g.detach(k)
+
+        ts = [threading.Thread(target=element, args=(k,)) for k in range(n_m)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        sets += g.stats()[1]
+        g.close()
+        for k in range(n_m):
+            c = mi355fx.Context(0)
+            c.loudnorm_setup(ch)
+            p = [c.loudnorm_push(xs[k])]
+            d = c.loudnorm_drain()
+            exp = np.concatenate(p + ([d] if d is not None else []))
+            c.close()
+            done += 1
+            bad += 0 if (got[k] is not None and got[k].size == exp.size and (got[k] == exp).all()) else 1
+    print("audioloudnorm groups: %d streams in %d rounds through %d launch sets, %d streams with a sample that differs" % (done, rnd, sets, bad), flush=True)
+    return bad
+
+
 if __name__ == "__main__":
-    sys.exit(1 if (part_compare() + part_echo()) else 0)
+    sys.exit(1 if (part_compare() + part_echo() + part_ebur128() + part_loudnorm()) else 0)
