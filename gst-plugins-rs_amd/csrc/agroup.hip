@@ -686,12 +686,16 @@ int mi355_agroup_wait(mi355_agroup *g, uint64_t ticket, size_t *out_frames) {
       const char *src = g->h_in + (size_t)member * g->cap_bytes;
       void *dst = s.data;
       const size_t bytes = s.n * (s.fmt ? 8 : 4);
-      g->copying++;   // (the slab must not be reallocated under this copy: ensure_staging waits for copies in either direction)
-      lk.unlock();
-      std::memcpy(dst, src, bytes);
-      lk.lock();
-      g->copying--;
-      g->cv.notify_all();
+      if (bytes <= (size_t)65536) {
+        std::memcpy(dst, src, bytes);   // (a 10 ms audio buffer is a few KB: cheaper than giving the lock away and taking it again)
+      } else {
+        g->copying++;   // (the slab must not be reallocated under this copy: ensure_staging waits for copies in either direction)
+        lk.unlock();
+        std::memcpy(dst, src, bytes);
+        lk.lock();
+        g->copying--;
+        g->cv.notify_all();
+      }
     }
     g->res_pending[(size_t)member] = 0;
   } else if (g->kind == KIND_LOUDNORM) {
